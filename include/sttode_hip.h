@@ -1,0 +1,98 @@
+/* sttode_hip.h -- C ABI of libsttode_hip.so (MI355X / gfx950), the drop-in boundary of the STTODE
+ * forward trajectory-forecasting hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (or int32 where noted) owned by the caller;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream), nothing
+ *     synchronises, nothing allocates: all workspaces are caller-provided (graph-capturable);
+ *   - return 0 on success, non-zero on failure; sttode_last_error() gives the calling thread's message;
+ *   - "PK16" = weights pre-packed in MFMA fragment order by sttode_amd/packing.py (csrc/chain.hpp);
+ *   - "columns" are agents (n) or trajectories (m = n*K, row = agent*K + k, model/STTODE.py:322-328).
+ *
+ * Each entry point names the reference interface it replaces (file:line in joyecnu/STTODE).
+ */
+#ifndef STTODE_HIP_H
+#define STTODE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sttode_abi_version(void);
+const char* sttode_last_error(void);
+
+/* STTODENet.set_data (model/STTODE.py:397-461), batched over S independent scenes (CSR scene_ptr ==
+ * seq_start_end, utils/dataloader.py:177-181): scene_orig = mean_n(last obs) (:417), normalised past (:429),
+ * first-difference velocities with the first duplicated (:432-433 / inference :588-589), cur_location (:461),
+ * last-agent flag for add_category (:206).  past [n,Tp,2] world coords; outputs: scene_orig [S,2],
+ * agent_scene [n] int32, xpad [n,16*TPX] (flattened (t,c), zero padded), enc_in [n,Tp,4], cur [n,2],
+ * orig [n,2] (scene_orig per agent), last_flag [n] int32.  vel_from_norm: 1 = inference() semantics. */
+int sttode_frontend_scenes(const float* past, const int* scene_ptr, int n, int S, int Tp, int TPX, int vel_from_norm,
+                           float* scene_orig, int* agent_scene, float* xpad, float* enc_in, float* cur, float* orig,
+                           int* last_flag, void* stream);
+
+/* STTODENet.set_data_nba / inference() NBA branch (model/STTODE.py:463-486,578-583): past [B*N,Tp,2], no
+ * normalisation, orig = 0, last_flag = (slot == N-1). */
+int sttode_frontend_nba(const float* past, int n, int N, int Tp, int TPX, float* xpad, float* enc_in, float* cur, float* orig,
+                        int* last_flag, void* stream);
+
+/* inputs_for_posterior (model/STTODE.py:430,434,457 ; 477,481): future [n,Tf,2], past_last [n,2] world. */
+int sttode_frontend_future(const float* future, const float* past_last, int n, int Tf, int mode, int nba_N,
+                           const float* scene_orig, const int* agent_scene, const int* scene_ptr, float* enc_in, void* stream);
+
+/* PastEncoder.forward up to the attention in-projection (model/STTODE.py:214-223; PositionalAgentEncoding
+ * :167-176; add_category :199-210; Hyp_mhsa packed in-proj hyptransformerlib.py:113-115).
+ * enc_in [n,Tlen,4] -> g [n,64] (ftraj_input), qkv [n,192] (raw q|k|v, q NOT yet scaled). */
+int sttode_embed_qkv(const float* fc1P, const float* fc1b, const float* posP, const float* peb, const float* fc2P,
+                     const float* fc2b, const float* fc3P, const float* fc3b, const float* fc3last, const float* inP,
+                     const float* inb, const float* enc_in, const int* last_flag, float* g, float* qkv, int n, int Tlen,
+                     void* stream);
+
+/* Multi-head geodesic attention core, 8 heads x 8 dims (hyptransformerlib.py:191,214-218,251-300;
+ * Oblique.proj/dist core/manifolds/oblique.py:15-16,36-43):
+ *   out_i = sum_j softmax_j( -acos(clamp(<r_i/|r_i|, c_j/|c_j|>, -1+1e-4, 1-1e-4)) ) v_j
+ * element (seq s, batch b, feature f) at base + s*seq_stride + b*batch_stride + f (strides in floats).
+ * Self-attention L == S (the reference's live path): R = k, C = q (cscale = hd^-0.5), i.e. the untransposed-score
+ * quirk (:261-265).  L != S: R = q (rscale = hd^-0.5), C = k.  rowsum [Nb,8,rows] and wout [Nb,rows,cols]
+ * (head-averaged weights, :306-309) are optional. */
+int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out, float* rowsum, float* wout, int rows,
+                      int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b, long os_seq,
+                      long os_b, float rscale, float cscale, void* stream);
+
+/* out_proj (hyptransformerlib.py:305) -> Hypattention gate tanh(info)*sigmoid(gate) (hypertransformer.py:81-83)
+ * -> TransformerEncoderLayer post-LN + FFN (hypertransformer.py:148-152) -> ODEG_Encoder: one explicit Euler step of
+ * size ode_time and relu (ode_demo.py:186-190,223-231) -> pf [n,128] = cat(g, ode) (model/STTODE.py:233-235). */
+int sttode_post_attn(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                     const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                     const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* g, const float* attn,
+                     int ld_attn, float* pf, int n, float ode_time, void* stream);
+
+/* DecomposeBlock front half (model/STTODE.py:62-69): conv1d(2->32,k3,pad1)+relu, GRU(32->96) final state.
+ * xin [ncols,16*TPX] = flattened (x_true - x_hat) -> state [ncols,96]. */
+int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
+                    const float* gbias, float* state, int ncols, int Tp, int TPX, void* stream);
+
+/* Generic per-column linear out[col, 0:N] = act(W [X1 | X2] + b) (nn.Linear; used for the per-agent part of
+ * decoder_x/decoder_y layer 0, model/utils.py:86-95). K1, K2, N multiples of 16. */
+int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, const float* bias,
+                       float* out, int ldo, int ncols, int N, int relu, void* stream);
+
+/* DecomposeBlock 0 back half for all K samples (model/STTODE.py:71-75, Decoder.forward :336-339):
+ * decoder_x and decoder_y MLPs; writes dbuf = x_true - x_hat0 [m,16*TPX] and ybuf = y_hat0 [m,16*NOY]. */
+int sttode_mlp_block0(const float* A0x, const float* chunks_x, const float* b2x, const float* w3x, const float* b3x,
+                      const float* A0y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
+                      const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
+                      void* stream);
+
+/* DecomposeBlock 1 back half + Decoder epilogue (model/STTODE.py:338,343-346) + "+ scene_orig" (:621-622):
+ * pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur_location) + scene_orig. */
+int sttode_mlp_block1(const float* A1y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
+                      const float* z, const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred,
+                      int ncols, int K, int Tf, int NOY, void* stream);
+
+/* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
+int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

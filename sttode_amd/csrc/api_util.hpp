@@ -1,0 +1,26 @@
+// Error plumbing for the C ABI: every entry point returns 0 on success, non-zero on failure, and
+// sttode_last_error() returns the message of the calling thread's last failure.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+void stt_set_error(const char* msg);
+
+#define STT_REQUIRE(cond, msg)      \
+    do {                            \
+        if (!(cond)) {              \
+            stt_set_error(msg);     \
+            return 1;               \
+        }                           \
+    } while (0)
+
+#define STT_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            char _b[512];                                                                   \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            stt_set_error(_b);                                                              \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)

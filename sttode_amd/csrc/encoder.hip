@@ -1,0 +1,311 @@
+// Encoder hot path (PastEncoder / FutureEncoder trunk): model/STTODE.py:214-236, hypertransformer.py:55-89,134-153,
+// hyptransformerlib.py:29-311, core/manifolds/oblique.py:15-16,36-45, ode_demo.py:186-190,223-231 (reference).
+//
+// Three kernels, all in the column-chain formulation of chain.hpp (agents on MFMA lane columns):
+//   embed_qkv   per agent: input_fc (K=4: ONE 16x16x4 MFMA per row tile) -> pos-enc fc (pe part folded
+//               into a per-frame constant table at pack time) -> input_fc2 accumulated over frames ->
+//               category one-hot folded into a per-lane bias -> input_fc3 -> packed QKV in-projection.
+//   mhgsa_attn  geodesic scoring  w_ij = -acos(clamp(<r_i/|r_i|, c_j/|c_j|>))  + softmax + value
+//               aggregation, one row per lane, column tiles (normalised c_j, v_j) staged in LDS.
+//               (For the reference's B=1 ETH path the attention length is 1 and this kernel is skipped:
+//               softmax over one element == 1  =>  attention output == v.)
+//   post_attn   out_proj -> tanh(info)*sigmoid(gate) -> +res, LN1 -> FFN 64->1024->64 (hidden tile by
+//               hidden tile, never materialised) -> +res, LN2 -> one explicit Euler step  x + T*f(x)  -> relu,
+//               writes past_feature = cat(ftraj_input, ode_out).
+#include "chain.hpp"
+#include "api_util.hpp"
+
+struct EmbedW {
+    const float* fc1P;    // [4 row tiles][64 lanes]  lane(i,q) -> W_fc[16it+i][q]
+    const float* fc1b;    // [64]
+    const f32x4* posP;    // PK16 of pos fc weight[:, :64]   [4][4][64]
+    const float* peb;     // [Tlen][64]  pos fc weight[:, 64:] @ pe[t] + pos fc bias
+    const f32x4* fc2P;    // PK16 of input_fc2 [64 x 64*Tlen] -> [4][4*Tlen][64]
+    const float* fc2b;    // [64]
+    const f32x4* fc3P;    // PK16 of input_fc3[:, :64]  [4][4][64]
+    const float* fc3b;    // [64]
+    const float* fc3last; // [64] = input_fc3.weight[:, 66]  (category [0,0,1] of the last agent)
+    const f32x4* inP;     // PK16 of in_proj_weight [192 x 64] -> [12][4][64]
+    const float* inb;     // [192]
+};
+
+__global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* __restrict__ enc_in,  // [n][Tlen][4]
+                                                        const int* __restrict__ last_flag,           // [n]
+                                                        float* __restrict__ g,                       // [n][64]
+                                                        float* __restrict__ qkv,                     // [n][192]
+                                                        int n, int Tlen) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 16 >= n) return;
+    const int col = tile * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 f[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) f[it] = ld4(w.fc2b + 16 * it + 4 * q);
+    for (int t = 0; t < Tlen; ++t) {
+        const float xin = enc_in[((size_t)colc * Tlen + t) * 4 + q];
+        f32x4 xt[4], pt[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            xt[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.fc1P[it * 64 + lane], xin, ld4(w.fc1b + 16 * it + 4 * q), 0, 0, 0);
+        STT_FENCE();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 a = ld4(w.peb + (size_t)t * 64 + 16 * it + 4 * q);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) a = mfma_k16(a, w.posP[(it * 4 + T) * 64 + lane], xt[T]);
+            pt[it] = a;
+        }
+        STT_FENCE();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) f[it] = mfma_k16(f[it], w.fc2P[((size_t)it * 4 * Tlen + 4 * t + T) * 64 + lane], pt[T]);
+        }
+        STT_FENCE();
+    }
+    const float lastf = last_flag[colc] ? 1.0f : 0.0f;
+    f32x4 gg[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 a = ld4(w.fc3b + 16 * it + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a = mfma_k16(a, w.fc3P[(it * 4 + T) * 64 + lane], f[T]);
+        // cat(x, category) @ W3^T : category is [0,0,1] for the scene's last agent, zeros otherwise
+        const f32x4 wl = ld4(w.fc3last + 16 * it + 4 * q);
+        gg[it] = a + wl * lastf;
+    }
+    if (col < n) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) st4(g + (size_t)col * 64 + 16 * it + 4 * q, gg[it]);
+    }
+    STT_FENCE();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        f32x4 a = ld4(w.inb + 16 * it + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a = mfma_k16(a, w.inP[(it * 4 + T) * 64 + lane], gg[T]);
+        if (col < n) st4(qkv + (size_t)col * 192 + 16 * it + 4 * q, a);
+        if ((it & 3) == 3) STT_FENCE();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// geodesic attention:  out_i = sum_j softmax_j( -acos(clamp(<rhat_i, chat_j>)) ) v_j      (hd = 8)
+// element (seq s, batch b, feature f) of R/C/V/out lives at  base + s*seq_stride + b*batch_stride + f
+// ---------------------------------------------------------------------------------------------------
+#define ATT_TJ 128
+__global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict__ R, const float* __restrict__ C,
+                                                         const float* __restrict__ V, float* __restrict__ out,
+                                                         float* __restrict__ rowsum,  // optional [Nb][8][rows]
+                                                         int rows, int cols, long rs_seq, long rs_b, long cs_seq, long cs_b,
+                                                         long vs_seq, long vs_b, long os_seq, long os_b, float rscale, float cscale) {
+    __shared__ float sC[ATT_TJ][8];
+    __shared__ float sV[ATT_TJ][8];
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ic = i < rows ? i : rows - 1;
+    float r[8];
+    {
+        const float* p = R + ic * rs_seq + b * rs_b + 8 * h;
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { r[d] = p[d] * rscale; ss += r[d] * r[d]; }
+        const float nrm = sqrtf(ss);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) r[d] = r[d] / nrm;
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float l = 0.f;
+    for (int j0 = 0; j0 < cols; j0 += ATT_TJ) {
+        __syncthreads();
+        if (threadIdx.x < ATT_TJ) {
+            const int j = j0 + threadIdx.x;
+            if (j < cols) {
+                const float* p = C + j * cs_seq + b * cs_b + 8 * h;
+                float v[8], ss = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) { v[d] = p[d] * cscale; ss += v[d] * v[d]; }
+                const float nrm = sqrtf(ss);
+#pragma unroll
+                for (int d = 0; d < 8; ++d) sC[threadIdx.x][d] = v[d] / nrm;
+            }
+        } else {
+            const int jj = threadIdx.x - ATT_TJ, j = j0 + jj;
+            if (j < cols) {
+                const float* p = V + j * vs_seq + b * vs_b + 8 * h;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) sV[jj][d] = p[d];
+            }
+        }
+        __syncthreads();
+        const int jn = min(ATT_TJ, cols - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dot += r[d] * sC[jj][d];
+            dot = fminf(fmaxf(dot, -1.0f + 1e-4f), 1.0f - 1e-4f);
+            const float p = expf(-acosf(dot));  // scores lie in [-pi, 0]: no running max needed
+            l += p;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[d] += p * sV[jj][d];
+        }
+    }
+    if (i < rows) {
+        float* o = out + i * os_seq + b * os_b + 8 * h;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = acc[d] * inv;
+        if (rowsum) rowsum[((size_t)b * 8 + h) * rows + i] = l;
+    }
+}
+
+// head-averaged attention weights (Hyp_mhsa need_weights=True, hyptransformerlib.py:306-309): w[b][i][j]
+__global__ __launch_bounds__(256) void mhgsa_weights_kernel(const float* __restrict__ R, const float* __restrict__ C,
+                                                            const float* __restrict__ rowsum, float* __restrict__ wout,
+                                                            int rows, int cols, int Nb, long rs_seq, long rs_b, long cs_seq,
+                                                            long cs_b, float rscale, float cscale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Nb * rows * cols) return;
+    const int j = idx % cols, i = (idx / cols) % rows, b = idx / ((long)cols * rows);
+    float s = 0.f;
+    for (int h = 0; h < 8; ++h) {
+        const float* pr = R + i * rs_seq + b * rs_b + 8 * h;
+        const float* pc = C + j * cs_seq + b * cs_b + 8 * h;
+        float rr[8], cc[8], sr = 0.f, sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { rr[d] = pr[d] * rscale; cc[d] = pc[d] * cscale; sr += rr[d] * rr[d]; sc += cc[d] * cc[d]; }
+        const float nr = sqrtf(sr), nc = sqrtf(sc);
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dot += (rr[d] / nr) * (cc[d] / nc);
+        dot = fminf(fmaxf(dot, -1.0f + 1e-4f), 1.0f - 1e-4f);
+        s += expf(-acosf(dot)) / rowsum[((size_t)b * 8 + h) * rows + i];
+    }
+    wout[idx] = s * 0.125f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct PostW {
+    const f32x4* outP;  const float* outb;    // out_proj       PK16 [4][4][64], [64]
+    const f32x4* infoP; const float* infob;   // temporal_info
+    const f32x4* gateP; const float* gateb;   // temporal_gate
+    const float* ln1w;  const float* ln1b;
+    const f32x4* l1P;   const float* l1b;     // linear1 [1024 x 64]  PK16 [64][4][64], [1024]
+    const f32x4* l2P;   const float* l2b;     // linear2 [64 x 1024]  PK16 [4][64][64], [64]
+    const float* ln2w;  const float* ln2b;
+};
+
+__global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g,  // [n][64]
+                                                        const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
+                                                        float* __restrict__ pf,                       // [n][128]
+                                                        int n, float ode_time) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 16 >= n) return;
+    const int col = tile * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 a[4], o[4], x[4], gg[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        a[T] = ld4(attn + (size_t)colc * ld_attn + 16 * T + 4 * q);
+        gg[T] = ld4(g + (size_t)colc * 64 + 16 * T + 4 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 v = ld4(w.outb + 16 * it + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) v = mfma_k16(v, w.outP[(it * 4 + T) * 64 + lane], a[T]);
+        o[it] = v;
+    }
+    STT_FENCE();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 vi = ld4(w.infob + 16 * it + 4 * q), vg = ld4(w.gateb + 16 * it + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            vi = mfma_k16(vi, w.infoP[(it * 4 + T) * 64 + lane], o[T]);
+            vg = mfma_k16(vg, w.gateP[(it * 4 + T) * 64 + lane], o[T]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[it][r] = gg[it][r] + tanhf(vi[r]) * sigmoidf_(vg[r]);
+    }
+    STT_FENCE();
+    layernorm64(x, w.ln1w, w.ln1b, q);
+    f32x4 ff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ff[it] = ld4(w.l2b + 16 * it + 4 * q);
+#pragma unroll 1
+    for (int ht = 0; ht < 64; ++ht) {
+        f32x4 hid = ld4(w.l1b + 16 * ht + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hid = mfma_k16(hid, w.l1P[(ht * 4 + T) * 64 + lane], x[T]);
+        hid = relu4(hid);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ff[it] = mfma_k16(ff[it], w.l2P[(it * 64 + ht) * 64 + lane], hid);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) x[it] = x[it] + ff[it];
+    layernorm64(x, w.ln2w, w.ln2b, q);
+    if (col < n) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            st4(pf + (size_t)col * 128 + 16 * it + 4 * q, gg[it]);
+            // torchdiffeq fixed-grid euler on t=[0,T]: y1 = y0 + T*f(y0); then relu (ode_demo.py:188,231)
+            st4(pf + (size_t)col * 128 + 64 + 16 * it + 4 * q, relu4(gg[it] + x[it] * ode_time));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sttode_embed_qkv(const float* fc1P, const float* fc1b, const float* posP, const float* peb, const float* fc2P,
+                                const float* fc2b, const float* fc3P, const float* fc3b, const float* fc3last, const float* inP,
+                                const float* inb, const float* enc_in, const int* last_flag, float* g, float* qkv, int n, int Tlen,
+                                void* stream) {
+    STT_REQUIRE(fc1P && fc1b && posP && peb && fc2P && fc2b && fc3P && fc3b && fc3last && inP && inb && enc_in && last_flag && g && qkv,
+                "sttode_embed_qkv: null pointer");
+    STT_REQUIRE(n > 0 && Tlen > 0 && Tlen <= 200, "sttode_embed_qkv: n must be > 0 and 0 < Tlen <= 200 (pe table length)");
+    EmbedW w;
+    w.fc1P = fc1P; w.fc1b = fc1b; w.posP = (const f32x4*)posP; w.peb = peb; w.fc2P = (const f32x4*)fc2P; w.fc2b = fc2b;
+    w.fc3P = (const f32x4*)fc3P; w.fc3b = fc3b; w.fc3last = fc3last; w.inP = (const f32x4*)inP; w.inb = inb;
+    hipLaunchKernelGGL(embed_qkv_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, enc_in, last_flag, g, qkv, n, Tlen);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out, float* rowsum, float* wout, int rows,
+                                 int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b,
+                                 long os_seq, long os_b, float rscale, float cscale, void* stream) {
+    STT_REQUIRE(R && C && V && out, "sttode_mhgsa_attn: null pointer");
+    STT_REQUIRE(rows > 0 && cols > 0 && Nb > 0 && Nb * 8 <= 65535, "sttode_mhgsa_attn: bad rows/cols/Nb (Nb*8 must fit gridDim.y)");
+    STT_REQUIRE(!wout || rowsum, "sttode_mhgsa_attn: weights output needs the rowsum workspace");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 255) / 256, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
+                       rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale);
+    STT_HIP(hipGetLastError());
+    if (wout) {
+        const long tot = (long)Nb * rows * cols;
+        hipLaunchKernelGGL(mhgsa_weights_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, R, C, rowsum, wout, rows, cols,
+                           Nb, rs_seq, rs_b, cs_seq, cs_b, rscale, cscale);
+        STT_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int sttode_post_attn(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                                const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                                const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* g,
+                                const float* attn, int ld_attn, float* pf, int n, float ode_time, void* stream) {
+    STT_REQUIRE(outP && outb && infoP && infob && gateP && gateb && ln1w && ln1b && l1P && l1b && l2P && l2b && ln2w && ln2b && g && attn && pf,
+                "sttode_post_attn: null pointer");
+    STT_REQUIRE(n > 0 && ld_attn >= 64 && ld_attn % 4 == 0, "sttode_post_attn: n must be > 0, ld_attn >= 64 and a multiple of 4");
+    PostW w;
+    w.outP = (const f32x4*)outP; w.outb = outb; w.infoP = (const f32x4*)infoP; w.infob = infob; w.gateP = (const f32x4*)gateP;
+    w.gateb = gateb; w.ln1w = ln1w; w.ln1b = ln1b; w.l1P = (const f32x4*)l1P; w.l1b = l1b; w.l2P = (const f32x4*)l2P; w.l2b = l2b;
+    w.ln2w = ln2w; w.ln2b = ln2b;
+    hipLaunchKernelGGL(post_attn_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, g, attn, ld_attn, pf, n, ode_time);
+    STT_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,152 @@
+// Batched scene front-end (set_data / set_data_nba equivalents) and best-of-K metrics.
+//   reference: model/STTODE.py:397-461 (scene normalisation, velocities, cur_location),
+//              model/STTODE.py:463-486,578-596 (NBA branch / inference() input assembly),
+//              utils/metrics.py:7-26 (min-over-K ADE / FDE).
+// HBM-bound byte shuffling: one thread per scene / agent, coalesced over agents.
+#include "api_util.hpp"
+#include <string>
+
+static thread_local std::string g_err;
+void stt_set_error(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" const char* sttode_last_error() { return g_err.c_str(); }
+extern "C" int sttode_abi_version() { return 1; }
+
+__global__ void scene_orig_kernel(const float* __restrict__ past, const int* __restrict__ scene_ptr, int S, int Tp,
+                                  float* __restrict__ scene_orig, int* __restrict__ agent_scene) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int a0 = scene_ptr[s], a1 = scene_ptr[s + 1];
+    float sx = 0.f, sy = 0.f;
+    for (int a = a0; a < a1; ++a) {
+        sx += past[((size_t)a * Tp + (Tp - 1)) * 2 + 0];
+        sy += past[((size_t)a * Tp + (Tp - 1)) * 2 + 1];
+        agent_scene[a] = s;
+    }
+    const float inv = (float)(a1 - a0);
+    scene_orig[2 * s] = sx / inv;
+    scene_orig[2 * s + 1] = sy / inv;
+}
+
+// mode 0: ETH/UCY/SDD (normalise by scene_orig, flag last agent of each scene)
+// mode 1: NBA (no normalisation, flag slot N-1)
+__global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T, int TPX, int mode, int vel_from_norm,
+                                    const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq (future encoder), world coords
+                                    const float* __restrict__ scene_orig, const int* __restrict__ agent_scene,
+                                    const int* __restrict__ scene_ptr, int nba_N, float* __restrict__ xpad,
+                                    float* __restrict__ enc_in, float* __restrict__ cur, float* __restrict__ orig,
+                                    int* __restrict__ last_flag) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    float ox = 0.f, oy = 0.f;
+    int last;
+    if (mode == 0) {
+        const int s = agent_scene[a];
+        ox = scene_orig[2 * s];
+        oy = scene_orig[2 * s + 1];
+        last = (a == scene_ptr[s + 1] - 1);
+    } else {
+        last = (a % nba_N == nba_N - 1);
+    }
+    const float* p = seq + (size_t)a * T * 2;
+    float* xp = xpad ? xpad + (size_t)a * 16 * TPX : nullptr;
+    float pnx = 0.f, pny = 0.f, pwx = 0.f, pwy = 0.f;  // previous frame: normalised / world
+    const bool have_prev = prev_last != nullptr;
+    if (have_prev) {
+        pwx = prev_last[2 * a];
+        pwy = prev_last[2 * a + 1];
+        pnx = pwx - ox;
+        pny = pwy - oy;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float wx = p[2 * t], wy = p[2 * t + 1];
+        const float nx = wx - ox, ny = wy - oy;
+        float vx, vy;
+        if (t == 0 && !have_prev) {
+            // first velocity duplicates the second one (model/STTODE.py:432-433,582-583)
+            const float w1x = p[2], w1y = p[3];
+            if (vel_from_norm) { vx = (w1x - ox) - nx; vy = (w1y - oy) - ny; }
+            else { vx = w1x - wx; vy = w1y - wy; }
+        } else {
+            if (vel_from_norm) { vx = nx - pnx; vy = ny - pny; }
+            else { vx = wx - pwx; vy = wy - pwy; }
+        }
+
+        float* e = enc_in + ((size_t)a * T + t) * 4;
+        e[0] = nx; e[1] = ny; e[2] = vx; e[3] = vy;
+        if (xp) { xp[2 * t] = nx; xp[2 * t + 1] = ny; }
+        pnx = nx; pny = ny; pwx = wx; pwy = wy;
+    }
+    if (xp)
+        for (int k = 2 * T; k < 16 * TPX; ++k) xp[k] = 0.f;
+    if (cur) { cur[2 * a] = pnx; cur[2 * a + 1] = pny; }
+    if (orig) { orig[2 * a] = ox; orig[2 * a + 1] = oy; }
+    if (last_flag) last_flag[a] = last;
+}
+
+__global__ void best_of_k_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n, int K, int Tf, float scale,
+                                 float* __restrict__ ade, float* __restrict__ fde) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const float* g = gt + (size_t)a * Tf * 2;
+    float best_a = INFINITY, best_f = INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const float* p = pred + ((size_t)a * K + k) * Tf * 2;
+        float sum = 0.f, dl = 0.f;
+        for (int t = 0; t < Tf; ++t) {
+            const float dx = (p[2 * t] - g[2 * t]) * scale, dy = (p[2 * t + 1] - g[2 * t + 1]) * scale;
+            dl = sqrtf(dx * dx + dy * dy);
+            sum += dl;
+        }
+        best_a = fminf(best_a, sum / (float)Tf);
+        best_f = fminf(best_f, dl);
+    }
+    ade[a] = best_a;
+    fde[a] = best_f;
+}
+
+extern "C" int sttode_frontend_scenes(const float* past, const int* scene_ptr, int n, int S, int Tp, int TPX, int vel_from_norm,
+                                      float* scene_orig, int* agent_scene, float* xpad, float* enc_in, float* cur, float* orig,
+                                      int* last_flag, void* stream) {
+    STT_REQUIRE(past && scene_ptr && scene_orig && agent_scene && xpad && enc_in && cur && orig && last_flag, "sttode_frontend_scenes: null pointer");
+    STT_REQUIRE(n > 0 && S > 0 && Tp >= 2 && 2 * Tp <= 16 * TPX, "sttode_frontend_scenes: need n,S > 0, Tp >= 2, 2*Tp <= 16*TPX");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(scene_orig_kernel, dim3((S + 127) / 128), dim3(128), 0, s, past, scene_ptr, S, Tp, scene_orig, agent_scene);
+    hipLaunchKernelGGL(agent_inputs_kernel, dim3((n + 127) / 128), dim3(128), 0, s, past, n, Tp, TPX, 0, vel_from_norm,
+                       (const float*)nullptr, scene_orig, agent_scene, scene_ptr, 1, xpad, enc_in, cur, orig, last_flag);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_frontend_nba(const float* past, int n, int N, int Tp, int TPX, float* xpad, float* enc_in, float* cur,
+                                   float* orig, int* last_flag, void* stream) {
+    STT_REQUIRE(past && xpad && enc_in && cur && orig && last_flag, "sttode_frontend_nba: null pointer");
+    STT_REQUIRE(n > 0 && N > 0 && n % N == 0 && Tp >= 2 && 2 * Tp <= 16 * TPX, "sttode_frontend_nba: need n % N == 0, Tp >= 2, 2*Tp <= 16*TPX");
+    hipLaunchKernelGGL(agent_inputs_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, past, n, Tp, TPX, 1, 1,
+                       (const float*)nullptr, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, N, xpad, enc_in, cur,
+                       orig, last_flag);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// inputs of the posterior (future) encoder: normalised future + velocity w.r.t. the preceding frame
+// (model/STTODE.py:434,457 ; :477,481).  mode as above; writes enc_in [n][Tf][4] only.
+extern "C" int sttode_frontend_future(const float* future, const float* past_last, int n, int Tf, int mode, int nba_N,
+                                      const float* scene_orig, const int* agent_scene, const int* scene_ptr, float* enc_in,
+                                      void* stream) {
+    STT_REQUIRE(future && past_last && enc_in, "sttode_frontend_future: null pointer");
+    STT_REQUIRE(n > 0 && Tf >= 1 && (mode == 1 || (scene_orig && agent_scene && scene_ptr)), "sttode_frontend_future: bad arguments");
+    hipLaunchKernelGGL(agent_inputs_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, future, n, Tf, 1, mode, 0,
+                       past_last, scene_orig, agent_scene, scene_ptr, nba_N > 0 ? nba_N : 1, (float*)nullptr, enc_in,
+                       (float*)nullptr, (float*)nullptr, (int*)nullptr);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde,
+                                void* stream) {
+    STT_REQUIRE(pred && gt && ade && fde, "sttode_best_of_k: null pointer");
+    STT_REQUIRE(n > 0 && K > 0 && Tf > 0, "sttode_best_of_k: n, K, Tf must be positive");
+    hipLaunchKernelGGL(best_of_k_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, pred, gt, n, K, Tf, scale, ade, fde);
+    STT_HIP(hipGetLastError());
+    return 0;
+}

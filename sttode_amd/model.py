@@ -1,0 +1,343 @@
+"""``STTODENet``: host-side mirror of the reference's model API over the HIP C-ABI library.
+
+Drop-in surface (reference: model/STTODE.py:349-623):
+    STTODENet(args, device); set_device(); set_data(batch, pre_motion, fut_motion, pre_mask, fut_mask);
+    set_data_nba(data); inference(data) -> Tensor[K, B*N, Tf, 2]; step_annealer();
+    attributes agent_num, batch_size, scene_orig, past_feature; identical state_dict names / shapes, so a
+    reference checkpoint's ``model_dict`` loads with ``load_state_dict(strict=True)``.
+Build-defined extension (the batched scene front-end):
+    set_scene_batch(past[n,Tp,2], future[n,Tf,2] | None, scene_ptr[S+1]) + inference()  -- many independent
+    scenes per call (the reference loops ``for scene: set_data; inference``, test.py:171-184).
+
+All compute runs in hand-written HIP kernels (sttode_amd/csrc); PyTorch only owns device memory and the
+stream.  There is no eager / CPU fallback: a missing library or a CPU tensor raises.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import capi, packing
+from .weights import sinusoid_table_np
+
+
+class _HypMHSA(nn.Module):
+    """Parameter holder, names of Hyp_mhsa (hyptransformerlib.py:340-381)."""
+
+    def __init__(self, d, h):
+        super().__init__()
+        self.embed_dim, self.num_heads = d, h
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _HypAttention(nn.Module):  # hypertransformer.py:19-33
+    def __init__(self, d, h):
+        super().__init__()
+        self.temporal_attention_before = _HypMHSA(d, h)
+        self.temporal_info = nn.Linear(d, d)
+        self.temporal_gate = nn.Linear(d, d)
+
+
+class _EncoderLayer(nn.Module):  # hypertransformer.py:108-122
+    def __init__(self, d, h, ff):
+        super().__init__()
+        self.self_attn = _HypAttention(d, h)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _Named(nn.Module):
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            setattr(self, k, v)
+
+
+class _PosEnc(nn.Module):  # model/STTODE.py:137-147
+    def __init__(self, d, max_t_len=200):
+        super().__init__()
+        self.fc = nn.Linear(2 * d, d)
+        self.register_buffer('pe', torch.from_numpy(sinusoid_table_np(max_t_len, d)))
+
+
+class _Trunk(nn.Module):
+    """PastEncoder / FutureEncoder parameter tree (model/STTODE.py:178-197, 238-261)."""
+
+    def __init__(self, args, length, future=False):
+        super().__init__()
+        D = args.hidden_dim
+        self.input_fc = nn.Linear(4, D)
+        self.input_fc2 = nn.Linear(D * length, D)
+        self.input_fc3 = nn.Linear(D + 3, D)
+        layers = nn.ModuleList([_EncoderLayer(D, 8, 1024)])
+        self.ODE_Encoder = _Named(odeblock=_Named(odefunc=_Named(layers=layers)))
+        self.pos_encoder = _PosEnc(D)
+        if future:
+            self.out_mlp = _Named(affine_layers=nn.ModuleList([nn.Linear((2 + len(args.hyper_scales)) * D, 128)]))
+            self.qz_layer = nn.Linear(128, 2 * args.zdim)
+            for m in (self.out_mlp.affine_layers[0], self.qz_layer):  # initialize_weights (model/utils.py:11-21)
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+
+
+class _MLP(nn.Module):  # model/utils.py:67-79
+    def __init__(self, din, dout, hidden=(512, 256)):
+        super().__init__()
+        dims = [din, *hidden, dout]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+class _DecomposeBlock(nn.Module):  # model/STTODE.py:20-48
+    def __init__(self, past_len, future_len, input_dim):
+        super().__init__()
+        self.conv_past = nn.Conv1d(2, 32, 3, stride=1, padding=1)
+        self.encoder_past = nn.GRU(32, 96, 1, batch_first=True)
+        self.decoder_y = _MLP(96 + input_dim, future_len * 2)
+        self.decoder_x = _MLP(96 + input_dim, past_len * 2)
+        nn.init.kaiming_normal_(self.conv_past.weight)
+        nn.init.kaiming_normal_(self.encoder_past.weight_ih_l0)
+        nn.init.kaiming_normal_(self.encoder_past.weight_hh_l0)
+        nn.init.zeros_(self.conv_past.bias)
+        nn.init.zeros_(self.encoder_past.bias_ih_l0)
+        nn.init.zeros_(self.encoder_past.bias_hh_l0)
+
+
+class _Decoder(nn.Module):  # model/STTODE.py:303-318
+    def __init__(self, args):
+        super().__init__()
+        din = 2 * args.hidden_dim + args.zdim
+        self.decompose = nn.ModuleList(_DecomposeBlock(args.past_length, args.future_length, din)
+                                       for _ in range(args.num_decompose))
+
+
+def _f32(t, device):
+    return torch.as_tensor(t, dtype=torch.float32).to(device).contiguous()
+
+
+class STTODENet(nn.Module):
+    ODE_TIME = 12.0  # ODEG_Encoder(encoder_layers, nlayer, 12): model/STTODE.py:195 -> one Euler step of size 12
+
+    def __init__(self, args, device):
+        super().__init__()
+        if args.hidden_dim != 64 or args.zdim != 32:
+            raise NotImplementedError('HIP kernels are built for hidden_dim=64, zdim=32 (reference defaults, train.py:21-52)')
+        if args.num_decompose != 2:
+            raise NotImplementedError('HIP decoder is built for num_decompose=2 (reference default)')
+        if packing.tiles_y(args.future_length) not in packing.SUPPORTED_NOY or 2 * args.past_length > 32:
+            raise NotImplementedError('unsupported past/future length for the built kernel instantiations')
+        self.device = torch.device(device)
+        self.args = args
+        self.max_train_agent = args.max_train_agent
+        self.rand_rot_scene = args.rand_rot_scene
+        self.discrete_rot = args.discrete_rot
+        scale_num = 2 + len(args.hyper_scales)
+        self.past_encoder = _Trunk(args, args.past_length)
+        self.pz_layer = nn.Linear(scale_num * args.hidden_dim, 2 * args.zdim)
+        self.future_encoder = _Trunk(args, args.future_length, future=True)
+        self.decoder = _Decoder(args)
+        self.param_annealers = nn.ModuleList()
+        self._packed = None
+        self._packed_key = None
+        self._mode = None
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ plumbing
+    def set_device(self, device):
+        self.device = torch.device(device)
+        self.to(self.device)
+
+    def step_annealer(self):  # model/STTODE.py:570-572 (no annealers are ever registered)
+        for anl in self.param_annealers:
+            anl.step()
+
+    def _weights_key(self):
+        return (str(self.device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self):
+        """Fragment-ordered device copies of the weights; re-packed whenever a parameter changes."""
+        key = self._weights_key()
+        if self._packed is None or key != self._packed_key:
+            sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+            a = self.args
+            host = {'past': packing.pack_trunk(sd, 'past_encoder.', a.past_length),
+                    'blk0': packing.pack_block(sd, 0, a.past_length, a.future_length, first=True),
+                    'blk1': packing.pack_block(sd, 1, a.past_length, a.future_length, first=False)}
+            self._packed = {g: {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in d.items()}
+                            for g, d in host.items()}
+            self._packed_key = key
+        return self._packed
+
+    def _require_gpu(self):
+        if self.device.type != 'cuda':
+            raise capi.SttodeError('STTODENet compute runs only on a HIP device (no CPU fallback); got device=%s' % self.device)
+
+    # ------------------------------------------------------------------ data entry
+    def set_data(self, batch, pre_motion, fut_motion, pre_motion_mask=None, fut_motion_mask=None):
+        """One scene, loader layout (model/STTODE.py:397-461): pre_motion [N,2,Tp], fut_motion [N,2,Tf].
+        ``batch`` is ignored, as in the reference.  Eval semantics (no random rotation / subsampling)."""
+        dev = self.device
+        past = _f32(pre_motion, dev).permute(0, 2, 1).contiguous()
+        fut = _f32(fut_motion, dev).permute(0, 2, 1).contiguous() if fut_motion is not None else None
+        N = past.shape[0]
+        self.set_scene_batch(past, fut, torch.tensor([0, N], dtype=torch.int32))
+        self.batch_size = 1
+        self.pre_motion_mask, self.fut_motion_mask = pre_motion_mask, fut_motion_mask
+
+    def set_scene_batch(self, past, future, scene_ptr):
+        """Many independent scenes: past [n,Tp,2] / future [n,Tf,2] world coordinates, agent-major;
+        scene_ptr [S+1] CSR offsets (== seq_start_end of utils/dataloader.py:177-181)."""
+        a, dev = self.args, self.device
+        self._past = _f32(past, dev)
+        self._future = _f32(future, dev) if future is not None else None
+        self._scene_ptr = torch.as_tensor(scene_ptr, dtype=torch.int32).to(dev).contiguous()
+        if self._past.dim() != 3 or self._past.shape[1] != a.past_length or self._past.shape[2] != 2:
+            raise ValueError(f'past must be [n, {a.past_length}, 2], got {tuple(self._past.shape)}')
+        sp = torch.as_tensor(scene_ptr).cpu()
+        if int(sp[0]) != 0 or int(sp[-1]) != self._past.shape[0] or bool((sp[1:] <= sp[:-1]).any()):
+            raise ValueError('scene_ptr must start at 0, end at n and be strictly increasing (no empty scenes)')
+        self._mode = 'scenes'
+        self.batch_size = 1
+        self.agent_num = self._past.shape[0]
+        self._S = self._scene_ptr.numel() - 1
+        self._N = 0
+
+    def set_data_nba(self, data):
+        """model/STTODE.py:463-486: dict with past_traj [B,N,Tp,2], future_traj [B,N,Tf,2]."""
+        a, dev = self.args, self.device
+        pt = _f32(data['past_traj'], dev)
+        self.data = data
+        self.batch_size, self.agent_num = pt.shape[0], pt.shape[1]
+        self._past = pt.reshape(self.batch_size * self.agent_num, a.past_length, 2).contiguous()
+        ft = data.get('future_traj') if hasattr(data, 'get') else None
+        self._future = _f32(ft, dev).reshape(-1, a.future_length, 2).contiguous() if ft is not None else None
+        self._mode = 'nba'
+        self._N = self.agent_num
+        self.scene_orig = self._past  # sic (model/STTODE.py:473)
+
+    # ------------------------------------------------------------------ compute
+    def _frontend(self):
+        a, dev = self.args, self.device
+        n, Tp = self._past.shape[0], a.past_length
+        TPX = packing.tiles_x(Tp)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        ws = {'xpad': f(n, 16 * TPX), 'enc_in': f(n, Tp, 4), 'cur': f(n, 2), 'orig': f(n, 2),
+              'last': torch.empty(n, dtype=torch.int32, device=dev)}
+        st = capi.stream_ptr()
+        if self._mode == 'scenes':
+            ws['scene_orig'] = f(self._S, 2)
+            ws['agent_scene'] = torch.empty(n, dtype=torch.int32, device=dev)
+            capi.call('sttode_frontend_scenes', self._past, self._scene_ptr, n, self._S, Tp, TPX, 1, ws['scene_orig'],
+                      ws['agent_scene'], ws['xpad'], ws['enc_in'], ws['cur'], ws['orig'], ws['last'], st)
+            self.scene_orig = ws['scene_orig'][0] if self._S == 1 else ws['scene_orig']
+        else:
+            capi.call('sttode_frontend_nba', self._past, n, self._N, Tp, TPX, ws['xpad'], ws['enc_in'], ws['cur'], ws['orig'],
+                      ws['last'], st)
+        return ws
+
+    def _encode(self, W, enc_in, last, Tlen, L, Nslots):
+        """Trunk forward: enc_in [n,Tlen,4] -> past_feature-like [n,128].  L = attention length (scenes per call
+        on the NBA path, 1 otherwise), Nslots = agent slots (attention batch)."""
+        dev = self.device
+        n = enc_in.shape[0]
+        st = capi.stream_ptr()
+        g = torch.empty(n, 64, dtype=torch.float32, device=dev)
+        qkv = torch.empty(n, 192, dtype=torch.float32, device=dev)
+        capi.call('sttode_embed_qkv', W['fc1P'], W['fc1b'], W['posP'], W['peb'], W['fc2P'], W['fc2b'], W['fc3P'], W['fc3b'],
+                  W['fc3last'], W['inP'], W['inb'], enc_in, last, g, qkv, n, Tlen, st)
+        if L > 1:
+            # self-attention with L == S: scores are used untransposed (hyptransformerlib.py:261-265), i.e.
+            # rows = keys, columns = queries, values indexed by the column:  out_i = sum_j softmax_j(-d(k_i, q_j)) v_j
+            attn = torch.empty(n, 64, dtype=torch.float32, device=dev)
+            e = qkv.element_size()
+            q_ptr, k_ptr, v_ptr = qkv.data_ptr(), qkv.data_ptr() + 64 * e, qkv.data_ptr() + 128 * e
+            capi.call('sttode_mhgsa_attn', k_ptr, q_ptr, v_ptr, attn, None, None, L, L, Nslots,
+                      Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192, Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
+            attn_ptr, ld = attn, 64
+        else:
+            # attention over one element: softmax == 1  =>  output == v
+            attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192
+        pf = torch.empty(n, 128, dtype=torch.float32, device=dev)
+        capi.call('sttode_post_attn', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
+                  W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], g, attn_ptr, ld, pf, n, self.ODE_TIME, st)
+        self._keep = (g, qkv)
+        return pf
+
+    def encode_history(self):
+        """model/STTODE.py:488-496."""
+        self._require_gpu()
+        P = self.packed()
+        self._ws = self._frontend()
+        L = self.batch_size if self._mode == 'nba' else 1
+        self.past_feature = self._encode(P['past'], self._ws['enc_in'], self._ws['last'], self.args.past_length, L,
+                                         self._N if self._mode == 'nba' else 1)
+        return self.past_feature
+
+    def _decode(self, pf, z, ws, K):
+        a, dev = self.args, self.device
+        P = self.packed()
+        b0, b1 = P['blk0'], P['blk1']
+        n, Tp, Tf = pf.shape[0], a.past_length, a.future_length
+        TPX, NOY = packing.tiles_x(Tp), packing.tiles_y(Tf)
+        m = n * K
+        st = capi.stream_ptr()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        state0 = f(n, 96)
+        capi.call('sttode_gru_cols', ws['xpad'], b0['convP'], b0['convB'], b0['wihP'], b0['whhP'], b0['gbias'], state0, n, Tp, TPX, st)
+        A0x, A0y, A1y = f(n, 512), f(n, 512), f(n, 512)
+        capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['x_WA'], b0['x_b1'], A0x, 512, n, 512, 0, st)
+        capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['y_WA'], b0['y_b1'], A0y, 512, n, 512, 0, st)
+        capi.call('sttode_linear_cols', pf, 128, 128, None, 0, 0, b1['y_WA'], b1['y_b1'], A1y, 512, n, 512, 0, st)
+        dbuf, ybuf = f(m, 16 * TPX), f(m, 16 * NOY)
+        capi.call('sttode_mlp_block0', A0x, b0['x_chunks'], b0['x_b2'], b0['x_w3'], b0['x_b3'],
+                  A0y, b0['y_chunks'], b0['y_b2'], b0['y_w3'], b0['y_b3'], z, ws['xpad'], dbuf, ybuf, m, K, TPX, NOY, st)
+        state1 = f(m, 96)
+        capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st)
+        pred = f(n, K, Tf, 2)
+        capi.call('sttode_mlp_block1', A1y, b1['y_chunks'], b1['y_b2'], b1['y_w3'], b1['y_b3'], z, state1, ybuf, ws['cur'],
+                  ws['orig'], pred, m, K, Tf, NOY, st)
+        self._dbg = dict(state0=state0, A0x=A0x, A0y=A0y, A1y=A1y, dbuf=dbuf, ybuf=ybuf, state1=state1)
+        return pred
+
+    @torch.no_grad()
+    def inference(self, data=None, z=None):
+        """model/STTODE.py:574-623 -> [K, n, Tf, 2] in world coordinates (a permuted view, as in the reference).
+        ``z`` ([n*K, zdim], row = agent*K + k) may be injected; otherwise drawn from torch's generator like
+        Normal.rsample (model/STTODE.py:89-93,609-616)."""
+        self._require_gpu()
+        a = self.args
+        if a.learn_prior:
+            raise NotImplementedError('learn_prior is broken in the reference (pz_layer in_features 256 != 128, model/STTODE.py:361,603)')
+        if a.dataset == 'nba' and data is not None and self._mode != 'nba':
+            self.set_data_nba(data)
+        if self._mode is None:
+            raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference()')
+        K = a.sample_k
+        pf = self.encode_history()
+        n = pf.shape[0]
+        if z is None:
+            z = torch.randn(n * K, a.zdim, device=self.device)
+        z = _f32(z, self.device)
+        if tuple(z.shape) != (n * K, a.zdim):
+            raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
+        pred = self._decode(pf, z, self._ws, K)
+        self.diverse_pred = pred
+        return pred.permute(1, 0, 2, 3)
+
+    @torch.no_grad()
+    def best_of_k(self, pred_nk, gt=None, scale=1.0):
+        """Device-side min-over-K ADE / FDE per agent (utils/metrics.py:7-26). pred_nk [n,K,Tf,2], gt [n,Tf,2]."""
+        gt = self._future if gt is None else _f32(gt, self.device)
+        pred_nk = pred_nk.contiguous()
+        n, K, Tf = pred_nk.shape[:3]
+        ade = torch.empty(n, dtype=torch.float32, device=self.device)
+        fde = torch.empty_like(ade)
+        capi.call('sttode_best_of_k', pred_nk, gt, n, K, Tf, float(scale), ade, fde, capi.stream_ptr())
+        return ade, fde
+
+    def forward(self):
+        raise NotImplementedError('training objective (model/STTODE.py:553-568) needs backward kernels: SURVEY.md §8f rank 1 (next)')

@@ -1,0 +1,139 @@
+"""Host-side weight packing into MFMA fragment order (done once per weight set).
+
+PK16 (see csrc/chain.hpp): for W [N, K] (N, K padded to multiples of 16)
+    P[it, T, lane, r] = W[16*it + (lane & 15), 16*T + 4*(lane >> 4) + r]
+so that a wave's A fragment for four consecutive v_mfma_f32_16x16x4_f32 is one contiguous 1 KiB read.
+
+Everything here is a pure re-layout of the reference's parameters (state_dict names in SURVEY.md §8b)
+plus three algebraic foldings that do not change the function computed:
+  * pos-encoder:  fc(cat(x, pe[t])) = W[:, :64] x + (W[:, 64:] pe[t] + b)          (model/STTODE.py:170-173)
+  * category:     input_fc3(cat(f, onehot)) = W[:, :64] f + b + [last agent] W[:, 66] (model/STTODE.py:199-210,223)
+  * decoder L1:   W1 [pf | z | state] = W1[:, pf] pf + W1[:, z] z + W1[:, state] state  (model/STTODE.py:71,74-75)
+"""
+import numpy as np
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pk16(W):
+    """[N, K] -> float32 [N/16, K/16, 64, 4] (zero padded)."""
+    W = np.asarray(W, np.float32)
+    N, K = W.shape
+    Np, Kp = _pad16(N), _pad16(K)
+    Wp = np.zeros((Np, Kp), np.float32)
+    Wp[:N, :K] = W
+    X = Wp.reshape(Np // 16, 16, Kp // 16, 4, 4)          # it, i, T, q, r
+    X = X.transpose(0, 2, 3, 1, 4)                         # it, T, q, i, r   (lane = q*16 + i)
+    return np.ascontiguousarray(X.reshape(Np // 16, Kp // 16, 64, 4))
+
+
+def pk4(W):
+    """[N, 4] (K = 4: a single MFMA) -> [N/16, 64] with lane(i, q) = W[16*it + i, q]."""
+    W = np.asarray(W, np.float32)
+    N = W.shape[0]
+    assert W.shape[1] == 4 and N % 16 == 0
+    return np.ascontiguousarray(W.reshape(N // 16, 16, 4).transpose(0, 2, 1).reshape(N // 16, 64))
+
+
+def pad_vec(b, n):
+    out = np.zeros(n, np.float32)
+    out[: len(b)] = b
+    return out
+
+
+def toeplitz_conv(w, Tp, TPX):
+    """Conv1d(2->32, k=3, pad=1) over Tp frames as a [Tp*32, 16*TPX] matrix acting on the flattened
+    (t, c) sequence: out[t*32 + o] = sum_{c,k} w[o, c, k] * x[c, t + k - 1]   (model/STTODE.py:30,65)."""
+    w = np.asarray(w, np.float32)
+    M = np.zeros((Tp * 32, 16 * TPX), np.float32)
+    for t in range(Tp):
+        for k in range(3):
+            tp = t + k - 1
+            if 0 <= tp < Tp:
+                for c in range(2):
+                    M[t * 32:(t + 1) * 32, 2 * tp + c] = w[:, c, k]
+    return M
+
+
+def mlp_chunks(W1v, W2, CHT):
+    """Chunk stream for csrc/decoder.hip run_mlp: NCH x { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] }."""
+    P1 = pk16(W1v)             # [32, KTV, 64, 4]
+    P2 = pk16(W2)              # [16, 32, 64, 4]
+    assert P1.shape[0] == 32 and P2.shape[:2] == (16, 32)
+    out = []
+    for ch in range(32 // CHT):
+        for hf in range(CHT):
+            out.append(P1[CHT * ch + hf].reshape(-1))
+        for hf in range(CHT):
+            out.append(P2[:, CHT * ch + hf].reshape(-1))
+    return np.ascontiguousarray(np.concatenate(out))
+
+
+def tiles_x(Tp):
+    return 1 if 2 * Tp <= 16 else 2
+
+
+def tiles_y(Tf):
+    return (2 * Tf + 15) // 16
+
+
+SUPPORTED_NOY = (1, 2, 3, 5)
+
+
+def pack_trunk(sd, prefix, Tlen):
+    """Encoder trunk (PastEncoder / FutureEncoder shared part)."""
+    g = lambda k: np.asarray(sd[prefix + k], np.float32)
+    att = 'ODE_Encoder.odeblock.odefunc.layers.0.'
+    Wpos = g('pos_encoder.fc.weight')
+    pe = g('pos_encoder.pe')
+    W3 = g('input_fc3.weight')
+    return {
+        'fc1P': pk4(g('input_fc.weight')), 'fc1b': g('input_fc.bias'),
+        'posP': pk16(Wpos[:, :64]),
+        'peb': np.ascontiguousarray(pe[:Tlen] @ Wpos[:, 64:].T + g('pos_encoder.fc.bias')),
+        'fc2P': pk16(g('input_fc2.weight')), 'fc2b': g('input_fc2.bias'),
+        'fc3P': pk16(W3[:, :64]), 'fc3b': g('input_fc3.bias'), 'fc3last': np.ascontiguousarray(W3[:, 66]),
+        'inP': pk16(g(att + 'self_attn.temporal_attention_before.in_proj_weight')),
+        'inb': g(att + 'self_attn.temporal_attention_before.in_proj_bias'),
+        'outP': pk16(g(att + 'self_attn.temporal_attention_before.out_proj.weight')),
+        'outb': g(att + 'self_attn.temporal_attention_before.out_proj.bias'),
+        'infoP': pk16(g(att + 'self_attn.temporal_info.weight')), 'infob': g(att + 'self_attn.temporal_info.bias'),
+        'gateP': pk16(g(att + 'self_attn.temporal_gate.weight')), 'gateb': g(att + 'self_attn.temporal_gate.bias'),
+        'ln1w': g(att + 'norm1.weight'), 'ln1b': g(att + 'norm1.bias'),
+        'l1P': pk16(g(att + 'linear1.weight')), 'l1b': g(att + 'linear1.bias'),
+        'l2P': pk16(g(att + 'linear2.weight')), 'l2b': g(att + 'linear2.bias'),
+        'ln2w': g(att + 'norm2.weight'), 'ln2b': g(att + 'norm2.bias'),
+    }
+
+
+def pack_block(sd, i, Tp, Tf, first):
+    """DecomposeBlock i.  ``first``: block 0 (state term is per-agent, z term per-trajectory, x and y MLPs);
+    otherwise block >= 1 (state per trajectory; the last block's decoder_x is dead in inference)."""
+    p = f'decoder.decompose.{i}.'
+    g = lambda k: np.asarray(sd[p + k], np.float32)
+    TPX, NOY = tiles_x(Tp), tiles_y(Tf)
+    bih, bhh = g('encoder_past.bias_ih_l0'), g('encoder_past.bias_hh_l0')
+    out = {
+        'convP': pk16(toeplitz_conv(g('conv_past.weight'), Tp, TPX)), 'convB': g('conv_past.bias'),
+        'wihP': pk16(g('encoder_past.weight_ih_l0')), 'whhP': pk16(g('encoder_past.weight_hh_l0')),
+        'gbias': np.ascontiguousarray(np.stack([bih[:96] + bhh[:96], bih[96:192] + bhh[96:192], bih[192:], bhh[192:]])),
+    }
+    for nm, NO in (('y', NOY), ('x', TPX)):
+        W1, b1 = g(f'decoder_{nm}.layers.0.weight'), g(f'decoder_{nm}.layers.0.bias')
+        W2, b2 = g(f'decoder_{nm}.layers.1.weight'), g(f'decoder_{nm}.layers.1.bias')
+        W3, b3 = g(f'decoder_{nm}.layers.2.weight'), g(f'decoder_{nm}.layers.2.bias')
+        if first:
+            out[nm + '_WA'] = pk16(np.concatenate([W1[:, :128], W1[:, 160:]], axis=1))   # [pf | state0] per agent
+            out[nm + '_chunks'] = mlp_chunks(W1[:, 128:160], W2, CHT=2)                   # z per trajectory
+        else:
+            out[nm + '_WA'] = pk16(W1[:, :128])                                           # pf per agent
+            out[nm + '_chunks'] = mlp_chunks(W1[:, 128:], W2, CHT=1)                      # [z | state] per trajectory
+        out[nm + '_b1'] = b1
+        out[nm + '_b2'] = b2
+        W3p = np.zeros((16 * NO, 256), np.float32)
+        W3p[: W3.shape[0]] = W3
+        out[nm + '_w3'] = pk16(W3p)
+        out[nm + '_b3'] = pad_vec(b3, 16 * NO)
+    return out
