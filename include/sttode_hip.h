@@ -77,20 +77,67 @@ int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld
                        float* out, int ldo, int ncols, int N, int relu, void* stream);
 
 /* DecomposeBlock 0 back half for all K samples (model/STTODE.py:71-75, Decoder.forward :336-339):
- * decoder_x and decoder_y MLPs; writes dbuf = x_true - x_hat0 [m,16*TPX] and ybuf = y_hat0 [m,16*NOY]. */
-int sttode_mlp_block0(const float* A0x, const float* chunks_x, const float* b2x, const float* w3x, const float* b3x,
-                      const float* A0y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
+ * decoder_x and decoder_y MLPs; writes dbuf = x_true - x_hat0 [m,16*TPX] and ybuf = y_hat0 [m,16*NOY].
+ * A0x/A0y [n,512]: per-agent part of layer 0 (sttode_linear_cols); stream: packed weight-chunk stream of both MLPs
+ * (packing.mlp_stream), total_chunks = 32 + ceil(TPX/2) + ceil(NOY/2); biases = [b2x | b3x | b2y | b3y]. */
+int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
                       const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
-                      void* stream);
+                      void* stream_);
 
 /* DecomposeBlock 1 back half + Decoder epilogue (model/STTODE.py:338,343-346) + "+ scene_orig" (:621-622):
- * pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur_location) + scene_orig. */
-int sttode_mlp_block1(const float* A1y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
-                      const float* z, const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred,
-                      int ncols, int K, int Tf, int NOY, void* stream);
+ * pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur_location) + scene_orig.  total_chunks = 32 + NOY; biases = [b2y | b3y]. */
+int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* biases, const float* z,
+                      const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred, int ncols,
+                      int K, int Tf, int NOY, void* stream_);
 
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native forward pipeline: one call enqueues STTODENet.inference (model/STTODE.py:574-623) end to end.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct SttodeModel SttodeModel;
+
+/* order of the packed-weight pointer table handed to sttode_model_create (sttode_amd/packing.py names) */
+enum SttodeWeight {
+    STT_W_FC1P, STT_W_FC1B, STT_W_POSP, STT_W_PEB, STT_W_FC2P, STT_W_FC2B, STT_W_FC3P, STT_W_FC3B, STT_W_FC3LAST, STT_W_INP,
+    STT_W_INB, STT_W_OUTP, STT_W_OUTB, STT_W_INFOP, STT_W_INFOB, STT_W_GATEP, STT_W_GATEB, STT_W_LN1W, STT_W_LN1B, STT_W_L1P,
+    STT_W_L1B, STT_W_L2P, STT_W_L2B, STT_W_LN2W, STT_W_LN2B,
+    STT_W_B0_CONVP, STT_W_B0_CONVB, STT_W_B0_WIHP, STT_W_B0_WHHP, STT_W_B0_GBIAS, STT_W_B0_XWA, STT_W_B0_XB1, STT_W_B0_YWA,
+    STT_W_B0_YB1, STT_W_B0_STREAM, STT_W_B0_BIASES,
+    STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
+    STT_W_B1_BIASES,
+    STT_W_COUNT
+};
+
+/* workspace buffers (offsets in floats from sttode_workspace_layout) */
+enum SttodeBuffer {
+    STT_B_SCENE_ORIG, STT_B_AGENT_SCENE, STT_B_XPAD, STT_B_ENC_IN, STT_B_CUR, STT_B_ORIG, STT_B_LAST, STT_B_G, STT_B_QKV,
+    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_COUNT
+};
+
+/* pipeline stages reported by sttode_timing_read */
+enum SttodeStage {
+    STT_STAGE_FRONTEND, STT_STAGE_EMBED, STT_STAGE_ATTN, STT_STAGE_POST, STT_STAGE_GRU0, STT_STAGE_LINEAR, STT_STAGE_MLP0,
+    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_COUNT
+};
+
+/* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366). */
+int sttode_model_create(SttodeModel** out, const void* const* weights, int count, int Tp, int Tf, int K, int n_chunks0,
+                        int n_chunks1);
+int sttode_model_destroy(SttodeModel* m);
+int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*[STT_B_COUNT]*/, long* total_floats);
+int sttode_timing_enable(SttodeModel* m, int on);
+int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);
+
+/* set_data (batched over scenes) + inference (model/STTODE.py:397-461,574-623; caller loop test.py:171-184).
+ * past [n,Tp,2] world coords, scene_ptr [S+1], z [n*K,32] -> pred [n,K,Tf,2] world coords. */
+int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
+                            float* workspace, float* pred, void* stream);
+/* set_data_nba + inference, NBA branch (model/STTODE.py:463-486,578-583; caller test.py:520-524):
+ * past [B*N,Tp,2]; attention length = B over the N agent slots. */
+int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
+                         void* stream);
 
 #ifdef __cplusplus
 }

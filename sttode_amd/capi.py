@@ -23,10 +23,75 @@ SIGNATURES = {
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sttode_mlp_block0': [_P] * 10 + [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sttode_mlp_block1': [_P] * 5 + [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
+    # native pipeline (csrc/pipeline.hip)
+    'sttode_model_create': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _I, _I, _I, _I, _I, _I],
+    'sttode_model_destroy': [_P],
+    'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
+    'sttode_timing_enable': [_P, _I],
+    'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
+    'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
+    'sttode_inference_nba': [_P, _P, _I, _I, _P, _P, _P, _P],
 }
+
+# enum SttodeWeight / SttodeBuffer / SttodeStage of include/sttode_hip.h (order is ABI)
+WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'fc2b', 'fc3P', 'fc3b', 'fc3last', 'inP', 'inb', 'outP',
+                                       'outb', 'infoP', 'infob', 'gateP', 'gateb', 'ln1w', 'ln1b', 'l1P', 'l1b', 'l2P', 'l2b', 'ln2w',
+                                       'ln2b')]
+                + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream', 'biases')]
+                + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream', 'biases')])
+BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
+           'A1y', 'dbuf', 'ybuf', 'state1')
+STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'linear_cols', 'mlp_block0',
+          'gru_cols[block1,trajectories]', 'mlp_block1')
+
+
+class NativeModel:
+    """Owner of a SttodeModel handle (csrc/pipeline.hip) plus the packed weight tensors it points into."""
+
+    def __init__(self, packed, Tp, Tf, K):
+        self.packed = packed  # keeps the device tensors alive
+        tbl = (ctypes.c_void_p * len(WEIGHT_ORDER))(*[packed[g][k].data_ptr() for g, k in WEIGHT_ORDER])
+        h = ctypes.c_void_p()
+        rc = lib().sttode_model_create(ctypes.byref(h), tbl, len(WEIGHT_ORDER), Tp, Tf, K, int(packed['blk0']['n_chunks']),
+                                       int(packed['blk1']['n_chunks']))
+        if rc != 0:
+            raise SttodeError('sttode_model_create failed: ' + lib().sttode_last_error().decode())
+        self.h = h
+        self._layouts = {}
+
+    def layout(self, n, S):
+        key = (n, S)
+        if key not in self._layouts:
+            off = (ctypes.c_long * len(BUFFERS))()
+            tot = ctypes.c_long()
+            rc = lib().sttode_workspace_layout(self.h, n, S, off, ctypes.byref(tot))
+            if rc != 0:
+                raise SttodeError('sttode_workspace_layout failed: ' + lib().sttode_last_error().decode())
+            self._layouts[key] = (dict(zip(BUFFERS, list(off))), int(tot.value))
+        return self._layouts[key]
+
+    def timing(self, on):
+        lib().sttode_timing_enable(self.h, int(on))
+
+    def read_timing(self):
+        ms = (ctypes.c_double * len(STAGES))()
+        cnt = (ctypes.c_int * len(STAGES))()
+        rc = lib().sttode_timing_read(self.h, ms, cnt)
+        if rc != 0:
+            raise SttodeError('sttode_timing_read failed: ' + lib().sttode_last_error().decode())
+        return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES)) if cnt[i]}
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().sttode_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
 
 
 class SttodeError(RuntimeError):
@@ -57,11 +122,24 @@ def _ptr(t):
     return t.data_ptr() if hasattr(t, 'data_ptr') else int(t)
 
 
-def call(name, *args):
+# When set to a list, every call is bracketed by HIP events recorded on the launch stream (torch's current
+# stream == the stream handed to the kernels); bench.py uses this for per-kernel durations in the timed region.
+TIMING = None
+
+
+def call(name, *args, tag=None):
     """Invoke an entry point; tensors are converted to device pointers; non-zero status raises."""
     L = lib()
     conv = [(_ptr(a) if (a is None or hasattr(a, 'data_ptr')) else a) for a in args]
-    rc = getattr(L, name)(*conv)
+    if TIMING is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(*conv)
+        e1.record()
+        TIMING.append((tag or name, e0, e1))
+    else:
+        rc = getattr(L, name)(*conv)
     if rc != 0:
         raise SttodeError(f'{name} failed (status {rc}): {L.sttode_last_error().decode()}')
 

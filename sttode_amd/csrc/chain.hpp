@@ -40,9 +40,16 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// tanh via exp: saturates correctly for |x| large (exp -> inf gives 1, exp -> 0 gives -1); abs error ~1e-7.
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
+// Gate nonlinearities on the hardware transcendental unit: v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32 (~1 ulp).
+// Absolute error ~1e-7 on outputs in [-1, 1]: two orders of magnitude inside the 1e-4 parity bar, and ~4x fewer
+// VALU instructions than expf + IEEE division (the gate math otherwise steals ~40% of the GRU's MFMA issue time).
+// Saturation: exp2 -> inf gives rcp -> 0; exp2 -> 0 gives rcp(1) = 1.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
 

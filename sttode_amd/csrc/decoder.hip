@@ -26,8 +26,11 @@
 #define GRU_WHH_F4 (18 * 6 * 64)
 #define GRU_LDS_BYTES ((GRU_WIH_F4 + GRU_WHH_F4) * 16 + 4 * 96 * 4)
 
+#ifndef GRU_THREADS
+#define GRU_THREADS 1024
+#endif
 template <int TPX>
-__global__ __launch_bounds__(512) void gru_cols_kernel(
+__global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
     const float* __restrict__ xin,    // [ncols][16*TPX]  flattened (t,c) input sequence, zero padded
     const f32x4* __restrict__ convP,  // PK16 Toeplitz conv  [2*Tp row tiles][TPX][64]
     const float* __restrict__ convB,  // [32]
@@ -48,6 +51,13 @@ __global__ __launch_bounds__(512) void gru_cols_kernel(
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int ntiles = (ncols + 15) >> 4;
+    const f32x4 cb0 = ld4(convB + 4 * q), cb1 = ld4(convB + 16 + 4 * q);
+    // conv fragments of step t are fetched one step ahead (step 0's are tile independent, so the prefetch wraps)
+    f32x4 cw[2][TPX];
+#pragma unroll
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
     // interleaved assignment: consecutive tiles go to different CUs first, then to different waves
     for (int tile = blockIdx.x + gridDim.x * wave; tile < ntiles; tile += gridDim.x * nw) {
         const int col = tile * 16 + c;
@@ -61,12 +71,20 @@ __global__ __launch_bounds__(512) void gru_cols_kernel(
 
         for (int t = 0; t < Tp; ++t) {
             f32x4 e[2];
+            e[0] = cb0;
+            e[1] = cb1;
 #pragma unroll
             for (int io = 0; io < 2; ++io) {
-                f32x4 a = ld4(convB + 16 * io + 4 * q);
 #pragma unroll
-                for (int T = 0; T < TPX; ++T) a = mfma_k16(a, convP[((2 * t + io) * TPX + T) * 64 + lane], d[T]);
-                e[io] = relu4(a);
+                for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
+                e[io] = relu4(e[io]);
+            }
+            {
+                const int tn = (t + 1 < Tp) ? t + 1 : 0;
+#pragma unroll
+                for (int io = 0; io < 2; ++io)
+#pragma unroll
+                    for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
             }
             f32x4 hn[6];
 #pragma unroll
@@ -84,6 +102,7 @@ __global__ __launch_bounds__(512) void gru_cols_kernel(
                 }
 #pragma unroll
                 for (int T = 0; T < 6; ++T) {
+                    if (T == 3) STT_FENCE();
                     ar = mfma_k16(ar, sWhh[((0 + j) * 6 + T) * 64 + lane], h[T]);
                     az = mfma_k16(az, sWhh[((6 + j) * 6 + T) * 64 + lane], h[T]);
                     ah = mfma_k16(ah, sWhh[((12 + j) * 6 + T) * 64 + lane], h[T]);
@@ -140,44 +159,70 @@ __global__ __launch_bounds__(256) void linear_cols_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // MLP over columns:  out = W3 * relu( W2 * relu( A0[agent] + W1v * B ) + b2 ) + b3
+//
+// Weight stream: per workgroup pass the weights of all MLPs of the block form ONE flat sequence of equally
+// sized chunks (fragment order, packed by sttode_amd/packing.py):
+//     per MLP:  NCH "L12" chunks { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] }   then  N3 "L3" chunks { W3 tiles [TP3][16] }
+// double-buffered in LDS; chunk p+1 is fetched (global -> registers) while chunk p feeds the MFMAs and is
+// committed (registers -> LDS, one barrier) afterwards.  The position counter never resets, so the stream wraps
+// from the last chunk of one column group to the first chunk of the next without a bubble.
 // ---------------------------------------------------------------------------------------------------
-struct MlpDesc {
-    const float* A0;      // [nagents][512] per-agent layer-1 pre-activation (bias folded in)
-    const f32x4* chunks;  // chunk stream: NCH x { W1v tiles [CHT][KTV][64] , W2 tiles [CHT][16][64] }
-    const float* b2;      // [256]
-    const f32x4* w3;      // PK16 [NO][16][64]
-    const float* b3;      // [16*NO] zero padded
+template <int CHW>
+struct WStream {
+    static constexpr int PER = CHW / 256;
+    const f32x4* blob;
+    f32x4* lds;
+    int total, pos;
+    f32x4 stage[PER];
+    __device__ __forceinline__ void init(const f32x4* b, f32x4* l, int tot) {
+        blob = b; lds = l; total = tot; pos = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) lds[i * 256 + threadIdx.x] = blob[i * 256 + threadIdx.x];
+    }
+    __device__ __forceinline__ const f32x4* cur() const { return lds + (pos & 1) * CHW; }
+    __device__ __forceinline__ void fetch_next() {
+        int nx = pos + 1;
+        nx = nx % total;
+        const f32x4* src = blob + (size_t)nx * CHW;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
+    }
+    __device__ __forceinline__ void commit() {
+        f32x4* dst = lds + ((pos + 1) & 1) * CHW;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[i * 256 + threadIdx.x] = stage[i];
+        __syncthreads();
+        ++pos;
+    }
 };
 
-template <int KTV, int CHT, int NO>
-__device__ __forceinline__ void run_mlp(const MlpDesc& m, const f32x4 (&B)[KTV], int agent, f32x4 (&out)[NO],
-                                        f32x4* __restrict__ lds, int lane, int q) {
-    constexpr int CHW = CHT * (KTV + 16) * 64;  // float4 per chunk
+// One MLP for this wave's 16 columns.  On entry a0n holds the layer-1 pre-activation of chunk 0 (prefetched by the
+// previous phase); on exit it holds chunk 0 of the NEXT phase (read from a0_next).  sBias (LDS) = [b2 (256) | b3 (16*NO)].
+template <int KTV, int CHT, int NO, int CHW>
+__device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV], const float* __restrict__ a0,
+                                          const float* __restrict__ a0_next, f32x4 (&a0n)[CHT], const float* sBias,
+                                          f32x4 (&out)[NO], int lane, int q) {
     constexpr int NCH = 32 / CHT;
-    static_assert(CHW % 256 == 0, "chunk must split evenly over 256 threads");
-    constexpr int PER = CHW / 256;
+    constexpr int TP3 = CHW / (16 * 64);
+    constexpr int N3 = (NO + TP3 - 1) / TP3;
+    static_assert(TP3 >= 1, "chunk too small for a layer-3 tile");
     f32x4 acc2[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) acc2[it] = ld4(m.b2 + 16 * it + 4 * q);
-    f32x4 stage[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) stage[i] = m.chunks[i * 256 + threadIdx.x];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) lds[i * 256 + threadIdx.x] = stage[i];
-    __syncthreads();
-    const float* a0 = m.A0 + (size_t)agent * 512 + 4 * q;
+    for (int it = 0; it < 16; ++it) acc2[it] = splat4(0.f);
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) {
-            const f32x4* src = m.chunks + (size_t)(ch + 1) * CHW;
+        f32x4 a0c[CHT];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
-        }
-        const f32x4* buf = lds + (ch & 1) * CHW;
+        for (int hf = 0; hf < CHT; ++hf) a0c[hf] = a0n[hf];
+        const float* nxt = (ch + 1 < NCH) ? a0 + (ch + 1) * CHT * 16 : a0_next;
+#pragma unroll
+        for (int hf = 0; hf < CHT; ++hf) a0n[hf] = ld4(nxt + hf * 16);
+        st.fetch_next();
+        const f32x4* buf = st.cur();
 #pragma unroll
         for (int hf = 0; hf < CHT; ++hf) {
             STT_FENCE();
-            f32x4 h1 = ld4(a0 + (ch * CHT + hf) * 16);
+            f32x4 h1 = a0c[hf];
 #pragma unroll
             for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, buf[(hf * KTV + T) * 64 + lane], B[T]);
             h1 = relu4(h1);
@@ -188,49 +233,80 @@ __device__ __forceinline__ void run_mlp(const MlpDesc& m, const f32x4 (&B)[KTV],
                 acc2[it] = mfma_k16(acc2[it], w2[it * 64], h1);
             }
         }
-        if (ch + 1 < NCH) {
-            f32x4* dst = lds + ((ch + 1) & 1) * CHW;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) dst[i * 256 + threadIdx.x] = stage[i];
-        }
-        __syncthreads();
+        STT_FENCE();
+        st.commit();
     }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) acc2[it] = relu4(acc2[it]);
+    for (int it = 0; it < 16; ++it) acc2[it] = relu4(acc2[it] + ld4(sBias + 16 * it + 4 * q));
 #pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        STT_FENCE();
-        f32x4 a = ld4(m.b3 + 16 * o + 4 * q);
+    for (int c3 = 0; c3 < N3; ++c3) {
+        st.fetch_next();
+        const f32x4* buf = st.cur();
 #pragma unroll
-        for (int T = 0; T < 16; ++T) {
-            if ((T & 7) == 0) STT_FENCE();
-            a = mfma_k16(a, m.w3[(o * 16 + T) * 64 + lane], acc2[T]);
+        for (int oo = 0; oo < TP3; ++oo) {
+            const int o = c3 * TP3 + oo;
+            if (o < NO) {
+                f32x4 a = ld4(sBias + 256 + 16 * o + 4 * q);
+#pragma unroll
+                for (int T = 0; T < 16; ++T) {
+                    if ((T & 7) == 0) STT_FENCE();
+                    a = mfma_k16(a, buf[(oo * 16 + T) * 64 + lane], acc2[T]);
+                }
+                out[o] = a;
+            }
         }
-        out[o] = a;
+        STT_FENCE();
+        st.commit();
     }
 }
+
+#define MLP0_CHW (2 * (2 + 16) * 64)  // CHT = 2, KTV = 2 : 2304 float4 = 36 KiB per chunk
+#define MLP1_CHW (1 * (8 + 16) * 64)  // CHT = 1, KTV = 8 : 1536 float4 = 24 KiB per chunk
 
 // block 0: x and y MLPs per trajectory.  d = x_true - x_hat0 -> dbuf ; y_hat0 -> ybuf
 template <int TPX, int NOY>
 __global__ __launch_bounds__(256, 2) void mlp_block0_kernel(
-    MlpDesc mx, MlpDesc my, const float* __restrict__ z,  // [ncols][32]
-    const float* __restrict__ xpad,                       // [nagents][16*TPX] normalised past (t,c), zero padded
-    float* __restrict__ dbuf,                             // [ncols][16*TPX]
-    float* __restrict__ ybuf,                             // [ncols][16*NOY]
+    const float* __restrict__ A0x, const float* __restrict__ A0y,  // [nagents][512]
+    const f32x4* __restrict__ blob, int total_chunks,              // weight stream (x then y)
+    const float* __restrict__ biases,                              // [b2x 256 | b3x 16*TPX | b2y 256 | b3y 16*NOY]
+    const float* __restrict__ z,                                   // [ncols][32]
+    const float* __restrict__ xpad,                                // [nagents][16*TPX] normalised past (t,c), zero padded
+    float* __restrict__ dbuf,                                      // [ncols][16*TPX]
+    float* __restrict__ ybuf,                                      // [ncols][16*NOY]
     int ncols, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
+    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP0_CHW);
+    constexpr int NB = 256 + 16 * TPX + 256 + 16 * NOY;
+    for (int i = threadIdx.x; i < NB; i += 256) sBias[i] = biases[i];
+    WStream<MLP0_CHW> st;
+    st.init(blob, lds, total_chunks);
+    __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int ngroups = (ncols + 63) >> 6;  // 4 waves x 16 columns per workgroup step
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    int g = blockIdx.x;
+    auto agent_of = [&](int gg) {
+        int col = gg * 64 + wave * 16 + c;
+        col = col < ncols ? col : ncols - 1;
+        return col / K;
+    };
+    f32x4 a0n[2];
+    {
+        const float* p = A0x + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q;
+        a0n[0] = ld4(p);
+        a0n[1] = ld4(p + 16);
+    }
+    for (; g < ngroups; g += gridDim.x) {
         const int col = g * 64 + wave * 16 + c;
         const int colc = col < ncols ? col : ncols - 1;
         const int agent = colc / K;
+        const int gn = g + (int)gridDim.x;
+        const int agent_nx = agent_of(gn < ngroups ? gn : g);
         f32x4 B[2];
         B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
         B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
         f32x4 xo[TPX];
-        run_mlp<2, 2, TPX>(mx, B, agent, xo, lds, lane, q);
+        mlp_phase<2, 2, TPX, MLP0_CHW>(st, B, A0x + (size_t)agent * 512 + 4 * q, A0y + (size_t)agent * 512 + 4 * q, a0n, sBias, xo, lane, q);
         if (col < ncols) {
 #pragma unroll
             for (int o = 0; o < TPX; ++o) {
@@ -239,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void mlp_block0_kernel(
             }
         }
         f32x4 yo[NOY];
-        run_mlp<2, 2, NOY>(my, B, agent, yo, lds, lane, q);
+        mlp_phase<2, 2, NOY, MLP0_CHW>(st, B, A0y + (size_t)agent * 512 + 4 * q, A0x + (size_t)agent_nx * 512 + 4 * q, a0n,
+                                       sBias + 256 + 16 * TPX, yo, lane, q);
         if (col < ncols) {
 #pragma unroll
             for (int o = 0; o < NOY; ++o) st4(ybuf + (size_t)col * (16 * NOY) + 16 * o + 4 * q, yo[o]);
@@ -250,8 +327,10 @@ __global__ __launch_bounds__(256, 2) void mlp_block0_kernel(
 // block 1: y MLP per trajectory with the per-trajectory GRU state; final epilogue
 //   pred[col][t][c] = ((y_hat0 + y_hat1) + cur[agent][c]) + orig[agent][c]      (model/STTODE.py:338,344,622)
 template <int NOY>
-__global__ __launch_bounds__(256, 2) void mlp_block1_kernel(
-    MlpDesc my, const float* __restrict__ z,  // [ncols][32]
+__global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
+    const float* __restrict__ A1y, const f32x4* __restrict__ blob, int total_chunks,
+    const float* __restrict__ biases,         // [b2y 256 | b3y 16*NOY]
+    const float* __restrict__ z,              // [ncols][32]
     const float* __restrict__ state1,         // [ncols][96]
     const float* __restrict__ ybuf,           // [ncols][16*NOY]  y_hat0
     const float* __restrict__ cur,            // [nagents][2]
@@ -260,19 +339,34 @@ __global__ __launch_bounds__(256, 2) void mlp_block1_kernel(
     int ncols, int K, int Tf2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
+    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP1_CHW);
+    for (int i = threadIdx.x; i < 256 + 16 * NOY; i += 256) sBias[i] = biases[i];
+    WStream<MLP1_CHW> st;
+    st.init(blob, lds, total_chunks);
+    __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int ngroups = (ncols + 63) >> 6;
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    int g = blockIdx.x;
+    auto agent_of = [&](int gg) {
+        int col = gg * 64 + wave * 16 + c;
+        col = col < ncols ? col : ncols - 1;
+        return col / K;
+    };
+    f32x4 a0n[1];
+    a0n[0] = ld4(A1y + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    for (; g < ngroups; g += gridDim.x) {
         const int col = g * 64 + wave * 16 + c;
         const int colc = col < ncols ? col : ncols - 1;
         const int agent = colc / K;
+        const int gn = g + (int)gridDim.x;
+        const int agent_nx = agent_of(gn < ngroups ? gn : g);
         f32x4 B[8];
         B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
         B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
 #pragma unroll
         for (int T = 0; T < 6; ++T) B[2 + T] = ld4(state1 + (size_t)colc * 96 + 16 * T + 4 * q);
         f32x4 yo[NOY];
-        run_mlp<8, 1, NOY>(my, B, agent, yo, lds, lane, q);
+        mlp_phase<8, 1, NOY, MLP1_CHW>(st, B, A1y + (size_t)agent * 512 + 4 * q, A1y + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, yo, lane, q);
         if (col < ncols) {
             const float cx = cur[2 * agent], cy = cur[2 * agent + 1];
             const float ox = orig[2 * agent], oy = orig[2 * agent + 1];
@@ -324,11 +418,11 @@ extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float
     if (grid > ntiles) grid = ntiles;
     if (TPX == 1) {
         STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
-        hipLaunchKernelGGL(gru_cols_kernel<1>, dim3(grid), dim3(512), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
+        hipLaunchKernelGGL(gru_cols_kernel<1>, dim3(grid), dim3(GRU_THREADS), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     } else {
         STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
-        hipLaunchKernelGGL(gru_cols_kernel<2>, dim3(grid), dim3(512), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
+        hipLaunchKernelGGL(gru_cols_kernel<2>, dim3(grid), dim3(GRU_THREADS), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     }
     STT_HIP(hipGetLastError());
@@ -348,31 +442,25 @@ extern "C" int sttode_linear_cols(const float* X1, int ld1, int K1, const float*
     return 0;
 }
 
-static MlpDesc mk(const float* A0, const float* chunks, const float* b2, const float* w3, const float* b3) {
-    MlpDesc m;
-    m.A0 = A0; m.chunks = (const f32x4*)chunks; m.b2 = b2; m.w3 = (const f32x4*)w3; m.b3 = b3;
-    return m;
-}
+#define MLP0_LDS(TX, NY) (2 * MLP0_CHW * 16 + (256 + 16 * (TX) + 256 + 16 * (NY)) * 4)
+#define MLP1_LDS(NY) (2 * MLP1_CHW * 16 + (256 + 16 * (NY)) * 4)
 
-#define MLP0_LDS (2 * 2 * (2 + 16) * 64 * 16)  // double buffer, CHT=2, KTV=2 : 73728 B
-#define MLP1_LDS (2 * 1 * (8 + 16) * 64 * 16)  // double buffer, CHT=1, KTV=8 : 49152 B
-
-extern "C" int sttode_mlp_block0(const float* A0x, const float* chunks_x, const float* b2x, const float* w3x, const float* b3x,
-                                 const float* A0y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
+extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
                                  const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
-                                 void* stream) {
-    STT_REQUIRE(A0x && chunks_x && b2x && w3x && b3x && A0y && chunks_y && b2y && w3y && b3y && z && xpad && dbuf && ybuf,
-                "sttode_mlp_block0: null pointer");
+                                 void* stream_) {
+    STT_REQUIRE(A0x && A0y && stream && biases && z && xpad && dbuf && ybuf, "sttode_mlp_block0: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0, "sttode_mlp_block0: ncols and K must be positive");
+    const int n3x = (TPX + 1) / 2, n3y = (NOY + 1) / 2;
+    STT_REQUIRE(total_chunks == 32 + n3x + n3y, "sttode_mlp_block0: weight stream must hold 16+N3x+16+N3y chunks");
     const int ngroups = (ncols + 63) / 64;
     int grid = 2 * num_cus();
     if (grid > ngroups) grid = ngroups;
-    hipStream_t s = (hipStream_t)stream;
-    MlpDesc mx = mk(A0x, chunks_x, b2x, w3x, b3x), my = mk(A0y, chunks_y, b2y, w3y, b3y);
-#define L0(TX, NY)                                                                                                            \
-    do {                                                                                                                      \
-        STT_HIP(hipFuncSetAttribute((const void*)mlp_block0_kernel<TX, NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP0_LDS)); \
-        hipLaunchKernelGGL((mlp_block0_kernel<TX, NY>), dim3(grid), dim3(256), MLP0_LDS, s, mx, my, z, xpad, dbuf, ybuf, ncols, K); \
+    hipStream_t s = (hipStream_t)stream_;
+#define L0(TX, NY)                                                                                                              \
+    do {                                                                                                                        \
+        STT_HIP(hipFuncSetAttribute((const void*)mlp_block0_kernel<TX, NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP0_LDS(TX, NY))); \
+        hipLaunchKernelGGL((mlp_block0_kernel<TX, NY>), dim3(grid), dim3(256), MLP0_LDS(TX, NY), s, A0x, A0y, (const f32x4*)stream, \
+                           total_chunks, biases, z, xpad, dbuf, ybuf, ncols, K);                                                \
     } while (0)
     if (TPX == 1 && NOY == 2) L0(1, 2);
     else if (TPX == 2 && NOY == 5) L0(2, 5);
@@ -386,20 +474,21 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* chunks_x, const 
     return 0;
 }
 
-extern "C" int sttode_mlp_block1(const float* A1y, const float* chunks_y, const float* b2y, const float* w3y, const float* b3y,
-                                 const float* z, const float* state1, const float* ybuf, const float* cur, const float* orig,
-                                 float* pred, int ncols, int K, int Tf, int NOY, void* stream) {
-    STT_REQUIRE(A1y && chunks_y && b2y && w3y && b3y && z && state1 && ybuf && cur && orig && pred, "sttode_mlp_block1: null pointer");
+extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* biases, const float* z,
+                                 const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred,
+                                 int ncols, int K, int Tf, int NOY, void* stream_) {
+    STT_REQUIRE(A1y && stream && biases && z && state1 && ybuf && cur && orig && pred, "sttode_mlp_block1: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && Tf > 0 && 2 * Tf <= 16 * NOY, "sttode_mlp_block1: bad ncols/K/Tf/NOY");
+    STT_REQUIRE(total_chunks == 32 + NOY, "sttode_mlp_block1: weight stream must hold 32+NOY chunks");
     const int ngroups = (ncols + 63) / 64;
-    int grid = 2 * num_cus();
+    int grid = 3 * num_cus();
     if (grid > ngroups) grid = ngroups;
-    hipStream_t s = (hipStream_t)stream;
-    MlpDesc my = mk(A1y, chunks_y, b2y, w3y, b3y);
+    hipStream_t s = (hipStream_t)stream_;
 #define L1(NY)                                                                                                              \
     do {                                                                                                                    \
-        STT_HIP(hipFuncSetAttribute((const void*)mlp_block1_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS)); \
-        hipLaunchKernelGGL((mlp_block1_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS, s, my, z, state1, ybuf, cur, orig, pred, ncols, K, 2 * Tf); \
+        STT_HIP(hipFuncSetAttribute((const void*)mlp_block1_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
+        hipLaunchKernelGGL((mlp_block1_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A1y, (const f32x4*)stream, total_chunks, \
+                           biases, z, state1, ybuf, cur, orig, pred, ncols, K, 2 * Tf);                                      \
     } while (0)
     switch (NOY) {
         case 1: L1(1); break;

@@ -1,0 +1,224 @@
+// Native forward pipeline: ONE C-ABI call enqueues the whole inference() hot path
+// (STTODENet.inference, model/STTODE.py:574-623) on the caller's stream.
+//
+//   front-end -> embed_qkv -> [mhgsa_attn if attention length > 1] -> post_attn            (main stream)
+//            \-> gru_cols(block 0, per agent)                                               (side stream, overlapped)
+//   -> linear_cols x3 (per-agent layer-1 pre-activations) -> mlp_block0 -> gru_cols(block 1) -> mlp_block1
+//
+// No allocation, no synchronisation: every intermediate lives in a caller-provided workspace whose layout is
+// returned by sttode_workspace_layout().  With timing enabled each stage is bracketed by hipEvents recorded on
+// the stream it runs on; sttode_timing_read() returns the accumulated per-stage durations (bench.py's roofline).
+#include "api_util.hpp"
+#include "../../include/sttode_hip.h"
+#include <vector>
+#include <cstring>
+
+struct TimRec { int stage; hipEvent_t e0, e1; };
+
+struct SttodeModel {
+    int Tp, Tf, TPX, NOY, K;
+    const float* w[STT_W_COUNT];
+    int n_chunks0, n_chunks1;
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool timing;
+    std::vector<TimRec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+static inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // 256-byte alignment in floats
+
+extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights, int count, int Tp, int Tf, int K,
+                                   int n_chunks0, int n_chunks1) {
+    STT_REQUIRE(out && weights, "sttode_model_create: null pointer");
+    STT_REQUIRE(count == STT_W_COUNT, "sttode_model_create: weight table must have STT_W_COUNT entries");
+    STT_REQUIRE(Tp >= 2 && 2 * Tp <= 32 && Tf >= 1 && K >= 1, "sttode_model_create: bad Tp/Tf/K");
+    for (int i = 0; i < count; ++i) STT_REQUIRE(weights[i] != nullptr, "sttode_model_create: null weight pointer");
+    SttodeModel* m = new SttodeModel();
+    m->Tp = Tp; m->Tf = Tf; m->K = K;
+    m->TPX = (2 * Tp <= 16) ? 1 : 2;
+    m->NOY = (2 * Tf + 15) / 16;
+    for (int i = 0; i < count; ++i) m->w[i] = (const float*)weights[i];
+    m->n_chunks0 = n_chunks0; m->n_chunks1 = n_chunks1;
+    m->timing = false;
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete m;
+        stt_set_error("sttode_model_create: could not create side stream / events");
+        return 2;
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int sttode_model_destroy(SttodeModel* m) {
+    if (!m) return 0;
+    for (auto& r : m->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto e : m->pool) hipEventDestroy(e);
+    hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join);
+    hipStreamDestroy(m->side);
+    delete m;
+    return 0;
+}
+
+extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets, long* total_floats) {
+    STT_REQUIRE(m && offsets && total_floats, "sttode_workspace_layout: null pointer");
+    STT_REQUIRE(n > 0 && S >= 0, "sttode_workspace_layout: bad n/S");
+    const size_t mm = (size_t)n * m->K;
+    size_t o = 0;
+    auto put = [&](int id, size_t cnt) { offsets[id] = (long)o; o += al(cnt); };
+    put(STT_B_SCENE_ORIG, (size_t)(S > 0 ? S : 1) * 2);
+    put(STT_B_AGENT_SCENE, n);
+    put(STT_B_XPAD, (size_t)n * 16 * m->TPX);
+    put(STT_B_ENC_IN, (size_t)n * m->Tp * 4);
+    put(STT_B_CUR, (size_t)n * 2);
+    put(STT_B_ORIG, (size_t)n * 2);
+    put(STT_B_LAST, n);
+    put(STT_B_G, (size_t)n * 64);
+    put(STT_B_QKV, (size_t)n * 192);
+    put(STT_B_ATTN, (size_t)n * 64);
+    put(STT_B_PF, (size_t)n * 128);
+    put(STT_B_STATE0, (size_t)n * 96);
+    put(STT_B_A0X, (size_t)n * 512);
+    put(STT_B_A0Y, (size_t)n * 512);
+    put(STT_B_A1Y, (size_t)n * 512);
+    put(STT_B_DBUF, mm * 16 * m->TPX);
+    put(STT_B_YBUF, mm * 16 * m->NOY);
+    put(STT_B_STATE1, mm * 96);
+    *total_floats = (long)o;
+    return 0;
+}
+
+extern "C" int sttode_timing_enable(SttodeModel* m, int on) {
+    STT_REQUIRE(m, "sttode_timing_enable: null model");
+    m->timing = on != 0;
+    return 0;
+}
+
+static hipEvent_t get_event(SttodeModel* m) {
+    if (!m->pool.empty()) { hipEvent_t e = m->pool.back(); m->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+// Reads (and clears) the per-stage totals accumulated since the last read.  Synchronises on the recorded events.
+extern "C" int sttode_timing_read(SttodeModel* m, double* total_ms, int* launches) {
+    STT_REQUIRE(m && total_ms && launches, "sttode_timing_read: null pointer");
+    for (int i = 0; i < STT_STAGE_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (auto& r : m->recs) {
+        STT_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        STT_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        total_ms[r.stage] += ms;
+        launches[r.stage] += 1;
+        m->pool.push_back(r.e0);
+        m->pool.push_back(r.e1);
+    }
+    m->recs.clear();
+    return 0;
+}
+
+struct StageTimer {
+    SttodeModel* m; int stage; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageTimer(SttodeModel* m_, int st, hipStream_t s_) : m(m_), stage(st), s(s_) {
+        if (m->timing) { e0 = get_event(m); e1 = get_event(m); hipEventRecord(e0, s); }
+    }
+    ~StageTimer() {
+        if (m->timing) { hipEventRecord(e1, s); m->recs.push_back({stage, e0, e1}); }
+    }
+};
+
+#define RUN(stage, s, call)                         \
+    do {                                            \
+        StageTimer _t(m, stage, s);                 \
+        int _rc = (call);                           \
+        if (_rc) return _rc;                        \
+    } while (0)
+
+static int forward_common(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z,
+                          float* pred, hipStream_t s) {
+    const float* const* W = m->w;
+    const int K = m->K, Tp = m->Tp, Tf = m->Tf, TPX = m->TPX, NOY = m->NOY;
+    const int mm = n * K;
+    float* xpad = ws + off[STT_B_XPAD];
+    float* g = ws + off[STT_B_G];
+    float* qkv = ws + off[STT_B_QKV];
+    float* attn = ws + off[STT_B_ATTN];
+    float* pf = ws + off[STT_B_PF];
+    float* state0 = ws + off[STT_B_STATE0];
+    float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
+    float *dbuf = ws + off[STT_B_DBUF], *ybuf = ws + off[STT_B_YBUF], *state1 = ws + off[STT_B_STATE1];
+
+    // fork: block-0 conv+GRU (per agent) only needs the front-end output; it runs beside the encoder
+    STT_HIP(hipEventRecord(m->ev_fork, s));
+    STT_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    RUN(STT_STAGE_GRU0, m->side,
+        sttode_gru_cols(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
+                        Tp, TPX, m->side));
+    STT_HIP(hipEventRecord(m->ev_join, m->side));
+
+    RUN(STT_STAGE_EMBED, s,
+        sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
+                         W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],
+                         (const int*)(ws + off[STT_B_LAST]), g, qkv, n, Tp, s));
+    const float* attn_src = qkv + 128;
+    int ld_attn = 192;
+    if (attn_len > 1) {
+        // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
+        const long st_seq = (long)attn_slots * 192;
+        RUN(STT_STAGE_ATTN, s,
+            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, attn, nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
+                              st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+        attn_src = attn;
+        ld_attn = 64;
+    }
+    RUN(STT_STAGE_POST, s,
+        sttode_post_attn(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
+                         W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], g,
+                         attn_src, ld_attn, pf, n, 12.0f, s));
+    STT_HIP(hipStreamWaitEvent(s, m->ev_join, 0));  // join
+    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, state0, 96, 96, W[STT_W_B0_XWA], W[STT_W_B0_XB1], A0x, 512, n, 512, 0, s));
+    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, state0, 96, 96, W[STT_W_B0_YWA], W[STT_W_B0_YB1], A0y, 512, n, 512, 0, s));
+    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, nullptr, 0, 0, W[STT_W_B1_YWA], W[STT_W_B1_YB1], A1y, 512, n, 512, 0, s));
+    RUN(STT_STAGE_MLP0, s,
+        sttode_mlp_block0(A0x, A0y, W[STT_W_B0_STREAM], m->n_chunks0, W[STT_W_B0_BIASES], z, xpad, dbuf, ybuf, mm, K, TPX, NOY, s));
+    RUN(STT_STAGE_GRU1, s,
+        sttode_gru_cols(dbuf, W[STT_W_B1_CONVP], W[STT_W_B1_CONVB], W[STT_W_B1_WIHP], W[STT_W_B1_WHHP], W[STT_W_B1_GBIAS], state1, mm, Tp,
+                        TPX, s));
+    RUN(STT_STAGE_MLP1, s,
+        sttode_mlp_block1(A1y, W[STT_W_B1_STREAM], m->n_chunks1, W[STT_W_B1_BIASES], z, state1, ybuf, ws + off[STT_B_CUR],
+                          ws + off[STT_B_ORIG], pred, mm, K, Tf, NOY, s));
+    return 0;
+}
+
+extern "C" int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
+                                       float* workspace, float* pred, void* stream) {
+    STT_REQUIRE(m && past && scene_ptr && z && workspace && pred, "sttode_inference_scenes: null pointer");
+    STT_REQUIRE(n > 0 && S > 0, "sttode_inference_scenes: n and S must be positive");
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = workspace;
+    RUN(STT_STAGE_FRONTEND, s,
+        sttode_frontend_scenes(past, scene_ptr, n, S, m->Tp, m->TPX, 1, ws + off[STT_B_SCENE_ORIG], (int*)(ws + off[STT_B_AGENT_SCENE]),
+                               ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR], ws + off[STT_B_ORIG],
+                               (int*)(ws + off[STT_B_LAST]), s));
+    return forward_common(m, ws, off, n, 1, 1, z, pred, s);
+}
+
+extern "C" int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
+                                    void* stream) {
+    STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba: null pointer");
+    STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba: B and N must be positive");
+    const int n = B * N;
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, 0, off, &tot)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = workspace;
+    RUN(STT_STAGE_FRONTEND, s,
+        sttode_frontend_nba(past, n, N, m->Tp, m->TPX, ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR],
+                            ws + off[STT_B_ORIG], (int*)(ws + off[STT_B_LAST]), s));
+    return forward_common(m, ws, off, n, B, N, z, pred, s);
+}

@@ -156,7 +156,13 @@ class STTODENet(nn.Module):
             anl.step()
 
     def _weights_key(self):
-        return (str(self.device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, '_plist', None) is None:
+            self._plist = list(self.parameters()) + list(self.buffers())
+        return (self.device.index,) + tuple([(p.data_ptr(), p._version) for p in self._plist])
+
+    def _apply(self, fn, *a, **k):
+        self._plist = None  # .to()/.cuda() may replace parameter storage
+        return super()._apply(fn, *a, **k)
 
     def packed(self):
         """Fragment-ordered device copies of the weights; re-packed whenever a parameter changes."""
@@ -167,10 +173,34 @@ class STTODENet(nn.Module):
             host = {'past': packing.pack_trunk(sd, 'past_encoder.', a.past_length),
                     'blk0': packing.pack_block(sd, 0, a.past_length, a.future_length, first=True),
                     'blk1': packing.pack_block(sd, 1, a.past_length, a.future_length, first=False)}
-            self._packed = {g: {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in d.items()}
-                            for g, d in host.items()}
+            self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
+                                for k, v in d.items()} for g, d in host.items()}
             self._packed_key = key
+            self._native = capi.NativeModel(self._packed, a.past_length, a.future_length, a.sample_k) if self.device.type == 'cuda' else None
+            self._wscache = {}
         return self._packed
+
+    def native(self):
+        self.packed()
+        return self._native
+
+    def _workspace(self, n, S):
+        """Cached workspace tensor + named views (layout from sttode_workspace_layout)."""
+        key = (n, S)
+        if key not in self._wscache:
+            if len(self._wscache) > 8:
+                self._wscache.clear()
+            off, tot = self._native.layout(n, S)
+            buf = torch.empty(tot, dtype=torch.float32, device=self.device)
+            self._wscache[key] = (buf, off)
+        return self._wscache[key]
+
+    def _view(self, buf, off, name, *shape, dtype=torch.float32):
+        cnt = int(np.prod(shape))
+        v = buf[off[name]: off[name] + cnt]
+        if dtype != torch.float32:
+            v = v.view(dtype)
+        return v.view(*shape)
 
     def _require_gpu(self):
         if self.device.type != 'cuda':
@@ -197,9 +227,12 @@ class STTODENet(nn.Module):
         self._scene_ptr = torch.as_tensor(scene_ptr, dtype=torch.int32).to(dev).contiguous()
         if self._past.dim() != 3 or self._past.shape[1] != a.past_length or self._past.shape[2] != 2:
             raise ValueError(f'past must be [n, {a.past_length}, 2], got {tuple(self._past.shape)}')
-        sp = torch.as_tensor(scene_ptr).cpu()
-        if int(sp[0]) != 0 or int(sp[-1]) != self._past.shape[0] or bool((sp[1:] <= sp[:-1]).any()):
-            raise ValueError('scene_ptr must start at 0, end at n and be strictly increasing (no empty scenes)')
+        if not (isinstance(scene_ptr, torch.Tensor) and scene_ptr.is_cuda):
+            # host-side CSR is validated here; a device-resident CSR is trusted (validating it would force a D2H sync
+            # per call -- callers on the hot loop keep their batches resident, bench.py)
+            sp = torch.as_tensor(scene_ptr)
+            if int(sp[0]) != 0 or int(sp[-1]) != self._past.shape[0] or bool((sp[1:] <= sp[:-1]).any()):
+                raise ValueError('scene_ptr must start at 0, end at n and be strictly increasing (no empty scenes)')
         self._mode = 'scenes'
         self.batch_size = 1
         self.agent_num = self._past.shape[0]
@@ -287,19 +320,21 @@ class STTODENet(nn.Module):
         st = capi.stream_ptr()
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         state0 = f(n, 96)
-        capi.call('sttode_gru_cols', ws['xpad'], b0['convP'], b0['convB'], b0['wihP'], b0['whhP'], b0['gbias'], state0, n, Tp, TPX, st)
+        capi.call('sttode_gru_cols', ws['xpad'], b0['convP'], b0['convB'], b0['wihP'], b0['whhP'], b0['gbias'], state0, n, Tp, TPX, st,
+                  tag='gru_cols[block0,agents]')
         A0x, A0y, A1y = f(n, 512), f(n, 512), f(n, 512)
         capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['x_WA'], b0['x_b1'], A0x, 512, n, 512, 0, st)
         capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['y_WA'], b0['y_b1'], A0y, 512, n, 512, 0, st)
         capi.call('sttode_linear_cols', pf, 128, 128, None, 0, 0, b1['y_WA'], b1['y_b1'], A1y, 512, n, 512, 0, st)
         dbuf, ybuf = f(m, 16 * TPX), f(m, 16 * NOY)
-        capi.call('sttode_mlp_block0', A0x, b0['x_chunks'], b0['x_b2'], b0['x_w3'], b0['x_b3'],
-                  A0y, b0['y_chunks'], b0['y_b2'], b0['y_w3'], b0['y_b3'], z, ws['xpad'], dbuf, ybuf, m, K, TPX, NOY, st)
+        capi.call('sttode_mlp_block0', A0x, A0y, b0['stream'], b0['n_chunks'], b0['biases'], z, ws['xpad'], dbuf, ybuf, m, K, TPX,
+                  NOY, st)
         state1 = f(m, 96)
-        capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st)
+        capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st,
+                  tag='gru_cols[block1,trajectories]')
         pred = f(n, K, Tf, 2)
-        capi.call('sttode_mlp_block1', A1y, b1['y_chunks'], b1['y_b2'], b1['y_w3'], b1['y_b3'], z, state1, ybuf, ws['cur'],
-                  ws['orig'], pred, m, K, Tf, NOY, st)
+        capi.call('sttode_mlp_block1', A1y, b1['stream'], b1['n_chunks'], b1['biases'], z, state1, ybuf, ws['cur'], ws['orig'], pred,
+                  m, K, Tf, NOY, st)
         self._dbg = dict(state0=state0, A0x=A0x, A0y=A0y, A1y=A1y, dbuf=dbuf, ybuf=ybuf, state1=state1)
         return pred
 
@@ -317,14 +352,32 @@ class STTODENet(nn.Module):
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference()')
         K = a.sample_k
-        pf = self.encode_history()
-        n = pf.shape[0]
+        nat = self.native()
+        n = self._past.shape[0]
         if z is None:
             z = torch.randn(n * K, a.zdim, device=self.device)
-        z = _f32(z, self.device)
+        elif not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
+            z = _f32(z, self.device)
         if tuple(z.shape) != (n * K, a.zdim):
             raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
-        pred = self._decode(pf, z, self._ws, K)
+        Tp, Tf = a.past_length, a.future_length
+        TPX, NOY = packing.tiles_x(Tp), packing.tiles_y(Tf)
+        S = self._S if self._mode == 'scenes' else 0
+        buf, off = self._workspace(n, S)
+        pred = torch.empty(n, K, Tf, 2, dtype=torch.float32, device=self.device)
+        st = capi.stream_ptr()
+        if self._mode == 'scenes':
+            capi.call('sttode_inference_scenes', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, st)
+            so = self._view(buf, off, 'scene_orig', S, 2)
+            self.scene_orig = so[0] if S == 1 else so
+        else:
+            capi.call('sttode_inference_nba', nat.h, self._past, self.batch_size, self._N, z, buf, pred, st)
+        m = n * K
+        self.past_feature = self._view(buf, off, 'pf', n, 128)
+        self._ws = {'xpad': self._view(buf, off, 'xpad', n, 16 * TPX), 'enc_in': self._view(buf, off, 'enc_in', n, Tp, 4),
+                    'cur': self._view(buf, off, 'cur', n, 2), 'orig': self._view(buf, off, 'orig', n, 2)}
+        self._dbg = {'state0': self._view(buf, off, 'state0', n, 96), 'dbuf': self._view(buf, off, 'dbuf', m, 16 * TPX),
+                     'ybuf': self._view(buf, off, 'ybuf', m, 16 * NOY), 'state1': self._view(buf, off, 'state1', m, 96)}
         self.diverse_pred = pred
         return pred.permute(1, 0, 2, 3)
 

@@ -57,18 +57,29 @@ def toeplitz_conv(w, Tp, TPX):
     return M
 
 
-def mlp_chunks(W1v, W2, CHT):
-    """Chunk stream for csrc/decoder.hip run_mlp: NCH x { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] }."""
+def mlp_stream(W1v, W2, W3p, CHT):
+    """Weight stream of ONE MLP for csrc/decoder.hip mlp_phase: 32/CHT "L12" chunks
+    { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] } followed by N3 "L3" chunks { W3 tiles [TP3][16] } (zero padded to
+    the common chunk size).  Returns a float32 array [n_chunks, CHW*4]."""
     P1 = pk16(W1v)             # [32, KTV, 64, 4]
     P2 = pk16(W2)              # [16, 32, 64, 4]
-    assert P1.shape[0] == 32 and P2.shape[:2] == (16, 32)
-    out = []
+    P3 = pk16(W3p)             # [NO, 16, 64, 4]
+    assert P1.shape[0] == 32 and P2.shape[:2] == (16, 32) and P3.shape[1] == 16
+    KTV, NO = P1.shape[1], P3.shape[0]
+    chw = CHT * (KTV + 16) * 64 * 4          # floats per chunk
+    tp3 = (chw // 4) // (16 * 64)            # layer-3 output tiles per chunk
+    chunks = []
     for ch in range(32 // CHT):
-        for hf in range(CHT):
-            out.append(P1[CHT * ch + hf].reshape(-1))
-        for hf in range(CHT):
-            out.append(P2[:, CHT * ch + hf].reshape(-1))
-    return np.ascontiguousarray(np.concatenate(out))
+        parts = [P1[CHT * ch + hf].reshape(-1) for hf in range(CHT)] + [P2[:, CHT * ch + hf].reshape(-1) for hf in range(CHT)]
+        chunks.append(np.concatenate(parts))
+    for c3 in range((NO + tp3 - 1) // tp3):
+        buf = np.zeros(chw, np.float32)
+        part = P3[c3 * tp3:(c3 + 1) * tp3].reshape(-1)
+        buf[: part.size] = part
+        chunks.append(buf)
+    out = np.stack(chunks)
+    assert out.shape[1] == chw
+    return np.ascontiguousarray(out)
 
 
 def tiles_x(Tp):
@@ -120,20 +131,22 @@ def pack_block(sd, i, Tp, Tf, first):
         'wihP': pk16(g('encoder_past.weight_ih_l0')), 'whhP': pk16(g('encoder_past.weight_hh_l0')),
         'gbias': np.ascontiguousarray(np.stack([bih[:96] + bhh[:96], bih[96:192] + bhh[96:192], bih[192:], bhh[192:]])),
     }
-    for nm, NO in (('y', NOY), ('x', TPX)):
+    streams, biases = [], []
+    for nm, NO in ((('x', TPX), ('y', NOY)) if first else (('y', NOY),)):
         W1, b1 = g(f'decoder_{nm}.layers.0.weight'), g(f'decoder_{nm}.layers.0.bias')
         W2, b2 = g(f'decoder_{nm}.layers.1.weight'), g(f'decoder_{nm}.layers.1.bias')
         W3, b3 = g(f'decoder_{nm}.layers.2.weight'), g(f'decoder_{nm}.layers.2.bias')
-        if first:
-            out[nm + '_WA'] = pk16(np.concatenate([W1[:, :128], W1[:, 160:]], axis=1))   # [pf | state0] per agent
-            out[nm + '_chunks'] = mlp_chunks(W1[:, 128:160], W2, CHT=2)                   # z per trajectory
-        else:
-            out[nm + '_WA'] = pk16(W1[:, :128])                                           # pf per agent
-            out[nm + '_chunks'] = mlp_chunks(W1[:, 128:], W2, CHT=1)                      # [z | state] per trajectory
-        out[nm + '_b1'] = b1
-        out[nm + '_b2'] = b2
         W3p = np.zeros((16 * NO, 256), np.float32)
         W3p[: W3.shape[0]] = W3
-        out[nm + '_w3'] = pk16(W3p)
-        out[nm + '_b3'] = pad_vec(b3, 16 * NO)
+        if first:
+            out[nm + '_WA'] = pk16(np.concatenate([W1[:, :128], W1[:, 160:]], axis=1))   # [pf | state0] per agent
+            streams.append(mlp_stream(W1[:, 128:160], W2, W3p, CHT=2))                    # z per trajectory
+        else:
+            out[nm + '_WA'] = pk16(W1[:, :128])                                           # pf per agent
+            streams.append(mlp_stream(W1[:, 128:], W2, W3p, CHT=1))                       # [z | state] per trajectory
+        out[nm + '_b1'] = b1
+        biases += [b2, pad_vec(b3, 16 * NO)]
+    out['stream'] = np.ascontiguousarray(np.concatenate(streams, axis=0))
+    out['n_chunks'] = out['stream'].shape[0]
+    out['biases'] = np.ascontiguousarray(np.concatenate(biases))
     return out
