@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU per step')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU-baseline sample')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -83,6 +84,8 @@ def main():
     ptr = torch.from_numpy(sb.scene_ptr).to(dev)
     model.set_scene_batch(past, fut, ptr)
     model.packed()
+    if args.col_parts:
+        model.native().set_col_parts(args.col_parts)
     n_dev = torch.tensor(float(n), dtype=torch.float32, device=dev)
     acc = None
 

@@ -94,6 +94,29 @@ int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, c
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stand-alone manifold op library (not on the model's data flow; op-level parity).
+ * Row ops, x/y/out [rows,d] (scalar results: out [rows]); op codes (hyptorch/pmath.py unless noted):
+ *  0 project :98-103   1 lambda_x :128-129  2 mobius_add :171-177  3 dist :205-208   4 dist0 :231-234
+ *  5 expmap :268-277 (y = u)  6 expmap0 :300-304  7 logmap :334-339  8 logmap0 :365-368  9 p2k :440-442
+ * 10 k2p :445-447  11 lorenz_factor :450-469  12 Oblique.proj (core/manifolds/oblique.py:15-16)
+ * 13/14 internal halves of mobius_matvec / poincare_mean.
+ * ------------------------------------------------------------------------------------------------ */
+int sttode_pmath_rowop(int op, const float* x, const float* y, float* out, float* out2, int rows, int d, float c, void* stream);
+/* which: 0 tanh (clamp 15, pmath.py:11-12), 1 artanh (:16-22), 2 arsinh (:51-55) */
+int sttode_pmath_scalar(int which, const float* x, float* out, long n, void* stream);
+/* mobius_matvec (pmath.py:399-408): m [O,d], x [rows,d] -> out [rows,O]; workspaces mx_ws [rows,O], xnorm_ws [rows]. */
+int sttode_pmath_matvec(const float* m, const float* x, float* mx_ws, float* xnorm_ws, float* out, int rows, int d, int O, float c,
+                        void* stream);
+/* which: 0 dist_matrix (pmath.py:482-493) out [P,R]; 1 _mobius_addition_batch (:416-427) out [P,R,d];
+ * 2 _hyperbolic_softmax (:430-437) with x = P [C,d], y = X [B,d], A [C,d] -> out [B,C]. */
+int sttode_pmath_pair(int which, const float* x, const float* y, const float* A, float* out, int P, int R, int d, float c,
+                      void* stream);
+/* poincare_mean over dim 0 (pmath.py:472-479): x [rows,d] -> out [d]; workspaces yl_ws [rows,d], lam_ws [rows]. */
+int sttode_pmath_mean(const float* x, float* yl_ws, float* lam_ws, float* out, int rows, int d, float c, void* stream);
+/* Oblique.dist (core/manifolds/oblique.py:36-43): p1 [nb,n1,d], p2 [nb,n2,d] -> acos(clamp(p2 p1^T)) [nb,n2,n1]. */
+int sttode_oblique_dist(const float* p1, const float* p2, float* out, int nb, int n1, int n2, int d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native forward pipeline: one call enqueues STTODENet.inference (model/STTODE.py:574-623) end to end.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct SttodeModel SttodeModel;
@@ -127,6 +150,9 @@ int sttode_model_create(SttodeModel** out, const void* const* weights, int count
                         int n_chunks1);
 int sttode_model_destroy(SttodeModel* m);
 int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*[STT_B_COUNT]*/, long* total_floats);
+/* number of column parts (1..8) the per-trajectory kernels are pipelined over on separate streams (default 1,
+ * or env STTODE_COL_PARTS); results are bitwise independent of it. */
+int sttode_set_col_parts(SttodeModel* m, int parts);
 int sttode_timing_enable(SttodeModel* m, int on);
 int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);
 

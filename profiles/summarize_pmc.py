@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs under gpurun_out/ into small committed files under profiles/<round>/.
+
+  python profiles/summarize_pmc.py gpurun_out profiles/r01
+
+Reads  <in>/pmc_*/**/_counter_collection.csv (+ kernel_trace.csv for durations) and <in>/prof*/**/_kernel_stats.csv.
+Writes <out>/pmc_summary.json (per kernel: mean duration, counters, derived MFMA utilisation and clock) and
+       profiles/traffic.json (HBM bytes per launch per pipeline stage; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+       for wide coalesced reads on gfx950, WRITE_SIZE as is; units KiB -> bytes).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+STAGE_OF = {'mlp_block0_kernel': 'mlp_block0', 'mlp_block1_kernel': 'mlp_block1', 'post_attn_kernel': 'post_attn',
+            'embed_qkv_kernel': 'embed_qkv', 'linear_cols_kernel': 'linear_cols', 'gru_cols_kernel': 'gru_cols'}
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, 'pmc_*', '*', '*_counter_collection.csv')):
+        trace = f.replace('_counter_collection.csv', '_kernel_trace.csv')
+        dur = {r['Dispatch_Id']: int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(trace))}
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            # gru_cols runs twice per step (per agent / per trajectory) with the same persistent grid: split by duration
+            if 'gru_cols' in name:
+                name += '[trajectories]' if dur[r['Dispatch_Id']] > 300000 else '[agents]'
+            agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
+            key = (f, r['Dispatch_Id'])
+            if key not in seen:
+                seen.add(key)
+                agg[name]['_dur_ns'].append(dur[r['Dispatch_Id']])
+    out = {}
+    for name, c in agg.items():
+        if not any(k in name for k in STAGE_OF):
+            continue
+        e = {k: sum(v) / len(v) for k, v in c.items()}
+        e['mean_us'] = e.pop('_dur_ns') / 1e3
+        if 'GRBM_GUI_ACTIVE' in e and 'SQ_VALU_MFMA_BUSY_CYCLES' in e:
+            cyc = e['GRBM_GUI_ACTIVE'] / 8.0                      # summed over the 8 XCDs
+            e['clock_GHz'] = cyc / (e['mean_us'] * 1e3)
+            e['mfma_busy_frac'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc)   # 1024 SIMDs
+        if 'FETCH_SIZE' in e or 'WRITE_SIZE' in e:
+            e['hbm_bytes_per_launch'] = (2.0 * e.get('FETCH_SIZE', 0.0) + e.get('WRITE_SIZE', 0.0)) * 1024.0
+        out[name] = e
+    json.dump(out, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+    traffic = {}
+    for name, e in out.items():
+        if 'hbm_bytes_per_launch' not in e:
+            continue
+        base = name.split('<')[0].split('[')[0]
+        st = STAGE_OF.get(base)
+        if st == 'gru_cols':
+            st = 'gru_cols[block1,trajectories]' if 'trajectories' in name else 'gru_cols[block0,agents]'
+        if st:
+            traffic[st] = e['hbm_bytes_per_launch']
+    json.dump(traffic, open(os.path.join(os.path.dirname(dst.rstrip('/')), 'traffic.json'), 'w'), indent=1, sort_keys=True)
+    for f in glob.glob(os.path.join(src, 'prof*', '*', '*_kernel_stats.csv')):
+        tag = f.split(os.sep)[-3]
+        rows = list(csv.DictReader(open(f)))[:14]
+        with open(os.path.join(dst, f'{tag}_kernel_stats.csv'), 'w') as fo:
+            w = csv.DictWriter(fo, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
+    print(json.dumps({k: {kk: round(vv, 4) for kk, vv in v.items() if kk in ('mean_us', 'clock_GHz', 'mfma_busy_frac', 'hbm_bytes_per_launch')}
+                      for k, v in out.items()}, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

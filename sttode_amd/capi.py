@@ -26,10 +26,18 @@ SIGNATURES = {
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
+    # manifold op library (csrc/pmath.hip)
+    'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
+    'sttode_pmath_scalar': [_I, _P, _P, _L, _P],
+    'sttode_pmath_matvec': [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    'sttode_pmath_pair': [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    'sttode_pmath_mean': [_P, _P, _P, _P, _I, _I, _F, _P],
+    'sttode_oblique_dist': [_P, _P, _P, _I, _I, _I, _I, _P],
     # native pipeline (csrc/pipeline.hip)
     'sttode_model_create': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _I, _I, _I, _I, _I, _I],
     'sttode_model_destroy': [_P],
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
+    'sttode_set_col_parts': [_P, _I],
     'sttode_timing_enable': [_P, _I],
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
@@ -72,6 +80,10 @@ class NativeModel:
                 raise SttodeError('sttode_workspace_layout failed: ' + lib().sttode_last_error().decode())
             self._layouts[key] = (dict(zip(BUFFERS, list(off))), int(tot.value))
         return self._layouts[key]
+
+    def set_col_parts(self, parts):
+        if lib().sttode_set_col_parts(self.h, int(parts)) != 0:
+            raise SttodeError('sttode_set_col_parts failed: ' + lib().sttode_last_error().decode())
 
     def timing(self, on):
         lib().sttode_timing_enable(self.h, int(on))

@@ -169,30 +169,43 @@ __global__ __launch_bounds__(256) void linear_cols_kernel(
 // ---------------------------------------------------------------------------------------------------
 template <int CHW>
 struct WStream {
+    // Register staging with a prefetch distance of TWO chunks: while chunk p feeds the MFMAs from LDS buffer p&1,
+    // chunk p+1 is already in the other LDS buffer and chunk p+2 is in flight from L2 into `stage`.  A step is
+    //     begin(): commit stage (chunk p+1, issued one whole step ago => landed) to LDS buffer (p+1)&1,
+    //              then issue the global loads of chunk p+2;
+    //     ... MFMAs on cur() ...
+    //     end():   one barrier (publishes buffer (p+1)&1, retires the reads of buffer p&1).
+    // sched_barrier(0) pins that order (hipcc otherwise sinks the LDS writes and their vmcnt waits into the MFMAs).
     static constexpr int PER = CHW / 256;
     const f32x4* blob;
     f32x4* lds;
     int total, pos;
     f32x4 stage[PER];
+    __device__ __forceinline__ void load_stage(int chunk) {
+        const f32x4* src = blob + (size_t)(chunk % total) * CHW;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
+    }
     __device__ __forceinline__ void init(const f32x4* b, f32x4* l, int tot) {
         blob = b; lds = l; total = tot; pos = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) lds[i * 256 + threadIdx.x] = blob[i * 256 + threadIdx.x];
+        load_stage(1);
     }
     __device__ __forceinline__ const f32x4* cur() const { return lds + (pos & 1) * CHW; }
-    __device__ __forceinline__ void fetch_next() {
-        int nx = pos + 1;
-        nx = nx % total;
-        const f32x4* src = blob + (size_t)nx * CHW;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
-    }
-    __device__ __forceinline__ void commit() {
+    __device__ __forceinline__ void begin() {
+        __builtin_amdgcn_sched_barrier(0);
         f32x4* dst = lds + ((pos + 1) & 1) * CHW;
 #pragma unroll
         for (int i = 0; i < PER; ++i) dst[i * 256 + threadIdx.x] = stage[i];
+        load_stage(pos + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void end() {
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         ++pos;
+        __builtin_amdgcn_sched_barrier(0);
     }
 };
 
@@ -217,7 +230,7 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
         const float* nxt = (ch + 1 < NCH) ? a0 + (ch + 1) * CHT * 16 : a0_next;
 #pragma unroll
         for (int hf = 0; hf < CHT; ++hf) a0n[hf] = ld4(nxt + hf * 16);
-        st.fetch_next();
+        st.begin();
         const f32x4* buf = st.cur();
 #pragma unroll
         for (int hf = 0; hf < CHT; ++hf) {
@@ -233,14 +246,13 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
                 acc2[it] = mfma_k16(acc2[it], w2[it * 64], h1);
             }
         }
-        STT_FENCE();
-        st.commit();
+        st.end();
     }
 #pragma unroll
     for (int it = 0; it < 16; ++it) acc2[it] = relu4(acc2[it] + ld4(sBias + 16 * it + 4 * q));
 #pragma unroll
     for (int c3 = 0; c3 < N3; ++c3) {
-        st.fetch_next();
+        st.begin();
         const f32x4* buf = st.cur();
 #pragma unroll
         for (int oo = 0; oo < TP3; ++oo) {
@@ -255,8 +267,7 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
                 out[o] = a;
             }
         }
-        STT_FENCE();
-        st.commit();
+        st.end();
     }
 }
 

@@ -1,0 +1,297 @@
+// Poincare-ball primitives (hyptorch/pmath.py) and Oblique-manifold primitives (core/manifolds/oblique.py)
+// as a stand-alone HIP op library.  None of these is called by the STTODE model path: parity is
+// op-level, against vectors produced by the reference's own functions (tests/golden/pmath.npz, ops.npz).
+//
+// Row-wise ops: ONE WAVE PER ROW (4 rows per 256-thread block), lanes stride the feature dim with coalesced loads,
+// the three row reductions (|x|^2, |y|^2, <x,y>) are a single pass + wavefront xor-shuffles; a second pass writes
+// the vector result (or lane 0 the scalar).  HBM-bound: 1 read of each operand + 1 write.  The reference's epsilons
+// and clamps are kept verbatim (cited per op).
+#include "api_util.hpp"
+
+enum PmathOp {
+    OP_PROJECT = 0, OP_LAMBDA_X, OP_MOBIUS_ADD, OP_DIST, OP_DIST0, OP_EXPMAP, OP_EXPMAP0, OP_LOGMAP, OP_LOGMAP0, OP_P2K, OP_K2P,
+    OP_LORENZ, OP_OBL_PROJ, OP_MATVEC_FIN, OP_PMEAN_PREP, OP_COUNT
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float tanh_clamped(float x) { return tanhf(fminf(fmaxf(x, -15.0f), 15.0f)); }  // pmath.py:11-12
+__device__ __forceinline__ float artanh_(float x) {                                                        // pmath.py:16-22
+    x = fminf(fmaxf(x, -1.0f + 1e-5f), 1.0f - 1e-5f);
+    return (logf(1.0f + x) - logf(1.0f - x)) * 0.5f;
+}
+__device__ __forceinline__ float arsinh_(float x) { return logf(fmaxf(x + sqrtf(1.0f + x * x), 1e-5f)); }    // pmath.py:51-55
+
+// mobius_add(a, b)_i for a = sx*x (sx = +-1) given the row scalars of the SIGNED operand (pmath.py:171-177)
+struct MobCoef { float ca, cb, den; };
+__device__ __forceinline__ MobCoef mob_coef(float a2, float b2, float ab, float c) {
+    MobCoef m;
+    m.ca = 1.0f + 2.0f * c * ab + c * b2;
+    m.cb = 1.0f - c * a2;
+    m.den = 1.0f + 2.0f * c * ab + c * c * a2 * b2 + 1e-5f;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void pmath_row_kernel(int op, const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ out, float* __restrict__ out2, int rows, int d, float c) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * d;
+    const float* yr = y ? y + (size_t)r * d : nullptr;
+    float x2 = 0.f, y2 = 0.f, xy = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float a = xr[i];
+        x2 += a * a;
+        if (yr) { const float b = yr[i]; y2 += b * b; xy += a * b; }
+    }
+    x2 = wsum(x2); y2 = wsum(y2); xy = wsum(xy);
+    const float sc = sqrtf(c);
+    float* o = out + (size_t)r * d;
+    switch (op) {
+        case OP_PROJECT: {  // pmath.py:98-103
+            const float norm = fmaxf(sqrtf(x2), 1e-5f), maxnorm = (1.0f - 1e-3f) / sc;
+            for (int i = lane; i < d; i += 64) o[i] = norm > maxnorm ? xr[i] / norm * maxnorm : xr[i];
+        } break;
+        case OP_LAMBDA_X:  // pmath.py:128-129
+            if (lane == 0) out[r] = 2.0f / (1.0f - c * x2);
+            break;
+        case OP_MOBIUS_ADD: {
+            const MobCoef m = mob_coef(x2, y2, xy, c);
+            for (int i = lane; i < d; i += 64) o[i] = (m.ca * xr[i] + m.cb * yr[i]) / m.den;
+        } break;
+        case OP_DIST:      // pmath.py:205-208 : artanh(sqrt_c |(-x) (+) y|) * 2 / sqrt_c
+        case OP_LOGMAP: {  // pmath.py:334-339
+            const MobCoef m = mob_coef(x2, y2, -xy, c);
+            float s2 = 0.f;
+            for (int i = lane; i < d; i += 64) { const float v = (m.ca * (-xr[i]) + m.cb * yr[i]) / m.den; s2 += v * v; }
+            const float sn = sqrtf(wsum(s2));
+            if (op == OP_DIST) {
+                if (lane == 0) out[r] = artanh_(sc * sn) * 2.0f / sc;
+            } else {
+                const float lam = 2.0f / (1.0f - c * x2);
+                const float k = 2.0f / sc / lam * artanh_(sc * sn);
+                for (int i = lane; i < d; i += 64) o[i] = k * ((m.ca * (-xr[i]) + m.cb * yr[i]) / m.den) / sn;
+            }
+        } break;
+        case OP_DIST0:  // pmath.py:231-234
+            if (lane == 0) out[r] = artanh_(sc * sqrtf(x2)) * 2.0f / sc;
+            break;
+        case OP_EXPMAP: {  // pmath.py:268-277 : x (+) tanh(sqrt_c/2 * lambda_x * |u|) u / (sqrt_c |u|)   (u passed as y)
+            const float un = fmaxf(sqrtf(y2), 1e-5f);
+            const float lam = 2.0f / (1.0f - c * x2);
+            const float t = tanh_clamped(sc / 2.0f * lam * un);
+            const float s = t / (sc * un);  // second_term = s * u (elementwise: t * u / (sc*un))
+            const MobCoef m = mob_coef(x2, s * s * y2, s * xy, c);
+            for (int i = lane; i < d; i += 64) o[i] = (m.ca * xr[i] + m.cb * (t * yr[i] / (sc * un))) / m.den;
+        } break;
+        case OP_EXPMAP0: {  // pmath.py:300-304
+            const float un = fmaxf(sqrtf(x2), 1e-5f);
+            const float t = tanh_clamped(sc * un);
+            for (int i = lane; i < d; i += 64) o[i] = t * xr[i] / (sc * un);
+        } break;
+        case OP_LOGMAP0: {  // pmath.py:365-368
+            const float yn = fmaxf(sqrtf(x2), 1e-5f);
+            const float a = artanh_(sc * yn);
+            for (int i = lane; i < d; i += 64) o[i] = xr[i] / yn / sc * a;
+        } break;
+        case OP_P2K:  // pmath.py:440-442
+            for (int i = lane; i < d; i += 64) o[i] = 2.0f * xr[i] / (1.0f + c * x2);
+            break;
+        case OP_K2P:  // pmath.py:445-447
+            for (int i = lane; i < d; i += 64) o[i] = xr[i] / (1.0f + sqrtf(1.0f - c * x2));
+            break;
+        case OP_LORENZ:  // pmath.py:450-469
+            if (lane == 0) out[r] = 1.0f / sqrtf(1.0f - c * x2);
+            break;
+        case OP_OBL_PROJ:  // core/manifolds/oblique.py:15-16
+            for (int i = lane; i < d; i += 64) o[i] = xr[i] / sqrtf(x2);
+            break;
+        case OP_MATVEC_FIN: {  // pmath.py:399-408 ; x = mx row [d], y = original x row passed via out2-stride trick (see host)
+            // here: xr = mx row (length d), yr = nullptr; out2 holds |x| per row
+            const float xn = fmaxf(out2[r], 1e-5f);
+            const float mxn = sqrtf(x2);
+            const float t = tanh_clamped(mxn / xn * artanh_(sc * xn));
+            const bool zero = x2 == 0.0f;
+            // res then _project
+            float r2 = 0.f;
+            for (int i = lane; i < d; i += 64) { const float v = zero ? 0.f : t * xr[i] / (mxn * sc); r2 += v * v; }
+            const float norm = fmaxf(sqrtf(wsum(r2)), 1e-5f), maxnorm = (1.0f - 1e-3f) / sc;
+            for (int i = lane; i < d; i += 64) {
+                const float v = zero ? 0.f : t * xr[i] / (mxn * sc);
+                o[i] = norm > maxnorm ? v / norm * maxnorm : v;
+            }
+        } break;
+        case OP_PMEAN_PREP: {  // pmath.py:472-476 : xk = p2k(x); lam = lorenz(xk); out = lam * xk, out2[r] = lam
+            const float den = 1.0f + c * x2;
+            float k2 = 0.f;
+            for (int i = lane; i < d; i += 64) { const float v = 2.0f * xr[i] / den; k2 += v * v; }
+            const float lam = 1.0f / sqrtf(1.0f - c * wsum(k2));
+            for (int i = lane; i < d; i += 64) o[i] = lam * (2.0f * xr[i] / den);
+            if (lane == 0) out2[r] = lam;
+        } break;
+    }
+}
+
+// poincare_mean tail (pmath.py:476-479): mean = sum_r(lam*xk) / sum_r(lam) ; k2p(mean).  One block.
+__global__ __launch_bounds__(1024) void pmean_fin_kernel(const float* __restrict__ yl, const float* __restrict__ lam,
+                                                         float* __restrict__ out, int rows, int d, float c) {
+    __shared__ float red[16];
+    __shared__ float tot;
+    float L = 0.f;
+    for (int r = 0; r < rows; ++r) L += lam[r];
+    float part = 0.f;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += yl[(size_t)r * d + i];
+        const float m = s / L;
+        out[i] = m;
+        part += m * m;
+    }
+    part = wsum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        tot = t;
+    }
+    __syncthreads();
+    const float den = 1.0f + sqrtf(1.0f - c * tot);
+    for (int i = threadIdx.x; i < d; i += blockDim.x) out[i] = out[i] / den;
+}
+
+// elementwise scalars: tanh (clamped), artanh, arsinh
+__global__ void pmath_scalar_kernel(int which, const float* __restrict__ x, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    out[i] = which == 0 ? tanh_clamped(v) : (which == 1 ? artanh_(v) : arsinh_(v));
+}
+
+// mx[r][o] = <x[r], m[o]>   (mobius_matvec front half)
+__global__ void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ mx, float* __restrict__ xnorm,
+                              int rows, int d, int O) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * O) return;
+    const int r = idx / O, o = idx % O;
+    float s = 0.f, n2 = 0.f;
+    for (int i = 0; i < d; ++i) { const float a = x[(size_t)r * d + i]; s += a * m[(size_t)o * d + i]; n2 += a * a; }
+    mx[idx] = s;
+    if (o == 0) xnorm[r] = sqrtf(n2);
+}
+
+// pairwise kernels: one thread per (p, q).  which: 0 dist_matrix [P,R]; 1 mobius_addition_batch [P,R,D]; 2 hyperbolic_softmax
+__global__ void pmath_pair_kernel(int which, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ A,
+                                  float* __restrict__ out, int P, int R, int d, float c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)P * R) return;
+    const int p = idx / R, q = idx % R;
+    const float* xr = x + (size_t)p * d;
+    const float* yr = y + (size_t)q * d;
+    const float sgn = (which == 1) ? 1.0f : -1.0f;  // dist_matrix / hyperbolic_softmax call batch(-x, y)
+    float x2 = 0.f, y2 = 0.f, xy = 0.f;
+    for (int i = 0; i < d; ++i) { const float a = sgn * xr[i], b = yr[i]; x2 += a * a; y2 += b * b; xy += a * b; }
+    const MobCoef m = mob_coef(x2, y2, xy, c);  // pmath.py:416-427
+    if (which == 1) {
+        for (int i = 0; i < d; ++i) out[idx * d + i] = (m.ca * xr[i] + m.cb * yr[i]) / m.den;
+        return;
+    }
+    float s2 = 0.f, sa = 0.f, a2 = 0.f;
+    for (int i = 0; i < d; ++i) {
+        const float v = (m.ca * (-xr[i]) + m.cb * yr[i]) / m.den;
+        s2 += v * v;
+        if (which == 2) { const float av = A[(size_t)p * d + i]; sa += v * av; a2 += av * av; }
+    }
+    const float sc = sqrtf(c);
+    if (which == 0) {
+        out[idx] = 2.0f / sc * artanh_(sc * sqrtf(s2));  // pmath.py:482-493
+    } else {
+        // _hyperbolic_softmax (pmath.py:430-437): x = P (classes, rows p), y = X (batch, rows q); result [B, C] = out[q][p]
+        const float an = sqrtf(a2);
+        const float lam = 2.0f / (1.0f - c * x2);
+        const float k = lam * an / sc;
+        const float num = 2.0f * sc * sa;
+        const float den = an * (1.0f - c * s2);
+        out[(size_t)q * P + p] = k * arsinh_(num / den);
+    }
+}
+
+// Oblique.dist(p1, p2) = acos(clamp(p2 @ p1^T)) -> [batch, rows(p2), rows(p1)]   (core/manifolds/oblique.py:36-43)
+__global__ void oblique_dist_kernel(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ out, int nb, int n1,
+                                    int n2, int d) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)nb * n2 * n1) return;
+    const int j = idx % n1, i = (idx / n1) % n2, b = idx / ((long)n1 * n2);
+    const float* a = p2 + ((size_t)b * n2 + i) * d;
+    const float* q = p1 + ((size_t)b * n1 + j) * d;
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) s += a[k] * q[k];
+    out[idx] = acosf(fminf(fmaxf(s, -1.0f + 1e-4f), 1.0f - 1e-4f));
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sttode_pmath_rowop(int op, const float* x, const float* y, float* out, float* out2, int rows, int d, float c,
+                                  void* stream) {
+    STT_REQUIRE(op >= 0 && op < OP_COUNT, "sttode_pmath_rowop: unknown op");
+    STT_REQUIRE(x && out && rows > 0 && d > 0, "sttode_pmath_rowop: null pointer or empty shape");
+    const bool needs_y = op == OP_MOBIUS_ADD || op == OP_DIST || op == OP_LOGMAP || op == OP_EXPMAP;
+    STT_REQUIRE(!needs_y || y, "sttode_pmath_rowop: this op needs a second operand");
+    STT_REQUIRE((op != OP_MATVEC_FIN && op != OP_PMEAN_PREP) || out2, "sttode_pmath_rowop: this op needs the out2 buffer");
+    STT_REQUIRE(c > 0.f || op == OP_OBL_PROJ, "sttode_pmath_rowop: curvature c must be positive");
+    hipLaunchKernelGGL(pmath_row_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, op, x, needs_y ? y : nullptr, out, out2,
+                       rows, d, c);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_pmath_scalar(int which, const float* x, float* out, long n, void* stream) {
+    STT_REQUIRE(x && out && n > 0 && which >= 0 && which <= 2, "sttode_pmath_scalar: bad arguments");
+    hipLaunchKernelGGL(pmath_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, x, out, n);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_pmath_matvec(const float* m, const float* x, float* mx_ws, float* xnorm_ws, float* out, int rows, int d, int O,
+                                   float c, void* stream) {
+    STT_REQUIRE(m && x && mx_ws && xnorm_ws && out && rows > 0 && d > 0 && O > 0 && c > 0.f, "sttode_pmath_matvec: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long tot = (long)rows * O;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, m, mx_ws, xnorm_ws, rows, d, O);
+    hipLaunchKernelGGL(pmath_row_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (int)OP_MATVEC_FIN, (const float*)mx_ws,
+                       (const float*)nullptr, out, xnorm_ws, rows, O, c);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_pmath_pair(int which, const float* x, const float* y, const float* A, float* out, int P, int R, int d, float c,
+                                 void* stream) {
+    STT_REQUIRE(x && y && out && P > 0 && R > 0 && d > 0 && c > 0.f && which >= 0 && which <= 2, "sttode_pmath_pair: bad arguments");
+    STT_REQUIRE(which != 2 || A, "sttode_pmath_pair: hyperbolic_softmax needs A");
+    const long tot = (long)P * R;
+    hipLaunchKernelGGL(pmath_pair_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, (hipStream_t)stream, which, x, y, A, out, P, R,
+                       d, c);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_pmath_mean(const float* x, float* yl_ws, float* lam_ws, float* out, int rows, int d, float c, void* stream) {
+    STT_REQUIRE(x && yl_ws && lam_ws && out && rows > 0 && d > 0 && c > 0.f, "sttode_pmath_mean: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pmath_row_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (int)OP_PMEAN_PREP, x, (const float*)nullptr, yl_ws, lam_ws,
+                       rows, d, c);
+    hipLaunchKernelGGL(pmean_fin_kernel, dim3(1), dim3(1024), 0, s, (const float*)yl_ws, (const float*)lam_ws, out, rows, d, c);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_oblique_dist(const float* p1, const float* p2, float* out, int nb, int n1, int n2, int d, void* stream) {
+    STT_REQUIRE(p1 && p2 && out && nb > 0 && n1 > 0 && n2 > 0 && d > 0, "sttode_oblique_dist: bad arguments");
+    const long tot = (long)nb * n1 * n2;
+    hipLaunchKernelGGL(oblique_dist_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p1, p2, out, nb, n1, n2, d);
+    STT_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,56 @@
+"""Multi-GPU: one process per GPU (torch.distributed; backend "nccl" == RCCL on ROCm, "gloo" in CPU tests).
+
+The ETH/UCY/SDD path shards embarrassingly: scenes are independent units (pedestrians interact only through their
+own scene's origin and last-agent flag; the reference's attention length is 1), so ranks take
+contiguous scene ranges balanced by agent count and run the whole hot path locally with replicated weights.  There
+is NO data-path collective.  Only the results are exchanged:
+  * gather_futures: one variable-size all-gather of the predicted futures [n_r, K, Tf, 2] (padded to the largest
+    shard; over xGMI every rank writes its shard to its 7 peers directly), or
+  * reduce_metrics: a 3-scalar all-reduce of (sum ADE, sum FDE, agents) when only metrics are needed.
+NBA path: the independent unit is the forward-call batch ("attention group", e.g. 128 scenes, test.py:618): whole
+groups go to ranks (shard_groups); results then match the reference exactly.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .scenes import shard_scenes
+
+
+def shard_scene_batch(sb, rank, world):
+    """This rank's contiguous slice of a SceneBatch (balanced by agent count) and its (scene0, scene1) range."""
+    s0, s1 = shard_scenes(sb.scene_ptr, world)[rank]
+    return sb.slice_scenes(s0, s1), (s0, s1)
+
+
+def shard_groups(n_groups, rank, world):
+    """NBA: contiguous range of attention groups for this rank."""
+    return (n_groups * rank) // world, (n_groups * (rank + 1)) // world
+
+
+def gather_futures(pred_local, group=None):
+    """All-gather of per-rank futures [n_r, K, Tf, 2] (n_r differs per rank) -> [sum n_r, K, Tf, 2] in rank order."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return pred_local
+    n_local = torch.tensor([pred_local.shape[0]], dtype=torch.int64, device=pred_local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c) for c in counts]
+    nmax = max(counts)
+    pad = pred_local.new_zeros((nmax,) + tuple(pred_local.shape[1:]))
+    pad[: pred_local.shape[0]] = pred_local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def reduce_metrics(ade_sum, fde_sum, count, group=None):
+    """Agent-weighted global ADE / FDE (AverageMeter(n=agent_num) semantics, test.py:205,208)."""
+    t = torch.stack([torch.as_tensor(ade_sum, dtype=torch.float64).reshape(()), torch.as_tensor(fde_sum, dtype=torch.float64).reshape(()),
+                     torch.as_tensor(float(count), dtype=torch.float64).reshape(())])
+    if isinstance(ade_sum, torch.Tensor):
+        t = t.to(ade_sum.device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return float(t[0] / t[2]), float(t[1] / t[2]), int(t[2])

@@ -1,0 +1,127 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds/loads without a GPU and exports exactly the
+entry points include/sttode_hip.h declares; the ctypes table mirrors the header; host-side packing is consistent."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'sttode_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|const char\*)\s+(sttode_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(',') if a.strip() and a.strip() != 'void']
+        out[m.group(1)] = args
+    return out
+
+
+def test_library_exports_every_header_symbol():
+    from sttode_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = ctypes.CDLL(capi.LIB_PATH)
+    fns = header_functions()
+    assert len(fns) >= 20
+    for name in fns:
+        assert hasattr(L, name), f'{name} declared in include/sttode_hip.h but not exported'
+    assert L.sttode_abi_version() == 1
+
+
+def test_ctypes_table_matches_header():
+    from sttode_amd import capi
+    fns = header_functions()
+    assert set(capi.SIGNATURES) == set(fns) - {'sttode_last_error'}
+    for name, args in capi.SIGNATURES.items():
+        assert len(args) == len(fns[name]), (name, len(args), fns[name])
+        for ct, decl in zip(args, fns[name]):
+            if ct is ctypes.c_int:
+                assert re.match(r'^int\s+\w+$', decl), (name, decl)
+            elif ct is ctypes.c_float:
+                assert decl.startswith('float '), (name, decl)
+            elif ct is ctypes.c_long:
+                assert decl.startswith('long '), (name, decl)
+            else:
+                assert '*' in decl, (name, decl)
+
+
+def test_enums_match_python_tables():
+    from sttode_amd import capi
+    src = open(os.path.join(ROOT, 'include', 'sttode_hip.h')).read()
+
+    def enum(name):
+        body = re.search(r'enum %s \{(.*?)\};' % name, src, flags=re.S).group(1)
+        return [t.strip() for t in body.replace('\n', ' ').split(',') if t.strip()]
+    assert len(enum('SttodeWeight')) - 1 == len(capi.WEIGHT_ORDER)
+    assert [e[len('STT_B_'):].lower() for e in enum('SttodeBuffer')[:-1]] == [b.lower() for b in capi.BUFFERS]
+    assert len(enum('SttodeStage')) - 1 == len(capi.STAGES)
+
+
+def test_calls_fail_loudly_without_gpu_or_with_bad_arguments():
+    from sttode_amd import capi
+    with pytest.raises(capi.SttodeError, match='null pointer'):
+        capi.call('sttode_best_of_k', None, None, 0, 0, 0, 1.0, None, None, None)
+    with pytest.raises(capi.SttodeError):
+        capi.call('sttode_linear_cols', None, 0, 0, None, 0, 0, None, None, None, 0, 0, 0, 0, None)
+
+
+def test_pk16_layout_and_mlp_stream_roundtrip():
+    """PK16[it, T, lane, r] == W[16 it + (lane & 15), 16 T + 4 (lane >> 4) + r]; chunk stream holds every weight once."""
+    from sttode_amd import packing
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal((40, 50)).astype(np.float32)
+    P = packing.pk16(W)
+    assert P.shape == (3, 4, 64, 4)
+    Wp = np.zeros((48, 64), np.float32)
+    Wp[:40, :50] = W
+    for it, T, lane, r in [(0, 0, 0, 0), (2, 3, 63, 3), (1, 2, 37, 1), (0, 3, 16, 2)]:
+        assert P[it, T, lane, r] == Wp[16 * it + (lane & 15), 16 * T + 4 * (lane >> 4) + r]
+    W1v, W2 = rng.standard_normal((512, 32)).astype(np.float32), rng.standard_normal((256, 512)).astype(np.float32)
+    W3 = rng.standard_normal((32, 256)).astype(np.float32)
+    st = packing.mlp_stream(W1v, W2, W3, CHT=2)
+    assert st.shape == (17, 2304 * 4)
+    assert np.isclose(np.abs(st).sum(), np.abs(W1v).sum() + np.abs(W2).sum() + np.abs(W3).sum(), rtol=1e-5)
+    st1 = packing.mlp_stream(rng.standard_normal((512, 128)).astype(np.float32), W2, W3, CHT=1)
+    assert st1.shape == (34, 1536 * 4)
+
+
+def test_toeplitz_conv_equals_conv1d():
+    import torch
+    from sttode_amd import packing
+    rng = np.random.default_rng(1)
+    for Tp in (5, 8, 10):
+        w = rng.standard_normal((32, 2, 3)).astype(np.float32)
+        x = rng.standard_normal((7, Tp, 2)).astype(np.float32)
+        M = packing.toeplitz_conv(w, Tp, packing.tiles_x(Tp))
+        flat = np.zeros((7, M.shape[1]), np.float32)
+        flat[:, :2 * Tp] = x.reshape(7, -1)
+        ref = torch.nn.functional.conv1d(torch.from_numpy(x).transpose(1, 2), torch.from_numpy(w), padding=1).transpose(1, 2)
+        np.testing.assert_allclose((flat @ M.T).reshape(7, Tp, 32), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_state_dict_surface_matches_reference_manifest():
+    import torch
+    from helpers import make_args
+    from sttode_amd import STTODENet
+    from sttode_amd.weights import make_weights, manifest, to_torch_state_dict
+    for ds, Tp, Tf in (('eth', 8, 12), ('nba', 5, 10), ('nba', 10, 40)):
+        m = STTODENet(make_args(ds, Tp, Tf), 'cpu')
+        man = manifest(past_length=Tp, future_length=Tf)
+        sd = m.state_dict()
+        assert list(sd) == list(man)
+        assert all(tuple(sd[k].shape) == tuple(man[k]) for k in man)
+        m.load_state_dict(to_torch_state_dict(make_weights(7, past_length=Tp, future_length=Tf)), strict=True)
+    assert sum(p.numel() for p in STTODENet(make_args(), 'cpu').parameters()) == 1627792
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'sttode_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), os.path.join(dirpath, f)
