@@ -76,10 +76,16 @@ int sttode_gru_cols(const float* xin, const float* convP, const float* convB, co
 int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, const float* bias,
                        float* out, int ldo, int ncols, int N, int relu, void* stream);
 
+/* The three per-agent layer-0 pre-activations of decoder_x/decoder_y (block 0) and decoder_y (block 1) in one launch:
+ * A0x, A0y = W[:, pf|state] [pf | state0] + b ; A1y = W[:, pf] pf + b   (model/STTODE.py:71,74-75 split). */
+int sttode_agent_preact(const float* pf, const float* state0, const float* WAx, const float* b1x, const float* WAy,
+                        const float* b1y, const float* WA1, const float* b11, float* A0x, float* A0y, float* A1y, int n,
+                        void* stream);
+
 /* DecomposeBlock 0 back half for all K samples (model/STTODE.py:71-75, Decoder.forward :336-339):
  * decoder_x and decoder_y MLPs; writes dbuf = x_true - x_hat0 [m,16*TPX] and ybuf = y_hat0 [m,16*NOY].
  * A0x/A0y [n,512]: per-agent part of layer 0 (sttode_linear_cols); stream: packed weight-chunk stream of both MLPs
- * (packing.mlp_stream), total_chunks = 32 + ceil(TPX/2) + ceil(NOY/2); biases = [b2x | b3x | b2y | b3y]. */
+ * (packing.mlp_stream), total_chunks = (32 + TPX) + (32 + NOY); biases = [b2x | b3x | b2y | b3y]. */
 int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
                       const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
                       void* stream_);
@@ -164,6 +170,16 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
  * past [B*N,Tp,2]; attention length = B over the N agent slots. */
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
+
+/* Pipelined forms: the per-agent stage runs on an internal stream beside the per-trajectory stage of the PREVIOUS call
+ * (its kernels fill the grid tails of the big kernels).  Two workspace/pred slots alternate (slot = call index & 1);
+ * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream.
+ * Results are bitwise identical to the serial forms. */
+int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
+                                  float* workspace, float* pred, int slot, void* stream);
+int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
+                               int slot, void* stream);
+int sttode_wait(SttodeModel* m, int slot, void* stream);
 
 #ifdef __cplusplus
 }

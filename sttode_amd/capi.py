@@ -23,6 +23,7 @@ SIGNATURES = {
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_agent_preact': [_P] * 11 + [_I, _P],
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
@@ -42,6 +43,9 @@ SIGNATURES = {
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     'sttode_inference_nba': [_P, _P, _I, _I, _P, _P, _P, _P],
+    'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
+    'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
+    'sttode_wait': [_P, _I, _P],
 }
 
 # enum SttodeWeight / SttodeBuffer / SttodeStage of include/sttode_hip.h (order is ABI)
@@ -52,7 +56,7 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                 + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream', 'biases')])
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
            'A1y', 'dbuf', 'ybuf', 'state1')
-STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'linear_cols', 'mlp_block0',
+STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',
           'gru_cols[block1,trajectories]', 'mlp_block1')
 
 

@@ -126,34 +126,61 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// generic per-column linear:  out[col][row0 + ...] = act( W * [X1 | X2] + b )
+// generic per-column linear:  out[col][0:N] = act( W * [X1 | X2] + b ), up to 3 independent jobs per launch
+// (blockIdx.z).  Each wave: 16 columns x RT row tiles; all B tiles are loaded up front and the A fragments of
+// k-tile T+1 are prefetched while k-tile T feeds the MFMAs (weights come straight from L2: few columns per launch).
 // ---------------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(256) void linear_cols_kernel(
-    const float* __restrict__ X1, int ld1, int KT1, const float* __restrict__ X2, int ld2, int KT2,
-    const f32x4* __restrict__ WP,  // PK16 [NT][KT1+KT2][64]
-    const float* __restrict__ bias, float* __restrict__ out, int ldo, int ncols, int NT, int relu) {
+struct LinJob {
+    const float* X1; const float* X2; const f32x4* WP; const float* bias; float* out;
+    int ld1, KT1, ld2, KT2, ldo, NT, relu;
+};
+struct LinJobs { LinJob j[3]; };
+
+template <int RT, int KTMAX>
+__global__ __launch_bounds__(256) void linear_cols_kernel(LinJobs jobs, int ncols) {
+    const LinJob J = jobs.j[blockIdx.z];
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = threadIdx.x >> 6;
     const int ctile = blockIdx.x * 4 + wave;
     const int rt0 = blockIdx.y * RT;
-    if (ctile * 16 >= ncols) return;
+    if (ctile * 16 >= ncols || rt0 >= J.NT) return;
     const int col = ctile * 16 + c;
     const int colc = col < ncols ? col : ncols - 1;
-    const int KT = KT1 + KT2;
-    f32x4 acc[RT];
+    const int KT = J.KT1 + J.KT2;
+    f32x4 B[KTMAX];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = (rt0 + i < NT && bias) ? ld4(bias + 16 * (rt0 + i) + 4 * q) : splat4(0.f);
-    for (int T = 0; T < KT; ++T) {
-        const f32x4 b = T < KT1 ? ld4(X1 + (size_t)colc * ld1 + 16 * T + 4 * q) : ld4(X2 + (size_t)colc * ld2 + 16 * (T - KT1) + 4 * q);
+    for (int T = 0; T < KTMAX; ++T) {
+        if (T < KT)
+            B[T] = T < J.KT1 ? ld4(J.X1 + (size_t)colc * J.ld1 + 16 * T + 4 * q) : ld4(J.X2 + (size_t)colc * J.ld2 + 16 * (T - J.KT1) + 4 * q);
+    }
+    f32x4 acc[RT], wn[RT];
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
-            if (rt0 + i < NT) acc[i] = mfma_k16(acc[i], WP[((size_t)(rt0 + i) * KT + T) * 64 + lane], b);
+    for (int i = 0; i < RT; ++i) {
+        const int rt = rt0 + i < J.NT ? rt0 + i : J.NT - 1;
+        acc[i] = J.bias ? ld4(J.bias + 16 * rt + 4 * q) : splat4(0.f);
+        wn[i] = J.WP[((size_t)rt * KT) * 64 + lane];
+    }
+#pragma unroll
+    for (int T = 0; T < KTMAX; ++T) {
+        if (T < KT) {
+            f32x4 wc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) wc[i] = wn[i];
+            if (T + 1 < KT) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int rt = rt0 + i < J.NT ? rt0 + i : J.NT - 1;
+                    wn[i] = J.WP[((size_t)rt * KT + T + 1) * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i] = mfma_k16(acc[i], wc[i], B[T]);
+        }
     }
     if (col < ncols) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
-            if (rt0 + i < NT) st4(out + (size_t)col * ldo + 16 * (rt0 + i) + 4 * q, relu ? relu4(acc[i]) : acc[i]);
+            if (rt0 + i < J.NT) st4(J.out + (size_t)col * J.ldo + 16 * (rt0 + i) + 4 * q, J.relu ? relu4(acc[i]) : acc[i]);
     }
 }
 
@@ -182,7 +209,7 @@ struct WStream {
     int total, pos;
     f32x4 stage[PER];
     __device__ __forceinline__ void load_stage(int chunk) {
-        const f32x4* src = blob + (size_t)(chunk % total) * CHW;
+        const f32x4* src = blob + (size_t)(chunk % total) * CHW;  // blob already points at this role's first chunk
 #pragma unroll
         for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
     }
@@ -271,14 +298,61 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
     }
 }
 
-#define MLP0_CHW (2 * (2 + 16) * 64)  // CHT = 2, KTV = 2 : 2304 float4 = 36 KiB per chunk
+#define MLP0_CHW 1280                 // CHT = 1, KTV = 2 : 18 tiles = 1152 float4, padded to 1280 (20 KiB) so 256 threads split it evenly
 #define MLP1_CHW (1 * (8 + 16) * 64)  // CHT = 1, KTV = 8 : 1536 float4 = 24 KiB per chunk
 
-// block 0: x and y MLPs per trajectory.  d = x_true - x_hat0 -> dbuf ; y_hat0 -> ybuf
+// block 0: decoder_x and decoder_y MLPs per trajectory as two WORKGROUP ROLES (even blockIdx: x, odd: y): a work item is
+// (64-column group, one MLP), half the size of "both MLPs", which halves the grid tail; each role streams only its own
+// MLP's chunks.   x role: d = x_true - x_hat0 -> dbuf ;  y role: y_hat0 -> ybuf
+template <int NO, bool IS_X>
+__device__ __forceinline__ void mlp0_role(const float* __restrict__ A0, const f32x4* __restrict__ blob, int nchunks,
+                                          const float* __restrict__ biases, const float* __restrict__ z,
+                                          const float* __restrict__ xpad, float* __restrict__ obuf, int ncols, int K, f32x4* lds) {
+    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP0_CHW);
+    for (int i = threadIdx.x; i < 256 + 16 * NO; i += 256) sBias[i] = biases[i];
+    WStream<MLP0_CHW> st;
+    st.init(blob, lds, nchunks);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int ngroups = (ncols + 63) >> 6;  // 4 waves x 16 columns per workgroup step
+    const int gstride = (int)gridDim.x >> 1;
+    int g = (int)blockIdx.x >> 1;
+    auto agent_of = [&](int gg) {
+        int col = gg * 64 + wave * 16 + c;
+        col = col < ncols ? col : ncols - 1;
+        return col / K;
+    };
+    f32x4 a0n[1];
+    a0n[0] = ld4(A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    for (; g < ngroups; g += gstride) {
+        const int col = g * 64 + wave * 16 + c;
+        const int colc = col < ncols ? col : ncols - 1;
+        const int agent = colc / K;
+        const int gn = g + gstride;
+        const int agent_nx = agent_of(gn < ngroups ? gn : g);
+        f32x4 B[2];
+        B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
+        B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
+        f32x4 o[NO];
+        mlp_phase<2, 1, NO, MLP0_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, o, lane, q);
+        if (col < ncols) {
+#pragma unroll
+            for (int t = 0; t < NO; ++t) {
+                if (IS_X) {
+                    const f32x4 xt = ld4(xpad + (size_t)agent * (16 * NO) + 16 * t + 4 * q);
+                    st4(obuf + (size_t)col * (16 * NO) + 16 * t + 4 * q, xt - o[t]);
+                } else {
+                    st4(obuf + (size_t)col * (16 * NO) + 16 * t + 4 * q, o[t]);
+                }
+            }
+        }
+    }
+}
+
 template <int TPX, int NOY>
-__global__ __launch_bounds__(256, 2) void mlp_block0_kernel(
+__global__ __launch_bounds__(256, 3) void mlp_block0_kernel(
     const float* __restrict__ A0x, const float* __restrict__ A0y,  // [nagents][512]
-    const f32x4* __restrict__ blob, int total_chunks,              // weight stream (x then y)
+    const f32x4* __restrict__ blob, int total_chunks,              // weight stream (x chunks, then y chunks)
     const float* __restrict__ biases,                              // [b2x 256 | b3x 16*TPX | b2y 256 | b3y 16*NOY]
     const float* __restrict__ z,                                   // [ncols][32]
     const float* __restrict__ xpad,                                // [nagents][16*TPX] normalised past (t,c), zero padded
@@ -287,52 +361,11 @@ __global__ __launch_bounds__(256, 2) void mlp_block0_kernel(
     int ncols, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
-    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP0_CHW);
-    constexpr int NB = 256 + 16 * TPX + 256 + 16 * NOY;
-    for (int i = threadIdx.x; i < NB; i += 256) sBias[i] = biases[i];
-    WStream<MLP0_CHW> st;
-    st.init(blob, lds, total_chunks);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
-    const int ngroups = (ncols + 63) >> 6;  // 4 waves x 16 columns per workgroup step
-    int g = blockIdx.x;
-    auto agent_of = [&](int gg) {
-        int col = gg * 64 + wave * 16 + c;
-        col = col < ncols ? col : ncols - 1;
-        return col / K;
-    };
-    f32x4 a0n[2];
-    {
-        const float* p = A0x + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q;
-        a0n[0] = ld4(p);
-        a0n[1] = ld4(p + 16);
-    }
-    for (; g < ngroups; g += gridDim.x) {
-        const int col = g * 64 + wave * 16 + c;
-        const int colc = col < ncols ? col : ncols - 1;
-        const int agent = colc / K;
-        const int gn = g + (int)gridDim.x;
-        const int agent_nx = agent_of(gn < ngroups ? gn : g);
-        f32x4 B[2];
-        B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
-        B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
-        f32x4 xo[TPX];
-        mlp_phase<2, 2, TPX, MLP0_CHW>(st, B, A0x + (size_t)agent * 512 + 4 * q, A0y + (size_t)agent * 512 + 4 * q, a0n, sBias, xo, lane, q);
-        if (col < ncols) {
-#pragma unroll
-            for (int o = 0; o < TPX; ++o) {
-                const f32x4 xt = ld4(xpad + (size_t)agent * (16 * TPX) + 16 * o + 4 * q);
-                st4(dbuf + (size_t)col * (16 * TPX) + 16 * o + 4 * q, xt - xo[o]);
-            }
-        }
-        f32x4 yo[NOY];
-        mlp_phase<2, 2, NOY, MLP0_CHW>(st, B, A0y + (size_t)agent * 512 + 4 * q, A0x + (size_t)agent_nx * 512 + 4 * q, a0n,
-                                       sBias + 256 + 16 * TPX, yo, lane, q);
-        if (col < ncols) {
-#pragma unroll
-            for (int o = 0; o < NOY; ++o) st4(ybuf + (size_t)col * (16 * NOY) + 16 * o + 4 * q, yo[o]);
-        }
-    }
+    constexpr int NCX = 32 + TPX;  // layer-1/2 chunks + one layer-3 chunk per output tile (TP3 = 1 at this chunk size)
+    if ((blockIdx.x & 1) == 0)
+        mlp0_role<TPX, true>(A0x, blob, NCX, biases, z, xpad, dbuf, ncols, K, lds);
+    else
+        mlp0_role<NOY, false>(A0y, blob + (size_t)NCX * MLP0_CHW, total_chunks - NCX, biases + 256 + 16 * TPX, z, xpad, ybuf, ncols, K, lds);
 }
 
 // block 1: y MLP per trajectory with the per-trajectory GRU state; final epilogue
@@ -440,20 +473,52 @@ extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float
     return 0;
 }
 
-extern "C" int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP,
-                                  const float* bias, float* out, int ldo, int ncols, int N, int relu, void* stream) {
+static int lin_check(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, float* out, int ldo, int N) {
     STT_REQUIRE(X1 && WP && out, "sttode_linear_cols: null pointer");
-    STT_REQUIRE(ncols > 0 && N > 0 && N % 16 == 0 && K1 > 0 && K1 % 16 == 0 && K2 >= 0 && K2 % 16 == 0, "sttode_linear_cols: N, K1, K2 must be multiples of 16");
+    STT_REQUIRE(N > 0 && N % 16 == 0 && K1 > 0 && K1 % 16 == 0 && K2 >= 0 && K2 % 16 == 0, "sttode_linear_cols: N, K1, K2 must be multiples of 16");
+    STT_REQUIRE(K1 + K2 <= 256, "sttode_linear_cols: K1 + K2 must be <= 256");
     STT_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && ldo % 4 == 0 && (K2 == 0 || X2), "sttode_linear_cols: leading dims must be multiples of 4");
-    const int NT = N / 16;
-    dim3 grid((ncols + 63) / 64, (NT + 7) / 8);
-    hipLaunchKernelGGL(linear_cols_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, X1, ld1, K1 / 16, X2, ld2, K2 / 16,
-                       (const f32x4*)WP, bias, out, ldo, ncols, NT, relu);
+    return 0;
+}
+static LinJob mkjob(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, const float* bias, float* out,
+                    int ldo, int N, int relu) {
+    LinJob j;
+    j.X1 = X1; j.X2 = X2; j.WP = (const f32x4*)WP; j.bias = bias; j.out = out;
+    j.ld1 = ld1; j.KT1 = K1 / 16; j.ld2 = ld2; j.KT2 = K2 / 16; j.ldo = ldo; j.NT = N / 16; j.relu = relu;
+    return j;
+}
+static int lin_launch(const LinJobs& jobs, int njobs, int ncols, int maxNT, int maxKT, hipStream_t s) {
+    dim3 grid((ncols + 63) / 64, (maxNT + 3) / 4, njobs);
+    if (maxKT <= 8) hipLaunchKernelGGL((linear_cols_kernel<4, 8>), grid, dim3(256), 0, s, jobs, ncols);
+    else hipLaunchKernelGGL((linear_cols_kernel<4, 16>), grid, dim3(256), 0, s, jobs, ncols);
     STT_HIP(hipGetLastError());
     return 0;
 }
 
-#define MLP0_LDS(TX, NY) (2 * MLP0_CHW * 16 + (256 + 16 * (TX) + 256 + 16 * (NY)) * 4)
+extern "C" int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP,
+                                  const float* bias, float* out, int ldo, int ncols, int N, int relu, void* stream) {
+    if (int rc = lin_check(X1, ld1, K1, X2, ld2, K2, WP, out, ldo, N)) return rc;
+    STT_REQUIRE(ncols > 0, "sttode_linear_cols: ncols must be positive");
+    LinJobs jobs;
+    jobs.j[0] = jobs.j[1] = jobs.j[2] = mkjob(X1, ld1, K1, X2, ld2, K2, WP, bias, out, ldo, N, relu);
+    return lin_launch(jobs, 1, ncols, N / 16, (K1 + K2) / 16, (hipStream_t)stream);
+}
+
+// The three per-agent layer-1 pre-activations of the decoder in ONE launch:
+//   A0x = W1x[:, pf|state] [pf | state0] + b1x ; A0y likewise (block 0) ; A1y = W1y'[:, pf] pf + b1y' (block 1)
+extern "C" int sttode_agent_preact(const float* pf, const float* state0, const float* WAx, const float* b1x, const float* WAy,
+                                   const float* b1y, const float* WA1, const float* b11, float* A0x, float* A0y, float* A1y,
+                                   int n, void* stream) {
+    STT_REQUIRE(pf && state0 && WAx && b1x && WAy && b1y && WA1 && b11 && A0x && A0y && A1y, "sttode_agent_preact: null pointer");
+    STT_REQUIRE(n > 0, "sttode_agent_preact: n must be positive");
+    LinJobs jobs;
+    jobs.j[0] = mkjob(pf, 128, 128, state0, 96, 96, WAx, b1x, A0x, 512, 512, 0);
+    jobs.j[1] = mkjob(pf, 128, 128, state0, 96, 96, WAy, b1y, A0y, 512, 512, 0);
+    jobs.j[2] = mkjob(pf, 128, 128, nullptr, 0, 0, WA1, b11, A1y, 512, 512, 0);
+    return lin_launch(jobs, 3, n, 32, 14, (hipStream_t)stream);
+}
+
+#define MLP0_LDS(TX, NY) (2 * MLP0_CHW * 16 + (256 + 16 * ((TX) > (NY) ? (TX) : (NY))) * 4)
 #define MLP1_LDS(NY) (2 * MLP1_CHW * 16 + (256 + 16 * (NY)) * 4)
 
 extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
@@ -461,11 +526,12 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
                                  void* stream_) {
     STT_REQUIRE(A0x && A0y && stream && biases && z && xpad && dbuf && ybuf, "sttode_mlp_block0: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0, "sttode_mlp_block0: ncols and K must be positive");
-    const int n3x = (TPX + 1) / 2, n3y = (NOY + 1) / 2;
-    STT_REQUIRE(total_chunks == 32 + n3x + n3y, "sttode_mlp_block0: weight stream must hold 16+N3x+16+N3y chunks");
+    STT_REQUIRE(total_chunks == 64 + TPX + NOY, "sttode_mlp_block0: weight stream must hold (32+TPX) + (32+NOY) chunks");
     const int ngroups = (ncols + 63) / 64;
-    int grid = 2 * num_cus();
-    if (grid > ngroups) grid = ngroups;
+    int grid = 3 * num_cus();          // 3 workgroups per CU; even blockIdx = x role, odd = y role
+    if (grid > 2 * ngroups) grid = 2 * ngroups;
+    grid &= ~1;
+    if (grid < 2) grid = 2;
     hipStream_t s = (hipStream_t)stream_;
 #define L0(TX, NY)                                                                                                              \
     do {                                                                                                                        \

@@ -34,6 +34,9 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
                                                         float* __restrict__ g,                       // [n][64]
                                                         float* __restrict__ qkv,                     // [n][192]
                                                         int n, int Tlen) {
+    __shared__ f32x4 sPos[16 * 64];  // pos-encoder fc fragments: identical for every frame, shared by the 4 waves
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) sPos[i] = w.posP[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * 16 >= n) return;
@@ -42,27 +45,36 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
     f32x4 f[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) f[it] = ld4(w.fc2b + 16 * it + 4 * q);
+    // fc2 fragments of frame t+1 are prefetched while frame t is consumed (16 x 1 KiB per frame, straight from L2)
+    f32x4 w2n[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w2n[i] = w.fc2P[((size_t)(i >> 2) * 4 * Tlen + (i & 3)) * 64 + lane];
     for (int t = 0; t < Tlen; ++t) {
         const float xin = enc_in[((size_t)colc * Tlen + t) * 4 + q];
-        f32x4 xt[4], pt[4];
+        f32x4 xt[4], pt[4], w2c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w2c[i] = w2n[i];
+        {
+            const int tn = t + 1 < Tlen ? t + 1 : t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w2n[i] = w.fc2P[((size_t)(i >> 2) * 4 * Tlen + 4 * tn + (i & 3)) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 4; ++it)
             xt[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.fc1P[it * 64 + lane], xin, ld4(w.fc1b + 16 * it + 4 * q), 0, 0, 0);
-        STT_FENCE();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             f32x4 a = ld4(w.peb + (size_t)t * 64 + 16 * it + 4 * q);
 #pragma unroll
-            for (int T = 0; T < 4; ++T) a = mfma_k16(a, w.posP[(it * 4 + T) * 64 + lane], xt[T]);
+            for (int T = 0; T < 4; ++T) a = mfma_k16(a, sPos[(it * 4 + T) * 64 + lane], xt[T]);
             pt[it] = a;
         }
-        STT_FENCE();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
 #pragma unroll
-            for (int T = 0; T < 4; ++T) f[it] = mfma_k16(f[it], w.fc2P[((size_t)it * 4 * Tlen + 4 * t + T) * 64 + lane], pt[T]);
+            for (int T = 0; T < 4; ++T) f[it] = mfma_k16(f[it], w2c[it * 4 + T], pt[T]);
         }
-        STT_FENCE();
     }
     const float lastf = last_flag[colc] ? 1.0f : 0.0f;
     f32x4 gg[4];
@@ -235,14 +247,30 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
     f32x4 ff[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) ff[it] = ld4(w.l2b + 16 * it + 4 * q);
+    // FFN 64 -> 1024 -> 64, one 16-wide hidden tile at a time; the 8 weight fragments of tile ht+1 are in flight
+    // from L2 while tile ht feeds the MFMAs
+    f32x4 wn1[4], wn2[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) { wn1[T] = w.l1P[T * 64 + lane]; wn2[T] = w.l2P[(T * 64) * 64 + lane]; }
+    f32x4 hbn = ld4(w.l1b + 4 * q);
 #pragma unroll 1
     for (int ht = 0; ht < 64; ++ht) {
-        f32x4 hid = ld4(w.l1b + 16 * ht + 4 * q);
+        f32x4 wc1[4], wc2[4];
 #pragma unroll
-        for (int T = 0; T < 4; ++T) hid = mfma_k16(hid, w.l1P[(ht * 4 + T) * 64 + lane], x[T]);
+        for (int T = 0; T < 4; ++T) { wc1[T] = wn1[T]; wc2[T] = wn2[T]; }
+        f32x4 hid = hbn;
+        {
+            const int hn = ht + 1 < 64 ? ht + 1 : ht;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { wn1[T] = w.l1P[(hn * 4 + T) * 64 + lane]; wn2[T] = w.l2P[(T * 64 + hn) * 64 + lane]; }
+            hbn = ld4(w.l1b + 16 * hn + 4 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch a whole tile ahead (hipcc otherwise sinks the loads to their uses)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hid = mfma_k16(hid, wc1[T], x[T]);
         hid = relu4(hid);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) ff[it] = mfma_k16(ff[it], w.l2P[(it * 64 + ht) * 64 + lane], hid);
+        for (int it = 0; it < 4; ++it) ff[it] = mfma_k16(ff[it], wc2[it], hid);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) x[it] = x[it] + ff[it];

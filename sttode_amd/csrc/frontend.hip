@@ -83,25 +83,52 @@ __global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T,
     if (last_flag) last_flag[a] = last;
 }
 
-__global__ void best_of_k_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n, int K, int Tf, float scale,
-                                 float* __restrict__ ade, float* __restrict__ fde) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per agent: lanes stride the K*Tf displacement norms (coalesced 8-byte reads), per-sample sums by a
+// segmented pass through LDS-free shuffles is overkill here: K*Tf <= a few hundred, so each lane owns whole samples
+// k = lane, lane+64, ... only when K > 64; otherwise lanes split (k, t) pairs and reduce with xor-shuffles per sample.
+__global__ __launch_bounds__(256) void best_of_k_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n, int K,
+                                                        int Tf, float scale, float* __restrict__ ade, float* __restrict__ fde) {
+    __shared__ float sd[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int a = blockIdx.x * 4 + w;
     if (a >= n) return;
-    const float* g = gt + (size_t)a * Tf * 2;
+    const float2* g = reinterpret_cast<const float2*>(gt + (size_t)a * Tf * 2);
+    const float2* p = reinterpret_cast<const float2*>(pred + (size_t)a * K * Tf * 2);
+    const int tot = K * Tf;
     float best_a = INFINITY, best_f = INFINITY;
-    for (int k = 0; k < K; ++k) {
-        const float* p = pred + ((size_t)a * K + k) * Tf * 2;
-        float sum = 0.f, dl = 0.f;
-        for (int t = 0; t < Tf; ++t) {
-            const float dx = (p[2 * t] - g[2 * t]) * scale, dy = (p[2 * t + 1] - g[2 * t + 1]) * scale;
-            dl = sqrtf(dx * dx + dy * dy);
-            sum += dl;
+    if (tot <= 1024) {
+        // stage all K*Tf distances in LDS (coalesced global reads), then lanes reduce whole samples
+        for (int i = lane; i < tot; i += 64) {
+            const float2 v = p[i], r = g[i % Tf];
+            const float dx = (v.x - r.x) * scale, dy = (v.y - r.y) * scale;
+            sd[w][i] = sqrtf(dx * dx + dy * dy);
         }
-        best_a = fminf(best_a, sum / (float)Tf);
-        best_f = fminf(best_f, dl);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < K; k += 64) {
+            float sum = 0.f;
+            for (int t = 0; t < Tf; ++t) sum += sd[w][k * Tf + t];
+            best_a = fminf(best_a, sum / (float)Tf);
+            best_f = fminf(best_f, sd[w][k * Tf + Tf - 1]);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            float sum = 0.f, dl = 0.f;
+            for (int t = 0; t < Tf; ++t) {
+                const float2 v = p[k * Tf + t], r = g[t];
+                const float dx = (v.x - r.x) * scale, dy = (v.y - r.y) * scale;
+                dl = sqrtf(dx * dx + dy * dy);
+                sum += dl;
+            }
+            best_a = fminf(best_a, sum / (float)Tf);
+            best_f = fminf(best_f, dl);
+        }
     }
-    ade[a] = best_a;
-    fde[a] = best_f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        best_a = fminf(best_a, __shfl_xor(best_a, o, 64));
+        best_f = fminf(best_f, __shfl_xor(best_f, o, 64));
+    }
+    if (lane == 0) { ade[a] = best_a; fde[a] = best_f; }
 }
 
 extern "C" int sttode_frontend_scenes(const float* past, const int* scene_ptr, int n, int S, int Tp, int TPX, int vel_from_norm,
@@ -146,7 +173,7 @@ extern "C" int sttode_best_of_k(const float* pred, const float* gt, int n, int K
                                 void* stream) {
     STT_REQUIRE(pred && gt && ade && fde, "sttode_best_of_k: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && Tf > 0, "sttode_best_of_k: n, K, Tf must be positive");
-    hipLaunchKernelGGL(best_of_k_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, pred, gt, n, K, Tf, scale, ade, fde);
+    hipLaunchKernelGGL(best_of_k_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, gt, n, K, Tf, scale, ade, fde);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,10 @@ struct SttodeModel {
     int col_parts;
     hipStream_t part_stream[STT_MAX_PARTS];
     hipEvent_t ev_agents, ev_part[STT_MAX_PARTS];
+    // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
+    // (per trajectory) of call i on sB; two workspace slots alternate.
+    hipStream_t sA, sB;
+    hipEvent_t ev_call, evA_done[2], evB_done[2];
     bool timing;
     std::vector<TimRec> recs;
     std::vector<hipEvent_t> pool;
@@ -61,6 +65,12 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
         ok = hipEventCreateWithFlags(&m->ev_part[p], hipEventDisableTiming) == hipSuccess &&
              (p == 0 || hipStreamCreateWithFlags(&m->part_stream[p], hipStreamNonBlocking) == hipSuccess);
     }
+    ok = ok && hipStreamCreateWithFlags(&m->sA, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&m->sB, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
+    for (int p = 0; p < 2 && ok; ++p)
+        ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->evB_done[p], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         delete m;
         stt_set_error("sttode_model_create: could not create streams / events");
@@ -76,7 +86,9 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     for (auto e : m->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); (void)hipEventDestroy(m->ev_agents);
     for (int p = 0; p < STT_MAX_PARTS; ++p) { (void)hipEventDestroy(m->ev_part[p]); if (p) (void)hipStreamDestroy(m->part_stream[p]); }
-    (void)hipStreamDestroy(m->side);
+    (void)hipStreamDestroy(m->side); (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB);
+    (void)hipEventDestroy(m->ev_call);
+    for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
     delete m;
     return 0;
 }
@@ -163,10 +175,10 @@ struct StageTimer {
         if (_rc) return _rc;                        \
     } while (0)
 
-static int forward_common(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z,
-                          float* pred, hipStream_t s) {
+// stage A: everything per AGENT (encoder, block-0 GRU on the side stream, layer-1 pre-activations), on stream s
+static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, hipStream_t s) {
     const float* const* W = m->w;
-    const int K = m->K, Tp = m->Tp, Tf = m->Tf, TPX = m->TPX, NOY = m->NOY;
+    const int Tp = m->Tp, TPX = m->TPX;
     float* xpad = ws + off[STT_B_XPAD];
     float* g = ws + off[STT_B_G];
     float* qkv = ws + off[STT_B_QKV];
@@ -174,7 +186,6 @@ static int forward_common(SttodeModel* m, float* ws, const long* off, int n, int
     float* pf = ws + off[STT_B_PF];
     float* state0 = ws + off[STT_B_STATE0];
     float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
-    float *dbuf = ws + off[STT_B_DBUF], *ybuf = ws + off[STT_B_YBUF], *state1 = ws + off[STT_B_STATE1];
 
     // fork: block-0 conv+GRU (per agent) only needs the front-end output; it runs beside the encoder
     STT_HIP(hipEventRecord(m->ev_fork, s));
@@ -204,10 +215,20 @@ static int forward_common(SttodeModel* m, float* ws, const long* off, int n, int
                          W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], g,
                          attn_src, ld_attn, pf, n, 12.0f, s));
     STT_HIP(hipStreamWaitEvent(s, m->ev_join, 0));  // join
-    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, state0, 96, 96, W[STT_W_B0_XWA], W[STT_W_B0_XB1], A0x, 512, n, 512, 0, s));
-    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, state0, 96, 96, W[STT_W_B0_YWA], W[STT_W_B0_YB1], A0y, 512, n, 512, 0, s));
-    RUN(STT_STAGE_LINEAR, s, sttode_linear_cols(pf, 128, 128, nullptr, 0, 0, W[STT_W_B1_YWA], W[STT_W_B1_YB1], A1y, 512, n, 512, 0, s));
-    // per-trajectory chain, split into column parts at agent boundaries (pointers are simply offset)
+    RUN(STT_STAGE_LINEAR, s,
+        sttode_agent_preact(pf, state0, W[STT_W_B0_XWA], W[STT_W_B0_XB1], W[STT_W_B0_YWA], W[STT_W_B0_YB1], W[STT_W_B1_YWA], W[STT_W_B1_YB1],
+                            A0x, A0y, A1y, n, s));
+    return 0;
+}
+
+// stage B: everything per TRAJECTORY (block-0 MLPs, block-1 GRU, block-1 MLP + epilogue), on stream s
+static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n, const float* z, float* pred, hipStream_t s) {
+    const float* const* W = m->w;
+    const int K = m->K, Tp = m->Tp, Tf = m->Tf, TPX = m->TPX, NOY = m->NOY;
+    const float* xpad = ws + off[STT_B_XPAD];
+    const float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
+    float *dbuf = ws + off[STT_B_DBUF], *ybuf = ws + off[STT_B_YBUF], *state1 = ws + off[STT_B_STATE1];
+    // optional split into column parts at agent boundaries (pointers are simply offset)
     int P = m->col_parts;
     if (P > n) P = n;
     if (P > 1) STT_HIP(hipEventRecord(m->ev_agents, s));
@@ -234,32 +255,81 @@ static int forward_common(SttodeModel* m, float* ws, const long* off, int n, int
     return 0;
 }
 
+static int frontend(SttodeModel* m, float* ws, const long* off, const float* past, const int* scene_ptr, int n, int S, int nbaN,
+                    hipStream_t s) {
+    if (scene_ptr) {
+        RUN(STT_STAGE_FRONTEND, s,
+            sttode_frontend_scenes(past, scene_ptr, n, S, m->Tp, m->TPX, 1, ws + off[STT_B_SCENE_ORIG],
+                                   (int*)(ws + off[STT_B_AGENT_SCENE]), ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR],
+                                   ws + off[STT_B_ORIG], (int*)(ws + off[STT_B_LAST]), s));
+    } else {
+        RUN(STT_STAGE_FRONTEND, s,
+            sttode_frontend_nba(past, n, nbaN, m->Tp, m->TPX, ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR],
+                                ws + off[STT_B_ORIG], (int*)(ws + off[STT_B_LAST]), s));
+    }
+    return 0;
+}
+
+// serial form: everything on the caller's stream
+static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
+                      float* pred, hipStream_t s) {
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
+    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s)) return rc;
+    return stage_trajectories(m, ws, off, n, z, pred, s);
+}
+
+// pipelined form: stage A on sA, stage B on sB, two workspace slots; the caller later waits with sttode_wait(slot)
+static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
+                     float* pred, int slot, hipStream_t s) {
+    STT_REQUIRE(slot == 0 || slot == 1, "sttode_inference_*_async: slot must be 0 or 1");
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
+    STT_HIP(hipStreamWaitEvent(m->sA, m->ev_call, 0));
+    STT_HIP(hipStreamWaitEvent(m->sA, m->evB_done[slot], 0));    // the slot's previous user (call i-2) has drained
+    if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, m->sA)) return rc;
+    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA)) return rc;
+    STT_HIP(hipEventRecord(m->evA_done[slot], m->sA));
+    STT_HIP(hipStreamWaitEvent(m->sB, m->ev_call, 0));
+    STT_HIP(hipStreamWaitEvent(m->sB, m->evA_done[slot], 0));
+    if (int rc = stage_trajectories(m, ws, off, n, z, pred, m->sB)) return rc;
+    STT_HIP(hipEventRecord(m->evB_done[slot], m->sB));
+    return 0;
+}
+
 extern "C" int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
                                        float* workspace, float* pred, void* stream) {
     STT_REQUIRE(m && past && scene_ptr && z && workspace && pred, "sttode_inference_scenes: null pointer");
     STT_REQUIRE(n > 0 && S > 0, "sttode_inference_scenes: n and S must be positive");
-    long off[STT_B_COUNT], tot;
-    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    float* ws = workspace;
-    RUN(STT_STAGE_FRONTEND, s,
-        sttode_frontend_scenes(past, scene_ptr, n, S, m->Tp, m->TPX, 1, ws + off[STT_B_SCENE_ORIG], (int*)(ws + off[STT_B_AGENT_SCENE]),
-                               ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR], ws + off[STT_B_ORIG],
-                               (int*)(ws + off[STT_B_LAST]), s));
-    return forward_common(m, ws, off, n, 1, 1, z, pred, s);
+    return run_serial(m, past, scene_ptr, n, S, 1, 1, z, workspace, pred, (hipStream_t)stream);
 }
 
 extern "C" int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                                     void* stream) {
     STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba: null pointer");
     STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba: B and N must be positive");
-    const int n = B * N;
-    long off[STT_B_COUNT], tot;
-    if (int rc = sttode_workspace_layout(m, n, 0, off, &tot)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    float* ws = workspace;
-    RUN(STT_STAGE_FRONTEND, s,
-        sttode_frontend_nba(past, n, N, m->Tp, m->TPX, ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR],
-                            ws + off[STT_B_ORIG], (int*)(ws + off[STT_B_LAST]), s));
-    return forward_common(m, ws, off, n, B, N, z, pred, s);
+    return run_serial(m, past, nullptr, B * N, 0, B, N, z, workspace, pred, (hipStream_t)stream);
+}
+
+extern "C" int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
+                                             float* workspace, float* pred, int slot, void* stream) {
+    STT_REQUIRE(m && past && scene_ptr && z && workspace && pred, "sttode_inference_scenes_async: null pointer");
+    STT_REQUIRE(n > 0 && S > 0, "sttode_inference_scenes_async: n and S must be positive");
+    return run_async(m, past, scene_ptr, n, S, 1, 1, z, workspace, pred, slot, (hipStream_t)stream);
+}
+
+extern "C" int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace,
+                                          float* pred, int slot, void* stream) {
+    STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba_async: null pointer");
+    STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba_async: B and N must be positive");
+    return run_async(m, past, nullptr, B * N, 0, B, N, z, workspace, pred, slot, (hipStream_t)stream);
+}
+
+// make `stream` wait until the async call that used `slot` has produced its predictions
+extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
+    STT_REQUIRE(m && (slot == 0 || slot == 1), "sttode_wait: bad arguments");
+    STT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->evB_done[slot], 0));
+    return 0;
 }

@@ -144,6 +144,8 @@ class STTODENet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._mode = None
+        self._async_calls = 0
+        self._async_bufs = {}
         self.to(self.device)
 
     # ------------------------------------------------------------------ plumbing
@@ -178,6 +180,7 @@ class STTODENet(nn.Module):
             self._packed_key = key
             self._native = capi.NativeModel(self._packed, a.past_length, a.future_length, a.sample_k) if self.device.type == 'cuda' else None
             self._wscache = {}
+            self._async_bufs = {}
         return self._packed
 
     def native(self):
@@ -380,6 +383,51 @@ class STTODENet(nn.Module):
                      'ybuf': self._view(buf, off, 'ybuf', m, 16 * NOY), 'state1': self._view(buf, off, 'state1', m, 96)}
         self.diverse_pred = pred
         return pred.permute(1, 0, 2, 3)
+
+    @torch.no_grad()
+    def inference_async(self, z=None):
+        """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  The per-agent stage
+        runs on an internal stream beside the per-trajectory kernels of the previous call; two slots alternate, so at most
+        two calls may be in flight: call ``wait(handle)`` (which returns the [K, n, Tf, 2] view) before the second-next call.
+        Inputs set by set_data / set_scene_batch / set_data_nba must stay unmodified until then.  Bitwise identical to inference()."""
+        self._require_gpu()
+        a = self.args
+        if self._mode is None:
+            raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference_async()')
+        nat = self.native()
+        K, n = a.sample_k, self._past.shape[0]
+        if z is None:
+            z = torch.randn(n * K, a.zdim, device=self.device)
+        elif not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
+            z = _f32(z, self.device)
+        if tuple(z.shape) != (n * K, a.zdim):
+            raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
+        S = self._S if self._mode == 'scenes' else 0
+        slot = self._async_calls & 1
+        self._async_calls += 1
+        key = (n, S, slot)
+        if key not in self._async_bufs:
+            if len(self._async_bufs) > 8:
+                raise capi.SttodeError('too many distinct batch shapes in flight for the async pipeline; call reset_async()')
+            _, tot = nat.layout(n, S)
+            self._async_bufs[key] = (torch.empty(tot, dtype=torch.float32, device=self.device),
+                                     torch.empty(n, K, a.future_length, 2, dtype=torch.float32, device=self.device))
+        buf, pred = self._async_bufs[key]
+        st = capi.stream_ptr()
+        if self._mode == 'scenes':
+            capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, st)
+        else:
+            capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, st)
+        return {'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None))}
+
+    def wait(self, handle):
+        """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
+        capi.call('sttode_wait', self.native().h, handle['slot'], capi.stream_ptr())
+        return handle['pred'].permute(1, 0, 2, 3)
+
+    def reset_async(self):
+        torch.cuda.synchronize(self.device)
+        self._async_bufs = {}
 
     @torch.no_grad()
     def best_of_k(self, pred_nk, gt=None, scale=1.0):

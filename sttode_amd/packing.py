@@ -57,7 +57,7 @@ def toeplitz_conv(w, Tp, TPX):
     return M
 
 
-def mlp_stream(W1v, W2, W3p, CHT):
+def mlp_stream(W1v, W2, W3p, CHT, pad_to=0):
     """Weight stream of ONE MLP for csrc/decoder.hip mlp_phase: 32/CHT "L12" chunks
     { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] } followed by N3 "L3" chunks { W3 tiles [TP3][16] } (zero padded to
     the common chunk size).  Returns a float32 array [n_chunks, CHW*4]."""
@@ -67,11 +67,17 @@ def mlp_stream(W1v, W2, W3p, CHT):
     assert P1.shape[0] == 32 and P2.shape[:2] == (16, 32) and P3.shape[1] == 16
     KTV, NO = P1.shape[1], P3.shape[0]
     chw = CHT * (KTV + 16) * 64 * 4          # floats per chunk
+    if pad_to:
+        assert pad_to * 4 >= chw
+    used = chw
+    chw = pad_to * 4 if pad_to else chw
     tp3 = (chw // 4) // (16 * 64)            # layer-3 output tiles per chunk
     chunks = []
     for ch in range(32 // CHT):
         parts = [P1[CHT * ch + hf].reshape(-1) for hf in range(CHT)] + [P2[:, CHT * ch + hf].reshape(-1) for hf in range(CHT)]
-        chunks.append(np.concatenate(parts))
+        buf = np.zeros(chw, np.float32)
+        buf[:used] = np.concatenate(parts)
+        chunks.append(buf)
     for c3 in range((NO + tp3 - 1) // tp3):
         buf = np.zeros(chw, np.float32)
         part = P3[c3 * tp3:(c3 + 1) * tp3].reshape(-1)
@@ -140,7 +146,7 @@ def pack_block(sd, i, Tp, Tf, first):
         W3p[: W3.shape[0]] = W3
         if first:
             out[nm + '_WA'] = pk16(np.concatenate([W1[:, :128], W1[:, 160:]], axis=1))   # [pf | state0] per agent
-            streams.append(mlp_stream(W1[:, 128:160], W2, W3p, CHT=2))                    # z per trajectory
+            streams.append(mlp_stream(W1[:, 128:160], W2, W3p, CHT=1, pad_to=1280))       # z per trajectory
         else:
             out[nm + '_WA'] = pk16(W1[:, :128])                                           # pf per agent
             streams.append(mlp_stream(W1[:, 128:], W2, W3p, CHT=1))                       # [z | state] per trajectory
