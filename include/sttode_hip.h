@@ -96,6 +96,11 @@ int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, c
                       const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred, int ncols,
                       int K, int Tf, int NOY, void* stream_);
 
+/* One decoder MLP of a non-first DecomposeBlock with B = [z | state] per column (model/STTODE.py:71-75): raw output tiles
+ * out [ncols,16*NO].  Used by the training-forward path for the last block's decoder_x (recover_traj, :339-341). */
+int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* biases, const float* z,
+                    const float* state, float* out, int ncols, int K, int NO, void* stream_);
+
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
 

@@ -26,6 +26,7 @@ SIGNATURES = {
     'sttode_agent_preact': [_P] * 11 + [_I, _P],
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],

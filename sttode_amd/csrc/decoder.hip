@@ -438,6 +438,49 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
     }
 }
 
+// generic single MLP over columns (training-forward needs decoder_x of the LAST block too: recover_traj sums the x_hat of
+// every block, model/STTODE.py:339-341).  KTV = 8: B = [z | state];  output raw tiles [ncols][16*NO].
+template <int NO>
+__global__ __launch_bounds__(256, 2) void mlp_cols_kernel(const float* __restrict__ A0, const f32x4* __restrict__ blob, int nchunks,
+                                                          const float* __restrict__ biases, const float* __restrict__ z,
+                                                          const float* __restrict__ state, float* __restrict__ out, int ncols, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* lds = reinterpret_cast<f32x4*>(smem);
+    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP1_CHW);
+    for (int i = threadIdx.x; i < 256 + 16 * NO; i += 256) sBias[i] = biases[i];
+    WStream<MLP1_CHW> st;
+    st.init(blob, lds, nchunks);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int ngroups = (ncols + 63) >> 6;
+    int g = blockIdx.x;
+    auto agent_of = [&](int gg) {
+        int col = gg * 64 + wave * 16 + c;
+        col = col < ncols ? col : ncols - 1;
+        return col / K;
+    };
+    f32x4 a0n[1];
+    a0n[0] = ld4(A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    for (; g < ngroups; g += gridDim.x) {
+        const int col = g * 64 + wave * 16 + c;
+        const int colc = col < ncols ? col : ncols - 1;
+        const int agent = colc / K;
+        const int gn = g + (int)gridDim.x;
+        const int agent_nx = agent_of(gn < ngroups ? gn : g);
+        f32x4 B[8];
+        B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
+        B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 6; ++T) B[2 + T] = ld4(state + (size_t)colc * 96 + 16 * T + 4 * q);
+        f32x4 o[NO];
+        mlp_phase<8, 1, NO, MLP1_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, o, lane, q);
+        if (col < ncols) {
+#pragma unroll
+            for (int t = 0; t < NO; ++t) st4(out + (size_t)col * (16 * NO) + 16 * t + 4 * q, o[t]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
@@ -575,6 +618,34 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
         default: STT_REQUIRE(false, "sttode_mlp_block1: unsupported NOY; built: 1 2 3 5");
     }
 #undef L1
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// One MLP with B = [z | state] per column (decoder_x / decoder_y of a non-first DecomposeBlock, model/STTODE.py:71-75):
+// out [ncols, 16*NO] raw output tiles.  stream: packing.mlp_stream(W1[:, 128:], W2, W3 padded, CHT = 1), 32 + NO chunks.
+extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* biases, const float* z,
+                               const float* state, float* out, int ncols, int K, int NO, void* stream_) {
+    STT_REQUIRE(A0 && stream && biases && z && state && out, "sttode_mlp_cols: null pointer");
+    STT_REQUIRE(ncols > 0 && K > 0 && total_chunks == 32 + NO, "sttode_mlp_cols: bad ncols/K/chunk count");
+    const int ngroups = (ncols + 63) / 64;
+    int grid = 2 * num_cus();
+    if (grid > ngroups) grid = ngroups;
+    hipStream_t s = (hipStream_t)stream_;
+#define LC(NY)                                                                                                              \
+    do {                                                                                                                    \
+        STT_HIP(hipFuncSetAttribute((const void*)mlp_cols_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
+        hipLaunchKernelGGL((mlp_cols_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A0, (const f32x4*)stream, total_chunks, biases, z, \
+                           state, out, ncols, K);                                                                           \
+    } while (0)
+    switch (NO) {
+        case 1: LC(1); break;
+        case 2: LC(2); break;
+        case 3: LC(3); break;
+        case 5: LC(5); break;
+        default: STT_REQUIRE(false, "sttode_mlp_cols: unsupported NO; built: 1 2 3 5");
+    }
+#undef LC
     STT_HIP(hipGetLastError());
     return 0;
 }

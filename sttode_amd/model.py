@@ -174,7 +174,9 @@ class STTODENet(nn.Module):
             a = self.args
             host = {'past': packing.pack_trunk(sd, 'past_encoder.', a.past_length),
                     'blk0': packing.pack_block(sd, 0, a.past_length, a.future_length, first=True),
-                    'blk1': packing.pack_block(sd, 1, a.past_length, a.future_length, first=False)}
+                    'blk1': packing.pack_block(sd, 1, a.past_length, a.future_length, first=False),
+                    'future': packing.pack_trunk(sd, 'future_encoder.', a.future_length),
+                    'post': packing.pack_posterior(sd)}
             self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
                                 for k, v in d.items()} for g, d in host.items()}
             self._packed_key = key
@@ -255,19 +257,21 @@ class STTODENet(nn.Module):
         self._N = self.agent_num
         self.scene_orig = self._past  # sic (model/STTODE.py:473)
 
-    # ------------------------------------------------------------------ compute
-    def _frontend(self):
+    # ------------------------------------------------------------------ compute (staged API, kernel by kernel)
+    def _f(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _frontend(self, vel_from_norm):
         a, dev = self.args, self.device
         n, Tp = self._past.shape[0], a.past_length
         TPX = packing.tiles_x(Tp)
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        ws = {'xpad': f(n, 16 * TPX), 'enc_in': f(n, Tp, 4), 'cur': f(n, 2), 'orig': f(n, 2),
+        ws = {'xpad': self._f(n, 16 * TPX), 'enc_in': self._f(n, Tp, 4), 'cur': self._f(n, 2), 'orig': self._f(n, 2),
               'last': torch.empty(n, dtype=torch.int32, device=dev)}
         st = capi.stream_ptr()
         if self._mode == 'scenes':
-            ws['scene_orig'] = f(self._S, 2)
+            ws['scene_orig'] = self._f(self._S, 2)
             ws['agent_scene'] = torch.empty(n, dtype=torch.int32, device=dev)
-            capi.call('sttode_frontend_scenes', self._past, self._scene_ptr, n, self._S, Tp, TPX, 1, ws['scene_orig'],
+            capi.call('sttode_frontend_scenes', self._past, self._scene_ptr, n, self._S, Tp, TPX, int(vel_from_norm), ws['scene_orig'],
                       ws['agent_scene'], ws['xpad'], ws['enc_in'], ws['cur'], ws['orig'], ws['last'], st)
             self.scene_orig = ws['scene_orig'][0] if self._S == 1 else ws['scene_orig']
         else:
@@ -275,71 +279,147 @@ class STTODENet(nn.Module):
                       ws['last'], st)
         return ws
 
-    def _encode(self, W, enc_in, last, Tlen, L, Nslots):
-        """Trunk forward: enc_in [n,Tlen,4] -> past_feature-like [n,128].  L = attention length (scenes per call
-        on the NBA path, 1 otherwise), Nslots = agent slots (attention batch)."""
-        dev = self.device
+    def _encode(self, W, enc_in, last, Tlen):
+        """Trunk forward (PastEncoder / FutureEncoder shared part): enc_in [n,Tlen,4] -> [n,128]."""
         n = enc_in.shape[0]
+        L, Nslots = (self.batch_size, self._N) if self._mode == 'nba' else (1, 1)
         st = capi.stream_ptr()
-        g = torch.empty(n, 64, dtype=torch.float32, device=dev)
-        qkv = torch.empty(n, 192, dtype=torch.float32, device=dev)
+        g, qkv = self._f(n, 64), self._f(n, 192)
         capi.call('sttode_embed_qkv', W['fc1P'], W['fc1b'], W['posP'], W['peb'], W['fc2P'], W['fc2b'], W['fc3P'], W['fc3b'],
                   W['fc3last'], W['inP'], W['inb'], enc_in, last, g, qkv, n, Tlen, st)
         if L > 1:
             # self-attention with L == S: scores are used untransposed (hyptransformerlib.py:261-265), i.e.
             # rows = keys, columns = queries, values indexed by the column:  out_i = sum_j softmax_j(-d(k_i, q_j)) v_j
-            attn = torch.empty(n, 64, dtype=torch.float32, device=dev)
+            attn = self._f(n, 64)
             e = qkv.element_size()
-            q_ptr, k_ptr, v_ptr = qkv.data_ptr(), qkv.data_ptr() + 64 * e, qkv.data_ptr() + 128 * e
-            capi.call('sttode_mhgsa_attn', k_ptr, q_ptr, v_ptr, attn, None, None, L, L, Nslots,
-                      Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192, Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
+            capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, None, None, L, L,
+                      Nslots, Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192, Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
             attn_ptr, ld = attn, 64
         else:
-            # attention over one element: softmax == 1  =>  output == v
-            attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192
-        pf = torch.empty(n, 128, dtype=torch.float32, device=dev)
+            attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192  # softmax over one element == 1  =>  output == v
+        pf = self._f(n, 128)
         capi.call('sttode_post_attn', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
                   W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], g, attn_ptr, ld, pf, n, self.ODE_TIME, st)
         self._keep = (g, qkv)
         return pf
 
+    @torch.no_grad()
     def encode_history(self):
-        """model/STTODE.py:488-496."""
+        """model/STTODE.py:488-496 (self.inputs uses velocities of the un-normalised track, :432-433,456)."""
         self._require_gpu()
         P = self.packed()
-        self._ws = self._frontend()
-        L = self.batch_size if self._mode == 'nba' else 1
-        self.past_feature = self._encode(P['past'], self._ws['enc_in'], self._ws['last'], self.args.past_length, L,
-                                         self._N if self._mode == 'nba' else 1)
+        self._ws = self._frontend(vel_from_norm=0)
+        self.past_feature = self._encode(P['past'], self._ws['enc_in'], self._ws['last'], self.args.past_length)
+        n, Tp = self._past.shape[0], self.args.past_length
+        self.past_traj = self._ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2)
+        self.cur_location = self.past_traj[:, -1:]
         return self.past_feature
 
-    def _decode(self, pf, z, ws, K):
-        a, dev = self.args, self.device
+    @torch.no_grad()
+    def fu_encoder(self, eps_q=None, eps_p=None):
+        """model/STTODE.py:498-525: posterior q(z | past, future) and prior samples."""
+        a, P = self.args, self.packed()
+        if self._future is None:
+            raise capi.SttodeError('fu_encoder needs the future (set_data / set_scene_batch with future, or set_data_nba)')
+        n, Tf = self._past.shape[0], a.future_length
+        st = capi.stream_ptr()
+        enc_f = self._f(n, Tf, 4)
+        last_past = self._past[:, -1].contiguous()
+        mode = 0 if self._mode == 'scenes' else 1
+        capi.call('sttode_frontend_future', self._future, last_past, n, Tf, mode, self._N or 1, self._ws.get('scene_orig'),
+                  self._ws.get('agent_scene'), self._scene_ptr if mode == 0 else None, enc_f, st)
+        ff = self._encode(P['future'], enc_f, self._ws['last'], Tf)
+        h = self._f(n, 128)
+        capi.call('sttode_linear_cols', self.past_feature, 128, 128, ff, 128, 128, P['post']['outP'], P['post']['outb'], h, 128, n, 128, 1, st)
+        self.qz_param = self._f(n, 2 * a.zdim)
+        capi.call('sttode_linear_cols', h, 128, 128, None, 0, 0, P['post']['qzP'], P['post']['qzb'], self.qz_param, 2 * a.zdim, n,
+                  2 * a.zdim, 0, st)
+        self.qz_mu, self.qz_logvar = self.qz_param[:, :a.zdim], self.qz_param[:, a.zdim:]
+        eps_q = torch.randn(n, a.zdim, device=self.device) if eps_q is None else _f32(eps_q, self.device)
+        self.qz_sampled = (self.qz_mu + eps_q * torch.exp(0.5 * self.qz_logvar)).contiguous()   # Normal.rsample, :89-93
+        self.pz_sampled = torch.randn(n, a.zdim, device=self.device) if eps_p is None else _f32(eps_p, self.device)
+        orig = self._ws['orig']
+        self.future_traj = self._future - orig[:, None, :]
+        return self.qz_param
+
+    def _decode(self, pf, z, ws, K, orig=None, want_recover=False):
+        """Decoder.forward (model/STTODE.py:320-347) kernel by kernel; returns pred [n,K,Tf,2] (+ recover [n*K,Tp,2])."""
+        a = self.args
         P = self.packed()
         b0, b1 = P['blk0'], P['blk1']
         n, Tp, Tf = pf.shape[0], a.past_length, a.future_length
         TPX, NOY = packing.tiles_x(Tp), packing.tiles_y(Tf)
         m = n * K
         st = capi.stream_ptr()
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        state0 = f(n, 96)
-        capi.call('sttode_gru_cols', ws['xpad'], b0['convP'], b0['convB'], b0['wihP'], b0['whhP'], b0['gbias'], state0, n, Tp, TPX, st,
-                  tag='gru_cols[block0,agents]')
-        A0x, A0y, A1y = f(n, 512), f(n, 512), f(n, 512)
-        capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['x_WA'], b0['x_b1'], A0x, 512, n, 512, 0, st)
-        capi.call('sttode_linear_cols', pf, 128, 128, state0, 96, 96, b0['y_WA'], b0['y_b1'], A0y, 512, n, 512, 0, st)
-        capi.call('sttode_linear_cols', pf, 128, 128, None, 0, 0, b1['y_WA'], b1['y_b1'], A1y, 512, n, 512, 0, st)
-        dbuf, ybuf = f(m, 16 * TPX), f(m, 16 * NOY)
-        capi.call('sttode_mlp_block0', A0x, A0y, b0['stream'], b0['n_chunks'], b0['biases'], z, ws['xpad'], dbuf, ybuf, m, K, TPX,
+        z = _f32(z, self.device)
+        orig = ws['orig'] if orig is None else orig
+        state0 = self._f(n, 96)
+        capi.call('sttode_gru_cols', ws['xpad'], b0['convP'], b0['convB'], b0['wihP'], b0['whhP'], b0['gbias'], state0, n, Tp, TPX, st)
+        A0x, A0y, A1y = self._f(n, 512), self._f(n, 512), self._f(n, 512)
+        capi.call('sttode_agent_preact', pf, state0, b0['x_WA'], b0['x_b1'], b0['y_WA'], b0['y_b1'], b1['y_WA'], b1['y_b1'], A0x, A0y, A1y, n, st)
+        dbuf, ybuf = self._f(m, 16 * TPX), self._f(m, 16 * NOY)
+        capi.call('sttode_mlp_block0', A0x, A0y, b0['stream'], b0['n_chunks'], b0['biases'], z, ws['xpad'], dbuf, ybuf, m, K, TPX, NOY, st)
+        state1 = self._f(m, 96)
+        capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st)
+        pred = self._f(n, K, Tf, 2)
+        capi.call('sttode_mlp_block1', A1y, b1['stream'], b1['n_chunks'], b1['biases'], z, state1, ybuf, ws['cur'], orig, pred, m, K, Tf,
                   NOY, st)
-        state1 = f(m, 96)
-        capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st,
-                  tag='gru_cols[block1,trajectories]')
-        pred = f(n, K, Tf, 2)
-        capi.call('sttode_mlp_block1', A1y, b1['stream'], b1['n_chunks'], b1['biases'], z, state1, ybuf, ws['cur'], ws['orig'], pred,
-                  m, K, Tf, NOY, st)
-        self._dbg = dict(state0=state0, A0x=A0x, A0y=A0y, A1y=A1y, dbuf=dbuf, ybuf=ybuf, state1=state1)
-        return pred
+        self._dbg = dict(state0=state0, dbuf=dbuf, ybuf=ybuf, state1=state1)
+        if not want_recover:
+            return pred
+        # reconstruction = x_hat0 + x_hat1 (the last block's decoder_x is live in training, :337-341)
+        A1x = self._f(n, 512)
+        capi.call('sttode_linear_cols', pf, 128, 128, None, 0, 0, b1['x_WA'], b1['x_b1'], A1x, 512, n, 512, 0, st)
+        xh1 = self._f(m, 16 * TPX)
+        capi.call('sttode_mlp_cols', A1x, b1['x_stream'], b1['x_n_chunks'], b1['x_biases'], z, state1, xh1, m, K, TPX, st)
+        x_true = ws['xpad'].repeat_interleave(K, dim=0) if K > 1 else ws['xpad']
+        x_hat0 = x_true - dbuf
+        recover = (x_hat0 + xh1)[:, :2 * Tp].reshape(m, Tp, 2)
+        return pred, recover
+
+    @torch.no_grad()
+    def decoder_future_0(self, qz_sampled, eps20=None):
+        """model/STTODE.py:534-551: K = 1 decode with the posterior sample (normalised coordinates), then draws the 20 prior samples."""
+        a = self.args
+        zeros = torch.zeros_like(self._ws['orig'])
+        pred, rec = self._decode(self.past_feature, qz_sampled, self._ws, 1, orig=zeros, want_recover=True)
+        self.pred_traj = pred.reshape(pred.shape[0], a.future_length, 2)
+        self.recover_traj = rec
+        n = self.past_feature.shape[0]
+        self.past_feature_repeat = self.past_feature.repeat_interleave(20, dim=0)
+        self.pz_sampled = torch.randn(n * 20, a.zdim, device=self.device) if eps20 is None else _f32(eps20, self.device)
+
+    @torch.no_grad()
+    def decoder_future_1(self, pz_sampled):
+        """model/STTODE.py:529-532: K = 20 decode with prior samples -> diverse_pred_traj [n,20,Tf,2] (normalised)."""
+        zeros = torch.zeros_like(self._ws['orig'])
+        self.diverse_pred_traj = self._decode(self.past_feature, pz_sampled, self._ws, 20, orig=zeros)
+        self.attn_weights = None
+
+    @torch.no_grad()
+    def forward(self, eps_q=None, eps_p=None, eps20=None):
+        """Training objective VALUES (model/STTODE.py:553-568, losses :372-395): (total_loss, loss_pred, loss_recover, loss_kl,
+        loss_diverse).  Every network evaluation runs on the HIP kernels; the four scalar reductions are host-side glue on
+        device tensors.  No autograd graph is built: backward kernels are SURVEY.md §8f rank 1 (next), so ``total_loss``
+        carries no grad (training itself still needs the reference module)."""
+        a = self.args
+        B = self.batch_size if self._mode == 'nba' else 1
+        N = self.agent_num
+        self.encode_history()
+        self.fu_encoder(eps_q, eps_p)
+        self.decoder_future_0(self.qz_sampled, eps20)
+        loss_pred = (self.future_traj - self.pred_traj).pow(2).sum() / B / self.pred_traj.shape[1]
+        loss_recover = (self.past_traj - self.recover_traj).pow(2).sum() / B / self.recover_traj.shape[1]
+        # KL(q || N(0, I)) in the reference's two-distribution form (Normal.kl with p given, :98-106)
+        t1 = self.qz_mu / (1.0 + 1e-8)
+        t2 = torch.exp(0.5 * self.qz_logvar) / (1.0 + 1e-8)
+        kl = 0.5 * (t1 * t1 + t2 * t2) - 0.5 - torch.log(t2)
+        loss_kl = (kl.sum() / (B * N)).clamp_min(a.min_clip)
+        self.decoder_future_1(self.pz_sampled)
+        diff = self.future_traj.unsqueeze(1) - self.diverse_pred_traj
+        loss_diverse = diff.pow(2).sum(dim=-1).sum(dim=-1).min(dim=1)[0].mean()
+        total = loss_pred + loss_recover + loss_kl + loss_diverse
+        return total, loss_pred.item(), loss_recover.item(), loss_kl.item(), loss_diverse.item()
 
     @torch.no_grad()
     def inference(self, data=None, z=None):
@@ -439,6 +519,3 @@ class STTODENet(nn.Module):
         fde = torch.empty_like(ade)
         capi.call('sttode_best_of_k', pred_nk, gt, n, K, Tf, float(scale), ade, fde, capi.stream_ptr())
         return ade, fde
-
-    def forward(self):
-        raise NotImplementedError('training objective (model/STTODE.py:553-568) needs backward kernels: SURVEY.md §8f rank 1 (next)')

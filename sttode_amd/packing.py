@@ -155,4 +155,21 @@ def pack_block(sd, i, Tp, Tf, first):
     out['stream'] = np.ascontiguousarray(np.concatenate(streams, axis=0))
     out['n_chunks'] = out['stream'].shape[0]
     out['biases'] = np.ascontiguousarray(np.concatenate(biases))
+    if not first:
+        # decoder_x of a non-first block: dead in inference(), needed by forward() (recover_traj, model/STTODE.py:339-341)
+        W1, W2, W3 = g('decoder_x.layers.0.weight'), g('decoder_x.layers.1.weight'), g('decoder_x.layers.2.weight')
+        W3p = np.zeros((16 * TPX, 256), np.float32)
+        W3p[: W3.shape[0]] = W3
+        out['x_WA'] = pk16(W1[:, :128])
+        out['x_b1'] = g('decoder_x.layers.0.bias')
+        out['x_stream'] = mlp_stream(W1[:, 128:], W2, W3p, CHT=1)
+        out['x_n_chunks'] = out['x_stream'].shape[0]
+        out['x_biases'] = np.ascontiguousarray(np.concatenate([g('decoder_x.layers.1.bias'), pad_vec(g('decoder_x.layers.2.bias'), 16 * TPX)]))
     return out
+
+
+def pack_posterior(sd):
+    """FutureEncoder head (model/STTODE.py:258-261,297-299): out_mlp 256->128 relu, qz_layer 128->2*zdim."""
+    g = lambda k: np.asarray(sd['future_encoder.' + k], np.float32)
+    return {'outP': pk16(g('out_mlp.affine_layers.0.weight')), 'outb': g('out_mlp.affine_layers.0.bias'),
+            'qzP': pk16(g('qz_layer.weight')), 'qzb': g('qz_layer.bias')}

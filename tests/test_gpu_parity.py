@@ -294,3 +294,18 @@ def test_async_pipeline_is_bitwise_identical_to_serial():
     for i, (a, b) in enumerate(zip(serial, outs)):
         assert torch.equal(a, b), f'batch {i}: async != serial'
     m.reset_async()
+
+
+def test_forward_loss_values_vs_reference_golden(golden):
+    """forward() objective values (posterior encoder, K=1 decode with recover_traj, K=20 decode,
+    four losses) against the reference's own forward() with injected noise."""
+    g = golden('eth_forward_losses')
+    m = hip_model('eth', 8, 12)
+    m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
+    tot, lp, lr, lk, ld = m.forward(eps_q=torch.from_numpy(g['eps_q']), eps_p=torch.from_numpy(g['eps_p1']),
+                                    eps20=torch.from_numpy(g['eps_p20']))
+    assert_close(m.qz_param.cpu().numpy(), g['qz_param'], what='qz_param')
+    assert_close(m.pred_traj.cpu().numpy(), g['pred_traj'], what='pred_traj')
+    assert_close(m.recover_traj.cpu().numpy(), g['recover_traj'], what='recover_traj')
+    assert_close(m.diverse_pred_traj.cpu().numpy(), g['diverse_pred_traj'], what='diverse_pred_traj')
+    np.testing.assert_allclose([float(tot), lp, lr, lk, ld], g['losses'], rtol=1e-4)
