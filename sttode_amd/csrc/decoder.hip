@@ -136,51 +136,61 @@ struct LinJob {
 };
 struct LinJobs { LinJob j[3]; };
 
-template <int RT, int KTMAX>
+template <int RT, int CT>
 __global__ __launch_bounds__(256) void linear_cols_kernel(LinJobs jobs, int ncols) {
+    // wave: CT column tiles x RT row tiles; every A fragment feeds CT MFMA quads (weight traffic from L2 / CT), every
+    // B tile RT quads; the operands of k-tile T+1 are in flight while k-tile T feeds the MFMAs.
     const LinJob J = jobs.j[blockIdx.z];
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = threadIdx.x >> 6;
-    const int ctile = blockIdx.x * 4 + wave;
-    const int rt0 = blockIdx.y * RT;
-    if (ctile * 16 >= ncols || rt0 >= J.NT) return;
-    const int col = ctile * 16 + c;
-    const int colc = col < ncols ? col : ncols - 1;
+    const int col0 = blockIdx.x * (16 * CT);
+    const int rt0 = (blockIdx.y * 4 + wave) * RT;
+    if (col0 >= ncols || rt0 >= J.NT) return;
     const int KT = J.KT1 + J.KT2;
-    f32x4 B[KTMAX];
+    int colc[CT];
 #pragma unroll
-    for (int T = 0; T < KTMAX; ++T) {
-        if (T < KT)
-            B[T] = T < J.KT1 ? ld4(J.X1 + (size_t)colc * J.ld1 + 16 * T + 4 * q) : ld4(J.X2 + (size_t)colc * J.ld2 + 16 * (T - J.KT1) + 4 * q);
-    }
-    f32x4 acc[RT], wn[RT];
+    for (int j = 0; j < CT; ++j) { const int col = col0 + 16 * j + c; colc[j] = col < ncols ? col : ncols - 1; }
+    auto ldB = [&](int j, int T) {
+        return T < J.KT1 ? ld4(J.X1 + (size_t)colc[j] * J.ld1 + 16 * T + 4 * q) : ld4(J.X2 + (size_t)colc[j] * J.ld2 + 16 * (T - J.KT1) + 4 * q);
+    };
+    int rts[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) rts[i] = rt0 + i < J.NT ? rt0 + i : J.NT - 1;
+    f32x4 acc[RT][CT], wn[RT], bn[CT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-        const int rt = rt0 + i < J.NT ? rt0 + i : J.NT - 1;
-        acc[i] = J.bias ? ld4(J.bias + 16 * rt + 4 * q) : splat4(0.f);
-        wn[i] = J.WP[((size_t)rt * KT) * 64 + lane];
+        const f32x4 bv = J.bias ? ld4(J.bias + 16 * rts[i] + 4 * q) : splat4(0.f);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = bv;
+        wn[i] = J.WP[((size_t)rts[i] * KT) * 64 + lane];
     }
 #pragma unroll
-    for (int T = 0; T < KTMAX; ++T) {
-        if (T < KT) {
-            f32x4 wc[RT];
+    for (int j = 0; j < CT; ++j) bn[j] = ldB(j, 0);
+#pragma unroll 1
+    for (int T = 0; T < KT; ++T) {
+        f32x4 wc[RT], bc[CT];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) wc[i] = wn[i];
-            if (T + 1 < KT) {
+        for (int i = 0; i < RT; ++i) wc[i] = wn[i];
 #pragma unroll
-                for (int i = 0; i < RT; ++i) {
-                    const int rt = rt0 + i < J.NT ? rt0 + i : J.NT - 1;
-                    wn[i] = J.WP[((size_t)rt * KT + T + 1) * 64 + lane];
-                }
-            }
+        for (int j = 0; j < CT; ++j) bc[j] = bn[j];
+        const int Tn = T + 1 < KT ? T + 1 : T;
 #pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i] = mfma_k16(acc[i], wc[i], B[T]);
-        }
-    }
-    if (col < ncols) {
+        for (int i = 0; i < RT; ++i) wn[i] = J.WP[((size_t)rts[i] * KT + Tn) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) bn[j] = ldB(j, Tn);
 #pragma unroll
         for (int i = 0; i < RT; ++i)
-            if (rt0 + i < J.NT) st4(J.out + (size_t)col * J.ldo + 16 * (rt0 + i) + 4 * q, J.relu ? relu4(acc[i]) : acc[i]);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = mfma_k16(acc[i][j], wc[i], bc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = col0 + 16 * j + c;
+        if (col < ncols) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                if (rt0 + i < J.NT) st4(J.out + (size_t)col * J.ldo + 16 * (rt0 + i) + 4 * q, J.relu ? relu4(acc[i][j]) : acc[i][j]);
+        }
     }
 }
 
@@ -501,15 +511,22 @@ extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float
     STT_REQUIRE(ncols > 0 && Tp > 0 && (TPX == 1 || TPX == 2) && 2 * Tp <= 16 * TPX, "sttode_gru_cols: bad ncols/Tp/TPX");
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (ncols + 15) / 16;
-    int grid = num_cus();
-    if (grid > ntiles) grid = ntiles;
+    // Workgroup shape follows the amount of work: a full launch uses 16 waves (4 per SIMD) on every CU; a small one
+    // (per-agent block 0: a few hundred tiles) uses just enough waves per workgroup to cover the tiles, so it occupies
+    // only as many CUs as it needs and the concurrently running encoder kernels get the rest of the chip.
+    int nw = (ntiles + num_cus() - 1) / num_cus();
+    if (nw < 4) nw = 4;
+    if (nw > GRU_THREADS / 64) nw = GRU_THREADS / 64;
+    const int threads = 64 * nw;
+    int grid = (ntiles + nw - 1) / nw;
+    if (grid > num_cus()) grid = num_cus();
     if (TPX == 1) {
         STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
-        hipLaunchKernelGGL(gru_cols_kernel<1>, dim3(grid), dim3(GRU_THREADS), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
+        hipLaunchKernelGGL(gru_cols_kernel<1>, dim3(grid), dim3(threads), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     } else {
         STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
-        hipLaunchKernelGGL(gru_cols_kernel<2>, dim3(grid), dim3(GRU_THREADS), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
+        hipLaunchKernelGGL(gru_cols_kernel<2>, dim3(grid), dim3(threads), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     }
     STT_HIP(hipGetLastError());
@@ -531,9 +548,14 @@ static LinJob mkjob(const float* X1, int ld1, int K1, const float* X2, int ld2, 
     return j;
 }
 static int lin_launch(const LinJobs& jobs, int njobs, int ncols, int maxNT, int maxKT, hipStream_t s) {
-    dim3 grid((ncols + 63) / 64, (maxNT + 3) / 4, njobs);
-    if (maxKT <= 8) hipLaunchKernelGGL((linear_cols_kernel<4, 8>), grid, dim3(256), 0, s, jobs, ncols);
-    else hipLaunchKernelGGL((linear_cols_kernel<4, 16>), grid, dim3(256), 0, s, jobs, ncols);
+    (void)maxKT;
+    if (ncols > 64) {
+        dim3 grid((ncols + 63) / 64, (maxNT + 15) / 16, njobs);  // wave = 64 columns x 4 row tiles, 4 waves = 16 row tiles
+        hipLaunchKernelGGL((linear_cols_kernel<4, 4>), grid, dim3(256), 0, s, jobs, ncols);
+    } else {
+        dim3 grid((ncols + 15) / 16, (maxNT + 15) / 16, njobs);  // few columns: one column tile per wave
+        hipLaunchKernelGGL((linear_cols_kernel<4, 1>), grid, dim3(256), 0, s, jobs, ncols);
+    }
     STT_HIP(hipGetLastError());
     return 0;
 }

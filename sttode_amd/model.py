@@ -232,6 +232,8 @@ class STTODENet(nn.Module):
         self._scene_ptr = torch.as_tensor(scene_ptr, dtype=torch.int32).to(dev).contiguous()
         if self._past.dim() != 3 or self._past.shape[1] != a.past_length or self._past.shape[2] != 2:
             raise ValueError(f'past must be [n, {a.past_length}, 2], got {tuple(self._past.shape)}')
+        if self._past.shape[0] == 0 or self._scene_ptr.numel() < 2:
+            raise ValueError('empty batch: need at least one scene with at least one agent')
         if not (isinstance(scene_ptr, torch.Tensor) and scene_ptr.is_cuda):
             # host-side CSR is validated here; a device-resident CSR is trusted (validating it would force a D2H sync
             # per call -- callers on the hot loop keep their batches resident, bench.py)

@@ -125,3 +125,29 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.hpp', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_input_validation_on_host():
+    """Empty / malformed batches are rejected before anything is launched (host logic, no GPU)."""
+    import torch
+    from helpers import make_args
+    from sttode_amd import STTODENet, capi
+    m = STTODENet(make_args(), 'cpu')
+    with pytest.raises(ValueError):
+        m.set_scene_batch(np.zeros((0, 8, 2), np.float32), None, np.array([0], np.int32))            # empty batch
+    with pytest.raises(ValueError):
+        m.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 3, 3, 5], np.int32))   # empty scene
+    with pytest.raises(ValueError):
+        m.set_scene_batch(np.zeros((5, 7, 2), np.float32), None, np.array([0, 5], np.int32))         # wrong obs_len
+    with pytest.raises(ValueError):
+        m.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 4], np.int32))         # CSR does not end at n
+    with pytest.raises(capi.SttodeError):
+        m.inference(None)                                                                              # nothing set
+    with pytest.raises(NotImplementedError):
+        STTODENet(make_args(Tp=8, Tf=12).__class__(**{**vars(make_args()), 'num_decompose': 3}), 'cpu')
+    a = make_args()
+    a.learn_prior = True
+    m2 = STTODENet(a, 'cpu')
+    m2.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 5], np.int32))
+    with pytest.raises((NotImplementedError, capi.SttodeError)):
+        m2.inference(None)

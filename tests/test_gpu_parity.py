@@ -309,3 +309,35 @@ def test_forward_loss_values_vs_reference_golden(golden):
     assert_close(m.recover_traj.cpu().numpy(), g['recover_traj'], what='recover_traj')
     assert_close(m.diverse_pred_traj.cpu().numpy(), g['diverse_pred_traj'], what='diverse_pred_traj')
     np.testing.assert_allclose([float(tot), lp, lr, lk, ld], g['losses'], rtol=1e-4)
+
+
+def test_nba_single_scene_batch_vs_oracle():
+    """NBA branch with B = 1 (attention length 1 inside the NBA code path) and an odd agent count."""
+    from sttode_amd import scenes
+    m = hip_model('nba', 5, 10)
+    ora = oracle_model('nba', 5, 10)
+    for B, N in ((1, 11), (3, 7)):
+        d = scenes.nba_batch(50 + B, B, N=N)
+        z = scenes.latents(60 + B, B * N)
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        m.set_data_nba(data)
+        out = m.inference(data, z=torch.from_numpy(z)).cpu().numpy()
+        with torch.no_grad():
+            ora.set_data_nba(data)
+            ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
+        assert_close(out, ref, what=f'nba B={B} N={N}')
+
+
+def test_random_latents_follow_torch_generator():
+    """z=None draws from torch's global generator like Normal.rsample (model/STTODE.py:89-93): seeding reproduces the call."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    obs, pred = scenes.eth_scene(77, n_min=5, n_max=5)
+    m.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred))
+    torch.manual_seed(3)
+    a = m.inference(None).clone()
+    torch.manual_seed(3)
+    b = m.inference(None).clone()
+    c = m.inference(None)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert tuple(a.shape) == (20, 5, 12, 2) and bool(torch.isfinite(a).all())
