@@ -85,20 +85,20 @@ int sttode_agent_preact(const float* pf, const float* state0, const float* WAx, 
 /* DecomposeBlock 0 back half for all K samples (model/STTODE.py:71-75, Decoder.forward :336-339):
  * decoder_x and decoder_y MLPs; writes dbuf = x_true - x_hat0 [m,16*TPX] and ybuf = y_hat0 [m,16*NOY].
  * A0x/A0y [n,512]: per-agent part of layer 0 (sttode_linear_cols); stream: packed weight-chunk stream of both MLPs
- * (packing.mlp_stream), total_chunks = (32 + TPX) + (32 + NOY); biases = [b2x | b3x | b2y | b3y]. */
-int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
+ * (packing.mlp_stream: fragment-ordered 18 KiB chunks, layer-2/3 biases inside), total_chunks = (32 + TPX) + (32 + NOY). */
+int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks,
                       const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
                       void* stream_);
 
 /* DecomposeBlock 1 back half + Decoder epilogue (model/STTODE.py:338,343-346) + "+ scene_orig" (:621-622):
- * pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur_location) + scene_orig.  total_chunks = 32 + NOY; biases = [b2y | b3y]. */
-int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* biases, const float* z,
+ * pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur_location) + scene_orig.  total_chunks = 32 + NOY (24 KiB chunks). */
+int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* z,
                       const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred, int ncols,
                       int K, int Tf, int NOY, void* stream_);
 
 /* One decoder MLP of a non-first DecomposeBlock with B = [z | state] per column (model/STTODE.py:71-75): raw output tiles
  * out [ncols,16*NO].  Used by the training-forward path for the last block's decoder_x (recover_traj, :339-341). */
-int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* biases, const float* z,
+int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* z,
                     const float* state, float* out, int ncols, int K, int NO, void* stream_);
 
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
@@ -138,9 +138,8 @@ enum SttodeWeight {
     STT_W_INB, STT_W_OUTP, STT_W_OUTB, STT_W_INFOP, STT_W_INFOB, STT_W_GATEP, STT_W_GATEB, STT_W_LN1W, STT_W_LN1B, STT_W_L1P,
     STT_W_L1B, STT_W_L2P, STT_W_L2B, STT_W_LN2W, STT_W_LN2B,
     STT_W_B0_CONVP, STT_W_B0_CONVB, STT_W_B0_WIHP, STT_W_B0_WHHP, STT_W_B0_GBIAS, STT_W_B0_XWA, STT_W_B0_XB1, STT_W_B0_YWA,
-    STT_W_B0_YB1, STT_W_B0_STREAM, STT_W_B0_BIASES,
+    STT_W_B0_YB1, STT_W_B0_STREAM,
     STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
-    STT_W_B1_BIASES,
     STT_W_COUNT
 };
 
@@ -175,6 +174,11 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
  * past [B*N,Tp,2]; attention length = B over the N agent slots. */
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
+
+/* Diagnostic (not on the product path): sustained TFLOP/s of a register-only v_mfma_f32_16x16x4_f32 loop on every CU
+ * (waves_per_cu in {4, 8, 16}; negative: the same with one ds_read_b128 A fragment per MFMA quad, the operand traffic of the
+ * real kernels); scratch: >= 256*1024 floats.  Synchronises. */
+int sttode_diag_mfma_peak(int waves_per_cu, int iters, int repeats, float* scratch, double* tflops, void* stream);
 
 /* Pipelined forms: the per-agent stage runs on an internal stream beside the per-trajectory stage of the PREVIOUS call
  * (its kernels fill the grid tails of the big kernels).  Two workspace/pred slots alternate (slot = call index & 1);

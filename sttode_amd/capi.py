@@ -24,9 +24,9 @@ SIGNATURES = {
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_agent_preact': [_P] * 11 + [_I, _P],
-    'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
@@ -47,14 +47,15 @@ SIGNATURES = {
     'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_wait': [_P, _I, _P],
+    'sttode_diag_mfma_peak': [_I, _I, _I, _P, ctypes.POINTER(ctypes.c_double), _P],
 }
 
 # enum SttodeWeight / SttodeBuffer / SttodeStage of include/sttode_hip.h (order is ABI)
 WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'fc2b', 'fc3P', 'fc3b', 'fc3last', 'inP', 'inb', 'outP',
                                        'outb', 'infoP', 'infob', 'gateP', 'gateb', 'ln1w', 'ln1b', 'l1P', 'l1b', 'l2P', 'l2b', 'ln2w',
                                        'ln2b')]
-                + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream', 'biases')]
-                + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream', 'biases')])
+                + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream')]
+                + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')])
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
            'A1y', 'dbuf', 'ybuf', 'state1')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
                 f32x4 az = ld4(sB + 1 * 96 + 16 * j + 4 * q);
                 f32x4 ai = ld4(sB + 2 * 96 + 16 * j + 4 * q);
                 f32x4 ah = ld4(sB + 3 * 96 + 16 * j + 4 * q);
+                // MFMA issue must win the SIMD's arbitration against the other waves' gate math (VALU bursts): high
+                // priority while this wave feeds the matrix pipe, low while it runs its own transcendental block.
+                __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int T = 0; T < 2; ++T) {
                     ar = mfma_k16(ar, sWih[((0 + j) * 2 + T) * 64 + lane], e[T]);
@@ -107,12 +110,17 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
                     az = mfma_k16(az, sWhh[((6 + j) * 6 + T) * 64 + lane], h[T]);
                     ah = mfma_k16(ah, sWhh[((12 + j) * 6 + T) * 64 + lane], h[T]);
                 }
+                __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#ifdef STT_DIAG_NOGATES
+                    hn[j][r] = (ar[r] + az[r]) * 1e-3f + (ai[r] + ah[r]) * 1e-3f + 0.5f * h[j][r];
+#else
                     const float rg = sigmoidf_(ar[r]);
                     const float zg = sigmoidf_(az[r]);
                     const float ng = tanhf_(ai[r] + rg * ah[r]);
                     hn[j][r] = (1.0f - zg) * ng + zg * h[j][r];
+#endif
                 }
             }
 #pragma unroll
@@ -204,38 +212,55 @@ __global__ __launch_bounds__(256) void linear_cols_kernel(LinJobs jobs, int ncol
 // committed (registers -> LDS, one barrier) afterwards.  The position counter never resets, so the stream wraps
 // from the last chunk of one column group to the first chunk of the next without a bubble.
 // ---------------------------------------------------------------------------------------------------
+// LDS-DMA weight stream: chunk p+1 is copied L2 -> LDS by global_load_lds_dwordx4 (no VGPR round trip, no ds_write) while
+// chunk p feeds the MFMAs from the other LDS buffer.  The fragment-ordered chunk is lane-linear, which is exactly the shape
+// the DMA writes (wave-uniform LDS base + lane*16 B).  The per-agent layer-1 pre-activations (a 16-byte gather per lane and
+// chunk) travel the same way into a 1 KiB per-wave slot: with a DMA in flight hipcc drains vmcnt(0) before the first use of
+// ANY register-destination global load, so the loop must not contain one.  A step is
+//     a0 = slot[lane] (ds_read, the value DMA'd during the previous step)
+//     begin(): DMA chunk p+1 -> buffer (p+1)&1 (its last readers passed the barrier of step p-1); DMA next a0 -> slot
+//     ... MFMAs on cur() ...
+//     end():   __syncthreads() -- the barrier's fence waits vmcnt(0) first, which is exactly the wait the DMAs need.
+// The layer-2/3 biases ride in the spare space of the layer-3 chunks (packing.mlp_stream), so they also arrive by DMA.
 template <int CHW>
 struct WStream {
-    // Register staging with a prefetch distance of TWO chunks: while chunk p feeds the MFMAs from LDS buffer p&1,
-    // chunk p+1 is already in the other LDS buffer and chunk p+2 is in flight from L2 into `stage`.  A step is
-    //     begin(): commit stage (chunk p+1, issued one whole step ago => landed) to LDS buffer (p+1)&1,
-    //              then issue the global loads of chunk p+2;
-    //     ... MFMAs on cur() ...
-    //     end():   one barrier (publishes buffer (p+1)&1, retires the reads of buffer p&1).
-    // sched_barrier(0) pins that order (hipcc otherwise sinks the LDS writes and their vmcnt waits into the MFMAs).
-    static constexpr int PER = CHW / 256;
     const f32x4* blob;
     f32x4* lds;
+    f32x4* slot;  // this wave's 64 x 16 B a0 slot
     int total, pos;
-    f32x4 stage[PER];
-    __device__ __forceinline__ void load_stage(int chunk) {
-        const f32x4* src = blob + (size_t)(chunk % total) * CHW;  // blob already points at this role's first chunk
-#pragma unroll
-        for (int i = 0; i < PER; ++i) stage[i] = src[i * 256 + threadIdx.x];
+    static __device__ __forceinline__ void glds16(const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
-    __device__ __forceinline__ void init(const f32x4* b, f32x4* l, int tot) {
-        blob = b; lds = l; total = tot; pos = 0;
+    __device__ __forceinline__ void dma(int chunk, int buf) {
+        // CHW/64 wave-instructions of 1 KiB each, dealt round-robin to the 4 waves (CHW need not be a multiple of 256)
+        constexpr int N16 = CHW / 64;
+        // readfirstlane makes the wave id provably uniform: scalar branch below, M0 (the LDS base) computed on the SALU
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const f32x4* src = blob + (size_t)(chunk % total) * CHW + lane;
+        f32x4* dst = lds + buf * CHW;  // wave-uniform base; the hardware adds lane * 16 B
 #pragma unroll
-        for (int i = 0; i < PER; ++i) lds[i * 256 + threadIdx.x] = blob[i * 256 + threadIdx.x];
-        load_stage(1);
+        for (int i = 0; i < (N16 + 3) / 4; ++i) {
+            const int idx = i * 4 + wave;
+            if (idx < N16) glds16(src + idx * 64, dst + idx * 64);
+        }
+    }
+    __device__ __forceinline__ void dma_a0(const float* lane_ptr) { glds16(lane_ptr, slot); }
+    __device__ __forceinline__ void init(const f32x4* b, f32x4* l, f32x4* a0slots, int tot, const float* a0_first) {
+        blob = b; lds = l; total = tot; pos = 0;
+        slot = a0slots + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 64;
+        dma(0, 0);
+        dma_a0(a0_first);
     }
     __device__ __forceinline__ const f32x4* cur() const { return lds + (pos & 1) * CHW; }
-    __device__ __forceinline__ void begin() {
+    __device__ __forceinline__ void begin(const float* a0_next) {
         __builtin_amdgcn_sched_barrier(0);
-        f32x4* dst = lds + ((pos + 1) & 1) * CHW;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) dst[i * 256 + threadIdx.x] = stage[i];
-        load_stage(pos + 2);
+        dma(pos + 1, (pos + 1) & 1);
+        dma_a0(a0_next);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void begin_nogather() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma(pos + 1, (pos + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void end() {
@@ -246,13 +271,12 @@ struct WStream {
     }
 };
 
-// One MLP for this wave's 16 columns.  On entry a0n holds the layer-1 pre-activation of chunk 0 (prefetched by the
-// previous phase); on exit it holds chunk 0 of the NEXT phase (read from a0_next).  sBias (LDS) = [b2 (256) | b3 (16*NO)].
-template <int KTV, int CHT, int NO, int CHW>
+// One MLP for this wave's 16 columns (CHT = 1: one 16-row tile of the hidden layer per chunk).  a0 points at this lane's
+// A0 row (+4q); a0_next at the row the NEXT phase starts with.
+template <int KTV, int NO, int CHW>
 __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV], const float* __restrict__ a0,
-                                          const float* __restrict__ a0_next, f32x4 (&a0n)[CHT], const float* sBias,
-                                          f32x4 (&out)[NO], int lane, int q) {
-    constexpr int NCH = 32 / CHT;
+                                          const float* __restrict__ a0_next, f32x4 (&out)[NO], int lane, int q) {
+    constexpr int NCH = 32;
     constexpr int TP3 = CHW / (16 * 64);
     constexpr int N3 = (NO + TP3 - 1) / TP3;
     static_assert(TP3 >= 1, "chunk too small for a layer-3 tile");
@@ -261,41 +285,38 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
     for (int it = 0; it < 16; ++it) acc2[it] = splat4(0.f);
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-        f32x4 a0c[CHT];
-#pragma unroll
-        for (int hf = 0; hf < CHT; ++hf) a0c[hf] = a0n[hf];
-        const float* nxt = (ch + 1 < NCH) ? a0 + (ch + 1) * CHT * 16 : a0_next;
-#pragma unroll
-        for (int hf = 0; hf < CHT; ++hf) a0n[hf] = ld4(nxt + hf * 16);
-        st.begin();
+        f32x4 h1 = st.slot[lane];  // A0[agent][16 ch + 4q ..], DMA'd during the previous step
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the DMA issued next
+        st.begin((ch + 1 < NCH) ? a0 + (ch + 1) * 16 : a0_next);
         const f32x4* buf = st.cur();
+        STT_FENCE();
 #pragma unroll
-        for (int hf = 0; hf < CHT; ++hf) {
-            STT_FENCE();
-            f32x4 h1 = a0c[hf];
+        for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, buf[T * 64 + lane], B[T]);
+        h1 = relu4(h1);
+        const f32x4* w2 = buf + KTV * 64 + lane;
 #pragma unroll
-            for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, buf[(hf * KTV + T) * 64 + lane], B[T]);
-            h1 = relu4(h1);
-            const f32x4* w2 = buf + (CHT * KTV + hf * 16) * 64 + lane;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                if ((it & 7) == 0) STT_FENCE();
-                acc2[it] = mfma_k16(acc2[it], w2[it * 64], h1);
-            }
+        for (int it = 0; it < 16; ++it) {
+            if ((it & 7) == 0) STT_FENCE();
+            acc2[it] = mfma_k16(acc2[it], w2[it * 64], h1);
         }
         st.end();
     }
+    {
+        // the first layer-3 chunk is already resident (landed at the last barrier): b2 sits behind its tiles and b3
+        const float* b2 = reinterpret_cast<const float*>(st.cur() + TP3 * 16 * 64) + 16 * TP3;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) acc2[it] = relu4(acc2[it] + ld4(sBias + 16 * it + 4 * q));
+        for (int it = 0; it < 16; ++it) acc2[it] = relu4(acc2[it] + ld4(b2 + 16 * it + 4 * q));
+    }
 #pragma unroll
     for (int c3 = 0; c3 < N3; ++c3) {
-        st.begin();
+        st.begin_nogather();
         const f32x4* buf = st.cur();
+        const float* b3 = reinterpret_cast<const float*>(buf + TP3 * 16 * 64);
 #pragma unroll
         for (int oo = 0; oo < TP3; ++oo) {
             const int o = c3 * TP3 + oo;
             if (o < NO) {
-                f32x4 a = ld4(sBias + 256 + 16 * o + 4 * q);
+                f32x4 a = ld4(b3 + 16 * oo + 4 * q);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) {
                     if ((T & 7) == 0) STT_FENCE();
@@ -308,7 +329,7 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
     }
 }
 
-#define MLP0_CHW 1280                 // CHT = 1, KTV = 2 : 18 tiles = 1152 float4, padded to 1280 (20 KiB) so 256 threads split it evenly
+#define MLP0_CHW 1152                 // CHT = 1, KTV = 2 : 18 fragment tiles = 18 KiB per chunk
 #define MLP1_CHW (1 * (8 + 16) * 64)  // CHT = 1, KTV = 8 : 1536 float4 = 24 KiB per chunk
 
 // block 0: decoder_x and decoder_y MLPs per trajectory as two WORKGROUP ROLES (even blockIdx: x, odd: y): a work item is
@@ -316,13 +337,9 @@ __device__ __forceinline__ void mlp_phase(WStream<CHW>& st, const f32x4 (&B)[KTV
 // MLP's chunks.   x role: d = x_true - x_hat0 -> dbuf ;  y role: y_hat0 -> ybuf
 template <int NO, bool IS_X>
 __device__ __forceinline__ void mlp0_role(const float* __restrict__ A0, const f32x4* __restrict__ blob, int nchunks,
-                                          const float* __restrict__ biases, const float* __restrict__ z,
+                                          const float* __restrict__ z,
                                           const float* __restrict__ xpad, float* __restrict__ obuf, int ncols, int K, f32x4* lds) {
-    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP0_CHW);
-    for (int i = threadIdx.x; i < 256 + 16 * NO; i += 256) sBias[i] = biases[i];
-    WStream<MLP0_CHW> st;
-    st.init(blob, lds, nchunks);
-    __syncthreads();
+    f32x4* a0slots = lds + 2 * MLP0_CHW;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int ngroups = (ncols + 63) >> 6;  // 4 waves x 16 columns per workgroup step
     const int gstride = (int)gridDim.x >> 1;
@@ -332,8 +349,9 @@ __device__ __forceinline__ void mlp0_role(const float* __restrict__ A0, const f3
         col = col < ncols ? col : ncols - 1;
         return col / K;
     };
-    f32x4 a0n[1];
-    a0n[0] = ld4(A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    WStream<MLP0_CHW> st;
+    st.init(blob, lds, a0slots, nchunks, A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    __syncthreads();
     for (; g < ngroups; g += gstride) {
         const int col = g * 64 + wave * 16 + c;
         const int colc = col < ncols ? col : ncols - 1;
@@ -344,7 +362,7 @@ __device__ __forceinline__ void mlp0_role(const float* __restrict__ A0, const f3
         B[0] = ld4(z + (size_t)colc * 32 + 4 * q);
         B[1] = ld4(z + (size_t)colc * 32 + 16 + 4 * q);
         f32x4 o[NO];
-        mlp_phase<2, 1, NO, MLP0_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, o, lane, q);
+        mlp_phase<2, NO, MLP0_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, o, lane, q);
         if (col < ncols) {
 #pragma unroll
             for (int t = 0; t < NO; ++t) {
@@ -359,11 +377,11 @@ __device__ __forceinline__ void mlp0_role(const float* __restrict__ A0, const f3
     }
 }
 
+#define MLP0_WGS 3
 template <int TPX, int NOY>
-__global__ __launch_bounds__(256, 3) void mlp_block0_kernel(
+__global__ __launch_bounds__(256, MLP0_WGS) void mlp_block0_kernel(
     const float* __restrict__ A0x, const float* __restrict__ A0y,  // [nagents][512]
-    const f32x4* __restrict__ blob, int total_chunks,              // weight stream (x chunks, then y chunks)
-    const float* __restrict__ biases,                              // [b2x 256 | b3x 16*TPX | b2y 256 | b3y 16*NOY]
+    const f32x4* __restrict__ blob, int total_chunks,              // weight stream (x chunks, then y chunks; biases inside)
     const float* __restrict__ z,                                   // [ncols][32]
     const float* __restrict__ xpad,                                // [nagents][16*TPX] normalised past (t,c), zero padded
     float* __restrict__ dbuf,                                      // [ncols][16*TPX]
@@ -373,17 +391,16 @@ __global__ __launch_bounds__(256, 3) void mlp_block0_kernel(
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
     constexpr int NCX = 32 + TPX;  // layer-1/2 chunks + one layer-3 chunk per output tile (TP3 = 1 at this chunk size)
     if ((blockIdx.x & 1) == 0)
-        mlp0_role<TPX, true>(A0x, blob, NCX, biases, z, xpad, dbuf, ncols, K, lds);
+        mlp0_role<TPX, true>(A0x, blob, NCX, z, xpad, dbuf, ncols, K, lds);
     else
-        mlp0_role<NOY, false>(A0y, blob + (size_t)NCX * MLP0_CHW, total_chunks - NCX, biases + 256 + 16 * TPX, z, xpad, ybuf, ncols, K, lds);
+        mlp0_role<NOY, false>(A0y, blob + (size_t)NCX * MLP0_CHW, total_chunks - NCX, z, xpad, ybuf, ncols, K, lds);
 }
 
 // block 1: y MLP per trajectory with the per-trajectory GRU state; final epilogue
 //   pred[col][t][c] = ((y_hat0 + y_hat1) + cur[agent][c]) + orig[agent][c]      (model/STTODE.py:338,344,622)
 template <int NOY>
 __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
-    const float* __restrict__ A1y, const f32x4* __restrict__ blob, int total_chunks,
-    const float* __restrict__ biases,         // [b2y 256 | b3y 16*NOY]
+    const float* __restrict__ A1y, const f32x4* __restrict__ blob, int total_chunks,  // weight stream (biases inside)
     const float* __restrict__ z,              // [ncols][32]
     const float* __restrict__ state1,         // [ncols][96]
     const float* __restrict__ ybuf,           // [ncols][16*NOY]  y_hat0
@@ -393,11 +410,7 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
     int ncols, int K, int Tf2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
-    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP1_CHW);
-    for (int i = threadIdx.x; i < 256 + 16 * NOY; i += 256) sBias[i] = biases[i];
-    WStream<MLP1_CHW> st;
-    st.init(blob, lds, total_chunks);
-    __syncthreads();
+    f32x4* a0slots = lds + 2 * MLP1_CHW;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int ngroups = (ncols + 63) >> 6;
     int g = blockIdx.x;
@@ -406,8 +419,9 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
         col = col < ncols ? col : ncols - 1;
         return col / K;
     };
-    f32x4 a0n[1];
-    a0n[0] = ld4(A1y + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    WStream<MLP1_CHW> st;
+    st.init(blob, lds, a0slots, total_chunks, A1y + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    __syncthreads();
     for (; g < ngroups; g += gridDim.x) {
         const int col = g * 64 + wave * 16 + c;
         const int colc = col < ncols ? col : ncols - 1;
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
 #pragma unroll
         for (int T = 0; T < 6; ++T) B[2 + T] = ld4(state1 + (size_t)colc * 96 + 16 * T + 4 * q);
         f32x4 yo[NOY];
-        mlp_phase<8, 1, NOY, MLP1_CHW>(st, B, A1y + (size_t)agent * 512 + 4 * q, A1y + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, yo, lane, q);
+        mlp_phase<8, NOY, MLP1_CHW>(st, B, A1y + (size_t)agent * 512 + 4 * q, A1y + (size_t)agent_nx * 512 + 4 * q, yo, lane, q);
         if (col < ncols) {
             const float cx = cur[2 * agent], cy = cur[2 * agent + 1];
             const float ox = orig[2 * agent], oy = orig[2 * agent + 1];
@@ -452,15 +466,11 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
 // every block, model/STTODE.py:339-341).  KTV = 8: B = [z | state];  output raw tiles [ncols][16*NO].
 template <int NO>
 __global__ __launch_bounds__(256, 2) void mlp_cols_kernel(const float* __restrict__ A0, const f32x4* __restrict__ blob, int nchunks,
-                                                          const float* __restrict__ biases, const float* __restrict__ z,
+                                                          const float* __restrict__ z,
                                                           const float* __restrict__ state, float* __restrict__ out, int ncols, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
-    float* sBias = reinterpret_cast<float*>(lds + 2 * MLP1_CHW);
-    for (int i = threadIdx.x; i < 256 + 16 * NO; i += 256) sBias[i] = biases[i];
-    WStream<MLP1_CHW> st;
-    st.init(blob, lds, nchunks);
-    __syncthreads();
+    f32x4* a0slots = lds + 2 * MLP1_CHW;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int ngroups = (ncols + 63) >> 6;
     int g = blockIdx.x;
@@ -469,8 +479,9 @@ __global__ __launch_bounds__(256, 2) void mlp_cols_kernel(const float* __restric
         col = col < ncols ? col : ncols - 1;
         return col / K;
     };
-    f32x4 a0n[1];
-    a0n[0] = ld4(A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    WStream<MLP1_CHW> st;
+    st.init(blob, lds, a0slots, nchunks, A0 + (size_t)agent_of(g < ngroups ? g : 0) * 512 + 4 * q);
+    __syncthreads();
     for (; g < ngroups; g += gridDim.x) {
         const int col = g * 64 + wave * 16 + c;
         const int colc = col < ncols ? col : ncols - 1;
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void mlp_cols_kernel(const float* __restric
 #pragma unroll
         for (int T = 0; T < 6; ++T) B[2 + T] = ld4(state + (size_t)colc * 96 + 16 * T + 4 * q);
         f32x4 o[NO];
-        mlp_phase<8, 1, NO, MLP1_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, a0n, sBias, o, lane, q);
+        mlp_phase<8, NO, MLP1_CHW>(st, B, A0 + (size_t)agent * 512 + 4 * q, A0 + (size_t)agent_nx * 512 + 4 * q, o, lane, q);
         if (col < ncols) {
 #pragma unroll
             for (int t = 0; t < NO; ++t) st4(out + (size_t)col * (16 * NO) + 16 * t + 4 * q, o[t]);
@@ -583,17 +594,17 @@ extern "C" int sttode_agent_preact(const float* pf, const float* state0, const f
     return lin_launch(jobs, 3, n, 32, 14, (hipStream_t)stream);
 }
 
-#define MLP0_LDS(TX, NY) (2 * MLP0_CHW * 16 + (256 + 16 * ((TX) > (NY) ? (TX) : (NY))) * 4)
-#define MLP1_LDS(NY) (2 * MLP1_CHW * 16 + (256 + 16 * (NY)) * 4)
+#define MLP0_LDS(TX, NY) (2 * MLP0_CHW * 16 + 4096)
+#define MLP1_LDS(NY) (2 * MLP1_CHW * 16 + 4096)
 
-extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks, const float* biases,
+extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float* stream, int total_chunks,
                                  const float* z, const float* xpad, float* dbuf, float* ybuf, int ncols, int K, int TPX, int NOY,
                                  void* stream_) {
-    STT_REQUIRE(A0x && A0y && stream && biases && z && xpad && dbuf && ybuf, "sttode_mlp_block0: null pointer");
+    STT_REQUIRE(A0x && A0y && stream && z && xpad && dbuf && ybuf, "sttode_mlp_block0: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0, "sttode_mlp_block0: ncols and K must be positive");
     STT_REQUIRE(total_chunks == 64 + TPX + NOY, "sttode_mlp_block0: weight stream must hold (32+TPX) + (32+NOY) chunks");
     const int ngroups = (ncols + 63) / 64;
-    int grid = 3 * num_cus();          // 3 workgroups per CU; even blockIdx = x role, odd = y role
+    int grid = MLP0_WGS * num_cus();   // workgroups per CU; even blockIdx = x role, odd = y role
     if (grid > 2 * ngroups) grid = 2 * ngroups;
     grid &= ~1;
     if (grid < 2) grid = 2;
@@ -602,7 +613,7 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     do {                                                                                                                        \
         STT_HIP(hipFuncSetAttribute((const void*)mlp_block0_kernel<TX, NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP0_LDS(TX, NY))); \
         hipLaunchKernelGGL((mlp_block0_kernel<TX, NY>), dim3(grid), dim3(256), MLP0_LDS(TX, NY), s, A0x, A0y, (const f32x4*)stream, \
-                           total_chunks, biases, z, xpad, dbuf, ybuf, ncols, K);                                                \
+                           total_chunks, z, xpad, dbuf, ybuf, ncols, K);                                                \
     } while (0)
     if (TPX == 1 && NOY == 2) L0(1, 2);
     else if (TPX == 2 && NOY == 5) L0(2, 5);
@@ -616,10 +627,10 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     return 0;
 }
 
-extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* biases, const float* z,
+extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, const float* z,
                                  const float* state1, const float* ybuf, const float* cur, const float* orig, float* pred,
                                  int ncols, int K, int Tf, int NOY, void* stream_) {
-    STT_REQUIRE(A1y && stream && biases && z && state1 && ybuf && cur && orig && pred, "sttode_mlp_block1: null pointer");
+    STT_REQUIRE(A1y && stream && z && state1 && ybuf && cur && orig && pred, "sttode_mlp_block1: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && Tf > 0 && 2 * Tf <= 16 * NOY, "sttode_mlp_block1: bad ncols/K/Tf/NOY");
     STT_REQUIRE(total_chunks == 32 + NOY, "sttode_mlp_block1: weight stream must hold 32+NOY chunks");
     const int ngroups = (ncols + 63) / 64;
@@ -630,7 +641,7 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
     do {                                                                                                                    \
         STT_HIP(hipFuncSetAttribute((const void*)mlp_block1_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
         hipLaunchKernelGGL((mlp_block1_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A1y, (const f32x4*)stream, total_chunks, \
-                           biases, z, state1, ybuf, cur, orig, pred, ncols, K, 2 * Tf);                                      \
+                           z, state1, ybuf, cur, orig, pred, ncols, K, 2 * Tf);                                      \
     } while (0)
     switch (NOY) {
         case 1: L1(1); break;
@@ -646,9 +657,9 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
 
 // One MLP with B = [z | state] per column (decoder_x / decoder_y of a non-first DecomposeBlock, model/STTODE.py:71-75):
 // out [ncols, 16*NO] raw output tiles.  stream: packing.mlp_stream(W1[:, 128:], W2, W3 padded, CHT = 1), 32 + NO chunks.
-extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* biases, const float* z,
+extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* z,
                                const float* state, float* out, int ncols, int K, int NO, void* stream_) {
-    STT_REQUIRE(A0 && stream && biases && z && state && out, "sttode_mlp_cols: null pointer");
+    STT_REQUIRE(A0 && stream && z && state && out, "sttode_mlp_cols: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && total_chunks == 32 + NO, "sttode_mlp_cols: bad ncols/K/chunk count");
     const int ngroups = (ncols + 63) / 64;
     int grid = 2 * num_cus();
@@ -657,7 +668,7 @@ extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_c
 #define LC(NY)                                                                                                              \
     do {                                                                                                                    \
         STT_HIP(hipFuncSetAttribute((const void*)mlp_cols_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
-        hipLaunchKernelGGL((mlp_cols_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A0, (const f32x4*)stream, total_chunks, biases, z, \
+        hipLaunchKernelGGL((mlp_cols_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A0, (const f32x4*)stream, total_chunks, z, \
                            state, out, ncols, K);                                                                           \
     } while (0)
     switch (NO) {

@@ -241,13 +241,13 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
         hipStream_t ps = p == 0 ? s : m->part_stream[p];
         if (p > 0) STT_HIP(hipStreamWaitEvent(ps, m->ev_agents, 0));
         RUN(STT_STAGE_MLP0, ps,
-            sttode_mlp_block0(A0x + a0 * 512, A0y + a0 * 512, W[STT_W_B0_STREAM], m->n_chunks0, W[STT_W_B0_BIASES], z + c0 * 32,
+            sttode_mlp_block0(A0x + a0 * 512, A0y + a0 * 512, W[STT_W_B0_STREAM], m->n_chunks0, z + c0 * 32,
                               xpad + a0 * 16 * TPX, dbuf + c0 * 16 * TPX, ybuf + c0 * 16 * NOY, nc, K, TPX, NOY, ps));
         RUN(STT_STAGE_GRU1, ps,
             sttode_gru_cols(dbuf + c0 * 16 * TPX, W[STT_W_B1_CONVP], W[STT_W_B1_CONVB], W[STT_W_B1_WIHP], W[STT_W_B1_WHHP],
                             W[STT_W_B1_GBIAS], state1 + c0 * 96, nc, Tp, TPX, ps));
         RUN(STT_STAGE_MLP1, ps,
-            sttode_mlp_block1(A1y + a0 * 512, W[STT_W_B1_STREAM], m->n_chunks1, W[STT_W_B1_BIASES], z + c0 * 32, state1 + c0 * 96,
+            sttode_mlp_block1(A1y + a0 * 512, W[STT_W_B1_STREAM], m->n_chunks1, z + c0 * 32, state1 + c0 * 96,
                               ybuf + c0 * 16 * NOY, cur + a0 * 2, orig + a0 * 2, pred + c0 * 2 * Tf, nc, K, Tf, NOY, ps));
         if (p > 0) STT_HIP(hipEventRecord(m->ev_part[p], ps));
     }

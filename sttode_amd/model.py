@@ -360,11 +360,11 @@ class STTODENet(nn.Module):
         A0x, A0y, A1y = self._f(n, 512), self._f(n, 512), self._f(n, 512)
         capi.call('sttode_agent_preact', pf, state0, b0['x_WA'], b0['x_b1'], b0['y_WA'], b0['y_b1'], b1['y_WA'], b1['y_b1'], A0x, A0y, A1y, n, st)
         dbuf, ybuf = self._f(m, 16 * TPX), self._f(m, 16 * NOY)
-        capi.call('sttode_mlp_block0', A0x, A0y, b0['stream'], b0['n_chunks'], b0['biases'], z, ws['xpad'], dbuf, ybuf, m, K, TPX, NOY, st)
+        capi.call('sttode_mlp_block0', A0x, A0y, b0['stream'], b0['n_chunks'], z, ws['xpad'], dbuf, ybuf, m, K, TPX, NOY, st)
         state1 = self._f(m, 96)
         capi.call('sttode_gru_cols', dbuf, b1['convP'], b1['convB'], b1['wihP'], b1['whhP'], b1['gbias'], state1, m, Tp, TPX, st)
         pred = self._f(n, K, Tf, 2)
-        capi.call('sttode_mlp_block1', A1y, b1['stream'], b1['n_chunks'], b1['biases'], z, state1, ybuf, ws['cur'], orig, pred, m, K, Tf,
+        capi.call('sttode_mlp_block1', A1y, b1['stream'], b1['n_chunks'], z, state1, ybuf, ws['cur'], orig, pred, m, K, Tf,
                   NOY, st)
         self._dbg = dict(state0=state0, dbuf=dbuf, ybuf=ybuf, state1=state1)
         if not want_recover:
@@ -373,7 +373,7 @@ class STTODENet(nn.Module):
         A1x = self._f(n, 512)
         capi.call('sttode_linear_cols', pf, 128, 128, None, 0, 0, b1['x_WA'], b1['x_b1'], A1x, 512, n, 512, 0, st)
         xh1 = self._f(m, 16 * TPX)
-        capi.call('sttode_mlp_cols', A1x, b1['x_stream'], b1['x_n_chunks'], b1['x_biases'], z, state1, xh1, m, K, TPX, st)
+        capi.call('sttode_mlp_cols', A1x, b1['x_stream'], b1['x_n_chunks'], z, state1, xh1, m, K, TPX, st)
         x_true = ws['xpad'].repeat_interleave(K, dim=0) if K > 1 else ws['xpad']
         x_hat0 = x_true - dbuf
         recover = (x_hat0 + xh1)[:, :2 * Tp].reshape(m, Tp, 2)

@@ -57,31 +57,32 @@ def toeplitz_conv(w, Tp, TPX):
     return M
 
 
-def mlp_stream(W1v, W2, W3p, CHT, pad_to=0):
-    """Weight stream of ONE MLP for csrc/decoder.hip mlp_phase: 32/CHT "L12" chunks
-    { W1v tiles [CHT][KTV] , W2 tiles [CHT][16] } followed by N3 "L3" chunks { W3 tiles [TP3][16] } (zero padded to
-    the common chunk size).  Returns a float32 array [n_chunks, CHW*4]."""
+def mlp_stream(W1v, W2, W3p, b2, b3p):
+    """Weight stream of ONE MLP for csrc/decoder.hip mlp_phase (one 16-row hidden tile per chunk):
+    32 "L12" chunks { W1v tiles [KTV] , W2 tiles [16] } followed by N3 "L3" chunks { W3 tiles [TP3][16] | b3 of those tiles |
+    (first L3 chunk only) b2 } -- the biases ride in the spare space of the L3 chunks and reach LDS by the same DMA.
+    Returns a float32 array [n_chunks, CHW*4]."""
     P1 = pk16(W1v)             # [32, KTV, 64, 4]
     P2 = pk16(W2)              # [16, 32, 64, 4]
     P3 = pk16(W3p)             # [NO, 16, 64, 4]
     assert P1.shape[0] == 32 and P2.shape[:2] == (16, 32) and P3.shape[1] == 16
     KTV, NO = P1.shape[1], P3.shape[0]
-    chw = CHT * (KTV + 16) * 64 * 4          # floats per chunk
-    if pad_to:
-        assert pad_to * 4 >= chw
-    used = chw
-    chw = pad_to * 4 if pad_to else chw
+    chw = (KTV + 16) * 64 * 4                # floats per chunk
     tp3 = (chw // 4) // (16 * 64)            # layer-3 output tiles per chunk
+    assert tp3 * 16 * 64 * 4 + tp3 * 16 + 256 <= chw, 'no room for the biases in the L3 chunk'
+    assert len(b2) == 256 and len(b3p) == 16 * NO
     chunks = []
-    for ch in range(32 // CHT):
-        parts = [P1[CHT * ch + hf].reshape(-1) for hf in range(CHT)] + [P2[:, CHT * ch + hf].reshape(-1) for hf in range(CHT)]
-        buf = np.zeros(chw, np.float32)
-        buf[:used] = np.concatenate(parts)
-        chunks.append(buf)
+    for ch in range(32):
+        chunks.append(np.concatenate([P1[ch].reshape(-1), P2[:, ch].reshape(-1)]))
     for c3 in range((NO + tp3 - 1) // tp3):
         buf = np.zeros(chw, np.float32)
         part = P3[c3 * tp3:(c3 + 1) * tp3].reshape(-1)
         buf[: part.size] = part
+        o = tp3 * 16 * 64 * 4
+        bb = np.asarray(b3p[16 * c3 * tp3: 16 * (c3 + 1) * tp3], np.float32)
+        buf[o: o + bb.size] = bb
+        if c3 == 0:
+            buf[o + 16 * tp3: o + 16 * tp3 + 256] = b2
         chunks.append(buf)
     out = np.stack(chunks)
     assert out.shape[1] == chw
@@ -137,7 +138,7 @@ def pack_block(sd, i, Tp, Tf, first):
         'wihP': pk16(g('encoder_past.weight_ih_l0')), 'whhP': pk16(g('encoder_past.weight_hh_l0')),
         'gbias': np.ascontiguousarray(np.stack([bih[:96] + bhh[:96], bih[96:192] + bhh[96:192], bih[192:], bhh[192:]])),
     }
-    streams, biases = [], []
+    streams = []
     for nm, NO in ((('x', TPX), ('y', NOY)) if first else (('y', NOY),)):
         W1, b1 = g(f'decoder_{nm}.layers.0.weight'), g(f'decoder_{nm}.layers.0.bias')
         W2, b2 = g(f'decoder_{nm}.layers.1.weight'), g(f'decoder_{nm}.layers.1.bias')
@@ -146,15 +147,13 @@ def pack_block(sd, i, Tp, Tf, first):
         W3p[: W3.shape[0]] = W3
         if first:
             out[nm + '_WA'] = pk16(np.concatenate([W1[:, :128], W1[:, 160:]], axis=1))   # [pf | state0] per agent
-            streams.append(mlp_stream(W1[:, 128:160], W2, W3p, CHT=1, pad_to=1280))       # z per trajectory
+            streams.append(mlp_stream(W1[:, 128:160], W2, W3p, b2, pad_vec(b3, 16 * NO)))  # z per trajectory
         else:
             out[nm + '_WA'] = pk16(W1[:, :128])                                           # pf per agent
-            streams.append(mlp_stream(W1[:, 128:], W2, W3p, CHT=1))                       # [z | state] per trajectory
+            streams.append(mlp_stream(W1[:, 128:], W2, W3p, b2, pad_vec(b3, 16 * NO)))    # [z | state] per trajectory
         out[nm + '_b1'] = b1
-        biases += [b2, pad_vec(b3, 16 * NO)]
     out['stream'] = np.ascontiguousarray(np.concatenate(streams, axis=0))
     out['n_chunks'] = out['stream'].shape[0]
-    out['biases'] = np.ascontiguousarray(np.concatenate(biases))
     if not first:
         # decoder_x of a non-first block: dead in inference(), needed by forward() (recover_traj, model/STTODE.py:339-341)
         W1, W2, W3 = g('decoder_x.layers.0.weight'), g('decoder_x.layers.1.weight'), g('decoder_x.layers.2.weight')
@@ -162,9 +161,8 @@ def pack_block(sd, i, Tp, Tf, first):
         W3p[: W3.shape[0]] = W3
         out['x_WA'] = pk16(W1[:, :128])
         out['x_b1'] = g('decoder_x.layers.0.bias')
-        out['x_stream'] = mlp_stream(W1[:, 128:], W2, W3p, CHT=1)
+        out['x_stream'] = mlp_stream(W1[:, 128:], W2, W3p, g('decoder_x.layers.1.bias'), pad_vec(g('decoder_x.layers.2.bias'), 16 * TPX))
         out['x_n_chunks'] = out['x_stream'].shape[0]
-        out['x_biases'] = np.ascontiguousarray(np.concatenate([g('decoder_x.layers.1.bias'), pad_vec(g('decoder_x.layers.2.bias'), 16 * TPX)]))
     return out
 
 

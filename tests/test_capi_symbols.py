@@ -83,10 +83,13 @@ def test_pk16_layout_and_mlp_stream_roundtrip():
         assert P[it, T, lane, r] == Wp[16 * it + (lane & 15), 16 * T + 4 * (lane >> 4) + r]
     W1v, W2 = rng.standard_normal((512, 32)).astype(np.float32), rng.standard_normal((256, 512)).astype(np.float32)
     W3 = rng.standard_normal((32, 256)).astype(np.float32)
-    st = packing.mlp_stream(W1v, W2, W3, CHT=1, pad_to=1280)
-    assert st.shape == (34, 1280 * 4)
-    assert np.isclose(np.abs(st).sum(), np.abs(W1v).sum() + np.abs(W2).sum() + np.abs(W3).sum(), rtol=1e-5)
-    st1 = packing.mlp_stream(rng.standard_normal((512, 128)).astype(np.float32), W2, W3, CHT=1)
+    b2, b3 = rng.standard_normal(256).astype(np.float32), rng.standard_normal(32).astype(np.float32)
+    st = packing.mlp_stream(W1v, W2, W3, b2, b3)
+    assert st.shape == (34, 1152 * 4)
+    tot = np.abs(W1v).sum() + np.abs(W2).sum() + np.abs(W3).sum() + np.abs(b2).sum() + np.abs(b3).sum()
+    assert np.isclose(np.abs(st).sum(), tot, rtol=1e-5)
+    assert np.array_equal(st[32, 4096 + 16: 4096 + 16 + 256], b2) and np.array_equal(st[33, 4096: 4096 + 16], b3[16:])
+    st1 = packing.mlp_stream(rng.standard_normal((512, 128)).astype(np.float32), W2, W3, b2, b3)
     assert st1.shape == (34, 1536 * 4)
 
 
