@@ -16,13 +16,18 @@ import os
 import sys
 
 STAGE_OF = {'mlp_block0_kernel': 'mlp_block0', 'mlp_block1_kernel': 'mlp_block1', 'post_attn_kernel': 'post_attn',
-            'embed_qkv_kernel': 'embed_qkv', 'linear_cols_kernel': 'linear_cols', 'gru_cols_kernel': 'gru_cols'}
+            'embed_qkv_kernel': 'embed_qkv', 'linear_cols_kernel': 'agent_preact', 'gru_cols_kernel': 'gru_cols'}
 
 
 def main(src, dst):
     os.makedirs(dst, exist_ok=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    newest = {}
     for f in glob.glob(os.path.join(src, 'pmc_*', '*', '*_counter_collection.csv')):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f   # gpurun merges runs into the same directory: keep only the latest pass of each counter set
+    for f in newest.values():
         trace = f.replace('_counter_collection.csv', '_kernel_trace.csv')
         dur = {r['Dispatch_Id']: int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(trace))}
         seen = set()
