@@ -163,7 +163,8 @@ int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*
 /* number of column parts (1..8) the per-trajectory kernels are pipelined over on separate streams (default 1,
  * or env STTODE_COL_PARTS); results are bitwise independent of it. */
 int sttode_set_col_parts(SttodeModel* m, int parts);
-int sttode_timing_enable(SttodeModel* m, int on);
+/* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams */
+int sttode_timing_enable(SttodeModel* m, int every);
 int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);
 
 /* set_data (batched over scenes) + inference (model/STTODE.py:397-461,574-623; caller loop test.py:171-184).

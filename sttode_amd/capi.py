@@ -91,8 +91,9 @@ class NativeModel:
         if lib().sttode_set_col_parts(self.h, int(parts)) != 0:
             raise SttodeError('sttode_set_col_parts failed: ' + lib().sttode_last_error().decode())
 
-    def timing(self, on):
-        lib().sttode_timing_enable(self.h, int(on))
+    def timing(self, every):
+        """0/False: off; n: bracket every n-th forward call (True == every call)."""
+        lib().sttode_timing_enable(self.h, int(every))
 
     def read_timing(self):
         ms = (ctypes.c_double * len(STAGES))()

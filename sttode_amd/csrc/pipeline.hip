@@ -32,7 +32,9 @@ struct SttodeModel {
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB;
     hipEvent_t ev_call, evA_done[2], evB_done[2];
-    bool timing;
+    bool timing;        // brackets active for the CURRENT call
+    int timing_every;   // 0 = off, n = bracket every n-th forward call
+    long calls;
     std::vector<TimRec> recs;
     std::vector<hipEvent_t> pool;
 };
@@ -52,6 +54,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     for (int i = 0; i < count; ++i) m->w[i] = (const float*)weights[i];
     m->n_chunks0 = n_chunks0; m->n_chunks1 = n_chunks1;
     m->timing = false;
+    m->timing_every = 0;
+    m->calls = 0;
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
     if (const char* e = getenv("STTODE_COL_PARTS")) m->col_parts = atoi(e);
     if (m->col_parts < 1) m->col_parts = 1;
@@ -130,9 +134,13 @@ extern "C" int sttode_set_col_parts(SttodeModel* m, int parts) {
     return 0;
 }
 
-extern "C" int sttode_timing_enable(SttodeModel* m, int on) {
-    STT_REQUIRE(m, "sttode_timing_enable: null model");
-    m->timing = on != 0;
+// every = 0: off; every = n > 0: the stages of every n-th forward call are bracketed by hipEvents (each bracket costs a few
+// microseconds of queue serialisation, so long runs sample instead of bracketing every call)
+extern "C" int sttode_timing_enable(SttodeModel* m, int every) {
+    STT_REQUIRE(m && every >= 0, "sttode_timing_enable: bad arguments");
+    m->timing_every = every;
+    m->timing = false;
+    m->calls = 0;
     return 0;
 }
 
@@ -273,8 +281,14 @@ static int frontend(SttodeModel* m, float* ws, const long* off, const float* pas
 }
 
 // serial form: everything on the caller's stream
+static inline void arm_timing(SttodeModel* m) {
+    m->timing = m->timing_every > 0 && (m->calls % m->timing_every) == 0;
+    ++m->calls;
+}
+
 static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
                       float* pred, hipStream_t s) {
+    arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
@@ -286,6 +300,7 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
 static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
                      float* pred, int slot, hipStream_t s) {
     STT_REQUIRE(slot == 0 || slot == 1, "sttode_inference_*_async: slot must be 0 or 1");
+    arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
