@@ -50,6 +50,10 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
+// Pre-scaled forms: the GRU packs its gate rows already multiplied by -log2(e) (r, z) and 2*log2(e) (n), so the
+// argument arrives as t = -x*log2(e) resp. t = 2*x*log2(e) and the multiply disappears from the (non-overlappable) VALU work.
+__device__ __forceinline__ float sigmoid_prescaled(float t) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t)); }
+__device__ __forceinline__ float tanh_prescaled(float t) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t)), 1.0f); }
 
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
 

@@ -18,33 +18,84 @@
 // wrappers at the bottom (persistent grids sized to the 256 CUs, interleaved tile assignment for tail balance).
 #include "chain.hpp"
 #include "api_util.hpp"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------
 // conv + GRU over columns
 // ---------------------------------------------------------------------------------------------------
-#define GRU_WIH_F4 (18 * 2 * 64)
-#define GRU_WHH_F4 (18 * 6 * 64)
-#define GRU_LDS_BYTES ((GRU_WIH_F4 + GRU_WHH_F4) * 16 + 4 * 96 * 4)
+#define GRU_LDS_BYTES ((18 * 2 * 64 + 18 * 6 * 64) * 16 + 4 * 96 * 4)
 
 #ifndef GRU_THREADS
 #define GRU_THREADS 1024
 #endif
+// LDS image: per gate-tile j (6 of them) the 24 fragments it needs are contiguous:
+//     sW[j][g][T]  g = 0,1,2 (r,z,n rows)  T = 0,1 (W_ih k-tiles) then 2..7 (W_hh k-tiles)        -> 6 x 24 KiB
+// so one base address per j plus immediate offsets covers every ds_read (no per-read address arithmetic).
+// Gate rows arrive PRE-SCALED from packing.pack_block (r,z rows by -log2 e, n rows by 2 log2 e; biases alike).
+#define GRU_W_F4 (6 * 3 * 8 * 64)
+template <int TPX>
+__device__ __forceinline__ void gru_step(const f32x4* __restrict__ sW, const float* __restrict__ sB, const f32x4 (&e)[2],
+                                         const f32x4 (&h)[6], f32x4 (&hn)[6], int lane, int q) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        STT_FENCE();
+        // one opaque LDS base per gate tile: its 24 fragment reads then use immediate offsets (< 24 KiB) instead of one
+        // v_add_u32 per read for everything beyond the 64 KiB immediate range (VALU work does not hide behind fp32 MFMA)
+        typedef const __attribute__((address_space(3))) f32x4* lds_f4p;
+        lds_f4p wj = (lds_f4p)sW + ((j * 24) * 64 + lane);
+        asm volatile("" : "+v"(wj));
+        f32x4 ar = ld4(sB + 0 * 96 + 16 * j + 4 * q);
+        f32x4 az = ld4(sB + 1 * 96 + 16 * j + 4 * q);
+        f32x4 ai = ld4(sB + 2 * 96 + 16 * j + 4 * q);
+        f32x4 ah = ld4(sB + 3 * 96 + 16 * j + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            ar = mfma_k16(ar, wj[(0 * 8 + T) * 64], e[T]);
+            az = mfma_k16(az, wj[(1 * 8 + T) * 64], e[T]);
+            ai = mfma_k16(ai, wj[(2 * 8 + T) * 64], e[T]);
+        }
+#pragma unroll
+        for (int T = 0; T < 6; ++T) {
+            if (T == 3) STT_FENCE();
+            ar = mfma_k16(ar, wj[(0 * 8 + 2 + T) * 64], h[T]);
+            az = mfma_k16(az, wj[(1 * 8 + 2 + T) * 64], h[T]);
+            ah = mfma_k16(ah, wj[(2 * 8 + 2 + T) * 64], h[T]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#ifdef STT_DIAG_NOGATES
+            hn[j][r] = (ar[r] + az[r]) * 1e-3f + (ai[r] + ah[r]) * 1e-3f + 0.5f * h[j][r];
+#else
+            const float rg = sigmoid_prescaled(ar[r]);
+            const float zg = sigmoid_prescaled(az[r]);
+            const float ng = tanh_prescaled(fmaf(rg, ah[r], ai[r]));
+            hn[j][r] = fmaf(zg, h[j][r] - ng, ng);  // (1-z) n + z h
+#endif
+        }
+    }
+}
+
 template <int TPX>
 __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
     const float* __restrict__ xin,    // [ncols][16*TPX]  flattened (t,c) input sequence, zero padded
     const f32x4* __restrict__ convP,  // PK16 Toeplitz conv  [2*Tp row tiles][TPX][64]
     const float* __restrict__ convB,  // [32]
-    const f32x4* __restrict__ wihP,   // PK16 [18][2][64]
-    const f32x4* __restrict__ whhP,   // PK16 [18][6][64]
-    const float* __restrict__ gbias,  // [4][96] : b_ir+b_hr, b_iz+b_hz, b_in, b_hn
+    const f32x4* __restrict__ wihP,   // PK16 [18][2][64]   (gate rows pre-scaled)
+    const f32x4* __restrict__ whhP,   // PK16 [18][6][64]   (gate rows pre-scaled)
+    const float* __restrict__ gbias,  // [4][96] : b_ir+b_hr, b_iz+b_hz, b_in, b_hn   (pre-scaled like their rows)
     float* __restrict__ state,        // [ncols][96]
     int ncols, int Tp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* sWih = reinterpret_cast<f32x4*>(smem);
-    f32x4* sWhh = sWih + GRU_WIH_F4;
-    float* sB = reinterpret_cast<float*>(sWhh + GRU_WHH_F4);
-    for (int i = threadIdx.x; i < GRU_WIH_F4; i += blockDim.x) sWih[i] = wihP[i];
-    for (int i = threadIdx.x; i < GRU_WHH_F4; i += blockDim.x) sWhh[i] = whhP[i];
+    f32x4* sW = reinterpret_cast<f32x4*>(smem);
+    float* sB = reinterpret_cast<float*>(sW + GRU_W_F4);
+    // fill by LDS-DMA: every wave-instruction moves one 1 KiB fragment L2 -> LDS with no VGPR round trip, so all of a wave's
+    // copies are in flight at once (the register-staged loop left the matrix pipe idle for ~15 us at every launch)
+    for (int i = threadIdx.x; i < GRU_W_F4; i += blockDim.x) {
+        const int l = i & 63, T = (i >> 6) & 7, g = (i >> 9) % 3, j = i / (64 * 8 * 3);
+        const f32x4* src = T < 2 ? wihP + ((g * 6 + j) * 2 + T) * 64 + l : whhP + ((g * 6 + j) * 6 + (T - 2)) * 64 + l;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sW + (i - l)), 16, 0, 0);
+    }
     for (int i = threadIdx.x; i < 4 * 96; i += blockDim.x) sB[i] = gbias[i];
     __syncthreads();
 
@@ -58,6 +109,21 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
     for (int io = 0; io < 2; ++io)
 #pragma unroll
         for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
+    auto conv = [&](int t, f32x4 (&e)[2], const f32x4 (&d)[TPX]) {
+        e[0] = cb0;
+        e[1] = cb1;
+#pragma unroll
+        for (int io = 0; io < 2; ++io) {
+#pragma unroll
+            for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
+            e[io] = relu4(e[io]);
+        }
+        const int tn = (t + 1 < Tp) ? t + 1 : 0;
+#pragma unroll
+        for (int io = 0; io < 2; ++io)
+#pragma unroll
+            for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
+    };
     // interleaved assignment: consecutive tiles go to different CUs first, then to different waves
     for (int tile = blockIdx.x + gridDim.x * wave; tile < ntiles; tile += gridDim.x * nw) {
         const int col = tile * 16 + c;
@@ -65,66 +131,16 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
         f32x4 d[TPX];
 #pragma unroll
         for (int T = 0; T < TPX; ++T) d[T] = ld4(xin + (size_t)colc * (16 * TPX) + 16 * T + 4 * q);
-        f32x4 h[6];
+        f32x4 h[6], h2[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) h[j] = splat4(0.f);
-
+#pragma unroll 1
         for (int t = 0; t < Tp; ++t) {
             f32x4 e[2];
-            e[0] = cb0;
-            e[1] = cb1;
+            conv(t, e, d);
+            gru_step<TPX>(sW, sB, e, h, h2, lane, q);
 #pragma unroll
-            for (int io = 0; io < 2; ++io) {
-#pragma unroll
-                for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
-                e[io] = relu4(e[io]);
-            }
-            {
-                const int tn = (t + 1 < Tp) ? t + 1 : 0;
-#pragma unroll
-                for (int io = 0; io < 2; ++io)
-#pragma unroll
-                    for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
-            }
-            f32x4 hn[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                STT_FENCE();
-                f32x4 ar = ld4(sB + 0 * 96 + 16 * j + 4 * q);
-                f32x4 az = ld4(sB + 1 * 96 + 16 * j + 4 * q);
-                f32x4 ai = ld4(sB + 2 * 96 + 16 * j + 4 * q);
-                f32x4 ah = ld4(sB + 3 * 96 + 16 * j + 4 * q);
-                // MFMA issue must win the SIMD's arbitration against the other waves' gate math (VALU bursts): high
-                // priority while this wave feeds the matrix pipe, low while it runs its own transcendental block.
-                __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    ar = mfma_k16(ar, sWih[((0 + j) * 2 + T) * 64 + lane], e[T]);
-                    az = mfma_k16(az, sWih[((6 + j) * 2 + T) * 64 + lane], e[T]);
-                    ai = mfma_k16(ai, sWih[((12 + j) * 2 + T) * 64 + lane], e[T]);
-                }
-#pragma unroll
-                for (int T = 0; T < 6; ++T) {
-                    if (T == 3) STT_FENCE();
-                    ar = mfma_k16(ar, sWhh[((0 + j) * 6 + T) * 64 + lane], h[T]);
-                    az = mfma_k16(az, sWhh[((6 + j) * 6 + T) * 64 + lane], h[T]);
-                    ah = mfma_k16(ah, sWhh[((12 + j) * 6 + T) * 64 + lane], h[T]);
-                }
-                __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#ifdef STT_DIAG_NOGATES
-                    hn[j][r] = (ar[r] + az[r]) * 1e-3f + (ai[r] + ah[r]) * 1e-3f + 0.5f * h[j][r];
-#else
-                    const float rg = sigmoidf_(ar[r]);
-                    const float zg = sigmoidf_(az[r]);
-                    const float ng = tanhf_(ai[r] + rg * ah[r]);
-                    hn[j][r] = (1.0f - zg) * ng + zg * h[j][r];
-#endif
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) h[j] = hn[j];
+            for (int j = 0; j < 6; ++j) h[j] = h2[j];
         }
         if (col < ncols) {
 #pragma unroll
@@ -505,6 +521,12 @@ __global__ __launch_bounds__(256, 2) void mlp_cols_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
+// STTODE_NONPERSISTENT=1 (experiment): one work item per workgroup instead of persistent grids
+static int nonpersistent() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("STTODE_NONPERSISTENT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static int g_num_cu = 0;
 static int num_cus() {
     if (!g_num_cu) {
@@ -605,7 +627,7 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     STT_REQUIRE(total_chunks == 64 + TPX + NOY, "sttode_mlp_block0: weight stream must hold (32+TPX) + (32+NOY) chunks");
     const int ngroups = (ncols + 63) / 64;
     int grid = MLP0_WGS * num_cus();   // workgroups per CU; even blockIdx = x role, odd = y role
-    if (grid > 2 * ngroups) grid = 2 * ngroups;
+    if (grid > 2 * ngroups || nonpersistent()) grid = 2 * ngroups;
     grid &= ~1;
     if (grid < 2) grid = 2;
     hipStream_t s = (hipStream_t)stream_;
@@ -635,7 +657,7 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
     STT_REQUIRE(total_chunks == 32 + NOY, "sttode_mlp_block1: weight stream must hold 32+NOY chunks");
     const int ngroups = (ncols + 63) / 64;
     int grid = 3 * num_cus();
-    if (grid > ngroups) grid = ngroups;
+    if (grid > ngroups || nonpersistent()) grid = ngroups;
     hipStream_t s = (hipStream_t)stream_;
 #define L1(NY)                                                                                                              \
     do {                                                                                                                    \

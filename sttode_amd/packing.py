@@ -133,10 +133,18 @@ def pack_block(sd, i, Tp, Tf, first):
     g = lambda k: np.asarray(sd[p + k], np.float32)
     TPX, NOY = tiles_x(Tp), tiles_y(Tf)
     bih, bhh = g('encoder_past.bias_ih_l0'), g('encoder_past.bias_hh_l0')
+    # Gate rows are pre-scaled so the kernel's sigmoid / tanh need no multiply (csrc/chain.hpp *_prescaled):
+    #   r, z rows (0..191) by -log2(e):   sigmoid(x) = 1 / (1 + 2^(-x log2 e))
+    #   n rows (192..287)  by 2 log2(e):  tanh(x)    = 1 - 2 / (1 + 2^(2 x log2 e));  x = a_in + r * a_hn is linear in both parts
+    L2E = np.float32(1.4426950408889634)
+    sc = np.concatenate([np.full(192, -L2E, np.float32), np.full(96, 2 * L2E, np.float32)])
+    wih = g('encoder_past.weight_ih_l0') * sc[:, None]
+    whh = g('encoder_past.weight_hh_l0') * sc[:, None]
     out = {
         'convP': pk16(toeplitz_conv(g('conv_past.weight'), Tp, TPX)), 'convB': g('conv_past.bias'),
-        'wihP': pk16(g('encoder_past.weight_ih_l0')), 'whhP': pk16(g('encoder_past.weight_hh_l0')),
-        'gbias': np.ascontiguousarray(np.stack([bih[:96] + bhh[:96], bih[96:192] + bhh[96:192], bih[192:], bhh[192:]])),
+        'wihP': pk16(wih), 'whhP': pk16(whh),
+        'gbias': np.ascontiguousarray(np.stack([(bih[:96] + bhh[:96]) * -L2E, (bih[96:192] + bhh[96:192]) * -L2E,
+                                                bih[192:] * (2 * L2E), bhh[192:] * (2 * L2E)]).astype(np.float32)),
     }
     streams = []
     for nm, NO in ((('x', TPX), ('y', NOY)) if first else (('y', NOY),)):
