@@ -30,7 +30,8 @@ struct SttodeModel {
     hipEvent_t ev_agents, ev_part[STT_MAX_PARTS];
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
-    hipStream_t sA, sB;
+    hipStream_t sA, sB, sB2;
+    int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate slots between sB and sB2
     hipEvent_t ev_call, evA_done[2], evB_done[2];
     bool timing;        // brackets active for the CURRENT call
     int timing_every;   // 0 = off, n = bracket every n-th forward call
@@ -56,6 +57,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->timing = false;
     m->timing_every = 0;
     m->calls = 0;
+    m->b_streams = 1;
+    if (const char* e = getenv("STTODE_B_STREAMS")) m->b_streams = atoi(e) == 2 ? 2 : 1;
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
     if (const char* e = getenv("STTODE_COL_PARTS")) m->col_parts = atoi(e);
     if (m->col_parts < 1) m->col_parts = 1;
@@ -73,6 +76,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     }
     ok = ok && hipStreamCreateWithFlags(&m->sA, hipStreamNonBlocking) == hipSuccess &&
          hipStreamCreateWithFlags(&m->sB, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&m->sB2, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < 2 && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
@@ -92,7 +96,7 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     for (auto e : m->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); (void)hipEventDestroy(m->ev_agents);
     for (int p = 0; p < STT_MAX_PARTS; ++p) { (void)hipEventDestroy(m->ev_part[p]); if (p) (void)hipStreamDestroy(m->part_stream[p]); }
-    (void)hipStreamDestroy(m->side); (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB);
+    (void)hipStreamDestroy(m->side); (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB); (void)hipStreamDestroy(m->sB2);
     (void)hipEventDestroy(m->ev_call);
     for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
     delete m;
@@ -309,10 +313,11 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, m->sA)) return rc;
     if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA)) return rc;
     STT_HIP(hipEventRecord(m->evA_done[slot], m->sA));
-    STT_HIP(hipStreamWaitEvent(m->sB, m->ev_call, 0));
-    STT_HIP(hipStreamWaitEvent(m->sB, m->evA_done[slot], 0));
-    if (int rc = stage_trajectories(m, ws, off, n, z, pred, m->sB)) return rc;
-    STT_HIP(hipEventRecord(m->evB_done[slot], m->sB));
+    hipStream_t sb = (m->b_streams == 2 && slot == 1) ? m->sB2 : m->sB;
+    STT_HIP(hipStreamWaitEvent(sb, m->ev_call, 0));
+    STT_HIP(hipStreamWaitEvent(sb, m->evA_done[slot], 0));
+    if (int rc = stage_trajectories(m, ws, off, n, z, pred, sb)) return rc;
+    STT_HIP(hipEventRecord(m->evB_done[slot], sb));
     return 0;
 }
 
