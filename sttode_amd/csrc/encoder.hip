@@ -107,13 +107,30 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
 // element (seq s, batch b, feature f) of R/C/V/out lives at  base + s*seq_stride + b*batch_stride + f
 // ---------------------------------------------------------------------------------------------------
 #define ATT_TJ 128
+// exp(-acos(x)) for x in [-1+1e-4, 1-1e-4].  acos by the 8-term minimax form acos(|x|) = sqrt(1-|x|) * P7(|x|)
+// (Abramowitz & Stegun 4.4.46, |error| <= 2e-8), reflected for x < 0; exp on v_exp_f32.  ~14 VALU instructions instead of
+// the ~35 of acosf + expf: the geodesic scoring loop is VALU-bound (one score per lane per column).
+__device__ __forceinline__ float exp_neg_acos(float x) {
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = fmaf(p, ax, 0.0066700901f);
+    p = fmaf(p, ax, -0.0170881256f);
+    p = fmaf(p, ax, 0.0308918810f);
+    p = fmaf(p, ax, -0.0501743046f);
+    p = fmaf(p, ax, 0.0889789874f);
+    p = fmaf(p, ax, -0.2145988016f);
+    p = fmaf(p, ax, 1.5707963050f);
+    const float a = __builtin_amdgcn_sqrtf(1.0f - ax) * p;  // acos(|x|); v_sqrt_f32 (1 ulp) instead of the ~12-instruction IEEE sqrtf
+    const float ac = x < 0.f ? 3.14159265358979f - a : a;  // acos(x)
+    return __builtin_amdgcn_exp2f(-1.4426950408889634f * ac);
+}
 __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict__ R, const float* __restrict__ C,
                                                          const float* __restrict__ V, float* __restrict__ out,
                                                          float* __restrict__ rowsum,  // optional [Nb][8][rows]
                                                          int rows, int cols, long rs_seq, long rs_b, long cs_seq, long cs_b,
                                                          long vs_seq, long vs_b, long os_seq, long os_b, float rscale, float cscale) {
-    __shared__ float sC[ATT_TJ][8];
-    __shared__ float sV[ATT_TJ][8];
+    __shared__ __attribute__((aligned(16))) float sC[ATT_TJ][8];
+    __shared__ __attribute__((aligned(16))) float sV[ATT_TJ][8];
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ic = i < rows ? i : rows - 1;
@@ -152,15 +169,19 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
         }
         __syncthreads();
         const int jn = min(ATT_TJ, cols - j0);
+#pragma unroll 8
         for (int jj = 0; jj < jn; ++jj) {
-            float dot = 0.f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) dot += r[d] * sC[jj][d];
+            // all lanes read the same column (LDS broadcast): two b128 reads for c_j, two for v_j
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[jj][0]), c1 = *reinterpret_cast<const f32x4*>(&sC[jj][4]);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sV[jj][0]), v1 = *reinterpret_cast<const f32x4*>(&sV[jj][4]);
+            float dot = r[0] * c0[0];
+            dot = fmaf(r[1], c0[1], dot); dot = fmaf(r[2], c0[2], dot); dot = fmaf(r[3], c0[3], dot);
+            dot = fmaf(r[4], c1[0], dot); dot = fmaf(r[5], c1[1], dot); dot = fmaf(r[6], c1[2], dot); dot = fmaf(r[7], c1[3], dot);
             dot = fminf(fmaxf(dot, -1.0f + 1e-4f), 1.0f - 1e-4f);
-            const float p = expf(-acosf(dot));  // scores lie in [-pi, 0]: no running max needed
+            const float p = exp_neg_acos(dot);  // scores lie in [-pi, 0]: no running max needed
             l += p;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc[d] += p * sV[jj][d];
+            acc[0] = fmaf(p, v0[0], acc[0]); acc[1] = fmaf(p, v0[1], acc[1]); acc[2] = fmaf(p, v0[2], acc[2]); acc[3] = fmaf(p, v0[3], acc[3]);
+            acc[4] = fmaf(p, v1[0], acc[4]); acc[5] = fmaf(p, v1[1], acc[5]); acc[6] = fmaf(p, v1[2], acc[6]); acc[7] = fmaf(p, v1[3], acc[7]);
         }
     }
     if (i < rows) {
