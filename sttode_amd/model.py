@@ -467,6 +467,42 @@ class STTODENet(nn.Module):
         return pred.permute(1, 0, 2, 3)
 
     @torch.no_grad()
+    def inference_nba_sharded(self, data_local, z=None, gather=None):
+        """NBA path with ONE attention group spanning ranks (SURVEY.md §8e, config 5 read literally): this rank holds
+        ``data_local['past_traj'] [B_r, N, Tp, 2]``, scenes ordered by rank.  The only exchange is one all-gather of the raw
+        q|k|v rows [B_r*N, 192] (RCCL; ``gather`` may be injected for single-process tests).  Because self-attention uses the
+        scores untransposed (rows = keys, columns = queries, hyptransformerlib.py:261-265) every LOCAL key row needs ALL
+        queries and values; everything downstream is local.  Returns this rank's [K, B_r*N, Tf, 2]."""
+        self._require_gpu()
+        a, P = self.args, self.packed()
+        self.set_data_nba(data_local)
+        ws = self._frontend(vel_from_norm=1)
+        n, N, W = self._past.shape[0], self._N, P['past']
+        st = capi.stream_ptr()
+        g, qkv = self._f(n, 64), self._f(n, 192)
+        capi.call('sttode_embed_qkv', W['fc1P'], W['fc1b'], W['posP'], W['peb'], W['fc2P'], W['fc2b'], W['fc3P'], W['fc3b'],
+                  W['fc3last'], W['inP'], W['inb'], ws['enc_in'], ws['last'], g, qkv, n, a.past_length, st)
+        if gather is None:
+            from . import parallel
+            gather = parallel.gather_futures  # variable-size row all-gather in rank order
+        qkv_all = gather(qkv).contiguous()
+        L_all, L_loc = qkv_all.shape[0] // N, n // N
+        attn = self._f(n, 64)
+        e = qkv.element_size()
+        capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv_all.data_ptr(), qkv_all.data_ptr() + 128 * e, attn, None, None,
+                  L_loc, L_all, N, N * 192, 192, N * 192, 192, N * 192, 192, N * 64, 64, 1.0, 8.0 ** -0.5, st)
+        pf = self._f(n, 128)
+        capi.call('sttode_post_attn', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
+                  W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], g, attn, 64, pf, n, self.ODE_TIME, st)
+        self.past_feature, self._ws = pf, ws
+        K = a.sample_k
+        if z is None:
+            z = torch.randn(n * K, a.zdim, device=self.device)
+        pred = self._decode(pf, z, ws, K)
+        self._keep = (g, qkv, qkv_all)
+        return pred.permute(1, 0, 2, 3)
+
+    @torch.no_grad()
     def inference_async(self, z=None):
         """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  The per-agent stage
         runs on an internal stream beside the per-trajectory kernels of the previous call; two slots alternate, so at most

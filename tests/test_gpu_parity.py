@@ -341,3 +341,22 @@ def test_random_latents_follow_torch_generator():
     c = m.inference(None)
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert tuple(a.shape) == (20, 5, 12, 2) and bool(torch.isfinite(a).all())
+
+
+def test_nba_group_spanning_two_ranks_matches_single_rank():
+    """one attention group sharded over ranks, with an all-gather of q|k|v.  Two ranks are simulated in one
+    process (the gather is injected); every rank's slice must equal the single-rank result."""
+    from sttode_amd import scenes
+    m = hip_model('nba', 5, 10)
+    B, N, split = 24, 11, 10
+    d = scenes.nba_batch(321, B, N=N)
+    z = torch.from_numpy(scenes.latents(322, B * N)).to(m.device)
+    full_data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+    m.set_data_nba(full_data)
+    full = m.inference(full_data, z=z).clone()
+    qkv_full = m._view(*m._workspace(B * N, 0), 'qkv', B * N, 192).clone()
+    parts = [(0, split), (split, B)]
+    for (b0, b1) in parts:
+        loc = {'past_traj': torch.from_numpy(d['past_traj'][b0:b1]), 'future_traj': torch.from_numpy(d['future_traj'][b0:b1])}
+        out = m.inference_nba_sharded(loc, z=z[b0 * N * 20:b1 * N * 20], gather=lambda q: qkv_full)
+        assert_close(out.cpu().numpy(), full[:, b0 * N:b1 * N].cpu().numpy(), rtol=1e-6, atol=1e-6, what=f'rank slice {b0}:{b1}')
