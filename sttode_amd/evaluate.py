@@ -1,0 +1,51 @@
+"""Caller-side evaluation loops over the HIP path (the reference's test.py flows, without plotting):
+
+  eval_scenes  == test.py:163-208  (ETH/UCY/SDD): per scene set_data + inference, ADE/FDE best-of-K per agent,
+                  AverageMeter weighted by agent_num  ==  plain mean over all agents of the per-agent minima.
+                  Here many scenes go through ONE batched call (set_scene_batch) instead of a Python loop per scene.
+  eval_nba     == test.py:495-552  (NBA): per DataLoader batch, min-over-K of the mean / final displacement at the horizons
+                  1..future_length (the reference prints every 0.4 s step), weighted by batch size.
+"""
+import numpy as np
+import torch
+
+
+@torch.no_grad()
+def eval_scenes(model, dataset, traj_scale=1.0, scenes_per_call=512, z_fn=None):
+    """dataset: sttode_amd.datasets.TrajectoryDataset / SDD_Dataset (or anything with ``scene_batch(indices)``).
+    Returns (ADE, FDE, n_agents).  ``z_fn(n_rows)`` may supply latents (tests); otherwise torch.randn like the reference."""
+    tot_a = tot_f = 0.0
+    tot_n = 0
+    for s0 in range(0, len(dataset), scenes_per_call):
+        sb = dataset.scene_batch(range(s0, min(s0 + scenes_per_call, len(dataset))))
+        model.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        z = z_fn(sb.n_agents * model.args.sample_k) if z_fn is not None else None
+        pred = model.inference(None, z=z)                                  # [K, n, Tf, 2]
+        ade, fde = model.best_of_k(pred.permute(1, 0, 2, 3), scale=traj_scale)
+        tot_a += float(ade.double().sum())
+        tot_f += float(fde.double().sum())
+        tot_n += sb.n_agents
+    return tot_a / tot_n, tot_f / tot_n, tot_n
+
+
+@torch.no_grad()
+def eval_nba(model, loader, traj_scale=1.0, z_fn=None):
+    """loader yields seq_collate dicts (data/dataloader_nba.py:7-18).  Returns {h: (avg_h, dest_h)} for h = 1..Tf, each the
+    batch-size-weighted mean over batches of mean_n min_k (test.py:530-551)."""
+    Tf = model.args.future_length
+    acc = np.zeros((Tf, 2))
+    count = 0
+    for data in loader:
+        model.set_data_nba(data)
+        n = data['past_traj'].shape[0] * data['past_traj'].shape[1]
+        z = z_fn(n * model.args.sample_k) if z_fn is not None else None
+        pred = model.inference(data, z=z) * traj_scale                     # [K, n, Tf, 2]
+        gt = torch.as_tensor(data['future_traj'], dtype=torch.float32).to(pred.device).reshape(n, Tf, 2) * traj_scale
+        d = (pred - gt[None]).norm(dim=-1)                                 # [K, n, Tf]
+        cum = d.cumsum(dim=2) / torch.arange(1, Tf + 1, device=d.device)   # mean over the first h frames
+        B = data['past_traj'].shape[0]
+        acc[:, 0] += cum.min(dim=0)[0].mean(dim=0).double().cpu().numpy() * B
+        acc[:, 1] += d.min(dim=0)[0].mean(dim=0).double().cpu().numpy() * B
+        count += B
+    acc /= count
+    return {h + 1: (float(acc[h, 0]), float(acc[h, 1])) for h in range(Tf)}

@@ -360,3 +360,53 @@ def test_nba_group_spanning_two_ranks_matches_single_rank():
         loc = {'past_traj': torch.from_numpy(d['past_traj'][b0:b1]), 'future_traj': torch.from_numpy(d['future_traj'][b0:b1])}
         out = m.inference_nba_sharded(loc, z=z[b0 * N * 20:b1 * N * 20], gather=lambda q: qkv_full)
         assert_close(out.cpu().numpy(), full[:, b0 * N:b1 * N].cpu().numpy(), rtol=1e-6, atol=1e-6, what=f'rank slice {b0}:{b1}')
+
+
+def test_evaluation_loops_vs_oracle_metrics(tmp_path):
+    """test.py-style evaluation on top of the batched HIP path: ETH/UCY CSV dataset and NBA loader, checked against the
+    CPU oracle run scene by scene / batch by batch with the same latents and the NumPy metric restatement."""
+    from oracle.metrics_ref import best_of_k_ade_fde, nba_horizon_errors
+    from sttode_amd import scenes
+    from sttode_amd.datasets import NBADataset, TrajectoryDataset, seq_collate
+    from sttode_amd.evaluate import eval_nba, eval_scenes
+    rng = np.random.default_rng(4)
+    # --- ETH/UCY-like CSV: 30 frames, 6 pedestrians present throughout
+    rows = []
+    for p in range(6):
+        start, vel = rng.uniform(0, 10, 2), rng.normal(0, 0.3, 2)
+        for t in range(30):
+            x, y = start + vel * t + rng.normal(0, 0.02, 2)
+            rows.append((10 * t, p + 1, x, y))
+    rows.sort()
+    np.savetxt(tmp_path / 'a.csv', np.asarray(rows).T, delimiter=',', fmt='%.6f')
+    ds = TrajectoryDataset(str(tmp_path), obs_len=8, pred_len=12, skip=3, min_ped=1, files=['a.csv'])
+    m = hip_model('eth', 8, 12)
+    zall = scenes.latents(8, ds.obs_traj.shape[0])
+    ade, fde, n = eval_scenes(m, ds, traj_scale=1.0, z_fn=lambda rows_: torch.from_numpy(zall[:rows_]))
+    ora = oracle_model('eth', 8, 12)
+    a_ref, f_ref = [], []
+    for i in range(len(ds)):
+        s, e = ds.seq_start_end[i]
+        out = oracle_scene_inference(ora, ds.obs_traj[s:e].numpy(), ds.pred_traj[s:e].numpy(), zall[s * 20:e * 20])
+        a, f = best_of_k_ade_fde(out.transpose(1, 0, 2, 3), ds.pred_traj[s:e].permute(0, 2, 1).numpy())
+        a_ref.append(a); f_ref.append(f)
+    assert n == ds.obs_traj.shape[0]
+    assert abs(ade - np.concatenate(a_ref).mean()) < 1e-4 and abs(fde - np.concatenate(f_ref).mean()) < 1e-4
+    # --- NBA loader, two batches of 3 scenes
+    np.save(tmp_path / 'test.npy', rng.uniform(10, 80, (6, 15, 11, 2)))
+    nds = NBADataset(obs_len=5, pred_len=10, training=False, data_root=str(tmp_path / 'test.npy'))
+    batches = [seq_collate([nds[i] for i in range(b, b + 3)]) for b in (0, 3)]
+    mn = hip_model('nba', 5, 10)
+    zn = scenes.latents(9, 33)
+    res = eval_nba(mn, batches, traj_scale=1.0, z_fn=lambda rows_: torch.from_numpy(zn[:rows_]))
+    on = oracle_model('nba', 5, 10)
+    acc = np.zeros((10, 2))
+    for data in batches:
+        with torch.no_grad():
+            on.set_data_nba(data)
+            out = on.inference(data, z=torch.from_numpy(zn)).numpy()
+        e = nba_horizon_errors(out, data['future_traj'].reshape(33, 10, 2).numpy(), range(1, 11))
+        acc += np.array([e[h] for h in range(1, 11)]) * 3
+    acc /= 6
+    for h in range(1, 11):
+        assert abs(res[h][0] - acc[h - 1, 0]) < 1e-4 and abs(res[h][1] - acc[h - 1, 1]) < 1e-4
