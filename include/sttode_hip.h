@@ -72,9 +72,10 @@ int sttode_gru_cols(const float* xin, const float* convP, const float* convB, co
                     const float* gbias, float* state, int ncols, int Tp, int TPX, void* stream);
 
 /* Generic per-column linear out[col, 0:N] = act(W [X1 | X2] + b) (nn.Linear; used for the per-agent part of
- * decoder_x/decoder_y layer 0, model/utils.py:86-95). K1, K2, N multiples of 16. */
+ * decoder_x/decoder_y layer 0, model/utils.py:86-95, and for the stage-2 Q-net, sampler.py:39,48-52 / utils/mlp.py:26-29).
+ * K1, K2, N multiples of 16.  act: 0 none, 1 relu, 2 tanh. */
 int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, const float* bias,
-                       float* out, int ldo, int ncols, int N, int relu, void* stream);
+                       float* out, int ldo, int ncols, int N, int act, void* stream);
 
 /* The three per-agent layer-0 pre-activations of decoder_x/decoder_y (block 0) and decoder_y (block 1) in one launch:
  * A0x, A0y = W[:, pf|state] [pf | state0] + b ; A1y = W[:, pf] pf + b   (model/STTODE.py:71,74-75 split). */
@@ -103,6 +104,17 @@ int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, cons
 
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
+
+/* Stage-2 latent sampler (sampler.py:47-54): z = b (eps_mode 0) or A*eps + b with eps shared [nz] (1, share_eps) or per agent
+ * [n,nz] (2); logvar = log(A^2 + 1e-8).  A, b, z, logvar [n*K, nz] (row = agent*K + k). */
+int sttode_sampler_latent(const float* A, const float* b, const float* eps, int eps_mode, float* z, float* logvar, int n, int K,
+                          int nz, void* stream);
+
+/* Stage-2 objective, per agent (samplerloss.py:4-20, utils/dist.py:22-30): kld[a] = sum_{k,d} KL(N(mu,logvar) || N(pmu,plogvar))
+ * (pmu / plogvar NULL = standard normal); div[a] = mean over the K(K-1)/2 sample pairs of exp(-|m_i - m_j|^2 / scale),
+ * motion [n,K,D] (D = 2*Tf).  The caller sums over agents, divides by agent_num, clamps and weights. */
+int sttode_sampler_loss(const float* mu, const float* logvar, const float* pmu, const float* plogvar, const float* motion, int n,
+                        int K, int nz, int D, float scale, float* kld, float* div, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).

@@ -427,6 +427,27 @@ class STTODENetRef(nn.Module):
             out = out + self.scene_orig
         return out
 
+    # -- staged API driven by the stage-2 sampler (sampler.py:36-60) ------
+    @torch.no_grad()
+    def encode_history(self):
+        """model/STTODE.py:488-496."""
+        self.past_feature = self.past_encoder(self.inputs, self.batch_size, self.agent_num)
+
+    @torch.no_grad()
+    def decoder_future_0(self, z, eps20=None):
+        """model/STTODE.py:534-551: K=1 decode, then the N(0,I) prior over the 20 samples (drawn, stored as pz_dis)."""
+        a = self.args
+        self.pred_traj, self.recover_traj = self.decoder(self.past_feature, z, self.past_traj, self.cur_location, sample_num=1)
+        m = self.past_feature.shape[0] * 20
+        self.pz_dis = Normal(mu=torch.zeros(m, a.zdim), logvar=torch.zeros(m, a.zdim))
+        self.pz_sampled = self.pz_dis.rsample(eps20)
+
+    @torch.no_grad()
+    def decoder_future_1(self, pz):
+        """model/STTODE.py:529-532."""
+        self.diverse_pred_traj, _ = self.decoder(self.past_feature.repeat_interleave(20, dim=0), pz, self.past_traj,
+                                                 self.cur_location, sample_num=20, mode='inference')
+
     @torch.no_grad()
     def forward_losses(self, eps_q, eps_p1, eps_p20):
         """model/STTODE.py:553-568 with injected noises; returns the five loss values as floats."""

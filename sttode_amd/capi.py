@@ -28,6 +28,9 @@ SIGNATURES = {
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
+    # stage-2 sampler (csrc/sampler.hip)
+    'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
+    'sttode_sampler_loss': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
     'sttode_pmath_scalar': [_I, _P, _P, _L, _P],

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
 // ---------------------------------------------------------------------------------------------------
 struct LinJob {
     const float* X1; const float* X2; const f32x4* WP; const float* bias; float* out;
-    int ld1, KT1, ld2, KT2, ldo, NT, relu;
+    int ld1, KT1, ld2, KT2, ldo, NT, act;  // act: 0 none, 1 relu, 2 tanh
 };
 struct LinJobs { LinJob j[3]; };
 
@@ -213,7 +213,12 @@ __global__ __launch_bounds__(256) void linear_cols_kernel(LinJobs jobs, int ncol
         if (col < ncols) {
 #pragma unroll
             for (int i = 0; i < RT; ++i)
-                if (rt0 + i < J.NT) st4(J.out + (size_t)col * J.ldo + 16 * (rt0 + i) + 4 * q, J.relu ? relu4(acc[i][j]) : acc[i][j]);
+                if (rt0 + i < J.NT) {
+                    f32x4 v = acc[i][j];
+                    if (J.act == 1) v = relu4(v);
+                    else if (J.act == 2) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+                    st4(J.out + (size_t)col * J.ldo + 16 * (rt0 + i) + 4 * q, v);
+                }
         }
     }
 }
@@ -569,15 +574,15 @@ extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float
 static int lin_check(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, float* out, int ldo, int N) {
     STT_REQUIRE(X1 && WP && out, "sttode_linear_cols: null pointer");
     STT_REQUIRE(N > 0 && N % 16 == 0 && K1 > 0 && K1 % 16 == 0 && K2 >= 0 && K2 % 16 == 0, "sttode_linear_cols: N, K1, K2 must be multiples of 16");
-    STT_REQUIRE(K1 + K2 <= 256, "sttode_linear_cols: K1 + K2 must be <= 256");
+    STT_REQUIRE(K1 + K2 <= 4096, "sttode_linear_cols: K1 + K2 must be <= 4096");
     STT_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && ldo % 4 == 0 && (K2 == 0 || X2), "sttode_linear_cols: leading dims must be multiples of 4");
     return 0;
 }
 static LinJob mkjob(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP, const float* bias, float* out,
-                    int ldo, int N, int relu) {
+                    int ldo, int N, int act) {
     LinJob j;
     j.X1 = X1; j.X2 = X2; j.WP = (const f32x4*)WP; j.bias = bias; j.out = out;
-    j.ld1 = ld1; j.KT1 = K1 / 16; j.ld2 = ld2; j.KT2 = K2 / 16; j.ldo = ldo; j.NT = N / 16; j.relu = relu;
+    j.ld1 = ld1; j.KT1 = K1 / 16; j.ld2 = ld2; j.KT2 = K2 / 16; j.ldo = ldo; j.NT = N / 16; j.act = act;
     return j;
 }
 static int lin_launch(const LinJobs& jobs, int njobs, int ncols, int maxNT, int maxKT, hipStream_t s) {
@@ -594,11 +599,12 @@ static int lin_launch(const LinJobs& jobs, int njobs, int ncols, int maxNT, int 
 }
 
 extern "C" int sttode_linear_cols(const float* X1, int ld1, int K1, const float* X2, int ld2, int K2, const float* WP,
-                                  const float* bias, float* out, int ldo, int ncols, int N, int relu, void* stream) {
+                                  const float* bias, float* out, int ldo, int ncols, int N, int act, void* stream) {
     if (int rc = lin_check(X1, ld1, K1, X2, ld2, K2, WP, out, ldo, N)) return rc;
     STT_REQUIRE(ncols > 0, "sttode_linear_cols: ncols must be positive");
+    STT_REQUIRE(act >= 0 && act <= 2, "sttode_linear_cols: act must be 0 (none), 1 (relu) or 2 (tanh)");
     LinJobs jobs;
-    jobs.j[0] = jobs.j[1] = jobs.j[2] = mkjob(X1, ld1, K1, X2, ld2, K2, WP, bias, out, ldo, N, relu);
+    jobs.j[0] = jobs.j[1] = jobs.j[2] = mkjob(X1, ld1, K1, X2, ld2, K2, WP, bias, out, ldo, N, act);
     return lin_launch(jobs, 1, ncols, N / 16, (K1 + K2) / 16, (hipStream_t)stream);
 }
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .dist import Normal
 from . import capi, packing
 from .weights import sinusoid_table_np
 
@@ -390,6 +391,8 @@ class STTODENet(nn.Module):
         n = self.past_feature.shape[0]
         self.past_feature_repeat = self.past_feature.repeat_interleave(20, dim=0)
         self.pz_sampled = torch.randn(n * 20, a.zdim, device=self.device) if eps20 is None else _f32(eps20, self.device)
+        zero = torch.zeros(n * 20, a.zdim, device=self.device)
+        self.pz_dis = Normal(mu=zero, logvar=zero)          # N(0, I) prior over the 20 samples (:541-551)
 
     @torch.no_grad()
     def decoder_future_1(self, pz_sampled):

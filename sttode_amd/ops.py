@@ -13,22 +13,28 @@ _PK_CACHE = {}
 
 
 def _pk16_cached(w):
+    """Fragment-ordered copy of a weight, cached per (storage address, version).  The entry keeps ``w`` alive, so the address
+    cannot be recycled for a different tensor while the entry exists."""
     key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
     if key not in _PK_CACHE:
         if len(_PK_CACHE) > 64:
             _PK_CACHE.clear()
-        _PK_CACHE[key] = torch.from_numpy(packing.pk16(w.detach().cpu().numpy())).to(w.device)
-    return _PK_CACHE[key]
+        _PK_CACHE[key] = (w, torch.from_numpy(packing.pk16(w.detach().cpu().numpy())).to(w.device))
+    return _PK_CACHE[key][1]
 
 
-def linear_cols(x, weight, bias=None, relu=False):
-    """y = x @ weight.T + bias on the MFMA column-chain kernel. x [cols, K] (K, N multiples of 16)."""
+_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2}
+
+
+def linear_cols(x, weight, bias=None, relu=False, act=None):
+    """y = act(x @ weight.T + bias) on the MFMA column-chain kernel. x [cols, K] (K, N multiples of 16); act None|'relu'|'tanh'."""
+    code = 1 if relu else _ACT[act]
     x = x.contiguous()
     cols, K = x.shape
     N = weight.shape[0]
     out = torch.empty(cols, N, dtype=torch.float32, device=x.device)
     capi.call('sttode_linear_cols', x, K, K, None, 0, 0, _pk16_cached(weight), bias.contiguous() if bias is not None else None,
-              out, N, cols, N, int(relu), capi.stream_ptr())
+              out, N, cols, N, code, capi.stream_ptr())
     return out
 
 

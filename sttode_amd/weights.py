@@ -92,6 +92,31 @@ def make_weights(seed=1234, **hp):
     return out
 
 
+def sampler_manifest(nk=20, nz=32, qnet_mlp=(512, 256), pred_model_dim=64):
+    """Ordered name -> shape map of the stage-2 Sampler state_dict (sampler.py:7-27, utils/mlp.py:5-22)."""
+    items, last = [], pred_model_dim
+    for i, nh in enumerate(qnet_mlp):
+        items += [(f'q_mlp.affine_layers.{i}.weight', (nh, last)), (f'q_mlp.affine_layers.{i}.bias', (nh,))]
+        last = nh
+    for nm, (o, i) in (('q_A', (nk * nz, last)), ('q_b', (nk * nz, last)), ('q_c', (nz, nk * nz)), ('linear', (64, 128))):
+        items += [(f'{nm}.weight', (o, i)), (f'{nm}.bias', (o,))]
+    return OrderedDict(items)
+
+
+def make_sampler_weights(seed=4321, **hp):
+    """Deterministic Sampler state_dict: q_A spread enough that the K latent codes of an agent differ."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shape in sampler_manifest(**hp).items():
+        if name.endswith('bias'):
+            w = (0.3 if name.startswith(('q_A', 'q_b')) else 0.05) * rng.standard_normal(shape)
+        else:
+            a = (2.0 if name.startswith(('q_A', 'q_b')) else 1.0) * np.sqrt(3.0 / shape[1])
+            w = rng.uniform(-a, a, size=shape)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
 def to_torch_state_dict(weights):
     import torch
     return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in weights.items())

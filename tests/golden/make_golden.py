@@ -127,9 +127,74 @@ def eth_like_case(m, noise, obs, pred, zseed):
                 ade=np.float64(ade), fde=np.float64(fde))
 
 
+def sampler_args(dataset, Tp, Tf):
+    a = make_args(dataset, Tp, Tf)
+    a.nz, a.qnet_mlp, a.share_eps, a.train_w_mean = 32, [512, 256], True, True
+    a.kld_weight, a.kld_min_clamp, a.recon_weight = 0.1, 10.0, 5.0
+    return a
+
+
+def sampler_cases(noise):
+    """Stage-2 Sampler (sampler.py:32-70) + its objective (samplerloss.py:41-73) on an ETH scene and an NBA batch,
+    mean and sampled latent codes (shared and per-agent eps).  torch.randn (sampler.py:42,45) is replaced by the fixture eps."""
+    from sampler import Sampler
+    from samplerloss import compute_sampler_loss, compute_sampler_loss_nba
+    from sttode_amd import scenes
+    from sttode_amd.weights import make_sampler_weights, to_torch_state_dict
+    out = {}
+    _randn = torch.randn
+    # NB the reference sizes eps by net.agent_num (agents PER SCENE, sampler.py:43,45), so for NBA the sampled modes only
+    # work with one scene per forward call (B = 1); mean mode takes any B.
+    for tag, dataset, Tp, Tf, B, modes in (('eth', 'eth', 8, 12, 1, ('mean', 'shared', 'peragent')),
+                                           ('nba', 'nba', 5, 10, 6, ('mean',)), ('nba1', 'nba', 5, 10, 1, ('shared', 'peragent'))):
+        net = build_ref(dataset, Tp, Tf)
+        a = sampler_args(dataset, Tp, Tf)
+        smp = Sampler(a).eval()
+        smp.load_state_dict(to_torch_state_dict(make_sampler_weights()), strict=True)
+        if dataset == 'eth':
+            o, p = scenes.eth_scene(5011, n_min=11, n_max=11)
+            n = 11
+            setd = lambda: net.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(n, Tp), torch.ones(n, Tf))
+            fut = torch.from_numpy(p).transpose(1, 2)
+            out['eth_obs'], out['eth_pred'] = o, p
+            div_cfg = {'weight': 1, 'scale': 1}       # trainsampler.py:102-116
+        else:
+            d = scenes.nba_batch(6, B)
+            n = B * 11
+            data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+            setd = lambda: net.set_data_nba(data)
+            fut = data['future_traj'].reshape(n, Tf, 2)
+            out[tag + '_seed'], out[tag + '_B'] = np.int64(6), np.int64(B)
+            div_cfg = {'weight': 1, 'scale': 1.0}
+        rng = np.random.default_rng(808 + n)
+        for mode in modes:
+            smp.share_eps = mode != 'peragent'
+            eps = rng.standard_normal((1, 32) if smp.share_eps else (n, 32)).astype(np.float32)
+            e_q, e_p, e20 = (rng.standard_normal(sh).astype(np.float32) for sh in ((n, 32), (n, 32), (n * 20, 32)))
+            torch.randn = lambda *a_, **k_: torch.from_numpy(eps)
+            with torch.no_grad():
+                setd()
+                noise.push(e_q, e_p, e20)
+                dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'))
+                if dataset == 'nba':   # trainsampler.py:142-146
+                    tot, ld, _ = compute_sampler_loss_nba(a, fut, dec.reshape(-1, 20, Tf, 2), 1, vd, sd, div_cfg)
+                else:                  # trainsampler.py:176-180
+                    tot, ld, _ = compute_sampler_loss(a, fut, dec, 1, torch.ones(n, Tf), vd, sd, div_cfg)
+            torch.randn = _randn
+            k = f'{tag}_{mode}_'
+            out.update({k + 'eps': eps, k + 'dec': npy(dec), k + 'mu': npy(sd.mu), k + 'logvar': npy(sd.logvar),
+                        k + 'pred_traj': npy(aw), k + 'loss': np.array([float(tot), float(ld['kld']), float(ld['diverse'])], np.float64)})
+    np.savez(os.path.join(HERE, 'sampler.npz'), **out)
+    print('sampler.npz bytes:', os.path.getsize(os.path.join(HERE, 'sampler.npz')))
+
+
 def main():
     install_shims()
     noise = NoiseQueue()
+    if '--only-sampler' in sys.argv:
+        sampler_cases(noise)
+        assert not noise.q
+        return
     from sttode_amd import scenes
     from sttode_amd.weights import make_weights
 
@@ -263,6 +328,7 @@ def main():
     gt = rng.standard_normal((13, 12, 2)).astype(np.float32)
     np.savez(os.path.join(HERE, 'metrics.npz'), pred=pr, gt=gt, ade=np.float64(compute_ADE(list(pr), gt)),
              fde=np.float64(compute_FDE(list(pr), gt)))
+    sampler_cases(noise)
     assert not noise.q
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print('golden bytes:', tot)

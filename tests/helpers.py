@@ -46,3 +46,47 @@ def assert_close(a, b, rtol=RTOL, atol=ATOL, what=''):
     bound = atol + rtol * np.abs(b)
     bad = err > bound
     assert not bad.any(), f'{what}: {bad.sum()} / {bad.size} out of tolerance, max err {err.max():.3e} (max |ref| {np.abs(b).max():.3e})'
+
+
+def sampler_args(dataset='eth', Tp=8, Tf=12):
+    a = make_args(dataset, Tp, Tf)
+    a.nz, a.qnet_mlp, a.share_eps, a.train_w_mean = 32, [512, 256], True, True   # trainsampler.py:59-62
+    a.kld_weight, a.kld_min_clamp, a.recon_weight = 0.1, 10.0, 5.0               # trainsampler.py:90-92
+    return a
+
+
+SAMPLER_CASES = (('eth', 'eth', 8, 12, ('mean', 'shared', 'peragent')), ('nba', 'nba', 5, 10, ('mean',)),
+                 ('nba1', 'nba', 5, 10, ('shared', 'peragent')))
+
+
+def sampler_case_inputs(g, tag, dataset):
+    """Inputs of one tests/golden/sampler.npz case: (set_data kwargs for the model, future [n,Tf,2])."""
+    from sttode_amd import scenes
+    if dataset == 'eth':
+        return dict(obs=g['eth_obs'], pred=g['eth_pred']), np.ascontiguousarray(g['eth_pred'].transpose(0, 2, 1))
+    d = scenes.nba_batch(int(g[tag + '_seed']), int(g[tag + '_B']))
+    return dict(data=d), d['future_traj'].reshape(-1, d['future_traj'].shape[2], 2)
+
+
+def oracle_sampler(dataset='eth', Tp=8, Tf=12):
+    from oracle.sampler_ref import SamplerRef
+    from sttode_amd.weights import make_sampler_weights, to_torch_state_dict
+    s = SamplerRef(sampler_args(dataset, Tp, Tf)).eval()
+    s.load_state_dict(to_torch_state_dict(make_sampler_weights()), strict=True)
+    return s
+
+
+def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode):
+    """Runs one sampler.npz case on the oracle: returns (dec, mu, logvar, pred_traj, [total, kld, diverse])."""
+    from oracle import sampler_ref as SR
+    net, smp = oracle_model(dataset, Tp, Tf), oracle_sampler(dataset, Tp, Tf)
+    inp, fut = sampler_case_inputs(g, tag, dataset)
+    smp.share_eps = mode != 'peragent'
+    with torch.no_grad():
+        if dataset == 'eth':
+            net.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']))
+        else:
+            net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
+        dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
+        tot, ld = SR.compute_sampler_loss(smp.args, torch.from_numpy(fut), dec.reshape(-1, 20, Tf, 2), vd, sd, {'weight': 1, 'scale': 1.0})
+    return dec.numpy(), sd.mu.numpy(), sd.logvar.numpy(), aw.numpy(), np.array([float(tot), float(ld['kld']), float(ld['diverse'])])

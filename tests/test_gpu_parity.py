@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ATOL, RTOL, assert_close, make_args, oracle_model, oracle_scene_inference
+from helpers import (ATOL, RTOL, SAMPLER_CASES, assert_close, make_args, oracle_model, oracle_sampler_case, oracle_scene_inference,
+                     sampler_args, sampler_case_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -442,3 +443,81 @@ def test_repeated_runs_are_bitwise_identical():
     ref = m.inference(None, z=z).clone()
     for _ in range(6):
         assert torch.equal(m.inference(None, z=z), ref)
+
+
+def test_linear_cols_tanh_and_long_k():
+    """Q-net shapes of the stage-2 sampler: tanh epilogue (utils/mlp.py:26-29) and the K = 640 contraction of q_c (sampler.py:26)."""
+    from sttode_amd.ops import linear_cols
+    dev = _gpu()
+    rng = np.random.default_rng(3)
+    for ncols, K, N, act in ((11, 64, 512, 'tanh'), (70, 512, 256, 'tanh'), (66, 640, 32, None), (9, 256, 640, None)):
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        X = rng.standard_normal((ncols, K)).astype(np.float32)
+        out = linear_cols(torch.from_numpy(X).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(b).to(dev), act=act)
+        ref = X.astype(np.float64) @ W.T.astype(np.float64) + b
+        assert_close(out.cpu().numpy(), np.tanh(ref) if act else ref, rtol=1e-5, atol=2e-5, what=f'linear_cols {act} {ncols}x{K}->{N}')
+
+
+@pytest.mark.parametrize('tag,dataset,Tp,Tf,modes', SAMPLER_CASES)
+def test_sampler_vs_reference_golden(golden, tag, dataset, Tp, Tf, modes):
+    """Stage-2 Sampler.forward + compute_sampler_loss (sampler.py:32-70, samplerloss.py:41-73) on the HIP path."""
+    from sttode_amd import Sampler, samplerloss
+    from sttode_amd.weights import make_sampler_weights, to_torch_state_dict
+    dev = _gpu()
+    g = golden('sampler')
+    net = hip_model(dataset, Tp, Tf)
+    smp = Sampler(sampler_args(dataset, Tp, Tf))
+    smp.load_state_dict(to_torch_state_dict(make_sampler_weights()), strict=True)
+    with pytest.raises(Exception):
+        smp.forward(net)                    # still on CPU: must refuse, not fall back
+    smp.set_device(dev)
+    inp, fut = sampler_case_inputs(g, tag, dataset)
+    for mode in modes:
+        smp.share_eps = mode != 'peragent'
+        if dataset == 'eth':
+            n = inp['obs'].shape[0]
+            net.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']), torch.ones(n, Tp), torch.ones(n, Tf))
+        else:
+            net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
+        k = f'{tag}_{mode}_'
+        dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[k + 'eps']))
+        assert_close(dec.cpu().numpy(), g[k + 'dec'], what=k + 'dec')
+        assert_close(sd.mu.cpu().numpy(), g[k + 'mu'], what=k + 'mu')
+        # logvar = log(A^2 + 1e-8) is ill-conditioned where A ~ 0; sigma = exp(logvar / 2) ~ |A| is what KL and rsample consume
+        assert_close(sd.sigma.cpu().numpy(), np.exp(0.5 * g[k + 'logvar']), what=k + 'sigma')
+        assert_close(aw.cpu().numpy(), g[k + 'pred_traj'], what=k + 'pred_traj')
+        futd = torch.from_numpy(fut).to(dev)
+        if dataset == 'nba':
+            tot, ld, _ = samplerloss.compute_sampler_loss_nba(smp.args, futd, dec.reshape(-1, 20, Tf, 2), 1, vd, sd, {'weight': 1, 'scale': 1.0})
+        else:
+            tot, ld, _ = samplerloss.compute_sampler_loss(smp.args, futd, dec, 1, torch.ones(n, Tf), vd, sd, {'weight': 1, 'scale': 1})
+        got = np.array([float(tot), float(ld['kld']), float(ld['diverse'])])
+        np.testing.assert_allclose(got, g[k + 'loss'], rtol=1e-4)
+        # and against the CPU oracle on the same inputs
+        odec, omu, _, _, oloss = oracle_sampler_case(g, tag, dataset, Tp, Tf, mode)
+        assert_close(dec.cpu().numpy(), odec, what=k + 'dec vs oracle')
+        np.testing.assert_allclose(got, oloss, rtol=1e-4)
+
+
+def test_sampler_loss_kernel_general_prior_and_scales():
+    """sttode_sampler_loss with a non-standard prior and the per-dataset diversity scales (trainsampler.py:102-116) vs torch fp64."""
+    from sttode_amd import samplerloss
+    from sttode_amd.dist import Normal
+    dev = _gpu()
+    rng = np.random.default_rng(12)
+    n, K, nz, Tf = 19, 20, 32, 12
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
+    q = Normal(mu=t(rng.standard_normal((n * K, nz))), logvar=t(0.5 * rng.standard_normal((n * K, nz))))
+    p = Normal(mu=t(0.3 * rng.standard_normal((n * K, nz))), logvar=t(0.3 * rng.standard_normal((n * K, nz))))
+    motion = t(0.6 * rng.standard_normal((n, K, Tf, 2)))
+    for ds in ('sdd', 'eth', 'univ', 'other'):
+        cfg = samplerloss.get_diversity_config(ds)
+        kld, div = samplerloss._per_agent(q, p, motion, cfg['scale'])
+        qm, ql, pm, pl, mo = (x.double().cpu() for x in (q.mu, q.logvar, p.mu, p.logvar, motion))
+        ps = torch.exp(0.5 * pl) + 1e-8
+        t1, t2 = (qm - pm) / ps, torch.exp(0.5 * ql) / ps
+        ref_k = (0.5 * (t1 * t1 + t2 * t2) - 0.5 - torch.log(t2)).view(n, -1).sum(1)
+        ref_d = torch.stack([(-(torch.nn.functional.pdist(m.reshape(K, -1)) ** 2) / cfg['scale']).exp().mean() for m in mo])
+        assert_close(kld.cpu().numpy(), ref_k.numpy(), rtol=1e-5, atol=1e-4, what='kld ' + ds)
+        assert_close(div.cpu().numpy(), ref_d.numpy(), rtol=1e-4, atol=1e-6, what='div ' + ds)
