@@ -117,6 +117,58 @@ int sttode_sampler_loss(const float* mu, const float* logvar, const float* pmu, 
                         int K, int nz, int D, float scale, float* kld, float* div, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training step (csrc/train.hip): forward-with-tape + backward of STTODENet.forward() (model/STTODE.py:553-568; losses
+ * :372-395; what train.py:81-87 drives through total_loss.backward()).  Generic kernels over row-major nn.Parameter storage;
+ * gradients are ACCUMULATED into the caller's .grad buffers.  All matrices row-major with explicit leading dimensions.
+ * ------------------------------------------------------------------------------------------------ */
+/* out[c, i] = mask( act( sum_j X[c / xdiv, j] * Wop[i, j] + bias[i] (+ out[c, i] if accumulate) ) ), c < cols, j < J, i < I.
+ * trans = 0: Wop[i, j] = W[i*ldw + j] (nn.Linear forward);  trans = 1: Wop[i, j] = W[j*ldw + i] (input gradient dX = dY W).
+ * act: 0 none | 1 relu | 2 tanh | 3 sigmoid.  mask (optional, [cols, ldm]): result zeroed where mask <= 0 (relu backward). */
+int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias, const float* mask,
+                   long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate, void* stream);
+/* dW[n, k] += sum_c dY[c, n] * X[c / xdiv, k];  db[n] += sum_c dY[c, n] (db may be NULL).  Deterministic: fixed column splits,
+ * partials in scratch (scratch_floats capacity; NULL = single split). */
+int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,
+                  int K, float* scratch, long scratch_floats, void* stream);
+/* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
+int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
+/* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */
+int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int rows_out, int width, int K, int accumulate, void* stream);
+/* Element-wise pieces, op codes: 0 p0=p1*p2 | 1 p0+=f0*p1 | 2 gate backward (dout=p0, tanh out p1, sigmoid out p2 -> p3, p4;
+ * hypertransformer.py:81-83) | 3 p0=relu(p1+f0*p2) (Euler step + relu, ode_demo.py:188,228) | 4 its backward (dout p0, out p1 ->
+ * p3 += d, p4 = f0*d) | 5 rsample z=mu+eps*exp(logvar/2) (model/STTODE.py:89-93; params p1 [rows,2*i0], eps p2) | 6 p0=p1*(p2>0) |
+ * 7 p0=f0 | 8 rsample backward (dz p0, params p1, eps p2 -> dparams p3 +=) | 9 p0[c,d] += p1[c / K, d % 2] (row length i0,
+ * K = f0: "+ cur_location", model/STTODE.py:343-344). */
+int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0,
+                       void* stream);
+/* y = LayerNorm(x + r) over 64 features (hypertransformer.py:146,151); saves xhat [rows,64], rstd [rows]. */
+int sttode_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
+                      int rows, void* stream);
+/* LayerNorm backward: dsum = grad wrt (x + r); dgamma, dbeta += ; scratch >= 64*128 floats. */
+int sttode_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dsum, float* dgamma,
+                  float* dbeta, int rows, float* scratch, long scratch_floats, void* stream);
+/* nn.GRU cell, gate order r|z|n (model/STTODE.py:68): gi [m rows, ld ldgi] = W_ih e_t + b_ih, gh [m,288] = W_hh h + b_hh;
+ * tape [m,384] = r, z, n, gh_n.  hprev NULL = zero state. */
+int sttode_gru_cell_fwd(const float* gi, long ldgi, const float* gh, const float* hprev, float* hnew, float* tape, int m, void* stream);
+/* dh [m,96] (grad wrt h') -> dgi (ld ldgi), dgh [m,288], dhprev = dh * z (the W_hh^T dgh term is added by sttode_tlinear). */
+int sttode_gru_cell_bwd(const float* dh, const float* tape, const float* hprev, float* dgi, long ldgi, float* dgh, float* dhprev,
+                        int m, void* stream);
+/* conv1d(2->32,k3,pad1)+relu (model/STTODE.py:65) on x = xa[c / adiv] - xb[c] ([m,T,2], xb optional); saves x; e [m,T,32]. */
+int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m, int T,
+                    void* stream);
+/* de (already relu-masked) -> dx [m,T,2] (optional), dw [32,2,3] +=, db [32] +=. */
+int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T, void* stream);
+/* Backward of the geodesic self-attention (hyptransformerlib.py:191-300, scores untransposed :261-265): qkv [L*Nb,192] (q|k|v,
+ * row = l*Nb + slot), dO [L*Nb,64] (grad wrt the merged-head output before out_proj) -> dqkv [L*Nb,192].  L <= 1024. */
+int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream);
+/* out[0] = scale * sum (pred - target)^2 (calculate_loss_pred / _recover, :372-376,384-388); dpred optional. */
+int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream);
+/* out[0] = clamp_min(sum KL(N(mu,logvar) || N(0,I)) / denom, min_clip) (:378-382, utils/dist.py:26-29); params [rows,2*zd]. */
+int sttode_loss_kl(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams, void* stream);
+/* out[0] = mean_a min_k sum (target_a - pred_ak)^2 (calculate_loss_diverse :390-395); pred [n,K,D], target [n,D]. */
+int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).
  * Row ops, x/y/out [rows,d] (scalar results: out [rows]); op codes (hyptorch/pmath.py unless noted):
  *  0 project :98-103   1 lambda_x :128-129  2 mobius_add :171-177  3 dist :205-208   4 dist0 :231-234

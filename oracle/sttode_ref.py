@@ -184,9 +184,12 @@ class PosEnc(nn.Module):
         self.fc = nn.Linear(2 * d_model, d_model)
         self.register_buffer('pe', sinusoid_table(max_t_len, d_model))
 
+    drop_mask = None   # training-mode nn.Dropout(0.1) (model/STTODE.py:140,176) as an injected [n, T, D] mask (kept / 0.9 | 0)
+
     def forward(self, x):  # [n, T, D]
         pe = self.pe[: x.shape[1]][None].expand(x.shape[0], -1, -1)
-        return self.fc(torch.cat([x, pe], dim=-1))
+        y = self.fc(torch.cat([x, pe], dim=-1))
+        return y if self.drop_mask is None else y * self.drop_mask.view_as(y)
 
 
 def add_category(x):
@@ -451,6 +454,11 @@ class STTODENetRef(nn.Module):
     @torch.no_grad()
     def forward_losses(self, eps_q, eps_p1, eps_p20):
         """model/STTODE.py:553-568 with injected noises; returns the five loss values as floats."""
+        return tuple(float(v) for v in self.forward_loss_tensors(eps_q, eps_p1, eps_p20))
+
+    def forward_loss_tensors(self, eps_q, eps_p1, eps_p20):
+        """Same, as tensors and WITHOUT no_grad: ``[0].backward()`` is the autograd reference for the HIP training step
+        (what train.py:83-85 does).  Dropout masks: set ``{past,future}_encoder.pos_encoder.drop_mask``."""
         a = self.args
         B, N = self.batch_size, self.agent_num
         pf = self.past_encoder(self.inputs, B, N)
@@ -466,4 +474,4 @@ class STTODENetRef(nn.Module):
         div, _ = self.decoder(pf.repeat_interleave(20, dim=0), pz20, self.past_traj, self.cur_location,
                               sample_num=20, mode='inference')
         ld = (self.future_traj.unsqueeze(1) - div).pow(2).sum(-1).sum(-1).min(dim=1)[0].mean()
-        return float(lp + lr + lk + ld), float(lp), float(lr), float(lk), float(ld)
+        return lp + lr + lk + ld, lp, lr, lk, ld

@@ -31,6 +31,22 @@ SIGNATURES = {
     # stage-2 sampler (csrc/sampler.hip)
     'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     'sttode_sampler_loss': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    # training step (csrc/train.hip)
+    'sttode_tlinear': [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
+    'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'sttode_train_ewise': [_I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
+    'sttode_add_ln_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'sttode_ln_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
+    'sttode_gru_cell_fwd': [_P, _L, _P, _P, _P, _P, _I, _P],
+    'sttode_gru_cell_bwd': [_P, _P, _P, _P, _L, _P, _P, _I, _P],
+    'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _P],
+    'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
+    'sttode_loss_kl': [_P, _I, _I, _F, _F, _P, _P, _P],
+    'sttode_loss_diverse': [_P, _P, _I, _I, _I, _P, _P, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
     'sttode_pmath_scalar': [_I, _P, _P, _L, _P],

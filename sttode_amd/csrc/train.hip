@@ -1,0 +1,728 @@
+// Training-step kernels: forward-with-tape and backward of STTODENet.forward()
+// (model/STTODE.py:553-568) at the reference's training shapes (one scene, n <= 32 agents, K in {1, 20};
+// NBA: 32 x 11 agents) -- a few hundred to a few thousand columns, so these are GENERIC kernels (any
+// N / K, row-major nn.Parameter storage read in place, gradients accumulated straight into .grad
+// storage), not the LDS-resident fused chains of the inference path.  The dense work still runs on
+// v_mfma_f32_16x16x4_f32 in the column-chain formulation of chain.hpp:
+//   tlinear      out[c, i] = epi( sum_j in[c / xdiv, j] * Wop[i, j] )   Wop = W or W^T (input gradient)
+//   twgrad       dW[n, k] += sum_c dY[c, n] * X[c / xdiv, k],  db[n] += sum_c dY[c, n]   (deterministic split + reduce)
+// plus the element-wise forward/backward pieces (GRU cell, conv1d k=3, LayerNorm, gate, Euler+relu,
+// geodesic attention backward, reparameterisation + KL, squared-error / best-of-K losses).
+#include "api_util.hpp"
+#include "chain.hpp"
+
+// ---------------------------------------------------------------------------------------------------
+// tlinear
+// ---------------------------------------------------------------------------------------------------
+struct TLin {
+    const float* X; const float* W; const float* bias; const float* mask; float* Y;
+    long ldx, ldw, ldy, ldm;
+    int cols, J, I, trans, act, accumulate, xdiv, xvec, wvec, yvec;
+};
+
+static __device__ __forceinline__ f32x4 ld_guard4(const float* row, int j, int J, bool rowok, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!rowok) return v;
+    if (vec && j + 3 < J) return ld4(row + j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (j + r < J) v[r] = row[j + r];
+    return v;
+}
+
+static __device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case 1: return fmaxf(v, 0.f);
+        case 2: return tanhf(v);
+        case 3: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tlinear_kernel(TLin a) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * 16;
+    const int it0 = (blockIdx.y * 4 + wave) * 4;  // first of 4 output tiles
+    if (it0 * 16 >= a.I) return;
+    const int col = col0 + c;
+    const bool colok = col < a.cols;
+    const float* xrow = a.X + (long)((colok ? col : 0) / a.xdiv) * a.ldx;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = splat4(0.f);
+    for (int j0 = 0; j0 < a.J; j0 += 16) {
+        const int j = j0 + 4 * q;
+        const f32x4 b = ld_guard4(xrow, j, a.J, colok, a.xvec);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = (it0 + t) * 16 + c;  // A-operand row held by this lane
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (i < a.I) {
+                if (!a.trans) {
+                    w = ld_guard4(a.W + (long)i * a.ldw, j, a.J, true, a.wvec);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j + r < a.J) w[r] = a.W[(long)(j + r) * a.ldw + i];
+                }
+            }
+            acc[t] = mfma_k16(acc[t], w, b);
+        }
+    }
+    if (!colok) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = (it0 + t) * 16 + 4 * q;
+        if (i >= a.I) continue;
+        float* yp = a.Y + (long)col * a.ldy + i;
+        f32x4 v = acc[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (i + r >= a.I) continue;
+            float x = v[r];
+            if (a.bias) x += a.bias[i + r];
+            if (a.accumulate) x += yp[r];
+            x = act_apply(x, a.act);
+            if (a.mask && !(a.mask[(long)col * a.ldm + i + r] > 0.f)) x = 0.f;
+            v[r] = x;
+        }
+        if (a.yvec && i + 3 < a.I) st4(yp, v);
+        else
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i + r < a.I) yp[r] = v[r];
+    }
+}
+
+static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
+
+extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
+                              const float* mask, long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate,
+                              void* stream) {
+    STT_REQUIRE(X && W && Y, "sttode_tlinear: null pointer");
+    STT_REQUIRE(cols > 0 && J > 0 && I > 0 && xdiv > 0, "sttode_tlinear: cols, J, I, xdiv must be positive");
+    STT_REQUIRE(act >= 0 && act <= 3, "sttode_tlinear: act must be 0 none | 1 relu | 2 tanh | 3 sigmoid");
+    STT_REQUIRE(ldx >= J && ldy >= I && ldw >= (trans ? I : J), "sttode_tlinear: leading dimension smaller than the row length");
+    TLin a;
+    a.X = X; a.W = W; a.bias = bias; a.mask = mask; a.Y = Y;
+    a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
+    a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
+    a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
+    dim3 grid((cols + 15) / 16, (I + 255) / 256);
+    hipLaunchKernelGGL(tlinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// twgrad: WG = 4 waves own a 32 x 32 block of [dW | db] for one column split; waves interleave 16-column chunks
+// ---------------------------------------------------------------------------------------------------
+struct TWg {
+    const float* dY; const float* X; float* dW; float* db; float* scratch;
+    long ldy, ldx, ldw;
+    int cols, N, K, xdiv, S, chunks_per_split;
+};
+
+__global__ __launch_bounds__(256) void twgrad_kernel(TWg a) {
+    __shared__ float red[4][32][33];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32, s = blockIdx.z;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = splat4(0.f);
+    const int ch0 = s * a.chunks_per_split, ch1 = min(ch0 + a.chunks_per_split, (a.cols + 15) / 16);
+    for (int ch = ch0 + wave; ch < ch1; ch += 4) {
+        f32x4 av[2], bv[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = ch * 16 + 4 * q + r;
+            const bool ok = cc < a.cols;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = n0 + 16 * i + c;
+                av[i][r] = (ok && n < a.N) ? a.dY[(long)cc * a.ldy + n] : 0.f;
+                const int k = k0 + 16 * i + c;
+                bv[i][r] = !ok ? 0.f : (k < a.K ? a.X[(long)(cc / a.xdiv) * a.ldx + k] : (k == a.K ? 1.0f : 0.f));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_k16(acc[i][j], av[i], bv[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][16 * i + 4 * q + r][16 * j + c] = acc[i][j][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int rn = e >> 5, rk = e & 31, n = n0 + rn, k = k0 + rk;
+        if (n >= a.N || k > a.K) continue;
+        const float tot = ((red[0][rn][rk] + red[1][rn][rk]) + red[2][rn][rk]) + red[3][rn][rk];
+        if (a.S == 1) {
+            if (k < a.K) a.dW[(long)n * a.ldw + k] += tot;
+            else if (a.db) a.db[n] += tot;
+        } else {
+            a.scratch[((long)s * a.N + n) * (a.K + 1) + k] = tot;
+        }
+    }
+}
+
+__global__ void twgrad_reduce_kernel(TWg a) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)a.N * (a.K + 1);
+    if (e >= per) return;
+    const int n = (int)(e / (a.K + 1)), k = (int)(e % (a.K + 1));
+    float tot = 0.f;
+    for (int s = 0; s < a.S; ++s) tot += a.scratch[(long)s * per + e];
+    if (k < a.K) a.dW[(long)n * a.ldw + k] += tot;
+    else if (a.db) a.db[n] += tot;
+}
+
+extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db,
+                             int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(dY && X && dW, "sttode_twgrad: null pointer");
+    STT_REQUIRE(cols > 0 && N > 0 && K > 0 && xdiv > 0, "sttode_twgrad: cols, N, K, xdiv must be positive");
+    STT_REQUIRE(ldy >= N && ldx >= K && ldw >= K, "sttode_twgrad: leading dimension smaller than the row length");
+    TWg a;
+    a.dY = dY; a.X = X; a.dW = dW; a.db = db; a.scratch = scratch;
+    a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.cols = cols; a.N = N; a.K = K; a.xdiv = xdiv;
+    const int chunks = (cols + 15) / 16;
+    const long per = (long)N * (K + 1);
+    int S = (chunks + 31) / 32;                       // >= 512 columns per split
+    if (S > 64) S = 64;
+    if (!scratch || per * S > scratch_floats) S = scratch && scratch_floats >= 2 * per ? (int)(scratch_floats / per) : 1;
+    if (S < 1) S = 1;
+    a.S = S;
+    a.chunks_per_split = (chunks + S - 1) / S;
+    dim3 grid((N + 31) / 32, (K + 1 + 31) / 32, S);
+    hipLaunchKernelGGL(twgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (S > 1) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// row shuffles
+// ---------------------------------------------------------------------------------------------------
+__global__ void rows_copy_kernel(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)rows * width) return;
+    const int r = (int)(e / width), f = (int)(e % width);
+    dst[(long)r * ldd + f] = src[(long)((r / div) % mod) * lds + f];
+}
+// dst[a, f] (+)= sum_{k<K} src[a*K + k, f]
+__global__ void rows_reduce_kernel(float* dst, long ldd, const float* src, long lds, int rows_out, int width, int K, int accumulate) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)rows_out * width) return;
+    const int r = (int)(e / width), f = (int)(e % width);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += src[((long)r * K + k) * lds + f];
+    float* d = dst + (long)r * ldd + f;
+    *d = accumulate ? *d + s : s;
+}
+extern "C" int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream) {
+    STT_REQUIRE(dst && src && rows > 0 && width > 0 && div > 0 && mod > 0, "sttode_rows_copy: bad argument");
+    const long tot = (long)rows * width;
+    hipLaunchKernelGGL(rows_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, rows, width, div, mod);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int rows_out, int width, int K, int accumulate,
+                                  void* stream) {
+    STT_REQUIRE(dst && src && rows_out > 0 && width > 0 && K > 0, "sttode_rows_reduce: bad argument");
+    const long tot = (long)rows_out * width;
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, rows_out, width, K, accumulate);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// element-wise pieces.  op codes of sttode_train_ewise(op, p0..p5, count, i0, i1, f0):
+// ---------------------------------------------------------------------------------------------------
+enum {
+    EW_MUL = 0,        // p0[i] = p1[i] * p2[i]                                 (dropout mask, gate product)
+    EW_AXPY = 1,       // p0[i] += f0 * p1[i]
+    EW_GATE_BWD = 2,   // given dout=p0, t=p1 (tanh out), s=p2 (sigmoid out): du=p3 = dout*s*(1-t^2), dv=p4 = dout*t*s*(1-s)
+    EW_EULER_FWD = 3,  // p0 = relu(p1 + f0 * p2)
+    EW_EULER_BWD = 4,  // d = dout(p0) * (out(p1) > 0): dx(p3) += d ; dy(p4) = f0 * d
+    EW_RSAMPLE = 5,    // params p1 [rows, 2*i0] (mu | logvar), eps p2 [rows, i0] -> z p0 = mu + eps * exp(logvar / 2)
+    EW_RELU_BWD = 6,   // p0[i] = p1[i] * (p2[i] > 0)
+    EW_FILL = 7,       // p0[i] = f0
+    EW_CUR_ADD = 9,    // p0[c, d] += p1[c / K, d % 2] with row length i0, K = (int)f0   ("+ cur_location", model/STTODE.py:343-344)
+    EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
+};
+
+__global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    switch (op) {
+        case EW_MUL: p0[i] = p1[i] * p2[i]; break;
+        case EW_AXPY: p0[i] += f0 * p1[i]; break;
+        case EW_GATE_BWD: {
+            const float d = p0[i], t = p1[i], s = p2[i];
+            p3[i] = d * s * (1.0f - t * t);
+            p4[i] = d * t * s * (1.0f - s);
+        } break;
+        case EW_EULER_FWD: p0[i] = fmaxf(p1[i] + f0 * p2[i], 0.f); break;
+        case EW_EULER_BWD: {
+            const float d = p1[i] > 0.f ? p0[i] : 0.f;
+            p3[i] += d;
+            p4[i] = f0 * d;
+        } break;
+        case EW_RSAMPLE: {
+            const long r = i / i0;
+            const int d = (int)(i % i0);
+            p0[i] = p1[r * 2 * i0 + d] + p2[i] * expf(0.5f * p1[r * 2 * i0 + i0 + d]);
+        } break;
+        case EW_RELU_BWD: p0[i] = p2[i] > 0.f ? p1[i] : 0.f; break;
+        case EW_FILL: p0[i] = f0; break;
+        case EW_CUR_ADD: {
+            const long c = i / i0;
+            p0[i] += p1[(c / (int)f0) * 2 + (i % i0) % 2];
+        } break;
+        case EW_RSAMPLE_BWD: {
+            const long r = i / i0;
+            const int d = (int)(i % i0);
+            p3[r * 2 * i0 + d] += p0[i];
+            p3[r * 2 * i0 + i0 + d] += p0[i] * p2[i] * 0.5f * expf(0.5f * p1[r * 2 * i0 + i0 + d]);
+        } break;
+    }
+}
+
+extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
+                                  float f0, void* stream) {
+    STT_REQUIRE(op >= 0 && op <= EW_CUR_ADD && p0 && count > 0, "sttode_train_ewise: bad argument");
+    hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, p0, p1, p2, p3, p4, count, i0, f0);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm(x + r) over 64 features, one wave per row (lane = feature); backward with per-WG partials
+// ---------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* x, const float* r, const float* gamma, const float* beta,
+                                                         float* y, float* xhat, float* rstd, int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float v = x[(long)row * 64 + lane] + (r ? r[(long)row * 64 + lane] : 0.f);
+    const float mean = wsum(v) * (1.0f / 64.0f);
+    const float d = v - mean;
+    const float rs = 1.0f / sqrtf(wsum(d * d) * (1.0f / 64.0f) + 1e-5f);
+    const float xh = d * rs;
+    xhat[(long)row * 64 + lane] = xh;
+    if (lane == 0) rstd[row] = rs;
+    y[(long)row * 64 + lane] = xh * gamma[lane] + beta[lane];
+}
+
+// dsum = grad wrt (x + r); dgamma / dbeta accumulated deterministically: WG g sums its rows, a single last pass adds the
+// per-WG partials in order (grid is small: rows <= a few thousand).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                                     float* dsum, float* part, int rows, int rows_per_wg) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, rows);
+    float ag = 0.f, ab = 0.f;
+    const float g = gamma[lane];
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float d = dy[(long)row * 64 + lane], xh = xhat[(long)row * 64 + lane];
+        ag += d * xh;
+        ab += d;
+        const float dh = d * g;
+        const float m1 = wsum(dh) * (1.0f / 64.0f), m2 = wsum(dh * xh) * (1.0f / 64.0f);
+        dsum[(long)row * 64 + lane] = rstd[row] * (dh - m1 - xh * m2);
+    }
+    sg[wave][lane] = ag;
+    sb[wave][lane] = ab;
+    __syncthreads();
+    if (wave == 0) {
+        part[(long)blockIdx.x * 128 + lane] = ((sg[0][lane] + sg[1][lane]) + sg[2][lane]) + sg[3][lane];
+        part[(long)blockIdx.x * 128 + 64 + lane] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    }
+}
+__global__ void ln_bwd_reduce_kernel(const float* part, int G, float* dgamma, float* dbeta) {
+    const int t = threadIdx.x;  // 128 threads
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(long)g * 128 + t];
+    if (t < 64) dgamma[t] += s;
+    else dbeta[t - 64] += s;
+}
+
+extern "C" int sttode_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* xhat,
+                                 float* rstd, int rows, void* stream) {
+    STT_REQUIRE(x && gamma && beta && y && xhat && rstd && rows > 0, "sttode_add_ln_fwd: bad argument");
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y, xhat, rstd, rows);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dsum, float* dgamma,
+                             float* dbeta, int rows, float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(dy && xhat && rstd && gamma && dsum && dgamma && dbeta && scratch && rows > 0, "sttode_ln_bwd: bad argument");
+    int G = (rows + 63) / 64;
+    if (G > 64) G = 64;
+    STT_REQUIRE(scratch_floats >= (long)G * 128, "sttode_ln_bwd: scratch too small");
+    const int rpw = (rows + G - 1) / G;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, scratch, G, dgamma, dbeta);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GRU cell (torch.nn.GRU gate order r | z | n, model/STTODE.py:68): gi = W_ih e_t + b_ih (rows m*Tp + t), gh = W_hh h + b_hh
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+// tape per step: r, z, n, gh_n  [m, 4*96]
+// ---------------------------------------------------------------------------------------------------
+__global__ void gru_cell_fwd_kernel(const float* gi, long ldgi, const float* gh, const float* hprev, float* hnew, float* tape, int m) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)m * 96) return;
+    const int c = (int)(e / 96), f = (int)(e % 96);
+    const float* gic = gi + (long)c * ldgi;
+    const float* ghc = gh + (long)c * 288;
+    const float r = 1.0f / (1.0f + expf(-(gic[f] + ghc[f])));
+    const float z = 1.0f / (1.0f + expf(-(gic[96 + f] + ghc[96 + f])));
+    const float hn = ghc[192 + f];
+    const float n = tanhf(gic[192 + f] + r * hn);
+    const float hp = hprev ? hprev[e] : 0.f;
+    hnew[e] = (1.0f - z) * n + z * hp;
+    float* t = tape + (long)c * 384;
+    t[f] = r; t[96 + f] = z; t[192 + f] = n; t[288 + f] = hn;
+}
+// dh: grad wrt h' (in) ; writes dgi [m, 288] (rows with ld ldgi), dgh [m, 288], dhprev = dh * z (out, overwrites)
+__global__ void gru_cell_bwd_kernel(const float* dh, const float* tape, const float* hprev, float* dgi, long ldgi, float* dgh,
+                                    float* dhprev, int m) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)m * 96) return;
+    const int c = (int)(e / 96), f = (int)(e % 96);
+    const float* t = tape + (long)c * 384;
+    const float r = t[f], z = t[96 + f], n = t[192 + f], hn = t[288 + f];
+    const float hp = hprev ? hprev[e] : 0.f;
+    const float d = dh[e];
+    const float dn = d * (1.0f - z), dz = d * (hp - n);
+    const float dnp = dn * (1.0f - n * n);
+    const float drp = dnp * hn * r * (1.0f - r);
+    const float dzp = dz * z * (1.0f - z);
+    float* gi = dgi + (long)c * ldgi;
+    float* gh = dgh + (long)c * 288;
+    gi[f] = drp; gi[96 + f] = dzp; gi[192 + f] = dnp;
+    gh[f] = drp; gh[96 + f] = dzp; gh[192 + f] = dnp * r;
+    dhprev[e] = d * z;
+}
+extern "C" int sttode_gru_cell_fwd(const float* gi, long ldgi, const float* gh, const float* hprev, float* hnew, float* tape, int m,
+                                   void* stream) {
+    STT_REQUIRE(gi && gh && hnew && tape && m > 0, "sttode_gru_cell_fwd: bad argument");
+    const long tot = (long)m * 96;
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, hprev, hnew, tape, m);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_gru_cell_bwd(const float* dh, const float* tape, const float* hprev, float* dgi, long ldgi, float* dgh,
+                                   float* dhprev, int m, void* stream) {
+    STT_REQUIRE(dh && tape && dgi && dgh && dhprev && m > 0, "sttode_gru_cell_bwd: bad argument");
+    const long tot = (long)m * 96;
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, tape, hprev, dgi, ldgi, dgh, dhprev, m);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv1d(2 -> 32, k = 3, pad = 1) + relu over x [m, T, 2] (model/STTODE.py:65); e [m, T, 32]
+// x = xa[c / adiv] - (xb ? xb[c] : 0)   (x_true - x_hat of the previous block)
+// ---------------------------------------------------------------------------------------------------
+__global__ void conv_fwd_kernel(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m, int T) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)m * T * 32) return;
+    const int oc = (int)(id % 32), t = (int)((id / 32) % T), c = (int)(id / (32L * T));
+    float acc = b[oc];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tt = t + k - 1;
+        if (tt < 0 || tt >= T) continue;
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic) {
+            float v = xa[((long)(c / adiv) * T + tt) * 2 + ic];
+            if (xb) v -= xb[((long)c * T + tt) * 2 + ic];
+            acc += w[(oc * 2 + ic) * 3 + k] * v;
+            if (oc == 0 && k == 1) x[((long)c * T + tt) * 2 + ic] = v;  // k == 1: tt == t, every (c, t) written once
+        }
+    }
+    e[id] = fmaxf(acc, 0.f);
+}
+// de already masked by relu.  dx[c, t, ic] = sum_{oc,k} w[oc,ic,k] * de[c, t - k + 1, oc]
+__global__ void conv_bwd_x_kernel(const float* de, const float* w, float* dx, int m, int T) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)m * T * 2) return;
+    const int ic = (int)(id % 2), t = (int)((id / 2) % T), c = (int)(id / (2L * T));
+    float acc = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const int te = t - k + 1;
+        if (te < 0 || te >= T) continue;
+        const float* d = de + ((long)c * T + te) * 32;
+        for (int oc = 0; oc < 32; ++oc) acc += w[(oc * 2 + ic) * 3 + k] * d[oc];
+    }
+    dx[id] = acc;
+}
+// one WG per (oc, ic, k) and one for each bias: dW += sum_{c,t} de[c,t,oc] * x[c,t+k-1,ic]
+__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const float* x, float* dw, float* db, int m, int T) {
+    __shared__ float red[256];
+    const int j = blockIdx.x;  // 0..191 weights, 192..223 biases
+    float acc = 0.f;
+    if (j < 192) {
+        const int k = j % 3, ic = (j / 3) % 2, oc = j / 6;
+        for (long i = threadIdx.x; i < (long)m * T; i += 256) {
+            const int t = (int)(i % T);
+            const int tt = t + k - 1;
+            if (tt < 0 || tt >= T) continue;
+            acc += de[i * 32 + oc] * x[(i - t + tt) * 2 + ic];
+        }
+    } else {
+        const int oc = j - 192;
+        for (long i = threadIdx.x; i < (long)m * T; i += 256) acc += de[i * 32 + oc];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (j < 192) dw[j] += red[0];
+        else db[j - 192] += red[0];
+    }
+}
+extern "C" int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m,
+                               int T, void* stream) {
+    STT_REQUIRE(xa && w && b && x && e && m > 0 && T > 0 && adiv > 0, "sttode_conv_fwd: bad argument");
+    const long tot = (long)m * T * 32;
+    hipLaunchKernelGGL(conv_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xa, adiv, xb, w, b, x, e, m, T);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T,
+                               void* stream) {
+    STT_REQUIRE(de && x && w && dw && db && m > 0 && T > 0, "sttode_conv_bwd: bad argument");
+    if (dx) {
+        const long tot = (long)m * T * 2;
+        hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, de, w, dx, m, T);
+    }
+    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(224), dim3(256), 0, (hipStream_t)stream, de, x, dw, db, m, T);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// geodesic self-attention backward (hyptransformerlib.py:191-300 with the untransposed-scores quirk :261-265):
+//   out_i = sum_j P_ij v_j,  P_ij = softmax_j( -acos(clamp(khat_i . qhat_j)) ),  rows i = keys, columns j = queries.
+// one WG per (slot, head); token (l, slot) is row l*Nb + slot of qkv [L*Nb, 192] = (q | k | v); L <= 1024.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* qkv, const float* dO, float* dqkv, int L, int Nb) {
+    extern __shared__ float sm[];
+    float* kh = sm;              // [L][8] normalised keys
+    float* qh = kh + L * 8;      // normalised queries
+    float* vv = qh + L * 8;
+    float* dd = vv + L * 8;      // dO
+    float* rinv = dd + L * 8;    // [L] 1 / row sum of exp
+    float* rdot = rinv + L;      // [L] sum_j P_ij dP_ij
+    float* kn = rdot + L;        // [L] 1/|k|
+    float* qn = kn + L;          // [L] 1/|q|
+    const int slot = blockIdx.x / 8, h = blockIdx.x % 8;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float* row = qkv + ((long)l * Nb + slot) * 192 + h * 8;
+        float q[8], k[8], sq = 0.f, sk = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { q[d] = row[d]; k[d] = row[64 + d]; sq += q[d] * q[d]; sk += k[d] * k[d]; }
+        const float iq = 1.0f / sqrtf(sq), ik = 1.0f / sqrtf(sk);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            qh[l * 8 + d] = q[d] * iq;
+            kh[l * 8 + d] = k[d] * ik;
+            vv[l * 8 + d] = row[128 + d];
+            dd[l * 8 + d] = dO[((long)l * Nb + slot) * 64 + h * 8 + d];
+        }
+        qn[l] = iq;
+        kn[l] = ik;
+    }
+    __syncthreads();
+    const float lo = -1.0f + 1e-4f, hi = 1.0f - 1e-4f;
+    // pass 1 (thread = key row i): softmax denominator, sum_j P dP, and dkhat_i
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        float se = 0.f, sp = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float dot = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            const float ex = expf(-acosf(fminf(fmaxf(dot, lo), hi)));
+            se += ex;
+            sp += ex * dp;
+        }
+        rinv[i] = 1.0f / se;
+        rdot[i] = sp / se;
+        float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < L; ++j) {
+            float dot = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            const bool inside = dot > lo && dot < hi;
+            const float cl = fminf(fmaxf(dot, lo), hi);
+            const float P = expf(-acosf(cl)) * rinv[i];
+            const float dS = P * (dp - rdot[i]);
+            const float g = inside ? dS / sqrtf(1.0f - cl * cl) : 0.f;   // d(-acos x)/dx = 1/sqrt(1-x^2)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dk[d] += g * qh[j * 8 + d];
+        }
+        float pr = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) pr += dk[d] * kh[i * 8 + d];
+        float* o = dqkv + ((long)i * Nb + slot) * 192 + 64 + h * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = (dk[d] - kh[i * 8 + d] * pr) * kn[i];
+    }
+    __syncthreads();
+    // pass 2 (thread = query column j): dqhat_j, dv_j
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < L; ++i) {
+            float dot = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            const bool inside = dot > lo && dot < hi;
+            const float cl = fminf(fmaxf(dot, lo), hi);
+            const float P = expf(-acosf(cl)) * rinv[i];
+            const float dS = P * (dp - rdot[i]);
+            const float g = inside ? dS / sqrtf(1.0f - cl * cl) : 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dq[d] += g * kh[i * 8 + d]; dv[d] += P * dd[i * 8 + d]; }
+        }
+        float pr = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) pr += dq[d] * qh[j * 8 + d];
+        float* o = dqkv + ((long)j * Nb + slot) * 192 + h * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            o[d] = (dq[d] - qh[j * 8 + d] * pr) * qn[j];
+            o[128 + d] = dv[d];
+        }
+    }
+}
+extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream) {
+    STT_REQUIRE(qkv && dO && dqkv && L > 0 && Nb > 0, "sttode_mhgsa_attn_bwd: bad argument");
+    STT_REQUIRE(L <= 1024, "sttode_mhgsa_attn_bwd: attention length must be <= 1024 for the training backward");
+    const size_t shm = (size_t)L * (32 + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        STT_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(Nb * 8), dim3(L < 256 ? ((L + 63) / 64) * 64 : 256), shm, (hipStream_t)stream, qkv, dO, dqkv, L, Nb);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// losses (model/STTODE.py:372-395) -- values and their gradients; out[] slots written by single-WG reductions
+// ---------------------------------------------------------------------------------------------------
+static __device__ float block_sum(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+// out[0] = scale * sum (pred - target)^2 ; dpred = 2 * scale * gscale * (pred - target)
+__global__ __launch_bounds__(256) void sqerr_kernel(const float* pred, const float* target, long count, float scale, float* out, float* dpred) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < count; i += 256) {
+        const float d = pred[i] - target[i];
+        acc += d * d;
+        if (dpred) dpred[i] = 2.0f * scale * d;
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+// KL(q || N(0, I)) in the two-distribution form (utils/dist.py:26-29 with p.sigma = 1), sum / denom, clamp_min(min_clip).
+// dparams [rows, 2*zd] = gradient of the CLAMPED value (zero when the clamp is active).
+__global__ __launch_bounds__(256) void kl_kernel(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams) {
+    __shared__ float red[256];
+    const float ps = 1.0f + 1e-8f;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < (long)rows * zd; i += 256) {
+        const long r = i / zd;
+        const int d = (int)(i % zd);
+        const float mu = params[r * 2 * zd + d], lv = params[r * 2 * zd + zd + d];
+        const float t1 = mu / ps, t2 = expf(0.5f * lv) / ps;
+        acc += 0.5f * (t1 * t1 + t2 * t2) - 0.5f - logf(t2);
+    }
+    const float s = block_sum(acc, red) / denom;
+    const bool live = s >= min_clip;   // clamp_min_: gradient passes where input >= min (torch convention)
+    if (threadIdx.x == 0) out[0] = live ? s : min_clip;
+    if (dparams) {
+        for (long i = threadIdx.x; i < (long)rows * zd; i += 256) {
+            const long r = i / zd;
+            const int d = (int)(i % zd);
+            const float mu = params[r * 2 * zd + d], lv = params[r * 2 * zd + zd + d];
+            const float t2 = expf(0.5f * lv) / ps;
+            dparams[r * 2 * zd + d] = live ? (mu / (ps * ps)) / denom : 0.f;
+            dparams[r * 2 * zd + zd + d] = live ? (0.5f * t2 * t2 - 0.5f) / denom : 0.f;  // d/dlv [0.5 t2^2 - log t2], dt2/dlv = t2/2
+        }
+    }
+}
+// best-of-K: per agent min_k sum_{t,xy} (target - pred)^2 (first minimum, like torch.min), mean over agents.
+__global__ __launch_bounds__(256) void diverse_kernel(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int a = threadIdx.x; a < n; a += 256) {
+        float best = 3.4e38f;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float t = target[(long)a * D + d] - pred[((long)a * K + k) * D + d];
+                s += t * t;
+            }
+            if (s < best) { best = s; arg = k; }
+        }
+        acc += best;
+        if (dpred) {
+            for (int k = 0; k < K; ++k)
+                for (int d = 0; d < D; ++d) {
+                    const long i = ((long)a * K + k) * D + d;
+                    dpred[i] = k == arg ? 2.0f * (pred[i] - target[(long)a * D + d]) / (float)n : 0.f;
+                }
+        }
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+extern "C" int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream) {
+    STT_REQUIRE(pred && target && out && count > 0, "sttode_loss_sqerr: bad argument");
+    hipLaunchKernelGGL(sqerr_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, count, scale, out, dpred);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_loss_kl(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams, void* stream) {
+    STT_REQUIRE(params && out && rows > 0 && zd > 0 && denom > 0.f, "sttode_loss_kl: bad argument");
+    hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, params, rows, zd, denom, min_clip, out, dparams);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, void* stream) {
+    STT_REQUIRE(pred && target && out && n > 0 && K > 0 && D > 0, "sttode_loss_diverse: bad argument");
+    hipLaunchKernelGGL(diverse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, n, K, D, out, dpred);
+    STT_HIP(hipGetLastError());
+    return 0;
+}

@@ -401,12 +401,20 @@ class STTODENet(nn.Module):
         self.diverse_pred_traj = self._decode(self.past_feature, pz_sampled, self._ws, 20, orig=zeros)
         self.attn_weights = None
 
-    @torch.no_grad()
-    def forward(self, eps_q=None, eps_p=None, eps20=None):
-        """Training objective VALUES (model/STTODE.py:553-568, losses :372-395): (total_loss, loss_pred, loss_recover, loss_kl,
-        loss_diverse).  Every network evaluation runs on the HIP kernels; the four scalar reductions are host-side glue on
-        device tensors.  No autograd graph is built: backward kernels are SURVEY.md §8f rank 1 (next), so ``total_loss``
-        carries no grad (training itself still needs the reference module)."""
+    def forward(self, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
+        """Training objective (model/STTODE.py:553-568, losses :372-395): (total_loss, loss_pred, loss_recover, loss_kl,
+        loss_diverse).  With autograd enabled (the train.py case) the step runs on the training kernels of csrc/train.hip and
+        ``total_loss.backward()`` fills ``.grad`` of every parameter (sttode_amd/training.py); under ``torch.no_grad()`` the
+        same values come from the fused inference kernels.  ``eps_*`` / ``drop_*`` inject the noises / dropout masks the
+        reference draws from torch's generator (Normal.rsample, nn.Dropout(0.1) of the positional encoders)."""
+        self._require_gpu()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .training import training_forward
+            return training_forward(self, eps_q, eps_p, eps20, drop_past, drop_future)
+        with torch.no_grad():
+            return self._forward_values(eps_q, eps_p, eps20)
+
+    def _forward_values(self, eps_q=None, eps_p=None, eps20=None):
         a = self.args
         B = self.batch_size if self._mode == 'nba' else 1
         N = self.agent_num

@@ -1,0 +1,369 @@
+"""Training step on the HIP kernels: forward-with-tape and backward of ``STTODENet.forward()``.
+
+Reference: model/STTODE.py:553-568 (objective), :372-395 (losses), :214-236 / :276-300 (encoders), :320-347 / :51-77
+(decoder), hypertransformer.py:134-153 + hyptransformerlib.py:191-300 (encoder layer / geodesic attention),
+ode_demo.py:188,228 (one Euler step of size 12 + relu); what ``train.py:81-87`` drives through ``total_loss.backward()``.
+
+Every network evaluation, loss and gradient runs in ``csrc/train.hip`` kernels (generic MFMA linear / weight-gradient
+kernels over the row-major nn.Parameter storage, plus the element-wise pieces).  PyTorch only allocates buffers and, via
+one ``autograd.Function``, hands the finished gradients to ``.grad`` so that ``optimizer.step()`` works unchanged.
+There is no eager / CPU fallback.
+"""
+import torch
+
+from . import capi
+
+EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
+ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
+_ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
+
+
+def _ld(t):
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0)
+
+
+class Engine:
+    """One training step: ``run_forward`` builds the tape and the loss values, ``run_backward`` returns name -> gradient."""
+
+    def __init__(self, net):
+        self.net = net
+        self.dev = net.device
+        self.scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
+
+    # ---------------------------------------------------------------- primitives
+    def new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def lin(self, X, W, b, act=None, xdiv=1, out=None, cols=None):
+        """out[c] = act(W X[c / xdiv] + b); X [rows, J] (row stride free), W [I, J] row-major view."""
+        cols = X.shape[0] * xdiv if cols is None else cols
+        I, J = W.shape
+        assert X.shape[1] == J
+        out = self.new(cols, I) if out is None else out
+        capi.call('sttode_tlinear', X, _ld(X), xdiv, W, _ld(W), 0, b, None, 0, out, _ld(out), cols, J, I, ACT[act], 0, self.st)
+        return out
+
+    def lin_dx(self, dY, W, mask=None, out=None, accumulate=False, in_features=None):
+        """dX = (dY W[:, :in_features]) (* (mask > 0));  W [N, K] is the forward weight."""
+        cols, N = dY.shape
+        K = W.shape[1] if in_features is None else in_features
+        out = self.new(cols, K) if out is None else out
+        capi.call('sttode_tlinear', dY, _ld(dY), 1, W, _ld(W), 1, None, mask, _ld(mask) if mask is not None else 0, out, _ld(out),
+                  cols, N, K, 0, int(accumulate), self.st)
+        return out
+
+    def wgrad(self, dY, X, gW, gb, xdiv=1):
+        cols, N = dY.shape
+        K = X.shape[1]
+        assert gW.shape[0] == N and gW.shape[1] == K, (gW.shape, N, K)
+        capi.call('sttode_twgrad', dY, _ld(dY), X, _ld(X), xdiv, gW, _ld(gW), gb, cols, N, K, self.scratch, self.scratch.numel(), self.st)
+
+    def ew(self, op, p0, p1=None, p2=None, p3=None, p4=None, i0=0, f0=0.0, count=None):
+        capi.call('sttode_train_ewise', op, p0, p1, p2, p3, p4, p0.numel() if count is None else count, i0, float(f0), self.st)
+
+    def grad(self, name):
+        """Zero-initialised gradient buffer of a parameter (allocated on first touch)."""
+        if name not in self.G:
+            self.G[name] = torch.zeros_like(self.P[name], dtype=torch.float32)
+        return self.G[name]
+
+    # ---------------------------------------------------------------- encoder trunk (PastEncoder / FutureEncoder shared part)
+    def trunk_fwd(self, pre, enc_in, last, feat, drop_mask):
+        """enc_in [n,T,4] -> feat[:, :64] = ftraj_input, feat[:, 64:128] = ODE encoder output.  Returns the tape."""
+        P, net = self.P, self.net
+        n, T = enc_in.shape[0], enc_in.shape[1]
+        t = {'n': n, 'T': T, 'pre': pre, 'feat': feat}
+        X0 = enc_in.reshape(n * T, 4)
+        posin = self.new(n * T, 128)
+        self.lin(X0, P[pre + 'input_fc.weight'], P[pre + 'input_fc.bias'], out=posin[:, :64])
+        pe = getattr(net, pre[:-1]).pos_encoder.pe
+        capi.call('sttode_rows_copy', posin[:, 64:], 128, pe, 64, n * T, 64, 1, T, self.st)
+        tp = self.lin(posin, P[pre + 'pos_encoder.fc.weight'], P[pre + 'pos_encoder.fc.bias'])
+        if drop_mask is not None:                       # nn.Dropout(0.1) of PositionalAgentEncoding (model/STTODE.py:140,176)
+            self.ew(EW_MUL, tp, tp, drop_mask)
+        h3in = self.zeros(n, 68)
+        self.lin(tp.view(n, T * 64), P[pre + 'input_fc2.weight'], P[pre + 'input_fc2.bias'], out=h3in[:, :64])
+        h3in[:, 66] = last.to(torch.float32)            # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
+        x = feat[:, :64]
+        self.lin(h3in[:, :67], P[pre + 'input_fc3.weight'], P[pre + 'input_fc3.bias'], out=x)
+        a = pre + _ATT
+        qkv = self.lin(x, P[a + 'self_attn.temporal_attention_before.in_proj_weight'],
+                       P[a + 'self_attn.temporal_attention_before.in_proj_bias'])
+        L, Nb = (net.batch_size, net._N) if net._mode == 'nba' else (1, n)
+        if L > 1:
+            attn = self.new(n, 64)
+            e = qkv.element_size()
+            capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, None, None, L, L,
+                      Nb, Nb * 192, 192, Nb * 192, 192, Nb * 192, 192, Nb * 64, 64, 1.0, 8.0 ** -0.5, self.st)
+        else:
+            attn = qkv[:, 128:]                         # softmax over a single key == 1  =>  output == v
+        ao = self.lin(attn, P[a + 'self_attn.temporal_attention_before.out_proj.weight'],
+                      P[a + 'self_attn.temporal_attention_before.out_proj.bias'])
+        tt = self.lin(ao, P[a + 'self_attn.temporal_info.weight'], P[a + 'self_attn.temporal_info.bias'], act='tanh')
+        ss = self.lin(ao, P[a + 'self_attn.temporal_gate.weight'], P[a + 'self_attn.temporal_gate.bias'], act='sigmoid')
+        gated = self.new(n, 64)
+        self.ew(EW_MUL, gated, tt, ss)
+        xc = x.contiguous()
+        h, xh1, rs1 = self.new(n, 64), self.new(n, 64), self.new(n)
+        capi.call('sttode_add_ln_fwd', xc, gated, P[a + 'norm1.weight'], P[a + 'norm1.bias'], h, xh1, rs1, n, self.st)
+        f1 = self.lin(h, P[a + 'linear1.weight'], P[a + 'linear1.bias'], act='relu')
+        f2 = self.lin(f1, P[a + 'linear2.weight'], P[a + 'linear2.bias'])
+        y, xh2, rs2 = self.new(n, 64), self.new(n, 64), self.new(n)
+        capi.call('sttode_add_ln_fwd', h, f2, P[a + 'norm2.weight'], P[a + 'norm2.bias'], y, xh2, rs2, n, self.st)
+        ode = self.new(n, 64)
+        self.ew(EW_EULER_FWD, ode, xc, y, f0=net.ODE_TIME)
+        feat[:, 64:128] = ode
+        t.update(X0=X0, posin=posin, tp=tp, drop=drop_mask, h3in=h3in, xc=xc, qkv=qkv, attn=attn, ao=ao, tt=tt, ss=ss, h=h, xh1=xh1,
+                 rs1=rs1, f1=f1, xh2=xh2, rs2=rs2, ode=ode, L=L, Nb=Nb)
+        return t
+
+    def trunk_bwd(self, t, dfeat):
+        """dfeat [n,128] (row stride free) = grad wrt cat(ftraj_input, ode_out).  Accumulates parameter grads."""
+        P, g, net = self.P, self.grad, self.net
+        pre, n, T = t['pre'], t['n'], t['T']
+        a = pre + _ATT
+        dx = dfeat[:, :64].contiguous()
+        dode = dfeat[:, 64:128].contiguous()
+        dy = self.new(n, 64)
+        self.ew(EW_EULER_BWD, dode, t['ode'], None, dx, dy, f0=net.ODE_TIME)
+        dsum2 = self.new(n, 64)
+        capi.call('sttode_ln_bwd', dy, t['xh2'], t['rs2'], P[a + 'norm2.weight'], dsum2, g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
+                  self.scratch, self.scratch.numel(), self.st)
+        self.wgrad(dsum2, t['f1'], g(a + 'linear2.weight'), g(a + 'linear2.bias'))
+        df1 = self.lin_dx(dsum2, P[a + 'linear2.weight'], mask=t['f1'])
+        self.wgrad(df1, t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'))
+        dh = dsum2                                           # residual branch of LN2(h + f)
+        self.lin_dx(df1, P[a + 'linear1.weight'], out=dh, accumulate=True)
+        dsum1 = self.new(n, 64)
+        capi.call('sttode_ln_bwd', dh, t['xh1'], t['rs1'], P[a + 'norm1.weight'], dsum1, g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
+                  self.scratch, self.scratch.numel(), self.st)
+        self.ew(EW_AXPY, dx, dsum1, f0=1.0)                  # residual branch of LN1(x + gated)
+        du, dv = self.new(n, 64), self.new(n, 64)
+        self.ew(EW_GATE_BWD, dsum1, t['tt'], t['ss'], du, dv)
+        self.wgrad(du, t['ao'], g(a + 'self_attn.temporal_info.weight'), g(a + 'self_attn.temporal_info.bias'))
+        self.wgrad(dv, t['ao'], g(a + 'self_attn.temporal_gate.weight'), g(a + 'self_attn.temporal_gate.bias'))
+        dao = self.lin_dx(du, P[a + 'self_attn.temporal_info.weight'])
+        self.lin_dx(dv, P[a + 'self_attn.temporal_gate.weight'], out=dao, accumulate=True)
+        op = a + 'self_attn.temporal_attention_before.'
+        self.wgrad(dao, t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
+        dattn = self.lin_dx(dao, P[op + 'out_proj.weight'])
+        dqkv = self.new(n, 192)
+        capi.call('sttode_mhgsa_attn_bwd', t['qkv'], dattn, dqkv, t['L'], t['Nb'], self.st)
+        self.wgrad(dqkv, t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'))
+        self.lin_dx(dqkv, P[op + 'in_proj_weight'], out=dx, accumulate=True)
+        # dx is now the gradient wrt ftraj_input
+        self.wgrad(dx, t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'))
+        dh2 = self.lin_dx(dx, P[pre + 'input_fc3.weight'], in_features=64)
+        self.wgrad(dh2, t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'), g(pre + 'input_fc2.bias'))
+        dtp = self.lin_dx(dh2, P[pre + 'input_fc2.weight']).view(n * T, 64)
+        if t['drop'] is not None:
+            self.ew(EW_MUL, dtp, dtp, t['drop'])
+        self.wgrad(dtp, t['posin'], g(pre + 'pos_encoder.fc.weight'), g(pre + 'pos_encoder.fc.bias'))
+        dtf = self.lin_dx(dtp, P[pre + 'pos_encoder.fc.weight'], in_features=64)
+        self.wgrad(dtf, t['X0'], g(pre + 'input_fc.weight'), g(pre + 'input_fc.bias'))
+
+    # ---------------------------------------------------------------- decoder (Decoder.forward, model/STTODE.py:320-347)
+    def mlp_fwd(self, pre, inp):
+        P = self.P
+        a1 = self.lin(inp, P[pre + 'layers.0.weight'], P[pre + 'layers.0.bias'], act='relu')
+        a2 = self.lin(a1, P[pre + 'layers.1.weight'], P[pre + 'layers.1.bias'], act='relu')
+        out = self.lin(a2, P[pre + 'layers.2.weight'], P[pre + 'layers.2.bias'])
+        return out, (a1, a2)
+
+    def mlp_bwd(self, pre, inp, saved, dout, din, accumulate):
+        P, g = self.P, self.grad
+        a1, a2 = saved
+        self.wgrad(dout, a2, g(pre + 'layers.2.weight'), g(pre + 'layers.2.bias'))
+        da2 = self.lin_dx(dout, P[pre + 'layers.2.weight'], mask=a2)
+        self.wgrad(da2, a1, g(pre + 'layers.1.weight'), g(pre + 'layers.1.bias'))
+        da1 = self.lin_dx(da2, P[pre + 'layers.1.weight'], mask=a1)
+        self.wgrad(da1, inp, g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias'))
+        self.lin_dx(da1, P[pre + 'layers.0.weight'], out=din, accumulate=accumulate)
+
+    def block_fwd(self, i, past, K, xhat_prev, pf, z, want_x):
+        P = self.P
+        pre = f'decoder.decompose.{i}.'
+        n, Tp = past.shape[0], past.shape[1]
+        m = n * K
+        x, e = self.new(m, Tp, 2), self.new(m * Tp, 32)
+        capi.call('sttode_conv_fwd', past, K, xhat_prev, P[pre + 'conv_past.weight'], P[pre + 'conv_past.bias'], x, e, m, Tp, self.st)
+        gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [m*Tp, 288], row c*Tp + t
+        H = self.zeros(Tp + 1, m, 96)                                                                    # H[0] = 0, H[t+1] = h_t
+        tapes = self.new(Tp, m, 384)
+        gh = self.new(m, 288)
+        for t in range(Tp):
+            self.lin(H[t], P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], out=gh)
+            capi.call('sttode_gru_cell_fwd', gi[t:], Tp * 288, gh, H[t], H[t + 1], tapes[t], m, self.st)
+        inp = self.new(m, 256)
+        capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
+        inp[:, 128:160] = z
+        inp[:, 160:] = H[Tp]
+        yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp)
+        xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp) if want_x else (None, None)
+        return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx)
+
+    def block_bwd(self, b, dyh, dxh, need_dx):
+        """Returns (din [m,256], dx [m,Tp,2] | None)."""
+        P, g = self.P, self.grad
+        pre, m, Tp = b['pre'], b['m'], b['Tp']
+        din = self.new(m, 256)
+        self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, accumulate=False)
+        if dxh is not None:
+            self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
+        dh = din[:, 160:].contiguous()
+        dgi = self.new(m * Tp, 288)
+        dgh = self.new(Tp, m, 288)
+        dhp = self.new(m, 96)
+        W_hh = P[pre + 'encoder_past.weight_hh_l0']
+        for t in range(Tp - 1, -1, -1):
+            capi.call('sttode_gru_cell_bwd', dh, b['tapes'][t], b['H'][t], dgi[t:], Tp * 288, dgh[t], dhp, m, self.st)
+            self.lin_dx(dgh[t], W_hh, out=dhp, accumulate=True)
+            dh, dhp = dhp, dh
+        self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
+        self.wgrad(dgi, b['e'], g(pre + 'encoder_past.weight_ih_l0'), g(pre + 'encoder_past.bias_ih_l0'))
+        de = self.lin_dx(dgi, P[pre + 'encoder_past.weight_ih_l0'], mask=b['e'])
+        dx = self.new(m, Tp, 2) if need_dx else None
+        capi.call('sttode_conv_bwd', de, b['x'], P[pre + 'conv_past.weight'], dx, g(pre + 'conv_past.weight'), g(pre + 'conv_past.bias'),
+                  m, Tp, self.st)
+        return din, dx
+
+    def decoder_fwd(self, pf, z, K, past, cur, want_recover):
+        n, Tp = past.shape[0], past.shape[1]
+        Tf = self.net.args.future_length
+        m = n * K
+        b0 = self.block_fwd(0, past, K, None, pf, z, True)
+        b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover)
+        pred = b0['yh'].clone()
+        self.ew(EW_AXPY, pred, b1['yh'], f0=1.0)
+        self.ew(EW_CUR_ADD, pred, cur, i0=2 * Tf, f0=K)
+        rec = None
+        if want_recover:
+            rec = b0['xh'].clone()
+            self.ew(EW_AXPY, rec, b1['xh'], f0=1.0)
+        return dict(b0=b0, b1=b1, n=n, K=K, m=m, pred=pred, rec=rec)
+
+    def decoder_bwd(self, d, dpred, drec, dpf, dz):
+        """Accumulates dpf [n,128] (+=); writes dz [m,32] if not None."""
+        n, K, m = d['n'], d['K'], d['m']
+        din1, dx1 = self.block_bwd(d['b1'], dpred, drec, True)
+        # x_1 = x_true - x_hat_0  =>  d x_hat_0 = (d recover) - d x_1
+        dxh0 = dx1.view(m, -1)
+        self.ew(EW_AXPY, dxh0, dxh0, f0=-2.0)                       # dxh0 = -dx1
+        if drec is not None:
+            self.ew(EW_AXPY, dxh0, drec, f0=1.0)
+        din0, _ = self.block_bwd(d['b0'], dpred, dxh0, False)
+        self.ew(EW_AXPY, din0, din1, f0=1.0)
+        capi.call('sttode_rows_reduce', dpf, _ld(dpf), din0, 256, n, 128, K, 1, self.st)
+        if dz is not None:
+            dz.copy_(din0[:, 128:160])
+
+    # ---------------------------------------------------------------- the objective (model/STTODE.py:553-568)
+    def run_forward(self, eps_q, eps20, drop_past=None, drop_future=None):
+        net, a = self.net, self.net.args
+        self.st = capi.stream_ptr()
+        self.P = {k: v for k, v in net.named_parameters()}
+        self.G = {}
+        B = net.batch_size if net._mode == 'nba' else 1
+        N = net.agent_num
+        ws = net._frontend(vel_from_norm=0)
+        n, Tp, Tf, zd = net._past.shape[0], a.past_length, a.future_length, a.zdim
+        past = ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2).contiguous()
+        cur = ws['cur']
+        enc_f = self.new(n, Tf, 4)
+        mode = 0 if net._mode == 'scenes' else 1
+        capi.call('sttode_frontend_future', net._future, net._past[:, -1].contiguous(), n, Tf, mode, net._N or 1, ws.get('scene_orig'),
+                  ws.get('agent_scene'), net._scene_ptr if mode == 0 else None, enc_f, self.st)
+        fut = (net._future - ws['orig'][:, None, :]).contiguous()
+        hcat = self.new(n, 256)
+        tp_ = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+        tf_ = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
+        P = self.P
+        hq = self.lin(hcat, P['future_encoder.out_mlp.affine_layers.0.weight'], P['future_encoder.out_mlp.affine_layers.0.bias'], act='relu')
+        qzp = self.lin(hq, P['future_encoder.qz_layer.weight'], P['future_encoder.qz_layer.bias'])
+        qz = self.new(n, zd)
+        self.ew(EW_RSAMPLE, qz, qzp, eps_q, i0=zd)
+        pf = hcat[:, :128]
+        d1 = self.decoder_fwd(pf, qz, 1, past, cur, True)
+        d20 = self.decoder_fwd(pf, eps20, 20, past, cur, False)
+        losses = self.new(4)
+        dpred1, drec1, dqzp, dpred20 = self.new(n, 2 * Tf), self.new(n, 2 * Tp), self.new(n, 2 * zd), self.new(n * 20, 2 * Tf)
+        capi.call('sttode_loss_sqerr', d1['pred'], fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], dpred1, self.st)
+        capi.call('sttode_loss_sqerr', d1['rec'], past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], drec1, self.st)
+        capi.call('sttode_loss_kl', qzp, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.st)
+        capi.call('sttode_loss_diverse', d20['pred'], fut, n, 20, 2 * Tf, losses[3:], dpred20, self.st)
+        self.tape = dict(tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
+                         dpred20=dpred20, n=n, zd=zd)
+        # attributes the reference sets (read by callers)
+        net.past_feature = pf
+        net.qz_param = qzp
+        net.qz_sampled = qz
+        net.pred_traj = d1['pred'].view(n, Tf, 2)
+        net.recover_traj = d1['rec'].view(n, Tp, 2)
+        net.diverse_pred_traj = d20['pred'].view(n, 20, Tf, 2)
+        net.past_traj, net.future_traj, net.cur_location = past, fut, past[:, -1:]
+        return losses
+
+    def run_backward(self):
+        T = self.tape
+        n, zd = T['n'], T['zd']
+        P, g = self.P, self.grad
+        dpf = self.zeros(n, 128)
+        self.decoder_bwd(T['d20'], T['dpred20'], None, dpf, None)
+        dqz = self.new(n, zd)
+        self.decoder_bwd(T['d1'], T['dpred1'], T['drec1'], dpf, dqz)
+        dqzp = T['dqzp']                                            # starts as the KL gradient
+        self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
+        self.wgrad(dqzp, T['hq'], g('future_encoder.qz_layer.weight'), g('future_encoder.qz_layer.bias'))
+        dhq = self.lin_dx(dqzp, P['future_encoder.qz_layer.weight'], mask=T['hq'])
+        self.wgrad(dhq, T['hcat'], g('future_encoder.out_mlp.affine_layers.0.weight'), g('future_encoder.out_mlp.affine_layers.0.bias'))
+        dhcat = self.lin_dx(dhq, P['future_encoder.out_mlp.affine_layers.0.weight'])
+        self.ew(EW_AXPY, dpf, dhcat[:, :128].contiguous(), f0=1.0)
+        self.trunk_bwd(T['tf'], dhcat[:, 128:])
+        self.trunk_bwd(T['tp'], dpf)
+        self.tape = None
+        return self.G
+
+
+class _LossFn(torch.autograd.Function):
+    """Hands the HIP-computed parameter gradients to autograd: ``total_loss.backward()`` fills ``.grad`` (train.py:83-87)."""
+
+    @staticmethod
+    def forward(ctx, total, engine, names, *params):
+        ctx.engine, ctx.names = engine, names
+        return total.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        G = ctx.engine.run_backward()
+        grads = tuple((G[nm] * gout if nm in G else None) for nm in ctx.names)
+        return (None, None, None) + grads
+
+
+def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
+    """STTODENet.forward() with autograd support (see module docstring).  Returns the reference's 5-tuple."""
+    a, dev = net.args, net.device
+    n = net._past.shape[0]
+    eps_q = torch.randn(n, a.zdim, device=dev) if eps_q is None else eps_q.to(dev, torch.float32).contiguous()
+    if eps_p is None:
+        torch.randn(n, a.zdim, device=dev)                          # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
+    eps20 = torch.randn(n * 20, a.zdim, device=dev) if eps20 is None else eps20.to(dev, torch.float32).contiguous()
+    if net.training:                                                # nn.Dropout(0.1) after the positional fc, both encoders
+        keep = 0.9
+        if drop_past is None:
+            drop_past = (torch.rand(n * a.past_length, 64, device=dev) < keep).float() / keep
+        if drop_future is None:
+            drop_future = (torch.rand(n * a.future_length, 64, device=dev) < keep).float() / keep
+    eng = getattr(net, '_engine', None)
+    if eng is None or eng.dev != dev:
+        eng = net._engine = Engine(net)
+    losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)
+    total_v = losses.sum()
+    names = [k for k, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    total = _LossFn.apply(total_v, eng, names, *params)
+    lv = losses.tolist()
+    return total, lv[0], lv[1], lv[2], lv[3]

@@ -188,9 +188,53 @@ def sampler_cases(noise):
     print('sampler.npz bytes:', os.path.getsize(os.path.join(HERE, 'sampler.npz')))
 
 
+def grad_summary(t):
+    """Per-parameter gradient digest kept in the fixture: [sum, L2 norm, max |g|] + the first 48 entries."""
+    g = t.detach().double().flatten()
+    return np.concatenate([[g.sum().item(), g.norm().item(), g.abs().max().item()], g[:48].numpy()])
+
+
+def grad_cases(noise):
+    """total_loss.backward() of the reference (train.py:83-85) with injected noises, module in eval() so that the random
+    rotation / sub-sampling of set_data (model/STTODE.py:405-426) and the positional dropout are off: ETH N=7 and NBA B=4."""
+    from sttode_amd import scenes
+    out = {}
+    for tag, dataset, Tp, Tf in (('eth', 'eth', 8, 12), ('nba', 'nba', 5, 10)):
+        m = build_ref(dataset, Tp, Tf)
+        m.zero_grad()
+        if dataset == 'eth':
+            o, p = scenes.eth_scene(5007, n_min=7, n_max=7)
+            n = 7
+            m.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(n, Tp), torch.ones(n, Tf))
+            out['eth_obs'], out['eth_pred'] = o, p
+        else:
+            d = scenes.nba_batch(9, 4)
+            n = 44
+            m.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+            out['nba_seed'], out['nba_B'] = np.int64(9), np.int64(4)
+        rng = np.random.default_rng(1300 + n)
+        eq, ep1, ep20 = (rng.standard_normal(s).astype(np.float32) for s in ((n, 32), (n, 32), (n * 20, 32)))
+        noise.push(eq, ep1, ep20)
+        tot, lp, lr, lk, ld = m.forward()
+        tot.backward()
+        out.update({f'{tag}_eps_q': eq, f'{tag}_eps_p1': ep1, f'{tag}_eps_p20': ep20,
+                    f'{tag}_losses': np.array([float(tot), lp, lr, lk, ld], np.float64)})
+        for name, prm in m.named_parameters():
+            if prm.grad is not None:
+                out[f'{tag}_grad::{name}'] = grad_summary(prm.grad)
+            else:
+                out[f'{tag}_nograd::{name}'] = np.zeros(0)
+    np.savez(os.path.join(HERE, 'forward_grads.npz'), **out)
+    print('forward_grads.npz bytes:', os.path.getsize(os.path.join(HERE, 'forward_grads.npz')))
+
+
 def main():
     install_shims()
     noise = NoiseQueue()
+    if '--only-grads' in sys.argv:
+        grad_cases(noise)
+        assert not noise.q
+        return
     if '--only-sampler' in sys.argv:
         sampler_cases(noise)
         assert not noise.q
@@ -329,6 +373,7 @@ def main():
     np.savez(os.path.join(HERE, 'metrics.npz'), pred=pr, gt=gt, ade=np.float64(compute_ADE(list(pr), gt)),
              fde=np.float64(compute_FDE(list(pr), gt)))
     sampler_cases(noise)
+    grad_cases(noise)
     assert not noise.q
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print('golden bytes:', tot)

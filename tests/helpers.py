@@ -90,3 +90,50 @@ def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode):
         dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
         tot, ld = SR.compute_sampler_loss(smp.args, torch.from_numpy(fut), dec.reshape(-1, 20, Tf, 2), vd, sd, {'weight': 1, 'scale': 1.0})
     return dec.numpy(), sd.mu.numpy(), sd.logvar.numpy(), aw.numpy(), np.array([float(tot), float(ld['kld']), float(ld['diverse'])])
+
+
+def grad_digest(t):
+    """Same digest as tests/golden/make_golden.py:grad_summary."""
+    g = t.detach().double().flatten().cpu()
+    return np.concatenate([[g.sum().item(), g.norm().item(), g.abs().max().item()], g[:48].numpy()])
+
+
+def grad_case_setup(g, tag, model, dev='cpu'):
+    """Feeds one forward_grads.npz case into ``model`` (oracle or HIP); returns the three injected noises as tensors."""
+    from sttode_amd import scenes
+    if tag == 'eth':
+        o, p = g['eth_obs'], g['eth_pred']
+        n = o.shape[0]
+        model.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(n, o.shape[2]), torch.ones(n, p.shape[2]))
+    else:
+        d = scenes.nba_batch(int(g['nba_seed']), int(g['nba_B']))
+        model.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+    return tuple(torch.from_numpy(g[f'{tag}_eps_{k}']).to(dev) for k in ('q', 'p1', 'p20'))
+
+
+def oracle_grads(tag, dataset, Tp, Tf, g, drop=None, double=False):
+    """Autograd gradients of the oracle objective: name -> tensor (None for unused parameters), and the 5 loss values.
+    ``double``: evaluate the same graph in float64 (the rounding-free yardstick for two fp32 implementations)."""
+    m = oracle_model(dataset, Tp, Tf)
+    if double:
+        import copy
+        m = copy.deepcopy(m).double()
+    m.zero_grad()
+    eq, ep1, ep20 = grad_case_setup(g, tag, m)
+    if double:
+        for attr in ('inputs', 'inputs_for_posterior', 'past_traj', 'future_traj', 'cur_location', 'scene_orig'):
+            setattr(m, attr, getattr(m, attr).double())
+        eq, ep1, ep20 = eq.double(), ep1.double(), ep20.double()
+        drop = tuple(d.double() for d in drop) if drop is not None else None
+    m.past_encoder.pos_encoder.drop_mask, m.future_encoder.pos_encoder.drop_mask = drop if drop is not None else (None, None)
+    prev = torch.get_default_dtype()
+    try:
+        torch.set_default_dtype(torch.float64 if double else torch.float32)
+        vals = m.forward_loss_tensors(eq, ep1, ep20)
+        vals[0].backward()
+    finally:
+        torch.set_default_dtype(prev)
+        m.past_encoder.pos_encoder.drop_mask = m.future_encoder.pos_encoder.drop_mask = None
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    m.zero_grad()
+    return grads, [float(v.detach()) for v in vals]

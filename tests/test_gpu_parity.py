@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (ATOL, RTOL, SAMPLER_CASES, assert_close, make_args, oracle_model, oracle_sampler_case, oracle_scene_inference,
-                     sampler_args, sampler_case_inputs)
+from helpers import (ATOL, RTOL, SAMPLER_CASES, assert_close, grad_case_setup, grad_digest, make_args, oracle_grads, oracle_model,
+                     oracle_sampler_case, oracle_scene_inference, sampler_args, sampler_case_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -521,3 +521,146 @@ def test_sampler_loss_kernel_general_prior_and_scales():
         ref_d = torch.stack([(-(torch.nn.functional.pdist(m.reshape(K, -1)) ** 2) / cfg['scale']).exp().mean() for m in mo])
         assert_close(kld.cpu().numpy(), ref_k.numpy(), rtol=1e-5, atol=1e-4, what='kld ' + ds)
         assert_close(div.cpu().numpy(), ref_d.numpy(), rtol=1e-4, atol=1e-6, what='div ' + ds)
+
+
+def test_tlinear_and_twgrad_vs_torch():
+    """Generic training kernels: forward / input-gradient / weight-gradient of nn.Linear at the model's awkward shapes
+    (K = 4, 67; N = 24; ragged columns; broadcast rows; strided views; relu mask; accumulation; >1 column split)."""
+    from sttode_amd import capi
+    dev = _gpu()
+    rng = np.random.default_rng(21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    scratch = torch.empty(1 << 20, device=dev)
+    st = capi.stream_ptr()
+    for cols, J, I, xdiv, act in ((37, 67, 64, 1, 0), (7, 4, 64, 1, 0), (640, 256, 512, 20, 1), (33, 512, 24, 1, 0), (5000, 96, 288, 1, 3),
+                                  (19, 1024, 64, 1, 2)):
+        rows = (cols + xdiv - 1) // xdiv
+        Xw = rng.standard_normal((rows, J + 5)).astype(np.float32)          # strided view: ld = J + 5 (unaligned unless J+5 % 4 == 0)
+        W = (rng.standard_normal((I, J)) / np.sqrt(J)).astype(np.float32)
+        b = rng.standard_normal(I).astype(np.float32)
+        X = t(Xw)[:, :J]
+        Y = torch.full((cols, I + 3), 7.0, device=dev)[:, :I]
+        capi.call('sttode_tlinear', X, X.stride(0), xdiv, t(W), J, 0, t(b), None, 0, Y, Y.stride(0), cols, J, I, act, 0, st)
+        xr = Xw[:, :J].astype(np.float64)[np.arange(cols) // xdiv]
+        ref = xr @ W.T.astype(np.float64) + b
+        ref = {0: ref, 1: np.maximum(ref, 0), 2: np.tanh(ref), 3: 1 / (1 + np.exp(-ref))}[act]
+        assert_close(Y.cpu().numpy(), ref, rtol=1e-5, atol=2e-5, what=f'tlinear fwd {cols}x{J}->{I}')
+        # input gradient with relu mask and accumulation
+        dY = rng.standard_normal((cols, I)).astype(np.float32)
+        mask = rng.standard_normal((cols, J)).astype(np.float32)
+        base = rng.standard_normal((cols, J)).astype(np.float32)
+        dX = t(base)
+        capi.call('sttode_tlinear', t(dY), I, 1, t(W), J, 1, None, t(mask), J, dX, J, cols, I, J, 0, 1, st)
+        ref = (dY.astype(np.float64) @ W.astype(np.float64) + base) * (mask > 0)
+        assert_close(dX.cpu().numpy(), ref, rtol=1e-5, atol=2e-5, what=f'tlinear dX {cols}x{I}->{J}')
+        # weight / bias gradient (accumulating), broadcast rows
+        gW0, gb0 = rng.standard_normal((I, J)).astype(np.float32), rng.standard_normal(I).astype(np.float32)
+        gW, gb = t(gW0), t(gb0)
+        capi.call('sttode_twgrad', t(dY), I, X, X.stride(0), xdiv, gW, J, gb, cols, I, J, scratch, scratch.numel(), st)
+        refW = dY.astype(np.float64).T @ xr + gW0
+        refb = dY.astype(np.float64).sum(0) + gb0
+        tol = 1e-5 * max(1.0, np.sqrt(cols))
+        assert_close(gW.cpu().numpy(), refW, rtol=1e-5, atol=tol, what=f'twgrad dW {cols}')
+        assert_close(gb.cpu().numpy(), refb, rtol=1e-5, atol=tol, what=f'twgrad db {cols}')
+
+
+def _hip_grads(tag, dataset, Tp, Tf, g, drop=None, train_mode=False):
+    m = hip_model(dataset, Tp, Tf)
+    m.zero_grad()
+    eq, ep1, ep20 = grad_case_setup(g, tag, m)
+    m.train(train_mode)
+    try:
+        out = m.forward(eq, ep1, ep20, *(drop if drop is not None else (None, None)))
+        out[0].backward()
+    finally:
+        m.eval()
+    grads = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    m.zero_grad()
+    return grads, [float(out[0].detach())] + list(out[1:])
+
+
+def _compare_grads(got, ref, rtol=2e-4):
+    worst = ('', 0.0)
+    for name, r in ref.items():
+        gt = got[name]
+        if r is None:
+            assert gt is None, name
+            continue
+        assert gt is not None, name
+        scale = float(r.abs().max()) + 1e-12
+        err = float((gt.double() - r.double()).abs().max()) / scale
+        if err > worst[1]:
+            worst = (name, err)
+    assert worst[1] <= rtol, f'gradient mismatch: {worst[0]} off by {worst[1]:.3e} of its max |g|'
+    return worst
+
+
+@pytest.mark.parametrize('tag,dataset,Tp,Tf', [('eth', 'eth', 8, 12), ('nba', 'nba', 5, 10)])
+def test_training_step_gradients_vs_reference_and_oracle(golden, tag, dataset, Tp, Tf):
+    """forward() + total_loss.backward() on the HIP training kernels (train.py:81-85): losses and all 88 live parameter
+    gradients vs the reference's own digests (tests/golden/forward_grads.npz) and, entry by entry, vs oracle autograd."""
+    _gpu()
+    g = golden('forward_grads')
+    grads, losses = _hip_grads(tag, dataset, Tp, Tf, g)
+    np.testing.assert_allclose(losses, g[f'{tag}_losses'], rtol=1e-4)
+    for name, gr in grads.items():
+        if f'{tag}_nograd::{name}' in g:
+            assert gr is None, name
+            continue
+        ref = g[f'{tag}_grad::{name}']
+        got = grad_digest(gr)
+        assert abs(got[1] - ref[1]) <= 2e-4 * ref[1] + 1e-9, (name, got[1], ref[1])
+        assert np.abs(got[3:] - ref[3:]).max() <= 2e-4 * (ref[2] + 1e-12), (name, np.abs(got[3:] - ref[3:]).max(), ref[2])
+    # entry by entry: against the float64 evaluation of the same graph (torch's own fp32 autograd is 0.8e-4 .. 4.6e-4 of
+    # max |g| away from it on these cases, the HIP step 1.8e-4 .. 2.0e-4), and against the fp32 oracle
+    g64, l64 = oracle_grads(tag, dataset, Tp, Tf, g, double=True)
+    np.testing.assert_allclose(losses, l64, rtol=1e-4)
+    _compare_grads(grads, g64, rtol=5e-4)
+    ograds, olosses = oracle_grads(tag, dataset, Tp, Tf, g)
+    np.testing.assert_allclose(losses, olosses, rtol=1e-4)
+    _compare_grads(grads, ograds, rtol=1e-3)
+
+
+def test_training_step_with_dropout_masks_vs_oracle(golden):
+    """train() mode: nn.Dropout(0.1) of both positional encoders as injected masks (model/STTODE.py:140,176)."""
+    dev = _gpu()
+    g = golden('forward_grads')
+    rng = np.random.default_rng(4)
+    n = g['eth_obs'].shape[0]
+    dp = torch.from_numpy(((rng.random((n * 8, 64)) < 0.9) / 0.9).astype(np.float32))
+    df = torch.from_numpy(((rng.random((n * 12, 64)) < 0.9) / 0.9).astype(np.float32))
+    grads, losses = _hip_grads('eth', 'eth', 8, 12, g, drop=(dp.to(dev), df.to(dev)), train_mode=True)
+    ograds, olosses = oracle_grads('eth', 'eth', 8, 12, g, drop=(dp, df), double=True)
+    np.testing.assert_allclose(losses, olosses, rtol=1e-4)
+    _compare_grads(grads, ograds, rtol=5e-4)
+    assert abs(losses[0] - float(g['eth_losses'][0])) > 1e-3      # the masks really changed the objective
+
+
+def test_adam_steps_track_the_oracle(golden):
+    """train.py:81-87 loop (zero_grad / backward / Adam step) for 5 iterations on the HIP model vs the oracle, same noises."""
+    from sttode_amd import STTODENet
+    from oracle.sttode_ref import STTODENetRef
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    g = golden('forward_grads')
+    sd = to_torch_state_dict(make_weights(1234, past_length=8, future_length=12))
+    hip = STTODENet(make_args('eth', 8, 12), dev)
+    hip.load_state_dict(sd, strict=True)
+    hip.eval()                                                     # deterministic data path (no rotation / dropout)
+    ora = STTODENetRef(make_args('eth', 8, 12)).eval()
+    ora.load_state_dict(sd, strict=True)
+    oh, oo = torch.optim.Adam(hip.parameters(), lr=1e-3), torch.optim.Adam(ora.parameters(), lr=1e-3)
+    lh, lo = [], []
+    for it in range(5):
+        eq, ep1, ep20 = grad_case_setup(g, 'eth', hip)
+        grad_case_setup(g, 'eth', ora)
+        tot = hip.forward(eq, ep1, ep20)[0]
+        oh.zero_grad(); tot.backward(); oh.step()
+        vo = ora.forward_loss_tensors(eq, ep1, ep20)[0]
+        oo.zero_grad(); vo.backward(); oo.step()
+        lh.append(float(tot.detach())); lo.append(float(vo.detach()))
+    assert lh[-1] < lh[0]                                          # it learns
+    np.testing.assert_allclose(lh, lo, rtol=2e-3)
+    w_h = hip.state_dict()['decoder.decompose.0.decoder_y.layers.0.weight'].cpu()
+    w_o = ora.state_dict()['decoder.decompose.0.decoder_y.layers.0.weight']
+    assert float((w_h - w_o).abs().max()) < 5e-4
