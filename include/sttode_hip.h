@@ -165,8 +165,10 @@ int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L,
 int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream);
 /* out[0] = clamp_min(sum KL(N(mu,logvar) || N(0,I)) / denom, min_clip) (:378-382, utils/dist.py:26-29); params [rows,2*zd]. */
 int sttode_loss_kl(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams, void* stream);
-/* out[0] = mean_a min_k sum (target_a - pred_ak)^2 (calculate_loss_diverse :390-395); pred [n,K,D], target [n,D]. */
-int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, void* stream);
+/* out[0] = mean_a min_k sum (target_a - pred_ak)^2 (calculate_loss_diverse :390-395); pred [n,K,D], target [n,D], K <= 64;
+ * scratch >= n floats (per-agent minima). */
+int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, float* scratch,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).

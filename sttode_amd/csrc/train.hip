@@ -39,37 +39,63 @@ static __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-__global__ __launch_bounds__(256) void tlinear_kernel(TLin a) {
+// WG = 4 waves.  A wave owns 16 columns x 64 outputs (4 tiles); when the layer has few outputs (I <= 128) the idle waves
+// split the reduction range instead (ksplit waves per 64-output chunk, partial sums combined through LDS), because at the
+// training shapes (32 .. 7040 columns) these launches are latency-bound, not throughput-bound.  Operands of 4 k-steps
+// (64 reduction indices) are fetched back to back before their 64 MFMAs so one memory latency is paid per 4 steps.
+__global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
+    __shared__ f32x4 part[4][4][64];
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
-    const int col0 = blockIdx.x * 16;
-    const int it0 = (blockIdx.y * 4 + wave) * 4;  // first of 4 output tiles
-    if (it0 * 16 >= a.I) return;
-    const int col = col0 + c;
+    const int chunks_per_wg = 4 / ksplit;
+    const int chunk = blockIdx.y * chunks_per_wg + wave / ksplit, ksub = wave % ksplit;
+    const int it0 = chunk * 4;
+    const bool active = it0 * 16 < a.I;
+    const int col = blockIdx.x * 16 + c;
     const bool colok = col < a.cols;
     const float* xrow = a.X + (long)((colok ? col : 0) / a.xdiv) * a.ldx;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = splat4(0.f);
-    for (int j0 = 0; j0 < a.J; j0 += 16) {
-        const int j = j0 + 4 * q;
-        const f32x4 b = ld_guard4(xrow, j, a.J, colok, a.xvec);
+    if (active) {
+        for (int j0 = ksub * 64; j0 < a.J; j0 += 64 * ksplit) {
+            f32x4 b[4], w[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = (it0 + t) * 16 + c;  // A-operand row held by this lane
-            f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (i < a.I) {
-                if (!a.trans) {
-                    w = ld_guard4(a.W + (long)i * a.ldw, j, a.J, true, a.wvec);
-                } else {
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 16 * u + 4 * q;
+                b[u] = ld_guard4(xrow, j, a.J, colok, a.xvec);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j + r < a.J) w[r] = a.W[(long)(j + r) * a.ldw + i];
+                for (int t = 0; t < 4; ++t) {
+                    const int i = (it0 + t) * 16 + c;  // A-operand row held by this lane
+                    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+                    if (i < a.I) {
+                        if (!a.trans) {
+                            wv = ld_guard4(a.W + (long)i * a.ldw, j, a.J, true, a.wvec);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (j + r < a.J) wv[r] = a.W[(long)(j + r) * a.ldw + i];
+                        }
+                    }
+                    w[u][t] = wv;
                 }
             }
-            acc[t] = mfma_k16(acc[t], w, b);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_k16(acc[t], w[u][t], b[u]);
         }
     }
-    if (!colok) return;
+    if (ksplit > 1) {
+        if (ksub > 0)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) part[wave][t][lane] = acc[t];
+        __syncthreads();
+        if (ksub == 0)
+            for (int k = 1; k < ksplit; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] += part[wave + k][t][lane];
+    }
+    if (!active || ksub != 0 || !colok) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = (it0 + t) * 16 + 4 * q;
@@ -108,8 +134,10 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
     a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
-    dim3 grid((cols + 15) / 16, (I + 255) / 256);
-    hipLaunchKernelGGL(tlinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int ksplit = (I <= 64 && J > 64) ? 4 : ((I <= 128 && J > 64) ? 2 : 1);
+    const int outs_per_wg = 256 / ksplit;
+    dim3 grid((cols + 15) / 16, (I + outs_per_wg - 1) / outs_per_wg);
+    hipLaunchKernelGGL(tlinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -682,29 +710,38 @@ __global__ __launch_bounds__(256) void kl_kernel(const float* params, int rows, 
     }
 }
 // best-of-K: per agent min_k sum_{t,xy} (target - pred)^2 (first minimum, like torch.min), mean over agents.
-__global__ __launch_bounds__(256) void diverse_kernel(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred) {
-    __shared__ float red[256];
-    float acc = 0.f;
-    for (int a = threadIdx.x; a < n; a += 256) {
-        float best = 3.4e38f;
-        int arg = 0;
-        for (int k = 0; k < K; ++k) {
-            float s = 0.f;
-            for (int d = 0; d < D; ++d) {
-                const float t = target[(long)a * D + d] - pred[((long)a * K + k) * D + d];
-                s += t * t;
-            }
-            if (s < best) { best = s; arg = k; }
-        }
-        acc += best;
-        if (dpred) {
-            for (int k = 0; k < K; ++k)
-                for (int d = 0; d < D; ++d) {
-                    const long i = ((long)a * K + k) * D + d;
-                    dpred[i] = k == arg ? 2.0f * (pred[i] - target[(long)a * D + d]) / (float)n : 0.f;
-                }
+// one wave per agent (lane = sample k, K <= 64), then a single-WG mean over the per-agent minima (fixed order).
+__global__ __launch_bounds__(64) void diverse_agent_kernel(const float* pred, const float* target, int n, int K, int D, float* best,
+                                                           float* dpred) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    float s = 3.4e38f;
+    if (lane < K) {
+        s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float t = target[(long)a * D + d] - pred[((long)a * K + lane) * D + d];
+            s += t * t;
         }
     }
+    float bs = s;
+    int bk = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float os = __shfl_xor(bs, o, 64);
+        const int ok = __shfl_xor(bk, o, 64);
+        if (os < bs || (os == bs && ok < bk)) { bs = os; bk = ok; }
+    }
+    if (lane == 0) best[a] = bs;
+    if (dpred)
+        for (int i = lane; i < K * D; i += 64) {
+            const int k = i / D, d = i % D;
+            const long idx = ((long)a * K + k) * D + d;
+            dpred[idx] = k == bk ? 2.0f * (pred[idx] - target[(long)a * D + d]) / (float)n : 0.f;
+        }
+}
+__global__ __launch_bounds__(256) void mean_kernel(const float* v, int n, float* out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
     const float s = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = s / (float)n;
 }
@@ -720,9 +757,11 @@ extern "C" int sttode_loss_kl(const float* params, int rows, int zd, float denom
     STT_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, void* stream) {
-    STT_REQUIRE(pred && target && out && n > 0 && K > 0 && D > 0, "sttode_loss_diverse: bad argument");
-    hipLaunchKernelGGL(diverse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, n, K, D, out, dpred);
+extern "C" int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred,
+                                   float* scratch, void* stream) {
+    STT_REQUIRE(pred && target && out && scratch && n > 0 && K > 0 && K <= 64 && D > 0, "sttode_loss_diverse: bad argument (K <= 64, scratch >= n floats)");
+    hipLaunchKernelGGL(diverse_agent_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, pred, target, n, K, D, scratch, dpred);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, out);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -213,12 +213,33 @@ class STTODENet(nn.Module):
             raise capi.SttodeError('STTODENet compute runs only on a HIP device (no CPU fallback); got device=%s' % self.device)
 
     # ------------------------------------------------------------------ data entry
-    def set_data(self, batch, pre_motion, fut_motion, pre_motion_mask=None, fut_motion_mask=None):
-        """One scene, loader layout (model/STTODE.py:397-461): pre_motion [N,2,Tp], fut_motion [N,2,Tf].
-        ``batch`` is ignored, as in the reference.  Eval semantics (no random rotation / subsampling)."""
+    def set_data(self, batch, pre_motion, fut_motion, pre_motion_mask=None, fut_motion_mask=None, theta=None):
+        """model/STTODE.py:397-461: one scene, pre_motion [N,2,Tp], fut_motion [N,2,Tf] (loader layout).
+        ``batch`` is ignored, as in the reference.  In ``train()`` mode the reference's augmentation applies (:405-426):
+        random sub-sampling to ``max_train_agent`` agents (np.random.choice, with replacement) and a random rotation of the
+        scene about ``scene_orig`` (``theta`` may be injected; otherwise torch.rand(1)*2pi, or a multiple of pi/12 when
+        ``discrete_rot``).  This is data preparation on a [N, T, 2] track, done with torch ops before the kernels run."""
         dev = self.device
         past = _f32(pre_motion, dev).permute(0, 2, 1).contiguous()
         fut = _f32(fut_motion, dev).permute(0, 2, 1).contiguous() if fut_motion is not None else None
+        if self.training and past.shape[0] > self.max_train_agent:
+            ind = torch.tensor(np.random.choice(past.shape[0], self.max_train_agent).tolist(), device=dev)
+            past = past.index_select(0, ind).contiguous()
+            fut = fut.index_select(0, ind).contiguous() if fut is not None else None
+            pre_motion_mask = pre_motion_mask.to(dev).index_select(0, ind) if pre_motion_mask is not None else None
+            fut_motion_mask = fut_motion_mask.to(dev).index_select(0, ind) if fut_motion_mask is not None else None
+        if (self.training and self.rand_rot_scene) or theta is not None:
+            if theta is None:
+                theta = (torch.randint(high=24, size=(1,)) * (np.pi / 12)) if self.discrete_rot else torch.rand(1) * np.pi * 2
+            th = torch.as_tensor(theta, dtype=torch.float32).reshape(()).to(dev)
+            c, s_ = torch.cos(th), torch.sin(th)
+            orig = past[:, -1].mean(dim=0)                       # scene_orig (:417); invariant under the rotation about itself
+
+            def rot(x):                                          # rotation_2d_torch (:6-14)
+                d = x - orig
+                return torch.stack([d[..., 0] * c - d[..., 1] * s_, d[..., 0] * s_ + d[..., 1] * c], dim=-1) + orig
+            past = rot(past).contiguous()
+            fut = rot(fut).contiguous() if fut is not None else None
         N = past.shape[0]
         self.set_scene_batch(past, fut, torch.tensor([0, N], dtype=torch.int32))
         self.batch_size = 1

@@ -66,10 +66,20 @@ class Engine:
         capi.call('sttode_train_ewise', op, p0, p1, p2, p3, p4, p0.numel() if count is None else count, i0, float(f0), self.st)
 
     def grad(self, name):
-        """Zero-initialised gradient buffer of a parameter (allocated on first touch)."""
-        if name not in self.G:
-            self.G[name] = torch.zeros_like(self.P[name], dtype=torch.float32)
+        """Gradient buffer of a parameter: a view into one flat buffer that is zeroed once per step."""
+        self.touched.add(name)
         return self.G[name]
+
+    def _grad_views(self):
+        # a FRESH flat buffer per backward (one memset): autograd may adopt the returned views as .grad, so they must not
+        # alias the next step's buffer
+        tot = sum(((v.numel() + 3) // 4) * 4 for v in self.P.values())           # 16-byte aligned sub-buffers
+        self.Gflat = torch.zeros(tot, dtype=torch.float32, device=self.dev)
+        self.G, off = {}, 0
+        for k, v in self.P.items():
+            self.G[k] = self.Gflat[off: off + v.numel()].view(v.shape)
+            off += ((v.numel() + 3) // 4) * 4
+        self.touched = set()
 
     # ---------------------------------------------------------------- encoder trunk (PastEncoder / FutureEncoder shared part)
     def trunk_fwd(self, pre, enc_in, last, feat, drop_mask):
@@ -266,7 +276,6 @@ class Engine:
         net, a = self.net, self.net.args
         self.st = capi.stream_ptr()
         self.P = {k: v for k, v in net.named_parameters()}
-        self.G = {}
         B = net.batch_size if net._mode == 'nba' else 1
         N = net.agent_num
         ws = net._frontend(vel_from_norm=0)
@@ -294,7 +303,7 @@ class Engine:
         capi.call('sttode_loss_sqerr', d1['pred'], fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], dpred1, self.st)
         capi.call('sttode_loss_sqerr', d1['rec'], past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], drec1, self.st)
         capi.call('sttode_loss_kl', qzp, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.st)
-        capi.call('sttode_loss_diverse', d20['pred'], fut, n, 20, 2 * Tf, losses[3:], dpred20, self.st)
+        capi.call('sttode_loss_diverse', d20['pred'], fut, n, 20, 2 * Tf, losses[3:], dpred20, self.scratch, self.st)
         self.tape = dict(tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
                          dpred20=dpred20, n=n, zd=zd)
         # attributes the reference sets (read by callers)
@@ -307,8 +316,9 @@ class Engine:
         net.past_traj, net.future_traj, net.cur_location = past, fut, past[:, -1:]
         return losses
 
-    def run_backward(self):
+    def run_backward(self, gout=None):
         T = self.tape
+        self._grad_views()
         n, zd = T['n'], T['zd']
         P, g = self.P, self.grad
         dpf = self.zeros(n, 128)
@@ -325,7 +335,9 @@ class Engine:
         self.trunk_bwd(T['tf'], dhcat[:, 128:])
         self.trunk_bwd(T['tp'], dpf)
         self.tape = None
-        return self.G
+        if gout is not None:
+            self.Gflat.mul_(gout)
+        return {k: self.G[k] for k in self.touched}
 
 
 class _LossFn(torch.autograd.Function):
@@ -338,8 +350,8 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        G = ctx.engine.run_backward()
-        grads = tuple((G[nm] * gout if nm in G else None) for nm in ctx.names)
+        G = ctx.engine.run_backward(gout)
+        grads = tuple(G.get(nm) for nm in ctx.names)
         return (None, None, None) + grads
 
 
