@@ -116,6 +116,11 @@ int sttode_sampler_latent(const float* A, const float* b, const float* eps, int 
 int sttode_sampler_loss(const float* mu, const float* logvar, const float* pmu, const float* plogvar, const float* motion, int n,
                         int K, int nz, int D, float scale, float* kld, float* div, void* stream);
 
+/* Backward of sttode_sampler_loss: upstream g_kld[a], g_div[a] -> dmu, dlogvar [n*K,nz], dmotion [n,K,D]. */
+int sttode_sampler_loss_bwd(const float* mu, const float* logvar, const float* pmu, const float* plogvar, const float* motion,
+                            const float* g_kld, const float* g_div, int n, int K, int nz, int D, float scale, float* dmu,
+                            float* dlogvar, float* dmotion, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training step (csrc/train.hip): forward-with-tape + backward of STTODENet.forward() (model/STTODE.py:553-568; losses
  * :372-395; what train.py:81-87 drives through total_loss.backward()).  Generic kernels over row-major nn.Parameter storage;
@@ -138,7 +143,9 @@ int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int row
  * hypertransformer.py:81-83) | 3 p0=relu(p1+f0*p2) (Euler step + relu, ode_demo.py:188,228) | 4 its backward (dout p0, out p1 ->
  * p3 += d, p4 = f0*d) | 5 rsample z=mu+eps*exp(logvar/2) (model/STTODE.py:89-93; params p1 [rows,2*i0], eps p2) | 6 p0=p1*(p2>0) |
  * 7 p0=f0 | 8 rsample backward (dz p0, params p1, eps p2 -> dparams p3 +=) | 9 p0[c,d] += p1[c / K, d % 2] (row length i0,
- * K = f0: "+ cur_location", model/STTODE.py:343-344). */
+ * K = f0: "+ cur_location", model/STTODE.py:343-344) | 10 p0=p1*(1-p2^2) (tanh backward from its output) | 11 stage-2 latent
+ * backward (sampler.py:51-53): dz p0, dlogvar p1, A p2, eps p3 -> dA p4 = dz*eps + dlogvar*2A/(A^2+1e-8); i0 = nz*4 + eps_mode,
+ * f0 = K*nz. */
 int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0,
                        void* stream);
 /* y = LayerNorm(x + r) over 64 features (hypertransformer.py:146,151); saves xhat [rows,64], rstd [rows]. */

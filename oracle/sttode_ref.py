@@ -430,13 +430,11 @@ class STTODENetRef(nn.Module):
             out = out + self.scene_orig
         return out
 
-    # -- staged API driven by the stage-2 sampler (sampler.py:36-60) ------
-    @torch.no_grad()
+    # -- staged API driven by the stage-2 sampler (sampler.py:36-60); differentiable (callers wrap in no_grad for values) --
     def encode_history(self):
         """model/STTODE.py:488-496."""
         self.past_feature = self.past_encoder(self.inputs, self.batch_size, self.agent_num)
 
-    @torch.no_grad()
     def decoder_future_0(self, z, eps20=None):
         """model/STTODE.py:534-551: K=1 decode, then the N(0,I) prior over the 20 samples (drawn, stored as pz_dis)."""
         a = self.args
@@ -445,7 +443,6 @@ class STTODENetRef(nn.Module):
         self.pz_dis = Normal(mu=torch.zeros(m, a.zdim), logvar=torch.zeros(m, a.zdim))
         self.pz_sampled = self.pz_dis.rsample(eps20)
 
-    @torch.no_grad()
     def decoder_future_1(self, pz):
         """model/STTODE.py:529-532."""
         self.diverse_pred_traj, _ = self.decoder(self.past_feature.repeat_interleave(20, dim=0), pz, self.past_traj,

@@ -31,6 +31,7 @@ SIGNATURES = {
     # stage-2 sampler (csrc/sampler.hip)
     'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     'sttode_sampler_loss': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    'sttode_sampler_loss_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     # training step (csrc/train.hip)
     'sttode_tlinear': [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],

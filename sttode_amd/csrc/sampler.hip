@@ -70,6 +70,43 @@ __global__ __launch_bounds__(64) void sampler_loss_kernel(const float* __restric
     }
 }
 
+// backward of sampler_loss_kernel: upstream gradients g_kld[a], g_div[a] of the per-agent outputs
+__global__ __launch_bounds__(64) void sampler_loss_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                              const float* __restrict__ pmu, const float* __restrict__ plogvar,
+                                                              const float* __restrict__ motion, const float* __restrict__ g_kld,
+                                                              const float* __restrict__ g_div, int n, int K, int nz, int D, float scale,
+                                                              float* __restrict__ dmu, float* __restrict__ dlogvar,
+                                                              float* __restrict__ dmotion) {
+    __shared__ float sM[4096];
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const size_t base = (size_t)a * K * nz;
+    const float gk = g_kld[a], gd = g_div[a];
+    for (int i = lane; i < K * nz; i += 64) {
+        const float ps = (plogvar ? expf(0.5f * plogvar[base + i]) : 1.f) + 1e-8f;
+        const float t1 = (mu[base + i] - (pmu ? pmu[base + i] : 0.f)) / ps, t2 = expf(0.5f * logvar[base + i]) / ps;
+        dmu[base + i] = gk * t1 / ps;
+        dlogvar[base + i] = gk * 0.5f * (t2 * t2 - 1.0f);
+    }
+    for (int i = lane; i < K * D; i += 64) sM[i] = motion[(size_t)a * K * D + i];
+    __syncthreads();
+    const float coef = gd * (-2.0f / scale) / (float)(K * (K - 1) / 2);
+    // thread = (sample i, coordinate d): d/dm_i = coef * sum_{j != i} exp(-|m_i - m_j|^2 / scale) * (m_i - m_j)
+    for (int e = lane; e < K * D; e += 64) {
+        const int i = e / D, d = e % D;
+        float acc = 0.f;
+        for (int j = 0; j < K; ++j) {
+            if (j == i) continue;
+            float s = 0.f;
+            for (int t = 0; t < D; ++t) {
+                const float df = sM[i * D + t] - sM[j * D + t];
+                s += df * df;
+            }
+            if (s > 0.f) acc += expf(-s / scale) * (sM[i * D + d] - sM[j * D + d]);   // F.pdist backward is 0 at zero distance
+        }
+        dmotion[(size_t)a * K * D + e] = coef * acc;
+    }
+}
+
 extern "C" int sttode_sampler_latent(const float* A, const float* b, const float* eps, int eps_mode, float* z, float* logvar,
                                      int n, int K, int nz, void* stream) {
     STT_REQUIRE(A && b && z && logvar, "sttode_sampler_latent: null pointer");
@@ -91,6 +128,17 @@ extern "C" int sttode_sampler_loss(const float* mu, const float* logvar, const f
     STT_REQUIRE(scale > 0.f, "sttode_sampler_loss: scale must be positive");
     hipLaunchKernelGGL(sampler_loss_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, mu, logvar, pmu, plogvar, motion, n, K, nz,
                        D, scale, kld, div);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_sampler_loss_bwd(const float* mu, const float* logvar, const float* pmu, const float* plogvar,
+                                       const float* motion, const float* g_kld, const float* g_div, int n, int K, int nz, int D,
+                                       float scale, float* dmu, float* dlogvar, float* dmotion, void* stream) {
+    STT_REQUIRE(mu && logvar && motion && g_kld && g_div && dmu && dlogvar && dmotion, "sttode_sampler_loss_bwd: null pointer");
+    STT_REQUIRE(n > 0 && K > 1 && nz > 0 && D > 0 && (long)K * D <= 4096 && scale > 0.f, "sttode_sampler_loss_bwd: bad shape");
+    hipLaunchKernelGGL(sampler_loss_bwd_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, mu, logvar, pmu, plogvar, motion, g_kld,
+                       g_div, n, K, nz, D, scale, dmu, dlogvar, dmotion);
     STT_HIP(hipGetLastError());
     return 0;
 }

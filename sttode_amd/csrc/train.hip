@@ -282,6 +282,8 @@ enum {
     EW_RELU_BWD = 6,   // p0[i] = p1[i] * (p2[i] > 0)
     EW_FILL = 7,       // p0[i] = f0
     EW_CUR_ADD = 9,    // p0[c, d] += p1[c / K, d % 2] with row length i0, K = (int)f0   ("+ cur_location", model/STTODE.py:343-344)
+    EW_TANH_BWD = 10,  // p0[i] = p1[i] * (1 - p2[i]^2)      (p2 = tanh output)
+    EW_LATENT_BWD = 11,  // sampler.py:51-53: dz=p0, dlogvar=p1, A=p2, eps p3 (mode i0: 0 none | 1 shared [nz] | 2 per agent) -> dA=p4
     EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
 };
 
@@ -309,6 +311,16 @@ __global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2
         } break;
         case EW_RELU_BWD: p0[i] = p2[i] > 0.f ? p1[i] : 0.f; break;
         case EW_FILL: p0[i] = f0; break;
+        case EW_TANH_BWD: p0[i] = p1[i] * (1.0f - p2[i] * p2[i]); break;
+        case EW_LATENT_BWD: {
+            // z = A * eps + b, logvar = log(A^2 + 1e-8); f0 = K * nz (row length of A viewed [n, K*nz]), nz = i0 >> 2, mode = i0 & 3
+            const int mode = i0 & 3, nz = i0 >> 2;
+            const float a = p2[i];
+            float e = 0.f;
+            if (mode == 1) e = p3[i % nz];
+            else if (mode == 2) e = p3[(i / (long)f0) * nz + i % nz];
+            p4[i] = p0[i] * e + p1[i] * 2.0f * a / (a * a + 1e-8f);
+        } break;
         case EW_CUR_ADD: {
             const long c = i / i0;
             p0[i] += p1[(c / (int)f0) * 2 + (i % i0) % 2];
@@ -324,7 +336,7 @@ __global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2
 
 extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
                                   float f0, void* stream) {
-    STT_REQUIRE(op >= 0 && op <= EW_CUR_ADD && p0 && count > 0, "sttode_train_ewise: bad argument");
+    STT_REQUIRE(op >= 0 && op <= EW_LATENT_BWD && p0 && count > 0, "sttode_train_ewise: bad argument");
     hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, p0, p1, p2, p3, p4, count, i0, f0);
     STT_HIP(hipGetLastError());
     return 0;

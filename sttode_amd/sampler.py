@@ -46,14 +46,30 @@ class Sampler(nn.Module):
         self.device = torch.device(device)
         self.to(self.device)
 
-    @torch.no_grad()
     def forward(self, net, mean=True, need_weights=False, eps=None):
+        """With autograd enabled (trainsampler.py:134-150,171-185) the outputs carry a graph to the sampler's parameters (backward
+        on csrc/train.hip + csrc/sampler.hip kernels, see ``_SamplerFn``); otherwise plain values.  See ``_forward_values``."""
+        if self.device.type != 'cuda':
+            raise capi.SttodeError('Sampler runs only on a HIP device (no CPU fallback): call set_device(cuda) first')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _sampler_forward_grad(self, net, mean, eps)
+        with torch.no_grad():
+            return self._forward_values(net, mean, need_weights, eps)
+
+    def _draw_eps(self, n, mean, eps):
+        if mean:
+            return 0, None
+        rows = 1 if self.share_eps else n
+        eps = torch.randn(rows, self.nz, device=self.device) if eps is None else eps.to(self.device, torch.float32).contiguous()
+        if tuple(eps.shape) != (rows, self.nz):
+            raise ValueError(f'eps must be [{rows}, {self.nz}]')
+        return (1 if self.share_eps else 2), eps
+
+    def _forward_values(self, net, mean=True, need_weights=False, eps=None):
         """sampler.py:32-70 -> (dec_motion [n,K,Tf,2], sampler_dist, vae_dist, attn_weights (= net.pred_traj, sic)).
         ``eps`` ([1,nz] when share_eps else [n,nz]) may be injected; otherwise drawn like sampler.py:41-46.  (The reference
         sizes eps by net.agent_num = agents per scene, so its sampled modes only run with one scene per call; here eps is
         per agent of the whole batch, identical in that case.)"""
-        if self.device.type != 'cuda':
-            raise capi.SttodeError('Sampler runs only on a HIP device (no CPU fallback): call set_device(cuda) first')
         K, nz = self.nk, self.nz
         net.encode_history()
         if net._future is not None:
@@ -65,14 +81,7 @@ class Sampler(nn.Module):
             h = linear_cols(h, lin.weight, lin.bias, act='tanh')                                    # :48
         A = linear_cols(h, self.q_A.weight, self.q_A.bias)                                          # [n, K*nz] == [n*K, nz]
         b = linear_cols(h, self.q_b.weight, self.q_b.bias)
-        if mean:
-            mode, eps = 0, None
-        else:
-            rows = 1 if self.share_eps else n
-            eps = torch.randn(rows, nz, device=self.device) if eps is None else eps.to(self.device, torch.float32).contiguous()
-            if tuple(eps.shape) != (rows, nz):
-                raise ValueError(f'eps must be [{rows}, {nz}]')
-            mode = 1 if self.share_eps else 2
+        mode, eps = self._draw_eps(n, mean, eps)
         z = torch.empty(n * K, nz, device=self.device)
         logvar = torch.empty(n * K, nz, device=self.device)
         capi.call('sttode_sampler_latent', A, b, eps, mode, z, logvar, n, K, nz, capi.stream_ptr())   # :51,53
@@ -89,3 +98,84 @@ class Sampler(nn.Module):
 
     def step_annealer(self):
         pass
+
+
+class _SamplerFn(torch.autograd.Function):
+    """Q-net + latent codes + K-sample decode with a tape; backward returns the gradients of the sampler's parameters
+    (the frozen STTODENet gets none: trainsampler.py:283 optimises ``sampler.parameters()`` only)."""
+
+    @staticmethod
+    def forward(ctx, smp, net, mode, eps, *params):
+        from .training import Engine
+        eng = getattr(net, '_engine', None)
+        if eng is None or eng.dev != net.device:
+            eng = net._engine = Engine(net)
+        eng.st = capi.stream_ptr()
+        eng.P = {k: v for k, v in net.named_parameters()}
+        K, nz, a = smp.nk, smp.nz, net.args
+        pf = net.past_feature
+        n = pf.shape[0]
+        h0 = eng.lin(pf, smp.linear.weight, smp.linear.bias)                                        # sampler.py:39
+        hs = [h0]
+        for lin in smp.q_mlp.affine_layers:
+            hs.append(eng.lin(hs[-1], lin.weight, lin.bias, act='tanh'))                            # :48
+        A = eng.lin(hs[-1], smp.q_A.weight, smp.q_A.bias)
+        b = eng.lin(hs[-1], smp.q_b.weight, smp.q_b.bias)
+        z, logvar = eng.new(n * K, nz), eng.new(n * K, nz)
+        capi.call('sttode_sampler_latent', A, b, eps, mode, z, logvar, n, K, nz, eng.st)
+        z0 = eng.lin(z.view(n, K * nz), smp.q_c.weight, smp.q_c.bias)                               # :52 (feeds pred_traj only)
+        net.decoder_future_0(z0)
+        Tp = a.past_length
+        past = net._ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2).contiguous()
+        d = eng.decoder_fwd(pf, z, K, past, net._ws['cur'], False)
+        ctx.eng, ctx.smp, ctx.d, ctx.hs, ctx.A, ctx.eps, ctx.mode, ctx.pf = eng, smp, d, hs, A, eps, mode, pf
+        dec = d['pred'].view(n, K, a.future_length, 2)
+        net.diverse_pred_traj = dec
+        if a.dataset != 'nba':
+            dec = dec + net._ws['orig'][:, None, None, :]                                           # :63-67
+        return dec.contiguous(), b.view(n * K, nz), logvar
+
+    @staticmethod
+    def backward(ctx, g_dec, g_mu, g_lv):
+        from .training import EW_AXPY, EW_LATENT_BWD, EW_TANH_BWD
+        eng, smp, d, hs, A = ctx.eng, ctx.smp, ctx.d, ctx.hs, ctx.A
+        n, K, nz = hs[0].shape[0], smp.nk, smp.nz
+        m = n * K
+        eng._grad_views()
+        eng.param_grads = False                                     # the STTODENet is frozen in stage 2
+        try:
+            dz = eng.zeros(m, nz)
+            if g_dec is not None:
+                eng.decoder_bwd(d, g_dec.contiguous().view(m, -1), None, eng.zeros(n, 128), dz)
+        finally:
+            eng.param_grads = True
+        g_lv = eng.zeros(m, nz) if g_lv is None else g_lv.contiguous()
+        dA = eng.new(n, K * nz)
+        eng.ew(EW_LATENT_BWD, dz, g_lv, A, ctx.eps, dA, i0=nz * 4 + ctx.mode, f0=K * nz)
+        db = dz.view(n, K * nz)
+        if g_mu is not None:
+            eng.ew(EW_AXPY, db, g_mu.contiguous(), f0=1.0)
+        G = {k: torch.zeros_like(p) for k, p in smp.named_parameters() if not k.startswith('q_c.')}
+        eng.wgrad(dA, hs[-1], G['q_A.weight'], G['q_A.bias'])
+        eng.wgrad(db, hs[-1], G['q_b.weight'], G['q_b.bias'])
+        dh = eng.lin_dx(dA, smp.q_A.weight)
+        eng.lin_dx(db, smp.q_b.weight, out=dh, accumulate=True)
+        for i in range(len(smp.q_mlp.affine_layers) - 1, -1, -1):
+            lin = smp.q_mlp.affine_layers[i]
+            eng.ew(EW_TANH_BWD, dh, dh, hs[i + 1])
+            eng.wgrad(dh, hs[i], G[f'q_mlp.affine_layers.{i}.weight'], G[f'q_mlp.affine_layers.{i}.bias'])
+            dh = eng.lin_dx(dh, lin.weight)
+        eng.wgrad(dh, ctx.pf, G['linear.weight'], G['linear.bias'])
+        return (None, None, None, None) + tuple(G.get(k) for k, _ in smp.named_parameters())
+
+
+def _sampler_forward_grad(smp, net, mean, eps):
+    with torch.no_grad():
+        net.encode_history()
+        if net._future is not None:
+            net.fu_encoder()
+    mode, eps = smp._draw_eps(net.past_feature.shape[0], mean, eps)
+    dec, mu, logvar = _SamplerFn.apply(smp, net, mode, eps, *[p for _, p in smp.named_parameters()])
+    if smp.args.dataset != 'nba':
+        smp.scene_orig = net.scene_orig
+    return dec, Normal(mu=mu, logvar=logvar), net.pz_dis, net.pred_traj

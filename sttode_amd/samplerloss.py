@@ -10,19 +10,39 @@ def get_diversity_config(dataset):
             'nba': {'weight': 1, 'scale': 1.0}}.get(dataset, {'weight': 3, 'scale': 2})
 
 
+class _PerAgentLoss(torch.autograd.Function):
+    """(kld[a], div[a]) = sttode_sampler_loss; backward = sttode_sampler_loss_bwd (gradients wrt mu, logvar, motion)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, motion, pmu, plogvar, scale):
+        n, K = motion.shape[:2]
+        D = motion[0, 0].numel()
+        nz = mu.shape[-1]
+        kld = torch.empty(n, device=mu.device)
+        div = torch.empty(n, device=mu.device)
+        capi.call('sttode_sampler_loss', mu, logvar, pmu, plogvar, motion, n, K, nz, D, float(scale), kld, div, capi.stream_ptr())
+        ctx.save_for_backward(mu, logvar, motion, *([pmu, plogvar] if pmu is not None else []))
+        ctx.dims = (n, K, nz, D, float(scale))
+        return kld, div
+
+    @staticmethod
+    def backward(ctx, g_kld, g_div):
+        mu, logvar, motion, *pp = ctx.saved_tensors
+        pmu, plogvar = pp if pp else (None, None)
+        n, K, nz, D, scale = ctx.dims
+        dmu, dlv, dmo = torch.empty_like(mu), torch.empty_like(logvar), torch.empty_like(motion)
+        capi.call('sttode_sampler_loss_bwd', mu, logvar, pmu, plogvar, motion, g_kld.contiguous(), g_div.contiguous(), n, K, nz, D, scale,
+                  dmu, dlv, dmo, capi.stream_ptr())
+        return dmu, dlv, dmo, None, None, None
+
+
 def _per_agent(q, p, motion, scale):
-    """(kld[a], div[a]) for motion [n,K,Tf,2], q/p Normal over [n*K, nz]."""
-    n, K = motion.shape[:2]
-    D = motion[0, 0].numel()
-    nz = q.mu.shape[-1]
+    """(kld[a], div[a]) for motion [n,K,Tf,2], q/p Normal over [n*K, nz]; differentiable wrt q.mu, q.logvar and motion."""
     if q.mu.device.type != 'cuda':
         raise capi.SttodeError('sampler loss runs only on a HIP device (no CPU fallback)')
-    kld = torch.empty(n, device=q.mu.device)
-    div = torch.empty(n, device=q.mu.device)
     f = lambda t: t.contiguous().float()
-    capi.call('sttode_sampler_loss', f(q.mu), f(q.logvar), None if p is None else f(p.mu), None if p is None else f(p.logvar),
-              f(motion), n, K, nz, D, float(scale), kld, div, capi.stream_ptr())
-    return kld, div
+    return _PerAgentLoss.apply(f(q.mu), f(q.logvar), f(motion), None if p is None else f(p.mu).detach(),
+                               None if p is None else f(p.logvar).detach(), scale)
 
 
 def compute_z_kld(q_z_dist_dlow, p_z_dist_infer, agent_num, min_clip, weight, _kld=None):

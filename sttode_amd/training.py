@@ -14,6 +14,7 @@ import torch
 from . import capi
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
+EW_TANH_BWD, EW_LATENT_BWD = 10, 11
 ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
@@ -30,6 +31,7 @@ class Engine:
         self.net = net
         self.dev = net.device
         self.scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
+        self.param_grads = True     # False: skip the weight-gradient GEMMs (stage-2 sampler training keeps this net frozen)
 
     # ---------------------------------------------------------------- primitives
     def new(self, *shape):
@@ -57,6 +59,8 @@ class Engine:
         return out
 
     def wgrad(self, dY, X, gW, gb, xdiv=1):
+        if not self.param_grads:
+            return
         cols, N = dY.shape
         K = X.shape[1]
         assert gW.shape[0] == N and gW.shape[1] == K, (gW.shape, N, K)

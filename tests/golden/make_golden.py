@@ -228,9 +228,63 @@ def grad_cases(noise):
     print('forward_grads.npz bytes:', os.path.getsize(os.path.join(HERE, 'forward_grads.npz')))
 
 
+def sampler_grad_cases(noise):
+    """Stage-2 training step of the reference (trainsampler.py:134-150,171-185): gradients of the Sampler's parameters for the
+    'shared' ETH case and the 'mean' NBA case of sampler.npz (same inputs / eps); net in eval() (no rotation / dropout)."""
+    from sampler import Sampler
+    from samplerloss import compute_sampler_loss, compute_sampler_loss_nba
+    from sttode_amd import scenes
+    from sttode_amd.weights import make_sampler_weights, to_torch_state_dict
+    g = dict(np.load(os.path.join(HERE, 'sampler.npz')))
+    out = {}
+    _randn = torch.randn
+    for tag, dataset, Tp, Tf, mode in (('eth', 'eth', 8, 12, 'shared'), ('nba', 'nba', 5, 10, 'mean')):
+        net = build_ref(dataset, Tp, Tf)
+        a = sampler_args(dataset, Tp, Tf)
+        smp = Sampler(a)
+        smp.load_state_dict(to_torch_state_dict(make_sampler_weights()), strict=True)
+        if dataset == 'eth':
+            o, p = g['eth_obs'], g['eth_pred']
+            n = o.shape[0]
+            net.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(n, Tp), torch.ones(n, Tf))
+            fut = torch.from_numpy(p).transpose(1, 2)
+        else:
+            d = scenes.nba_batch(int(g['nba_seed']), int(g['nba_B']))
+            data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+            n = data['past_traj'].shape[0] * 11
+            net.set_data_nba(data)
+            fut = data['future_traj'].reshape(n, Tf, 2)
+        rng = np.random.default_rng(99 + n)
+        eps = g[f'{tag}_{mode}_eps']
+        e_q, e_p, e20 = (rng.standard_normal(sh).astype(np.float32) for sh in ((n, 32), (n, 32), (n * 20, 32)))
+        torch.randn = lambda *a_, **k_: torch.from_numpy(eps)
+        noise.push(e_q, e_p, e20)
+        dec, sd, vd, _ = smp.forward(net, mean=(mode == 'mean'))
+        torch.randn = _randn
+        cfg = {'weight': 1, 'scale': 1.0}
+        if dataset == 'nba':
+            tot, ld, _ = compute_sampler_loss_nba(a, fut, dec.reshape(-1, 20, Tf, 2), 1, vd, sd, cfg)
+        else:
+            tot, ld, _ = compute_sampler_loss(a, fut, dec, 1, torch.ones(n, Tf), vd, sd, cfg)
+        tot.backward()
+        out[f'{tag}_mode'] = np.array(mode)
+        out[f'{tag}_loss'] = np.array([float(tot.detach()), float(ld['kld'].detach()), float(ld['diverse'].detach())], np.float64)
+        for name, prm in smp.named_parameters():
+            if prm.grad is not None:
+                out[f'{tag}_grad::{name}'] = grad_summary(prm.grad)
+            else:
+                out[f'{tag}_nograd::{name}'] = np.zeros(0)
+    np.savez(os.path.join(HERE, 'sampler_grads.npz'), **out)
+    print('sampler_grads.npz bytes:', os.path.getsize(os.path.join(HERE, 'sampler_grads.npz')))
+
+
 def main():
     install_shims()
     noise = NoiseQueue()
+    if '--only-sampler-grads' in sys.argv:
+        sampler_grad_cases(noise)
+        assert not noise.q
+        return
     if '--only-grads' in sys.argv:
         grad_cases(noise)
         assert not noise.q
@@ -374,6 +428,7 @@ def main():
              fde=np.float64(compute_FDE(list(pr), gt)))
     sampler_cases(noise)
     grad_cases(noise)
+    sampler_grad_cases(noise)
     assert not noise.q
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print('golden bytes:', tot)

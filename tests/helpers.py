@@ -76,20 +76,31 @@ def oracle_sampler(dataset='eth', Tp=8, Tf=12):
     return s
 
 
-def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode):
-    """Runs one sampler.npz case on the oracle: returns (dec, mu, logvar, pred_traj, [total, kld, diverse])."""
+def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode, grads=False):
+    """Runs one sampler.npz case on the oracle: returns (dec, mu, logvar, pred_traj, [total, kld, diverse]) and, with
+    ``grads``, additionally name -> gradient of the Sampler's parameters (trainsampler.py:148-150)."""
     from oracle import sampler_ref as SR
     net, smp = oracle_model(dataset, Tp, Tf), oracle_sampler(dataset, Tp, Tf)
     inp, fut = sampler_case_inputs(g, tag, dataset)
     smp.share_eps = mode != 'peragent'
-    with torch.no_grad():
+    smp.zero_grad()
+    with torch.set_grad_enabled(grads):
         if dataset == 'eth':
             net.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']))
         else:
             net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
         dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
         tot, ld = SR.compute_sampler_loss(smp.args, torch.from_numpy(fut), dec.reshape(-1, 20, Tf, 2), vd, sd, {'weight': 1, 'scale': 1.0})
-    return dec.numpy(), sd.mu.numpy(), sd.logvar.numpy(), aw.numpy(), np.array([float(tot), float(ld['kld']), float(ld['diverse'])])
+        if grads:
+            tot.backward()
+    res = (dec.detach().numpy(), sd.mu.detach().numpy(), sd.logvar.detach().numpy(), aw.detach().numpy(),
+           np.array([float(tot.detach()), float(ld['kld'].detach()), float(ld['diverse'].detach())]))
+    if grads:
+        gr = {k: (p.grad.clone() if p.grad is not None else None) for k, p in smp.named_parameters()}
+        smp.zero_grad()
+        net.zero_grad()
+        return res + (gr,)
+    return res
 
 
 def grad_digest(t):

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from helpers import (ATOL, RTOL, SAMPLER_CASES, assert_close, grad_case_setup, grad_digest, make_args, oracle_grads, oracle_model,
-                     oracle_sampler_case, oracle_scene_inference, sampler_args, sampler_case_inputs)
+                     oracle_sampler, oracle_sampler_case, oracle_scene_inference, sampler_args, sampler_case_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -303,13 +303,16 @@ def test_forward_loss_values_vs_reference_golden(golden):
     g = golden('eth_forward_losses')
     m = hip_model('eth', 8, 12)
     m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
-    tot, lp, lr, lk, ld = m.forward(eps_q=torch.from_numpy(g['eps_q']), eps_p=torch.from_numpy(g['eps_p1']),
-                                    eps20=torch.from_numpy(g['eps_p20']))
-    assert_close(m.qz_param.cpu().numpy(), g['qz_param'], what='qz_param')
-    assert_close(m.pred_traj.cpu().numpy(), g['pred_traj'], what='pred_traj')
-    assert_close(m.recover_traj.cpu().numpy(), g['recover_traj'], what='recover_traj')
-    assert_close(m.diverse_pred_traj.cpu().numpy(), g['diverse_pred_traj'], what='diverse_pred_traj')
-    np.testing.assert_allclose([float(tot), lp, lr, lk, ld], g['losses'], rtol=1e-4)
+    for grad_path in (False, True):        # fused inference kernels (no_grad) and the training kernels (autograd) give the same values
+        with torch.set_grad_enabled(grad_path):
+            tot, lp, lr, lk, ld = m.forward(eps_q=torch.from_numpy(g['eps_q']), eps_p=torch.from_numpy(g['eps_p1']),
+                                            eps20=torch.from_numpy(g['eps_p20']))
+        assert tot.requires_grad == grad_path
+        assert_close(m.qz_param.cpu().numpy(), g['qz_param'], what='qz_param')
+        assert_close(m.pred_traj.cpu().numpy(), g['pred_traj'], what='pred_traj')
+        assert_close(m.recover_traj.cpu().numpy(), g['recover_traj'], what='recover_traj')
+        assert_close(m.diverse_pred_traj.cpu().numpy(), g['diverse_pred_traj'], what='diverse_pred_traj')
+        np.testing.assert_allclose([float(tot.detach()), lp, lr, lk, ld], g['losses'], rtol=1e-4)
 
 
 def test_nba_single_scene_batch_vs_oracle():
@@ -481,7 +484,8 @@ def test_sampler_vs_reference_golden(golden, tag, dataset, Tp, Tf, modes):
         else:
             net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
         k = f'{tag}_{mode}_'
-        dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[k + 'eps']))
+        with torch.no_grad():                                   # value path (fused inference kernels); the autograd path is
+            dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[k + 'eps']))   # tested below
         assert_close(dec.cpu().numpy(), g[k + 'dec'], what=k + 'dec')
         assert_close(sd.mu.cpu().numpy(), g[k + 'mu'], what=k + 'mu')
         # logvar = log(A^2 + 1e-8) is ill-conditioned where A ~ 0; sigma = exp(logvar / 2) ~ |A| is what KL and rsample consume
@@ -725,3 +729,103 @@ def test_train_epoch_loop_on_csv_dataset(tmp_path):
     m2.set_data(None, batch[0], batch[1], batch[6], batch[7])
     out = m2.inference(None)
     assert out.shape == (20, batch[0].shape[0], 12, 2) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize('tag,dataset,Tp,Tf', [('eth', 'eth', 8, 12), ('nba', 'nba', 5, 10)])
+def test_sampler_training_step_vs_reference_and_oracle(golden, tag, dataset, Tp, Tf):
+    """Stage-2 training step (trainsampler.py:134-150,171-185) on the HIP path: loss + gradients of the Sampler's parameters
+    (through the K = 20 decode, the latent codes and the tanh Q-net) vs the reference's digests and vs oracle autograd."""
+    from sttode_amd import Sampler, samplerloss
+    from sttode_amd.weights import make_sampler_weights, to_torch_state_dict
+    dev = _gpu()
+    g, gg = golden('sampler'), golden('sampler_grads')
+    mode = str(gg[f'{tag}_mode'])
+    net = hip_model(dataset, Tp, Tf)
+    smp = Sampler(sampler_args(dataset, Tp, Tf))
+    smp.load_state_dict(to_torch_state_dict(make_sampler_weights()), strict=True)
+    smp.set_device(dev)
+    smp.train()
+    smp.share_eps = mode != 'peragent'
+    inp, fut = sampler_case_inputs(g, tag, dataset)
+    if dataset == 'eth':
+        n = inp['obs'].shape[0]
+        net.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']), torch.ones(n, Tp), torch.ones(n, Tf))
+    else:
+        net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
+    futd = torch.from_numpy(fut).to(dev)
+    cfg = {'weight': 1, 'scale': 1.0}
+    # Conditioning: logvar = log(A^2 + 1e-8) makes dKL/dA = A - A / (A^2 + 1e-8), which swings by several percent for a 1e-6
+    # change of an A near 3e-5 (a handful of the n*K*nz codes are always there).  Two fp32 evaluations of A therefore agree on
+    # the A-path gradients only to ~1e-2 of max |g| (torch-on-CPU vs torch-on-GPU would not do better); everything that does
+    # not pass through that factor -- the diversity term end to end, and q_b -- is checked at 1e-3 / 1e-4.
+    from oracle import sampler_ref as SR
+    onet, osmp = oracle_model(dataset, Tp, Tf), oracle_sampler(dataset, Tp, Tf)
+    osmp.share_eps = smp.share_eps
+    if dataset == 'eth':
+        onet.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']))
+    else:
+        onet.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
+    for which, tol_a, tol_b in (('diverse', 1e-3, 1e-3), ('kld', 2e-2, 1e-4), ('total', 2e-2, 1e-3)):
+        smp.zero_grad()
+        osmp.zero_grad()
+        dec, sd, vd, _ = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
+        assert dec.requires_grad and sd.mu.requires_grad
+        assert_close(dec.detach().cpu().numpy(), g[f'{tag}_{mode}_dec'], what='dec (training kernels)')
+        tot, ld, _ = samplerloss.compute_sampler_loss(smp.args, futd, dec.reshape(-1, 20, Tf, 2), 1, None, vd, sd, cfg)
+        (tot if which == 'total' else ld[which]).backward()
+        odec, osd, ovd, _ = osmp.forward(onet, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
+        otot, old = SR.compute_sampler_loss(osmp.args, torch.from_numpy(fut), odec.reshape(-1, 20, Tf, 2), ovd, osd, cfg)
+        (otot if which == 'total' else old[which]).backward()
+        for (name, prm), (_, o) in zip(smp.named_parameters(), osmp.named_parameters()):
+            if o.grad is None:                                      # unused by this loss term: ours reports None or exact zeros
+                assert prm.grad is None or not bool(prm.grad.any()), name
+                continue
+            err = float((prm.grad.cpu().double() - o.grad.double()).abs().max()) / (float(o.grad.abs().max()) + 1e-20)
+            assert err <= (tol_b if name.startswith('q_b.') else tol_a), (which, name, err)
+    got_loss = [float(tot.detach()), float(ld['kld'].detach()), float(ld['diverse'].detach())]
+    np.testing.assert_allclose(got_loss, gg[f'{tag}_loss'], rtol=1e-4)
+    for name, prm in smp.named_parameters():                        # the reference's own gradients (total loss)
+        if f'{tag}_nograd::{name}' in gg:
+            assert prm.grad is None, name
+            continue
+        ref, got = gg[f'{tag}_grad::{name}'], grad_digest(prm.grad)
+        tol = 1e-3 if name.startswith('q_b.') else 2e-2
+        assert abs(got[1] - ref[1]) <= tol * ref[1] + 1e-9, (name, got[1], ref[1])
+        assert np.abs(got[3:] - ref[3:]).max() <= tol * (ref[2] + 1e-12), (name, np.abs(got[3:] - ref[3:]).max(), ref[2])
+    assert all(p.grad is None for p in net.parameters())           # the prediction net stays frozen
+
+
+def test_sampler_backward_kernels_vs_torch_autograd():
+    """sttode_sampler_loss_bwd and the latent backward op on IDENTICAL inputs vs float64 torch autograd (well-conditioned check of
+    the pieces whose end-to-end comparison is limited by the log(A^2 + 1e-8) conditioning)."""
+    from sttode_amd import capi, samplerloss
+    from sttode_amd.dist import Normal
+    dev = _gpu()
+    rng = np.random.default_rng(33)
+    n, K, nz, Tf = 9, 20, 32, 12
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
+    mu, lv = t(rng.standard_normal((n * K, nz))), t(0.5 * rng.standard_normal((n * K, nz)))
+    mo = t(0.7 * rng.standard_normal((n, K, Tf, 2)))
+    mu.requires_grad_(True); lv.requires_grad_(True); mo.requires_grad_(True)
+    kld, div = samplerloss._per_agent(Normal(mu=mu, logvar=lv), None, mo, 2.0)
+    wk, wd = t(rng.standard_normal(n)), t(rng.standard_normal(n))
+    ((kld * wk).sum() + (div * wd).sum()).backward()
+    m64, l64, o64 = (x.detach().double().cpu().requires_grad_(True) for x in (mu, lv, mo))
+    t2 = torch.exp(0.5 * l64) / (1 + 1e-8)
+    kl = (0.5 * ((m64 / (1 + 1e-8)) ** 2 + t2 * t2) - 0.5 - torch.log(t2)).view(n, -1).sum(1)
+    dv = torch.stack([(-(torch.nn.functional.pdist(m.reshape(K, -1)) ** 2) / 2.0).exp().mean() for m in o64])
+    ((kl * wk.double().cpu()).sum() + (dv * wd.double().cpu()).sum()).backward()
+    for got, ref, nm in ((mu.grad, m64.grad, 'dmu'), (lv.grad, l64.grad, 'dlogvar'), (mo.grad, o64.grad, 'dmotion')):
+        assert_close(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6 * float(ref.abs().max()), what=nm)
+    # latent backward: dA = dz * eps + dlogvar * 2A / (A^2 + 1e-8), including A near zero
+    A = rng.standard_normal((n, K * nz)).astype(np.float32)
+    A[0, :8] = [0.0, 1e-6, -3e-5, 1e-4, -1e-4, 3e-4, 1e-3, -1e-2]
+    dz, dl = rng.standard_normal((n * K, nz)).astype(np.float32), rng.standard_normal((n * K, nz)).astype(np.float32)
+    for mode, eps in ((0, None), (1, rng.standard_normal((1, nz)).astype(np.float32)), (2, rng.standard_normal((n, nz)).astype(np.float32))):
+        dA = torch.empty(n, K * nz, device=dev)
+        capi.call('sttode_train_ewise', 11, t(dz), t(dl), t(A), t(eps) if eps is not None else None, dA, n * K * nz, nz * 4 + mode, float(K * nz),
+                  capi.stream_ptr())
+        a64 = A.astype(np.float64).reshape(n * K, nz)
+        e = 0.0 if eps is None else (np.broadcast_to(eps, (n * K, nz)) if mode == 1 else np.repeat(eps, K, axis=0)).astype(np.float64)
+        ref = dz * e + dl * 2 * a64 / (a64 * a64 + 1e-8)
+        assert_close(dA.cpu().numpy().reshape(n * K, nz), ref, rtol=1e-5, atol=1e-5, what=f'latent bwd mode {mode}')
