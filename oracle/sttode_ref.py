@@ -166,6 +166,43 @@ class ODEGEncoder(nn.Module):
         return F.relu(self.odeblock(src))
 
 
+class DecoderLayer(nn.Module):
+    """hypertransformer.py:156-236 (never instantiated by STTODENet; op-level parity only): self-attention, cross-attention
+    over a memory of a different length, relu FFN, three post-LayerNorms; every dropout is p = 0 in the configurations the
+    repo builds, and the masks are accepted and ignored by Hypattention.forward (:55-89)."""
+
+    def __init__(self, d_model, nhead, ff):
+        super().__init__()
+        self.self_attn = HypAttention(d_model, nhead)
+        self.cross_attn = HypAttention(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, ff)
+        self.linear2 = nn.Linear(ff, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+
+    def forward(self, tgt, memory):
+        a, w_self = self.self_attn(tgt, tgt, tgt)
+        tgt = self.norm1(tgt + a)
+        a, w_cross = self.cross_attn(tgt, memory, memory)
+        tgt = self.norm2(tgt + a)
+        tgt = self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return tgt, w_self, w_cross
+
+
+class ODEGDecoder(nn.Module):
+    """ode_demo.py:195-213 ``ODEG`` over ``TransformerDecoder_ode`` (:74-133): relu(tgt + T * Stack(tgt, memory)), one Euler step."""
+
+    def __init__(self, layers, time):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.time = float(time)
+
+    def forward(self, tgt, memory):
+        x = tgt
+        for m in self.layers:
+            x = m(x, memory)[0]
+        return F.relu(tgt + self.time * x)
+
+
 def sinusoid_table(max_len, d_model):
     """model/STTODE.py:149-155."""
     pe = torch.zeros(max_len, d_model)

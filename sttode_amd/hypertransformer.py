@@ -1,0 +1,152 @@
+"""Op-level drop-ins for the reference's geodesic transformer blocks (hypertransformer.py, ode_demo.py) on the HIP kernels,
+forward values only.  STTODENet itself uses the fused encoder path (csrc/encoder.hip); these classes cover the parts of the
+file the model never instantiates -- the decoder-side stack with cross-attention over a memory of a different length
+ -- with the reference's constructor arguments, parameter names and call signatures:
+
+    Hypattention(d_model, nhead)                      hypertransformer.py:19-89   (MHGSA, then tanh(info) * sigmoid(gate))
+    TransformerEncoderLayer(d_model, nhead, ff)       :91-153
+    TransformerDecoderLayer(d_model, nhead, ff)       :156-236  (self-attn, cross-attn, relu FFN, three post-LayerNorms)
+    ODEG(decoder_layer, nlayer, time)                 ode_demo.py:195-213 over TransformerDecoder_ode :74-133 (one Euler step + relu)
+    ODEG_Encoder(encoder_layer, nlayer, time)         ode_demo.py:217-231
+
+d_model = 64, nhead = 8 (the kernels' build); dropout must be 0 (the only value the repo passes); attention / padding masks
+and ``seq_mask`` are accepted and ignored exactly as Hypattention.forward ignores them (:69-72 builds a mask nobody reads).
+"""
+import copy
+
+import torch
+from torch import nn
+
+from . import capi
+from .ops import linear_cols, mhgsa
+from .model import _HypMHSA
+
+
+def _gpu(t):
+    if t.device.type != 'cuda':
+        raise capi.SttodeError('hypertransformer ops run only on a HIP device (no CPU fallback)')
+
+
+def _add_ln(x, r, norm):
+    """LayerNorm(x + r) over the last (64) dimension on sttode_add_ln_fwd."""
+    shape = x.shape
+    x2, r2 = x.reshape(-1, 64).contiguous(), r.reshape(-1, 64).contiguous()
+    rows = x2.shape[0]
+    y, xh, rs = torch.empty_like(x2), torch.empty_like(x2), torch.empty(rows, device=x.device)
+    capi.call('sttode_add_ln_fwd', x2, r2, norm.weight, norm.bias, y, xh, rs, rows, capi.stream_ptr())
+    return y.view(shape)
+
+
+class Hypattention(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0., motion_only=True, cross_range=0, num_conv_layer=3):
+        super().__init__()
+        if d_model != 64 or nhead != 8 or dropout != 0.:
+            raise NotImplementedError('HIP attention is built for d_model=64, nhead=8, dropout=0')
+        self.model_dim = d_model
+        self.temporal_attention_before = _HypMHSA(d_model, nhead)
+        self.temporal_info = nn.Linear(d_model, d_model)
+        self.temporal_gate = nn.Linear(d_model, d_model)
+
+    @torch.no_grad()
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=False, attn_mask=None, seq_mask=False):
+        _gpu(query)
+        assert len(query.shape) == len(key.shape) == len(value.shape) == 4            # [T, N, sample_num, D]
+        assert query.shape[1] == key.shape[1] == value.shape[1] and query.shape[2] == key.shape[2] == value.shape[2]
+        assert key.shape[0] == value.shape[0]
+        Lq, A, Sn, D = query.shape
+        Lk = key.shape[0]
+        m = self.temporal_attention_before
+        out, w = mhgsa(query.reshape(Lq, A * Sn, D), key.reshape(Lk, A * Sn, D), value.reshape(Lk, A * Sn, D), m.in_proj_weight,
+                       m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, need_weights=True)
+        rows = out.shape[0] * out.shape[1]
+        o2 = out.reshape(rows, D)
+        t = linear_cols(o2, self.temporal_info.weight, self.temporal_info.bias, act='tanh')
+        s = torch.empty_like(t)
+        capi.call('sttode_tlinear', o2, D, 1, self.temporal_gate.weight, D, 0, self.temporal_gate.bias, None, 0, s, D, rows, D, D, 3, 0,
+                  capi.stream_ptr())
+        g = torch.empty_like(t)
+        capi.call('sttode_train_ewise', 0, g, t, s, None, None, g.numel(), 0, 0.0, capi.stream_ptr())
+        # NB with L == S the reference's untransposed scores make the output rows follow the KEYS (hyptransformerlib.py:261-265);
+        # mhgsa returns [rows, A*Sn, D] accordingly and rows == Lq in every case
+        return g.view(out.shape[0], A, Sn, D), w
+
+
+def _ffn(x, lin1, lin2):
+    x2 = x.reshape(-1, 64).contiguous()
+    return linear_cols(linear_cols(x2, lin1.weight, lin1.bias, act='relu'), lin2.weight, lin2.bias).view(x.shape)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0., activation='relu'):
+        super().__init__()
+        if activation != 'relu' or dim_feedforward % 16:
+            raise NotImplementedError('relu FFN with a hidden width that is a multiple of 16')
+        self.self_attn = Hypattention(d_model, nhead, dropout=dropout)
+        self.linear1, self.linear2 = nn.Linear(d_model, dim_feedforward), nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+
+    @torch.no_grad()
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        src = _add_ln(src, self.self_attn(src, src, src)[0], self.norm1)
+        return _add_ln(src, _ffn(src, self.linear1, self.linear2), self.norm2)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0., activation='relu', cross_motion_only=False):
+        super().__init__()
+        if activation != 'relu' or dim_feedforward % 16:
+            raise NotImplementedError('relu FFN with a hidden width that is a multiple of 16')
+        self.self_attn = Hypattention(d_model, nhead, dropout=dropout)
+        self.cross_attn = Hypattention(d_model, nhead, dropout=dropout)
+        self.linear1, self.linear2 = nn.Linear(d_model, dim_feedforward), nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.cross_motion_only = cross_motion_only
+
+    @torch.no_grad()
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, seq_mask=False, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, need_weights=False):
+        a, w_self = self.self_attn(tgt, tgt, tgt, seq_mask=seq_mask)
+        tgt = _add_ln(tgt, a, self.norm1)
+        a, w_cross = self.cross_attn(tgt, memory, memory)
+        tgt = _add_ln(tgt, a, self.norm2)
+        tgt = _add_ln(tgt, _ffn(tgt, self.linear1, self.linear2), self.norm3)
+        return tgt, w_self, w_cross
+
+
+def _euler_relu(x, y, time):
+    out = torch.empty_like(x)
+    capi.call('sttode_train_ewise', 3, out, x.contiguous(), y.contiguous(), None, None, out.numel(), 0, float(time), capi.stream_ptr())
+    return out
+
+
+class ODEG(nn.Module):
+    """relu(tgt + time * DecoderStack(tgt, memory)): torchdiffeq's fixed-grid Euler on t = [0, time] is ONE step (ode_demo.py:151-166)."""
+
+    def __init__(self, decoder_layers, nlayer, time):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layers) for _ in range(nlayer)])     # _get_clones
+        self.time = float(time)
+
+    @torch.no_grad()
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, seq_mask=False, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, need_weights=False, num_agent=1):
+        x, ws, wc = tgt, [], []
+        for m in self.layers:
+            x, a, b = m(x, memory, seq_mask=seq_mask)
+            ws.append(a)
+            wc.append(b)
+        return _euler_relu(tgt, x, self.time), {'self_attn_weights': ws, 'cross_attn_weights': wc}
+
+
+class ODEG_Encoder(nn.Module):
+    def __init__(self, encoder_layer, nlayer, time):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(nlayer)])
+        self.time = float(time)
+
+    @torch.no_grad()
+    def forward(self, src, mask=None, src_key_padding_mask=None, num_agent=1):
+        x = src
+        for m in self.layers:
+            x = m(x)
+        return _euler_relu(src, x, self.time)

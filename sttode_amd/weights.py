@@ -117,6 +117,35 @@ def make_sampler_weights(seed=4321, **hp):
     return out
 
 
+def decoder_layer_manifest(d=64, ff=256):
+    """state_dict of the repo's (unused) TransformerDecoderLayer (hypertransformer.py:180-198)."""
+    items = []
+    for att in ('self_attn', 'cross_attn'):
+        p = att + '.temporal_attention_before.'
+        items += [(p + 'in_proj_weight', (3 * d, d)), (p + 'in_proj_bias', (3 * d,)), (p + 'out_proj.weight', (d, d)),
+                  (p + 'out_proj.bias', (d,))]
+        for nm in ('temporal_info', 'temporal_gate'):
+            items += [(f'{att}.{nm}.weight', (d, d)), (f'{att}.{nm}.bias', (d,))]
+    items += [('linear1.weight', (ff, d)), ('linear1.bias', (ff,)), ('linear2.weight', (d, ff)), ('linear2.bias', (d,))]
+    for i in (1, 2, 3):
+        items += [(f'norm{i}.weight', (d,)), (f'norm{i}.bias', (d,))]
+    return OrderedDict(items)
+
+
+def make_decoder_layer_weights(seed=61, **hp):
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shape in decoder_layer_manifest(**hp).items():
+        if 'norm' in name and name.endswith('weight'):
+            w = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith('bias'):
+            w = 0.05 * rng.standard_normal(shape)
+        else:
+            w = rng.standard_normal(shape) / np.sqrt(shape[-1])
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
 def to_torch_state_dict(weights):
     import torch
     return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in weights.items())

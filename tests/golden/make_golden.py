@@ -278,9 +278,34 @@ def sampler_grad_cases(noise):
     print('sampler_grads.npz bytes:', os.path.getsize(os.path.join(HERE, 'sampler_grads.npz')))
 
 
+def decoder_stack_cases():
+    """The repo's unused decoder-side stack (hypertransformer.py:156-236, ode_demo.py:74-133,195-213): one
+    TransformerDecoderLayer and ODEG (2 layers, time 3) with cross-attention over a memory of a different length."""
+    from hypertransformer import TransformerDecoderLayer
+    from ode_demo import ODEG
+    from sttode_amd.weights import make_decoder_layer_weights, to_torch_state_dict
+    rng = np.random.default_rng(62)
+    out = {}
+    layer = TransformerDecoderLayer(64, 8, 256, dropout=0.0).eval()
+    layer.load_state_dict(to_torch_state_dict(make_decoder_layer_weights(61, d=64, ff=256)), strict=True)   # weights: recipe, not stored
+    names = [k for k, _ in layer.named_parameters()]
+    tgt = rng.standard_normal((6, 5, 2, 64)).astype(np.float32)
+    mem = rng.standard_normal((9, 5, 2, 64)).astype(np.float32)
+    with torch.no_grad():
+        y, ws, wc = layer(torch.from_numpy(tgt), torch.from_numpy(mem), seq_mask=True, need_weights=True)
+        ode = ODEG(layer, 2, 3).eval()                      # _get_clones: both layers start as copies of ``layer``
+        z, _ = ode(torch.from_numpy(tgt), torch.from_numpy(mem), seq_mask=True)
+    out.update(tgt=tgt, mem=mem, layer_out=npy(y), odeg_out=npy(z))
+    np.savez(os.path.join(HERE, 'decoder_stack.npz'), **out)
+    print('decoder_stack.npz bytes:', os.path.getsize(os.path.join(HERE, 'decoder_stack.npz')), len(names), 'tensors')
+
+
 def main():
     install_shims()
     noise = NoiseQueue()
+    if '--only-decoder-stack' in sys.argv:
+        decoder_stack_cases()
+        return
     if '--only-sampler-grads' in sys.argv:
         sampler_grad_cases(noise)
         assert not noise.q
@@ -429,6 +454,7 @@ def main():
     sampler_cases(noise)
     grad_cases(noise)
     sampler_grad_cases(noise)
+    decoder_stack_cases()
     assert not noise.q
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print('golden bytes:', tot)

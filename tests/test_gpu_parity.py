@@ -829,3 +829,24 @@ def test_sampler_backward_kernels_vs_torch_autograd():
         e = 0.0 if eps is None else (np.broadcast_to(eps, (n * K, nz)) if mode == 1 else np.repeat(eps, K, axis=0)).astype(np.float64)
         ref = dz * e + dl * 2 * a64 / (a64 * a64 + 1e-8)
         assert_close(dA.cpu().numpy().reshape(n * K, nz), ref, rtol=1e-5, atol=1e-5, what=f'latent bwd mode {mode}')
+
+
+def test_decoder_stack_ops_vs_reference_golden(golden):
+    """The unused decoder-side stack as op-level drop-ins (hypertransformer.py:156-236, ode_demo.py:195-213): self-attention
+    over L = 6, cross-attention over a memory of S = 9 steps, FFN, LayerNorms, one Euler step + relu."""
+    from sttode_amd.hypertransformer import ODEG, TransformerDecoderLayer
+    from sttode_amd.weights import make_decoder_layer_weights, to_torch_state_dict
+    dev = _gpu()
+    g = golden('decoder_stack')
+    layer = TransformerDecoderLayer(64, 8, 256, dropout=0.0)
+    layer.load_state_dict(to_torch_state_dict(make_decoder_layer_weights(61, d=64, ff=256)), strict=True)
+    with pytest.raises(Exception):
+        layer(torch.from_numpy(g['tgt']), torch.from_numpy(g['mem']))          # CPU tensors: refuse
+    layer.to(dev)
+    tgt, mem = torch.from_numpy(g['tgt']).to(dev), torch.from_numpy(g['mem']).to(dev)
+    y, ws, wc = layer(tgt, mem, seq_mask=True, need_weights=True)
+    assert_close(y.cpu().numpy(), g['layer_out'], what='decoder layer')
+    assert ws.shape == (10, 6, 6) and wc.shape == (10, 6, 9)
+    np.testing.assert_allclose(wc.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+    z, w = ODEG(layer, 2, 3).to(dev)(tgt, mem, seq_mask=True)
+    assert_close(z.cpu().numpy(), g['odeg_out'], what='ODEG')
