@@ -39,84 +39,107 @@ static __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-// WG = 4 waves.  A wave owns 16 columns x 64 outputs (4 tiles); when the layer has few outputs (I <= 128) the idle waves
-// split the reduction range instead (ksplit waves per 64-output chunk, partial sums combined through LDS), because at the
-// training shapes (32 .. 7040 columns) these launches are latency-bound, not throughput-bound.  Operands of 4 k-steps
-// (64 reduction indices) are fetched back to back before their 64 MFMAs so one memory latency is paid per 4 steps.
+// WG = 4 waves; a wave owns CT column tiles x RT output tiles, and ``ksplit`` waves of the WG share one such block, splitting
+// the reduction range (partials combined through LDS).  Operands of U k-steps are fetched back to back before their MFMAs, so
+// one memory round trip is paid per 16*U reduction indices.  Two instantiations:
+//   <1,1,8>  latency mode (few columns: 32 .. 1024): 16 x 16 block per WG, 4-way K split -> one or two round trips per launch;
+//   <4,4,2>  throughput mode (NBA / long batches): 64 columns x 64 outputs per wave, weight fragments reused over 4 column tiles.
+template <int RT, int CT, int U>
 __global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
-    __shared__ f32x4 part[4][4][64];
+    __shared__ f32x4 part[3][RT * CT][64];
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
-    const int chunks_per_wg = 4 / ksplit;
-    const int chunk = blockIdx.y * chunks_per_wg + wave / ksplit, ksub = wave % ksplit;
-    const int it0 = chunk * 4;
+    const int blocks_per_wg = 4 / ksplit;
+    const int oblock = blockIdx.y * blocks_per_wg + wave / ksplit, ksub = wave % ksplit;
+    const int it0 = oblock * RT;
     const bool active = it0 * 16 < a.I;
-    const int col = blockIdx.x * 16 + c;
-    const bool colok = col < a.cols;
-    const float* xrow = a.X + (long)((colok ? col : 0) / a.xdiv) * a.ldx;
-    f32x4 acc[4];
+    int col[CT];
+    bool colok[CT];
+    const float* xrow[CT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = splat4(0.f);
+    for (int t = 0; t < CT; ++t) {
+        col[t] = (blockIdx.x * CT + t) * 16 + c;
+        colok[t] = col[t] < a.cols;
+        xrow[t] = a.X + (long)((colok[t] ? col[t] : 0) / a.xdiv) * a.ldx;
+    }
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t] = splat4(0.f);
     if (active) {
-        for (int j0 = ksub * 64; j0 < a.J; j0 += 64 * ksplit) {
-            f32x4 b[4], w[4][4];
+        for (int j0 = ksub * 16 * U; j0 < a.J; j0 += 16 * U * ksplit) {
+            f32x4 b[U][CT], w[U][RT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int j = j0 + 16 * u + 4 * q;
-                b[u] = ld_guard4(xrow, j, a.J, colok, a.xvec);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int i = (it0 + t) * 16 + c;  // A-operand row held by this lane
+                for (int t = 0; t < CT; ++t) b[u][t] = ld_guard4(xrow[t], j, a.J, colok[t], a.xvec);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int row = (it0 + i) * 16 + c;  // A-operand row held by this lane
                     f32x4 wv = {0.f, 0.f, 0.f, 0.f};
-                    if (i < a.I) {
+                    if (row < a.I) {
                         if (!a.trans) {
-                            wv = ld_guard4(a.W + (long)i * a.ldw, j, a.J, true, a.wvec);
+                            wv = ld_guard4(a.W + (long)row * a.ldw, j, a.J, true, a.wvec);
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (j + r < a.J) wv[r] = a.W[(long)(j + r) * a.ldw + i];
+                                if (j + r < a.J) wv[r] = a.W[(long)(j + r) * a.ldw + row];
                         }
                     }
-                    w[u][t] = wv;
+                    w[u][i] = wv;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma_k16(acc[t], w[u][t], b[u]);
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[i][t] = mfma_k16(acc[i][t], w[u][i], b[u][t]);
         }
     }
     if (ksplit > 1) {
+        // waves of one block are consecutive: block leader = wave - ksub; partial slot = (leader's block) * (ksplit-1) + ksub - 1
+        const int slot = (wave / ksplit) * (ksplit - 1) + ksub - 1;
         if (ksub > 0)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) part[wave][t][lane] = acc[t];
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) part[slot][i * CT + t][lane] = acc[i][t];
         __syncthreads();
         if (ksub == 0)
             for (int k = 1; k < ksplit; ++k)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] += part[wave + k][t][lane];
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[i][t] += part[(wave / ksplit) * (ksplit - 1) + k - 1][i * CT + t][lane];
     }
-    if (!active || ksub != 0 || !colok) return;
+    if (!active || ksub != 0) return;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = (it0 + t) * 16 + 4 * q;
-        if (i >= a.I) continue;
-        float* yp = a.Y + (long)col * a.ldy + i;
-        f32x4 v = acc[t];
+    for (int t = 0; t < CT; ++t) {
+        if (!colok[t]) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (i + r >= a.I) continue;
-            float x = v[r];
-            if (a.bias) x += a.bias[i + r];
-            if (a.accumulate) x += yp[r];
-            x = act_apply(x, a.act);
-            if (a.mask && !(a.mask[(long)col * a.ldm + i + r] > 0.f)) x = 0.f;
-            v[r] = x;
+        for (int i = 0; i < RT; ++i) {
+            const int o = (it0 + i) * 16 + 4 * q;
+            if (o >= a.I) continue;
+            float* yp = a.Y + (long)col[t] * a.ldy + o;
+            f32x4 v = acc[i][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (o + r >= a.I) continue;
+                float x = v[r];
+                if (a.bias) x += a.bias[o + r];
+                if (a.accumulate) x += yp[r];
+                x = act_apply(x, a.act);
+                if (a.mask && !(a.mask[(long)col[t] * a.ldm + o + r] > 0.f)) x = 0.f;
+                v[r] = x;
+            }
+            if (a.yvec && o + 3 < a.I) st4(yp, v);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < a.I) yp[r] = v[r];
         }
-        if (a.yvec && i + 3 < a.I) st4(yp, v);
-        else
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (i + r < a.I) yp[r] = v[r];
     }
 }
 
@@ -134,10 +157,18 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
     a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
-    const int ksplit = (I <= 64 && J > 64) ? 4 : ((I <= 128 && J > 64) ? 2 : 1);
-    const int outs_per_wg = 256 / ksplit;
-    dim3 grid((cols + 15) / 16, (I + outs_per_wg - 1) / outs_per_wg);
-    hipLaunchKernelGGL(tlinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
+    if (cols <= 1024) {
+        // latency mode: one 16 x 16 block per WG, reduction split over up to 4 waves (128 indices per round trip and wave)
+        const int ksplit = J > 256 ? 4 : (J > 128 ? 2 : 1);
+        const int blocks_per_wg = 4 / ksplit;
+        dim3 grid((cols + 15) / 16, ((I + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg);
+        hipLaunchKernelGGL((tlinear_kernel<1, 1, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
+    } else {
+        const int ksplit = (I <= 64 && J > 64) ? 4 : ((I <= 128 && J > 64) ? 2 : 1);
+        const int outs_per_wg = 256 / ksplit;
+        dim3 grid((cols + 63) / 64, (I + outs_per_wg - 1) / outs_per_wg);
+        hipLaunchKernelGGL((tlinear_kernel<4, 4, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
+    }
     STT_HIP(hipGetLastError());
     return 0;
 }

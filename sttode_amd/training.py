@@ -9,6 +9,8 @@ kernels over the row-major nn.Parameter storage, plus the element-wise pieces). 
 one ``autograd.Function``, hands the finished gradients to ``.grad`` so that ``optimizer.step()`` works unchanged.
 There is no eager / CPU fallback.
 """
+import os
+
 import torch
 
 from . import capi
@@ -348,19 +350,71 @@ class _LossFn(torch.autograd.Function):
     """Hands the HIP-computed parameter gradients to autograd: ``total_loss.backward()`` fills ``.grad`` (train.py:83-87)."""
 
     @staticmethod
-    def forward(ctx, total, engine, names, *params):
-        ctx.engine, ctx.names = engine, names
+    def forward(ctx, total, engine, names, ready, *params):
+        ctx.engine, ctx.names, ctx.ready = engine, names, ready
         return total.clone()
 
     @staticmethod
     def backward(ctx, gout):
-        G = ctx.engine.run_backward(gout)
-        grads = tuple(G.get(nm) for nm in ctx.names)
-        return (None, None, None) + grads
+        if ctx.ready is not None:                                  # graph replay already produced the gradients
+            flat, views = ctx.ready
+            flat.mul_(gout)
+            G = views
+        else:
+            G = ctx.engine.run_backward(gout)
+        return (None, None, None, None) + tuple(G.get(nm) for nm in ctx.names)
+
+
+class _GraphedStep:
+    """One hipGraph per step shape: the ~330 launches of forward-with-tape + backward replayed as a single graph launch
+    (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
+    the loss values and the flat gradient buffer are static outputs."""
+
+    def __init__(self, eng, net, inputs):
+        self.eng, self.net = eng, net
+        self.static = {k: (v.clone() if v is not None else None) for k, v in inputs.items()}
+        self.graph = None
+
+    def _bind(self):
+        net, st = self.net, self.static
+        net._past, net._future = st['past'], st['future']
+        if st['scene_ptr'] is not None:
+            net._scene_ptr = st['scene_ptr']
+
+    def _body(self):
+        st = self.static
+        losses = self.eng.run_forward(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'])
+        G = self.eng.run_backward(None)
+        return losses, self.eng.Gflat, G
+
+    def run(self, inputs):
+        for k, v in inputs.items():
+            if v is not None:
+                self.static[k].copy_(v)
+        self._bind()
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+            self.attrs = {k: getattr(self.net, k) for k in ('past_feature', 'qz_param', 'qz_sampled', 'pred_traj', 'recover_traj',
+                                                            'diverse_pred_traj', 'past_traj', 'future_traj', 'cur_location')}
+        self.graph.replay()
+        for k, v in self.attrs.items():
+            setattr(self.net, k, v)
+        losses, flat, G = self.out
+        flat = flat.clone()                                        # .grad must not alias the graph's static output
+        views, off = {}, 0
+        for k, v in self.eng.P.items():
+            if k in G:
+                views[k] = flat[off: off + v.numel()].view(v.shape)
+            off += ((v.numel() + 3) // 4) * 4
+        return losses.clone(), (flat, views)
 
 
 def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
-    """STTODENet.forward() with autograd support (see module docstring).  Returns the reference's 5-tuple."""
+    """STTODENet.forward() with autograd support (see module docstring).  Returns the reference's 5-tuple.
+    ``net.train_graphs`` (default True): after one eager step per shape the whole step is captured into a hipGraph."""
     a, dev = net.args, net.device
     n = net._past.shape[0]
     eps_q = torch.randn(n, a.zdim, device=dev) if eps_q is None else eps_q.to(dev, torch.float32).contiguous()
@@ -376,10 +430,27 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     eng = getattr(net, '_engine', None)
     if eng is None or eng.dev != dev:
         eng = net._engine = Engine(net)
-    losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)
-    total_v = losses.sum()
+        net._graphs, net._graph_seen = {}, set()
     names = [k for k, _ in net.named_parameters()]
     params = [p for _, p in net.named_parameters()]
-    total = _LossFn.apply(total_v, eng, names, *params)
+    ready = None
+    key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
+           params[0].data_ptr(), params[-1].data_ptr())     # graphs hold raw parameter pointers
+    # launch-bound regime only (one scene, <= ~100 agents): at NBA batch sizes the kernels dominate and replay is no faster
+    if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= 100:
+        if key in net._graphs or key in net._graph_seen:
+            inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,
+                          eps_q=eps_q, eps20=eps20, drop_past=drop_past, drop_future=drop_future)
+            if key not in net._graphs:
+                if len(net._graphs) >= 48:
+                    net._graphs.clear()
+                net._graphs[key] = _GraphedStep(eng, net, inputs)
+            losses, ready = net._graphs[key].run(inputs)
+        else:
+            net._graph_seen.add(key)                                # first time: eager (also warms one-time kernel attributes)
+    if ready is None:
+        losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)
+    total_v = losses.sum()
+    total = _LossFn.apply(total_v, eng, names, ready, *params)
     lv = losses.tolist()
     return total, lv[0], lv[1], lv[2], lv[3]
