@@ -54,3 +54,32 @@ def reduce_metrics(ade_sum, fde_sum, count, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, group=group)
     return float(t[0] / t[2]), float(t[1] / t[2]), int(t[2])
+
+
+def average_gradients(params, group=None, weight=1.0):
+    """Data-parallel training (one process per GPU, each stepping on its own scenes / NBA groups): ONE all-reduce of all gradients
+    as a single flat buffer (6.5 MB for STTODENet: a single bucket over xGMI, latency- not bandwidth-bound), then the average is
+    written back.  ``weight``: this rank's share (e.g. its agent count) for an agent-weighted mean; parameters whose gradient is
+    None on this rank contribute zeros, so ranks may disagree on which parameters were touched (the reference has no multi-GPU
+    training; this is the natural extension of its one-scene-per-step loop, train.py:72-95)."""
+    params = [p for p in params if p.requires_grad]
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1) or not params:
+        return
+    dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+    flat = torch.zeros(sum(p.numel() for p in params) + 1, dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        if p.grad is not None:
+            flat[off: off + p.numel()] = p.grad.reshape(-1) * weight
+        off += p.numel()
+    flat[-1] = weight
+    dist.all_reduce(flat, group=group)
+    flat[:-1] /= flat[-1]
+    off = 0
+    for p in params:
+        g = flat[off: off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()

@@ -850,3 +850,22 @@ def test_decoder_stack_ops_vs_reference_golden(golden):
     np.testing.assert_allclose(wc.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
     z, w = ODEG(layer, 2, 3).to(dev)(tgt, mem, seq_mask=True)
     assert_close(z.cpu().numpy(), g['odeg_out'], what='ODEG')
+
+
+@pytest.mark.parametrize('N', [1, 2, 33])
+def test_training_step_edge_scene_sizes_vs_oracle(N):
+    """Smallest scenes (SDD has single-pedestrian scenes; N = 2 is the ETH minimum) and a scene just past 32 agents (two column
+    tiles in the K = 1 decode, 42 in the K = 20 decode): losses and gradients vs float64 oracle autograd; eager and hipGraph steps agree."""
+    from sttode_amd import scenes
+    dev = _gpu()
+    o, p = scenes.eth_scene(7100 + N, n_min=N, n_max=N)
+    rng = np.random.default_rng(N)
+    g = {'eth_obs': o, 'eth_pred': p, 'eth_eps_q': rng.standard_normal((N, 32)).astype(np.float32),
+         'eth_eps_p1': rng.standard_normal((N, 32)).astype(np.float32), 'eth_eps_p20': rng.standard_normal((N * 20, 32)).astype(np.float32)}
+    grads, losses = _hip_grads('eth', 'eth', 8, 12, g)             # first step of this shape: eager
+    g64, l64 = oracle_grads('eth', 'eth', 8, 12, g, double=True)
+    np.testing.assert_allclose(losses, l64, rtol=1e-4)
+    _compare_grads(grads, g64, rtol=5e-4)
+    grads2, losses2 = _hip_grads('eth', 'eth', 8, 12, g)           # second step: captured + replayed hipGraph
+    np.testing.assert_allclose(losses2, losses, rtol=1e-6)
+    _compare_grads(grads2, {k: v for k, v in grads.items()}, rtol=1e-6)

@@ -71,3 +71,49 @@ def test_shard_scenes_balanced_and_complete():
         assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
         loads = [int(sb.scene_ptr[b] - sb.scene_ptr[a]) for a, b in parts]
         assert sum(loads) == sb.n_agents and max(loads) - min(loads) <= 64
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sttode_amd import parallel
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+    xs = x[rank * 4:(rank + 1) * 4] if rank == 0 else x[4:7]                       # ranks hold 4 and 3 rows
+    (net[2](torch.tanh(net[0](xs))).pow(2).sum() / xs.shape[0]).backward()         # local mean; net[3] is untouched everywhere
+    if rank == 1:
+        net[2].bias.grad = None                                                    # ... and one more only on this rank
+    parallel.average_gradients(net.parameters(), weight=float(xs.shape[0]))
+    if rank == 0:
+        q.put([None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_average_gradients_flat_allreduce():
+    """Row-weighted mean of per-rank gradients == gradient of the row-averaged objective on the union (minus the dropped bias)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+    (net[2](torch.tanh(net[0](x[:7]))).pow(2).sum() / 7).backward()
+    ref = [p.grad for p in net.parameters()]
+    for i, (g, r) in enumerate(zip(got, ref)):
+        if r is None:
+            assert g is not None and not g.any()                                    # untouched everywhere: zeros after the sync
+        elif i == 3:                                                                # net[2].bias: rank 1 contributed zeros
+            x0 = x[:4]
+            r0 = torch.autograd.grad(net[2](torch.tanh(net[0](x0))).pow(2).sum() / 7, net[2].bias)[0]
+            np.testing.assert_allclose(g, r0.numpy(), rtol=1e-5, atol=1e-6)
+        else:
+            np.testing.assert_allclose(g, r.numpy(), rtol=1e-5, atol=1e-6)
