@@ -47,6 +47,84 @@ def kernel_flops(tag, n, m):
             'embed_qkv+post_attn': F_ENC * n}.get(tag)
 
 
+def train_bench(args, rank, world, dev, dist):
+    """Training steps/s: the reference's per-scene loop (train.py:72-95: set_data with augmentation, forward, zero_grad, backward,
+    Adam step) over this rank's synthetic ETH scenes; with several ranks the gradients are averaged by one flat all-reduce per
+    step (sttode_amd.parallel.average_gradients).  One JSON line, same conventions as the headline bench."""
+    from helpers import make_args
+    from sttode_amd import STTODENet, parallel, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    sd = to_torch_state_dict(make_weights(1234))
+    model = STTODENet(make_args('eth', TP, TF), dev)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    nsc = 64
+    data = [scenes.eth_scene(100000 + rank * nsc + i) for i in range(nsc)]
+    data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]
+    agents = sum(o.shape[0] for o, _ in data) / nsc
+
+    def step(i):
+        o, p = data[i % nsc]
+        model.set_data(None, o, p, None, None)
+        tot = model.forward()[0]
+        opt.zero_grad()
+        tot.backward()
+        if world > 1:
+            parallel.average_gradients(model.parameters(), weight=float(o.shape[0]))
+        opt.step()
+
+    for i in range(max(args.warmup, 2 * nsc)):                     # every scene size is seen twice: hipGraphs captured
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
+    out = {'metric': 'training-steps/sec (one scene per step, forward + backward + Adam)', 'value': world * args.steps / dt,
+           'unit': 'steps/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': max(args.warmup, 2 * nsc),
+           'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+           'data': 'synthetic', 'config': {'workload': f'train.py:72-95 loop over {nsc} synthetic ETH-shaped scenes per GPU (2..32 '
+                                                       f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
+                                                       '(rotation + positional dropout), Adam lr 1e-4',
+                                           'parallelism': f'scenes x{world}' + (' + flat gradient all-reduce' if world > 1 else '')}}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle.sttode_ref import STTODENetRef                 # cpu_baseline leg only
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(16, ncpu)))
+        ora = STTODENetRef(make_args('eth', TP, TF)).eval()
+        ora.load_state_dict(sd, strict=True)
+        oo = torch.optim.Adam(ora.parameters(), lr=1e-4)
+        t_cpu, k = 0.0, 0
+        while t_cpu < args.cpu_seconds or k < 2:
+            o, p = data[k % nsc]
+            nn_ = o.shape[0]
+            tc = time.perf_counter()
+            ora.set_data(None, o.cpu(), p.cpu())
+            tot = ora.forward_loss_tensors(torch.randn(nn_, 32), torch.randn(nn_, 32), torch.randn(nn_ * 20, 32))[0]
+            oo.zero_grad()
+            tot.backward()
+            oo.step()
+            t_cpu += time.perf_counter() - tc
+            k += 1
+        out['cpu_baseline'] = {'value': k / t_cpu, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': f'{k} steps of the same loop on the PyTorch-eager fp32 oracle (torch autograd), {t_cpu:.1f} s'}
+        out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -58,6 +136,8 @@ def main():
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
+    ap.add_argument('--train', action='store_true', help='secondary metric: training steps/s (train.py:72-95 loop, one scene per step); '
+                                                         'the default run and the headline metric stay the inference path')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -78,6 +158,8 @@ def main():
     from sttode_amd import STTODENet, capi, scenes
     from sttode_amd.weights import make_weights, to_torch_state_dict
 
+    if args.train:
+        return train_bench(args, rank, world, dev, dist)
     model = STTODENet(make_args('eth', TP, TF), dev).eval()
     model.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
     sb = scenes.make_scene_batch(range(rank * args.scenes, (rank + 1) * args.scenes), 'eth')

@@ -160,6 +160,13 @@ int sttode_gru_cell_fwd(const float* gi, long ldgi, const float* gh, const float
 /* dh [m,96] (grad wrt h') -> dgi (ld ldgi), dgh [m,288], dhprev = dh * z (the W_hh^T dgh term is added by sttode_tlinear). */
 int sttode_gru_cell_bwd(const float* dh, const float* tape, const float* hprev, float* dgi, long ldgi, float* dgh, float* dhprev,
                         int m, void* stream);
+/* The same over the WHOLE sequence in one launch (columns are independent): gi [m*Tp,288] (row = col*Tp + t), H [(Tp+1),m,96]
+ * with H[0] = 0 on entry (H[t+1] = h_t written), tapes [Tp,m,384].  W_hh fragments stay in registers across the steps. */
+int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, int m, int Tp, void* stream);
+/* Whole BPTT in one launch: dh_last [m,96] = grad wrt the final state -> dgi [m*Tp,288], dgh [Tp,m,288]
+ * (dh_{t-1} = dh_t * z_t + dgh_t W_hh is carried in registers / LDS). */
+int sttode_gru_seq_bwd(const float* dh_last, const float* tapes, const float* H, const float* Whh, float* dgi, float* dgh, int m,
+                       int Tp, void* stream);
 /* conv1d(2->32,k3,pad1)+relu (model/STTODE.py:65) on x = xa[c / adiv] - xb[c] ([m,T,2], xb optional); saves x; e [m,T,32]. */
 int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m, int T,
                     void* stream);

@@ -1,16 +1,15 @@
-"""Training-step timing (forward + backward + Adam) on the HIP training kernels vs the CPU oracle's autograd step.
-ETH: one scene of 32 agents per step (train.py:72-95); NBA: 32 scenes x 11 agents per step (train.py:59-71, batch_size 32)."""
+"""Training-step timing (set_data + forward + backward + Adam) on the HIP training kernels, with a per-entry-point breakdown.
+ETH: one scene of 32 agents per step (train.py:72-95); NBA: 32 scenes x 11 agents per step (train.py:59-71, batch_size 32).
+(The CPU comparison lives in ``bench.py --train``'s cpu_baseline leg.)  STTODE_TRAIN_GRAPHS=0 disables the hipGraph replay."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(sys.path[0], 'tests'))
 from helpers import make_args
 from sttode_amd import STTODENet, scenes, capi
-from oracle.sttode_ref import STTODENetRef
 from sttode_amd.weights import make_weights, to_torch_state_dict
 dev = torch.device('cuda')
 for name, ds, Tp, Tf in (('eth N=32', 'eth', 8, 12), ('nba B=32 N=11', 'nba', 5, 10)):
     sd = to_torch_state_dict(make_weights(1234, past_length=Tp, future_length=Tf))
     m = STTODENet(make_args(ds, Tp, Tf), dev); m.load_state_dict(sd); m.train()
-    o = STTODENetRef(make_args(ds, Tp, Tf)); o.load_state_dict(sd); o.eval()
     if ds == 'eth':
         ob, pr = scenes.eth_scene(1, n_min=32, n_max=32)
         feed = lambda mod: mod.set_data(None, torch.from_numpy(ob), torch.from_numpy(pr), torch.ones(32, Tp), torch.ones(32, Tf))
@@ -33,23 +32,12 @@ for name, ds, Tp, Tf in (('eth N=32', 'eth', 8, 12), ('nba B=32 N=11', 'nba', 5,
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
     # kernel-only time of one step
+    m.train_graphs = False
     capi.TIMING = []
     step(); torch.cuda.synchronize()
     kt = sum(e0.elapsed_time(e1) for _, e0, e1 in capi.TIMING); nk = len(capi.TIMING)
     by = {}
     for tag, e0, e1 in capi.TIMING: by[tag] = by.get(tag, 0) + e0.elapsed_time(e1)
     capi.TIMING = None
-    # CPU oracle step (torch autograd, all host cores)
-    oo = torch.optim.Adam(o.parameters(), lr=1e-4)
-    def ostep():
-        feed(o)
-        eq, e1_, e20 = torch.randn(n, 32), torch.randn(n, 32), torch.randn(n * 20, 32)
-        tot = o.forward_loss_tensors(eq, e1_, e20)[0]
-        oo.zero_grad(); tot.backward(); oo.step()
-    ostep()
-    t = time.perf_counter()
-    for _ in range(3): ostep()
-    cdt = (time.perf_counter() - t) / 3
-    print(f'{name}: HIP {dt*1e3:.2f} ms/step wall ({nk} kernel calls, {kt:.2f} ms in kernels), CPU oracle {cdt*1e3:.1f} ms/step '
-          f'({torch.get_num_threads()} threads) -> {cdt/dt:.1f}x')
+    print(f'{name}: HIP {dt*1e3:.2f} ms/step wall; eager step: {nk} entry-point calls, {kt:.2f} ms between their HIP events')
     print('   ', {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:8]})

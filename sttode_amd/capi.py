@@ -42,6 +42,8 @@ SIGNATURES = {
     'sttode_ln_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
     'sttode_gru_cell_fwd': [_P, _L, _P, _P, _P, _P, _I, _P],
     'sttode_gru_cell_bwd': [_P, _P, _P, _P, _L, _P, _P, _I, _P],
+    'sttode_gru_seq_fwd': [_P, _P, _P, _P, _P, _I, _I, _P],
+    'sttode_gru_seq_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _P],

@@ -507,6 +507,127 @@ extern "C" int sttode_gru_cell_bwd(const float* dh, const float* tape, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Whole-sequence GRU for the training step: columns are independent, so ONE launch runs all Tp steps (forward) or the whole
+// BPTT (backward).  WG = 16 columns x 6 waves; wave j owns hidden features [16j, 16j+16) of all three gates.  The W_hh
+// fragments a wave needs (18 f32x4 forward: rows of its 3 gate tiles; 18 backward: its 16 columns of W_hh as the A operand
+// of dh_prev += dgh W_hh) stay in REGISTERS for all steps; h (forward) / dgh (backward) is exchanged through LDS once per step.
+// ---------------------------------------------------------------------------------------------------
+#define GSEQ_LDH 100   // padded row length of the h exchange buffer (floats)
+#define GSEQ_LDG 292   // padded row length of the dgh exchange buffer
+
+__global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ Whh,
+                                                          const float* __restrict__ bhh, float* __restrict__ H,
+                                                          float* __restrict__ tapes, int m, int Tp) {
+    __shared__ float sH[16 * GSEQ_LDH];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, j = threadIdx.x >> 6;
+    const int col = blockIdx.x * 16 + c;
+    const bool ok = col < m;
+    const int f = 16 * j + 4 * q;                       // first of this lane's 4 hidden features
+    f32x4 w[3][6], bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int T = 0; T < 6; ++T) w[g][T] = ld4(Whh + (long)(g * 96 + 16 * j + c) * 96 + 16 * T + 4 * q);
+        bias[g] = ld4(bhh + g * 96 + f);
+    }
+    for (int i = threadIdx.x; i < 16 * GSEQ_LDH; i += 384) sH[i] = 0.f;
+    __syncthreads();
+    for (int t = 0; t < Tp; ++t) {
+        f32x4 acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+        for (int T = 0; T < 6; ++T) {
+            const f32x4 b = ld4(sH + c * GSEQ_LDH + 16 * T + 4 * q);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = mfma_k16(acc[g], w[g][T], b);
+        }
+        const f32x4 hp = ld4(sH + c * GSEQ_LDH + f);
+        f32x4 hn = hp;
+        if (ok) {
+            const float* gic = gi + ((long)col * Tp + t) * 288;
+            const f32x4 gr = ld4(gic + f), gz = ld4(gic + 96 + f), gn = ld4(gic + 192 + f);
+            f32x4 r, z, n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = 1.0f / (1.0f + expf(-(gr[e] + acc[0][e])));
+                z[e] = 1.0f / (1.0f + expf(-(gz[e] + acc[1][e])));
+                n[e] = tanhf(gn[e] + r[e] * acc[2][e]);
+                hn[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
+            }
+            float* tp = tapes + ((long)t * m + col) * 384;
+            st4(tp + f, r); st4(tp + 96 + f, z); st4(tp + 192 + f, n); st4(tp + 288 + f, acc[2]);
+            st4(H + ((long)(t + 1) * m + col) * 96 + f, hn);
+        }
+        __syncthreads();                                // every wave has read h_{t-1}
+        st4(sH + c * GSEQ_LDH + f, hn);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restrict__ dh_last, const float* __restrict__ tapes,
+                                                          const float* __restrict__ H, const float* __restrict__ Whh,
+                                                          float* __restrict__ dgi, float* __restrict__ dgh, int m, int Tp) {
+    __shared__ float sG[16 * GSEQ_LDG];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, j = threadIdx.x >> 6;
+    const int col = blockIdx.x * 16 + c;
+    const bool ok = col < m;
+    const int f = 16 * j + 4 * q;
+    // A operand of dh_prev[:, 16j..16j+16) += dgh W_hh[:, 16j..]:  A[i = 16j + c][k] = W_hh[k][16j + c], k = 16T + 4q + r
+    f32x4 w[18];
+#pragma unroll
+    for (int T = 0; T < 18; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[T][r] = Whh[(long)(16 * T + 4 * q + r) * 96 + 16 * j + c];
+    f32x4 dh = ok ? ld4(dh_last + (long)col * 96 + f) : splat4(0.f);
+    for (int t = Tp - 1; t >= 0; --t) {
+        f32x4 dr = splat4(0.f), dz = dr, dn = dr, dhn = dr, dhz = dr;
+        if (ok) {
+            const float* tp = tapes + ((long)t * m + col) * 384;
+            const f32x4 r = ld4(tp + f), z = ld4(tp + 96 + f), n = ld4(tp + 192 + f), hn = ld4(tp + 288 + f);
+            const f32x4 hp = ld4(H + ((long)t * m + col) * 96 + f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = dh[e];
+                const float dnp = d * (1.0f - z[e]) * (1.0f - n[e] * n[e]);
+                dn[e] = dnp;
+                dr[e] = dnp * hn[e] * r[e] * (1.0f - r[e]);
+                dz[e] = d * (hp[e] - n[e]) * z[e] * (1.0f - z[e]);
+                dhn[e] = dnp * r[e];
+                dhz[e] = d * z[e];
+            }
+            float* gi = dgi + ((long)col * Tp + t) * 288;
+            st4(gi + f, dr); st4(gi + 96 + f, dz); st4(gi + 192 + f, dn);
+            float* gh = dgh + ((long)t * m + col) * 288;
+            st4(gh + f, dr); st4(gh + 96 + f, dz); st4(gh + 192 + f, dhn);
+        }
+        st4(sG + c * GSEQ_LDG + f, dr);
+        st4(sG + c * GSEQ_LDG + 96 + f, dz);
+        st4(sG + c * GSEQ_LDG + 192 + f, dhn);
+        __syncthreads();
+        f32x4 acc = dhz;
+#pragma unroll
+        for (int T = 0; T < 18; ++T) acc = mfma_k16(acc, w[T], ld4(sG + c * GSEQ_LDG + 16 * T + 4 * q));
+        dh = acc;
+        __syncthreads();                                // sG is rewritten by the next step
+    }
+}
+
+extern "C" int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, int m, int Tp,
+                                  void* stream) {
+    STT_REQUIRE(gi && Whh && bhh && H && tapes && m > 0 && Tp > 0, "sttode_gru_seq_fwd: bad argument");
+    STT_REQUIRE(((size_t)Whh) % 16 == 0 && ((size_t)gi) % 16 == 0, "sttode_gru_seq_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, m, Tp);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_gru_seq_bwd(const float* dh_last, const float* tapes, const float* H, const float* Whh, float* dgi, float* dgh,
+                                  int m, int Tp, void* stream) {
+    STT_REQUIRE(dh_last && tapes && H && Whh && dgi && dgh && m > 0 && Tp > 0, "sttode_gru_seq_bwd: bad argument");
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, dh_last, tapes, H, Whh, dgi, dgh, m, Tp);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // conv1d(2 -> 32, k = 3, pad = 1) + relu over x [m, T, 2] (model/STTODE.py:65); e [m, T, 32]
 // x = xa[c / adiv] - (xb ? xb[c] : 0)   (x_true - x_hat of the previous block)
 // ---------------------------------------------------------------------------------------------------

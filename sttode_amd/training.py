@@ -210,10 +210,8 @@ class Engine:
         gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [m*Tp, 288], row c*Tp + t
         H = self.zeros(Tp + 1, m, 96)                                                                    # H[0] = 0, H[t+1] = h_t
         tapes = self.new(Tp, m, 384)
-        gh = self.new(m, 288)
-        for t in range(Tp):
-            self.lin(H[t], P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], out=gh)
-            capi.call('sttode_gru_cell_fwd', gi[t:], Tp * 288, gh, H[t], H[t + 1], tapes[t], m, self.st)
+        capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes, m, Tp,
+                  self.st)                                                                               # all Tp steps, one launch
         inp = self.new(m, 256)
         capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
         inp[:, 128:160] = z
@@ -233,12 +231,7 @@ class Engine:
         dh = din[:, 160:].contiguous()
         dgi = self.new(m * Tp, 288)
         dgh = self.new(Tp, m, 288)
-        dhp = self.new(m, 96)
-        W_hh = P[pre + 'encoder_past.weight_hh_l0']
-        for t in range(Tp - 1, -1, -1):
-            capi.call('sttode_gru_cell_bwd', dh, b['tapes'][t], b['H'][t], dgi[t:], Tp * 288, dgh[t], dhp, m, self.st)
-            self.lin_dx(dgh[t], W_hh, out=dhp, accumulate=True)
-            dh, dhp = dhp, dh
+        capi.call('sttode_gru_seq_bwd', dh, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
         self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
         self.wgrad(dgi, b['e'], g(pre + 'encoder_past.weight_ih_l0'), g(pre + 'encoder_past.bias_ih_l0'))
         de = self.lin_dx(dgi, P[pre + 'encoder_past.weight_ih_l0'], mask=b['e'])

@@ -127,8 +127,10 @@ def oracle_grads(tag, dataset, Tp, Tf, g, drop=None, double=False):
     ``double``: evaluate the same graph in float64 (the rounding-free yardstick for two fp32 implementations)."""
     m = oracle_model(dataset, Tp, Tf)
     if double:
-        import copy
-        m = copy.deepcopy(m).double()
+        from oracle.sttode_ref import STTODENetRef
+        m64 = STTODENetRef(make_args(dataset, Tp, Tf)).eval()
+        m64.load_state_dict(m.state_dict(), strict=True)
+        m = m64.double()
     m.zero_grad()
     eq, ep1, ep20 = grad_case_setup(g, tag, m)
     if double:
