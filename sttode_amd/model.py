@@ -360,7 +360,8 @@ class STTODENet(nn.Module):
                   2 * a.zdim, 0, st)
         self.qz_mu, self.qz_logvar = self.qz_param[:, :a.zdim], self.qz_param[:, a.zdim:]
         eps_q = torch.randn(n, a.zdim, device=self.device) if eps_q is None else _f32(eps_q, self.device)
-        self.qz_sampled = (self.qz_mu + eps_q * torch.exp(0.5 * self.qz_logvar)).contiguous()   # Normal.rsample, :89-93
+        self.qz_sampled = self._f(n, a.zdim)                                                    # Normal.rsample, :89-93
+        capi.call('sttode_train_ewise', 5, self.qz_sampled, self.qz_param, eps_q.contiguous(), None, None, n * a.zdim, a.zdim, 0.0, st)
         self.pz_sampled = torch.randn(n, a.zdim, device=self.device) if eps_p is None else _f32(eps_p, self.device)
         orig = self._ws['orig']
         self.future_traj = self._future - orig[:, None, :]
@@ -442,18 +443,19 @@ class STTODENet(nn.Module):
         self.encode_history()
         self.fu_encoder(eps_q, eps_p)
         self.decoder_future_0(self.qz_sampled, eps20)
-        loss_pred = (self.future_traj - self.pred_traj).pow(2).sum() / B / self.pred_traj.shape[1]
-        loss_recover = (self.past_traj - self.recover_traj).pow(2).sum() / B / self.recover_traj.shape[1]
-        # KL(q || N(0, I)) in the reference's two-distribution form (Normal.kl with p given, :98-106)
-        t1 = self.qz_mu / (1.0 + 1e-8)
-        t2 = torch.exp(0.5 * self.qz_logvar) / (1.0 + 1e-8)
-        kl = 0.5 * (t1 * t1 + t2 * t2) - 0.5 - torch.log(t2)
-        loss_kl = (kl.sum() / (B * N)).clamp_min(a.min_clip)
+        n, Tp, Tf = self.past_feature.shape[0], a.past_length, a.future_length
+        st = capi.stream_ptr()
+        losses, scratch = self._f(4), self._f(max(n, 1))
+        pred1, rec1 = self.pred_traj.contiguous(), self.recover_traj.contiguous()
+        fut, past = self.future_traj.contiguous(), self.past_traj.contiguous()
+        # calculate_loss_pred / _recover / _kl (model/STTODE.py:372-388), on the loss kernels of csrc/train.hip
+        capi.call('sttode_loss_sqerr', pred1, fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], None, st)
+        capi.call('sttode_loss_sqerr', rec1, past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], None, st)
+        capi.call('sttode_loss_kl', self.qz_param, n, a.zdim, float(B * N), float(a.min_clip), losses[2:], None, st)
         self.decoder_future_1(self.pz_sampled)
-        diff = self.future_traj.unsqueeze(1) - self.diverse_pred_traj
-        loss_diverse = diff.pow(2).sum(dim=-1).sum(dim=-1).min(dim=1)[0].mean()
-        total = loss_pred + loss_recover + loss_kl + loss_diverse
-        return total, loss_pred.item(), loss_recover.item(), loss_kl.item(), loss_diverse.item()
+        capi.call('sttode_loss_diverse', self.diverse_pred_traj.contiguous(), fut, n, 20, 2 * Tf, losses[3:], None, scratch, st)   # :390-395
+        lv = losses.tolist()
+        return losses.sum(), lv[0], lv[1], lv[2], lv[3]
 
     @torch.no_grad()
     def inference(self, data=None, z=None):
