@@ -869,3 +869,37 @@ def test_training_step_edge_scene_sizes_vs_oracle(N):
     grads2, losses2 = _hip_grads('eth', 'eth', 8, 12, g)           # second step: captured + replayed hipGraph
     np.testing.assert_allclose(losses2, losses, rtol=1e-6)
     _compare_grads(grads2, {k: v for k, v in grads.items()}, rtol=1e-6)
+
+
+@pytest.mark.parametrize('B,N,Tp,Tf', [(16, 11, 5, 10), (3, 10, 10, 40)])
+def test_training_step_nba_shapes_vs_oracle(B, N, Tp, Tf):
+    """NBA training step at a longer attention group (L = 16: geodesic-attention backward over 16 x 16 score blocks) and at the
+    BASELINE config-5 horizon (obs 10 / pred 40, N = 10): losses and all gradients vs float64 oracle autograd."""
+    from sttode_amd import scenes
+    _gpu()
+    d = scenes.nba_batch(50 + B, B, N=N, obs_len=Tp, pred_len=Tf)
+    n = B * N
+    rng = np.random.default_rng(B)
+    eps = [rng.standard_normal(s).astype(np.float32) for s in ((n, 32), (n, 32), (n * 20, 32))]
+    data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+    m = hip_model('nba', Tp, Tf)
+    m.zero_grad()
+    m.set_data_nba(data)
+    out = m.forward(*[torch.from_numpy(e) for e in eps])
+    out[0].backward()
+    grads = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    m.zero_grad()
+    from oracle.sttode_ref import STTODENetRef
+    o = STTODENetRef(make_args('nba', Tp, Tf)).eval()
+    o.load_state_dict(oracle_model('nba', Tp, Tf).state_dict(), strict=True)
+    o = o.double()
+    o.set_data_nba({k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in data.items()})
+    prev = torch.get_default_dtype()
+    try:
+        torch.set_default_dtype(torch.float64)
+        vals = o.forward_loss_tensors(*[torch.from_numpy(e).double() for e in eps])
+        vals[0].backward()
+    finally:
+        torch.set_default_dtype(prev)
+    np.testing.assert_allclose([float(out[0].detach())] + list(out[1:]), [float(v.detach()) for v in vals], rtol=1e-4)
+    _compare_grads(grads, {k: p.grad for k, p in o.named_parameters()}, rtol=5e-4)
