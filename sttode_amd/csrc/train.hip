@@ -163,6 +163,13 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         const int blocks_per_wg = 4 / ksplit;
         dim3 grid((cols + 15) / 16, ((I + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg);
         hipLaunchKernelGGL((tlinear_kernel<1, 1, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
+    } else if ((long)((cols + 63) / 64) * ((I + 63) / 64) < 4096) {
+        // medium mode: 32 columns x 32 outputs per wave -- 4x the waves of the throughput tiling, for launches that would
+        // otherwise leave most SIMDs empty (e.g. 7040 columns x 512 outputs = 880 throughput-mode waves on 1024 SIMDs)
+        const int ksplit = (I <= 32 && J > 64) ? 4 : ((I <= 64 && J > 64) ? 2 : 1);
+        const int outs_per_wg = 128 / ksplit;
+        dim3 grid((cols + 31) / 32, (I + outs_per_wg - 1) / outs_per_wg);
+        hipLaunchKernelGGL((tlinear_kernel<2, 2, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
     } else {
         const int ksplit = (I <= 64 && J > 64) ? 4 : ((I <= 128 && J > 64) ? 2 : 1);
         const int outs_per_wg = 256 / ksplit;
