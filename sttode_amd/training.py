@@ -344,7 +344,7 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, total, engine, names, ready, *params):
-        ctx.engine, ctx.names, ctx.ready = engine, names, ready
+        ctx.engine, ctx.names, ctx.ready, ctx.params = engine, names, ready, params
         return total.clone()
 
     @staticmethod
@@ -355,7 +355,18 @@ class _LossFn(torch.autograd.Function):
             G = views
         else:
             G = ctx.engine.run_backward(gout)
-        return (None, None, None, None) + tuple(G.get(nm) for nm in ctx.names)
+        # Hand the gradients over directly instead of returning them: autograd's AccumulateGrad would copy each of the 88 views
+        # of the flat buffer into a fresh tensor (88 extra kernels per step).  The flat buffer is private to this step, so the
+        # views can BE the .grad tensors; an existing .grad (gradient accumulation) is added to in place.
+        for nm, p in zip(ctx.names, ctx.params):
+            g = G.get(nm)
+            if g is None or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return (None, None, None, None) + (None,) * len(ctx.names)
 
 
 class _GraphedStep:
