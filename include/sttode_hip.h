@@ -193,8 +193,11 @@ int sttode_loss_diverse(const float* pred, const float* target, int n, int K, in
  * 13/14 internal halves of mobius_matvec / poincare_mean.
  * ------------------------------------------------------------------------------------------------ */
 int sttode_pmath_rowop(int op, const float* x, const float* y, float* out, float* out2, int rows, int d, float c, void* stream);
-/* which: 0 tanh (clamp 15, pmath.py:11-12), 1 artanh (:16-22), 2 arsinh (:51-55) */
+/* which: 0 tanh (clamp 15, pmath.py:11-12), 1 artanh (:16-22), 2 arsinh (:51-55), 3 d artanh/dx at the clamped input
+ * (Artanh.backward :25-27), 4 d arsinh/dx (Arsinh.backward :57-60) */
 int sttode_pmath_scalar(int which, const float* x, float* out, long n, void* stream);
+/* RiemannianGradient.backward (pmath.py:39-45): out[r,:] = g[r,:] * (1 - c |x_r|^2)^2 / 4. */
+int sttode_pmath_riemannian_grad(const float* x, const float* g, float* out, int rows, int d, float c, void* stream);
 /* mobius_matvec (pmath.py:399-408): m [O,d], x [rows,d] -> out [rows,O]; workspaces mx_ws [rows,O], xnorm_ws [rows]. */
 int sttode_pmath_matvec(const float* m, const float* x, float* mx_ws, float* xnorm_ws, float* out, int rows, int d, int O, float c,
                         void* stream);

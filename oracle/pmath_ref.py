@@ -135,3 +135,17 @@ def poincare_mean(x, c=1.0):  # pmath.py:472-479 with dim=0 ; x [R,D] -> [D]
 def dist_matrix(x, y, c=1.0):  # pmath.py:482-493 ; [P,D],[R,D] -> [P,R]
     sc = _c(c, x) ** 0.5
     return 2 / sc * artanh(sc * mobius_addition_batch(-x, y, c).norm(dim=-1))
+
+
+# custom autograd functions of the library (backward rules restated; torch CPU)
+def artanh_backward(x, grad):  # Artanh.backward, pmath.py:24-27: the CLAMPED input is what was saved
+    xc = x.clamp(-1 + 1e-5, 1 - 1e-5)
+    return grad / (1 - xc ** 2)
+
+
+def arsinh_backward(x, grad):  # Arsinh.backward, pmath.py:57-60
+    return grad / (1 + x ** 2) ** 0.5
+
+
+def riemannian_gradient_backward(x, grad, c=1.0):  # RiemannianGradient.backward, pmath.py:39-45
+    return grad * (1 - c * x.pow(2).sum(-1, keepdim=True)).pow(2) / 4

@@ -53,6 +53,7 @@ SIGNATURES = {
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
     'sttode_pmath_scalar': [_I, _P, _P, _L, _P],
+    'sttode_pmath_riemannian_grad': [_P, _P, _P, _I, _I, _F, _P],
     'sttode_pmath_matvec': [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     'sttode_pmath_pair': [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     'sttode_pmath_mean': [_P, _P, _P, _P, _I, _I, _F, _P],

@@ -169,7 +169,27 @@ __global__ void pmath_scalar_kernel(int which, const float* __restrict__ x, floa
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    out[i] = which == 0 ? tanh_clamped(v) : (which == 1 ? artanh_(v) : arsinh_(v));
+    switch (which) {
+        case 0: out[i] = tanh_clamped(v); break;
+        case 1: out[i] = artanh_(v); break;
+        case 2: out[i] = arsinh_(v); break;
+        case 3: {  // d artanh / dx at the clamped input (Artanh.backward, hyptorch/pmath.py:25-27)
+            const float xc = fminf(fmaxf(v, -1.0f + 1e-5f), 1.0f - 1e-5f);
+            out[i] = 1.0f / (1.0f - __fmul_rn(xc, xc));   // no fma contraction: 1 - x^2 cancels to ~2e-5 at the clamp
+        } break;
+        default: out[i] = 1.0f / sqrtf(1.0f + __fmul_rn(v, v)); break;   // d arsinh / dx (Arsinh.backward, :57-60)
+    }
+}
+
+// RiemannianGradient.backward (hyptorch/pmath.py:39-45): out[r, :] = g[r, :] * (1 - c |x_r|^2)^2 / 4
+__global__ void riemannian_grad_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, int rows, int d, float c) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float n2 = 0.f;
+    for (int i = 0; i < d; ++i) { const float a = x[(size_t)r * d + i]; n2 += a * a; }
+    const float t = 1.0f - c * n2;
+    const float sc = t * t * 0.25f;
+    for (int i = 0; i < d; ++i) out[(size_t)r * d + i] = g[(size_t)r * d + i] * sc;
 }
 
 // mx[r][o] = <x[r], m[o]>   (mobius_matvec front half)
@@ -249,8 +269,15 @@ extern "C" int sttode_pmath_rowop(int op, const float* x, const float* y, float*
 }
 
 extern "C" int sttode_pmath_scalar(int which, const float* x, float* out, long n, void* stream) {
-    STT_REQUIRE(x && out && n > 0 && which >= 0 && which <= 2, "sttode_pmath_scalar: bad arguments");
+    STT_REQUIRE(x && out && n > 0 && which >= 0 && which <= 4, "sttode_pmath_scalar: bad arguments");
     hipLaunchKernelGGL(pmath_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, x, out, n);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_pmath_riemannian_grad(const float* x, const float* g, float* out, int rows, int d, float c, void* stream) {
+    STT_REQUIRE(x && g && out && rows > 0 && d > 0, "sttode_pmath_riemannian_grad: bad arguments");
+    hipLaunchKernelGGL(riemannian_grad_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, g, out, rows, d, c);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -45,12 +45,67 @@ def tanh(x, clamp=15):
     return _scalar(0, x)
 
 
+class Artanh(torch.autograd.Function):
+    """hyptorch/pmath.py:16-27 (forward clamps to +-(1 - 1e-5); backward grad / (1 - x_clamped^2))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _scalar(1, x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (x,) = ctx.saved_tensors
+        return _mul(grad_output, _scalar(3, x))
+
+
+class Arsinh(torch.autograd.Function):
+    """hyptorch/pmath.py:51-60."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _scalar(2, x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (x,) = ctx.saved_tensors
+        return _mul(grad_output, _scalar(4, x))
+
+
+class RiemannianGradient(torch.autograd.Function):
+    """hyptorch/pmath.py:30-45: identity forward, gradient rescaled by (1 - c |x|^2)^2 / 4 (class attribute ``c``)."""
+
+    c = 1
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (x,) = ctx.saved_tensors
+        xs, g = _prep(x), _prep(grad_output)
+        d = xs.shape[-1]
+        out = torch.empty_like(g)
+        capi.call('sttode_pmath_riemannian_grad', xs, g, out, xs.numel() // d, d, float(RiemannianGradient.c), capi.stream_ptr())
+        return out.view_as(grad_output)
+
+
+def _mul(a, b):
+    a, b = _prep(a), _prep(b)
+    out = torch.empty_like(a)
+    capi.call('sttode_train_ewise', 0, out, a, b, None, None, out.numel(), 0, 0.0, capi.stream_ptr())
+    return out
+
+
 def artanh(x):
-    return _scalar(1, x)
+    return Artanh.apply(x)
 
 
 def arsinh(x):
-    return _scalar(2, x)
+    return Arsinh.apply(x)
 
 
 def project(x, *, c=1.0):

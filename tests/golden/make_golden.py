@@ -300,9 +300,35 @@ def decoder_stack_cases():
     print('decoder_stack.npz bytes:', os.path.getsize(os.path.join(HERE, 'decoder_stack.npz')), len(names), 'tensors')
 
 
+def pmath_grad_cases():
+    """Backward rules of the library's custom autograd functions (hyptorch/pmath.py:16-60), through the reference's own classes."""
+    import hyptorch.pmath as pm
+    rng = np.random.default_rng(15)
+    x = np.concatenate([np.linspace(-1.2, 1.2, 49), [0.99999, -0.99999, 0.999995, 3.0]]).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    out = {'x': x, 'g': g}
+    for name, fn in (('artanh', pm.artanh), ('arsinh', lambda t: pm.arsinh(t * 20))):
+        t = torch.from_numpy(x).clone().requires_grad_(True)
+        fn(t).backward(torch.from_numpy(g))
+        out[name + '_grad'] = npy(t.grad)
+    xr = (rng.standard_normal((17, 16)) * 0.2).astype(np.float32)
+    gr = rng.standard_normal((17, 16)).astype(np.float32)
+    for c in (1.0, 0.5):
+        pm.RiemannianGradient.c = c
+        t = torch.from_numpy(xr).clone().requires_grad_(True)
+        pm.RiemannianGradient.apply(t).backward(torch.from_numpy(gr))
+        out[f'riem_c{c}_grad'] = npy(t.grad)
+    pm.RiemannianGradient.c = 1
+    out.update(xr=xr, gr=gr)
+    np.savez(os.path.join(HERE, 'pmath_grads.npz'), **out)
+
+
 def main():
     install_shims()
     noise = NoiseQueue()
+    if '--only-pmath-grads' in sys.argv:
+        pmath_grad_cases()
+        return
     if '--only-decoder-stack' in sys.argv:
         decoder_stack_cases()
         return
@@ -455,6 +481,7 @@ def main():
     grad_cases(noise)
     sampler_grad_cases(noise)
     decoder_stack_cases()
+    pmath_grad_cases()
     assert not noise.q
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print('golden bytes:', tot)

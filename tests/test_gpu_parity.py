@@ -903,3 +903,25 @@ def test_training_step_nba_shapes_vs_oracle(B, N, Tp, Tf):
         torch.set_default_dtype(prev)
     np.testing.assert_allclose([float(out[0].detach())] + list(out[1:]), [float(v.detach()) for v in vals], rtol=1e-4)
     _compare_grads(grads, {k: p.grad for k, p in o.named_parameters()}, rtol=5e-4)
+
+
+def test_pmath_autograd_functions_vs_reference_golden(golden):
+    """Artanh / Arsinh / RiemannianGradient (hyptorch/pmath.py:16-60) as autograd functions over the HIP ops."""
+    from sttode_amd import pmath
+    dev = _gpu()
+    g = golden('pmath_grads')
+    gr = torch.from_numpy(g['g']).to(dev)
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    pmath.artanh(x).backward(gr)
+    assert_close(x.grad.cpu().numpy(), g['artanh_grad'], rtol=1e-4, atol=1e-5, what='artanh backward')
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    pmath.arsinh(x * 20).backward(gr)
+    assert_close(x.grad.cpu().numpy(), g['arsinh_grad'], rtol=1e-4, atol=1e-5, what='arsinh backward')
+    for c in (1.0, 0.5):
+        pmath.RiemannianGradient.c = c
+        xr = torch.from_numpy(g['xr']).to(dev).requires_grad_(True)
+        y = pmath.RiemannianGradient.apply(xr)
+        assert torch.equal(y, xr)
+        y.backward(torch.from_numpy(g['gr']).to(dev))
+        assert_close(xr.grad.cpu().numpy(), g[f'riem_c{c}_grad'], rtol=1e-5, atol=1e-6, what='riemannian gradient')
+    pmath.RiemannianGradient.c = 1
