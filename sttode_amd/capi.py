@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
+LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
