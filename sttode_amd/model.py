@@ -231,15 +231,13 @@ class STTODENet(nn.Module):
         if (self.training and self.rand_rot_scene) or theta is not None:
             if theta is None:
                 theta = (torch.randint(high=24, size=(1,)) * (np.pi / 12)) if self.discrete_rot else torch.rand(1) * np.pi * 2
-            th = torch.as_tensor(theta, dtype=torch.float32).reshape(()).to(dev)
-            c, s_ = torch.cos(th), torch.sin(th)
+            th = float(theta)
+            c, s_ = float(np.cos(np.float32(th))), float(np.sin(np.float32(th)))
+            R = torch.tensor([[c, -s_], [s_, c]], dtype=torch.float32, device=dev)        # rotation_2d_torch (:6-14)
             orig = past[:, -1].mean(dim=0)                       # scene_orig (:417); invariant under the rotation about itself
-
-            def rot(x):                                          # rotation_2d_torch (:6-14)
-                d = x - orig
-                return torch.stack([d[..., 0] * c - d[..., 1] * s_, d[..., 0] * s_ + d[..., 1] * c], dim=-1) + orig
-            past = rot(past).contiguous()
-            fut = rot(fut).contiguous() if fut is not None else None
+            rot = lambda x: (((x - orig).unsqueeze(-2) * R).sum(-1) + orig).contiguous()  # x'_i = sum_j R[i][j] (x - orig)_j + orig_i
+            past = rot(past)
+            fut = rot(fut) if fut is not None else None
         N = past.shape[0]
         self.set_scene_batch(past, fut, torch.tensor([0, N], dtype=torch.int32))
         self.batch_size = 1

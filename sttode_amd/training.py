@@ -428,9 +428,9 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     if net.training:                                                # nn.Dropout(0.1) after the positional fc, both encoders
         keep = 0.9
         if drop_past is None:
-            drop_past = (torch.rand(n * a.past_length, 64, device=dev) < keep).float() / keep
+            drop_past = torch.empty(n * a.past_length, 64, device=dev).bernoulli_(keep).div_(keep)
         if drop_future is None:
-            drop_future = (torch.rand(n * a.future_length, 64, device=dev) < keep).float() / keep
+            drop_future = torch.empty(n * a.future_length, 64, device=dev).bernoulli_(keep).div_(keep)
     eng = getattr(net, '_engine', None)
     if eng is None or eng.dev != dev:
         eng = net._engine = Engine(net)
