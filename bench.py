@@ -281,24 +281,26 @@ def main():
         max_rel, traj_cpu, t_cpu, s = 0.0, 0, 0.0, 0
         ade_o, ade_h = [], []
         from oracle.metrics_ref import best_of_k_ade_fde
-        while s < sb.n_scenes and (t_cpu < args.cpu_seconds or s < 2):
-            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
-            obs, pr = sb.scene(s)
+        while t_cpu < args.cpu_seconds or s < 2:                  # bounded sample: whole passes over the workload's scenes, cycled
+            i = s % sb.n_scenes
+            a, b = int(sb.scene_ptr[i]), int(sb.scene_ptr[i + 1])
+            obs, pr = sb.scene(i)
             tc = time.perf_counter()
             ref = oracle_scene_inference(ora, obs, pr, z_all[a * K:b * K])
             t_cpu += time.perf_counter() - tc
             traj_cpu += (b - a) * K
-            err = np.abs(hip[:, a:b] - ref) / (np.abs(ref) + 1.0)
-            max_rel = max(max_rel, float(err.max()))
-            gt = sb.future[a:b]
-            ade_o.append(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0])
-            ade_h.append(best_of_k_ade_fde(hip[:, a:b].transpose(1, 0, 2, 3), gt)[0])
+            if s < sb.n_scenes:                                    # parity of every scene once (first pass)
+                err = np.abs(hip[:, a:b] - ref) / (np.abs(ref) + 1.0)
+                max_rel = max(max_rel, float(err.max()))
+                gt = sb.future[a:b]
+                ade_o.append(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0])
+                ade_h.append(best_of_k_ade_fde(hip[:, a:b].transpose(1, 0, 2, 3), gt)[0])
             s += 1
         ao, ah = float(np.concatenate(ade_o).mean()), float(np.concatenate(ade_h).mean())
         out['cpu_baseline'] = {'value': traj_cpu / t_cpu, 'unit': 'trajectories/s', 'cores': torch.get_num_threads(), 'host_cpus_visible': ncpu, 'kind': 'port',
-                               'sample': f'first {s} of the {sb.n_scenes} scenes of this workload, per-scene set_data+inference loop '
+                               'sample': f'{s} scene evaluations cycling over the {sb.n_scenes} scenes of this workload, per-scene set_data+inference loop '
                                          f'(test.py:171-184 structure), PyTorch-eager fp32 oracle, {t_cpu:.1f} s of CPU time'}
-        out['parity'] = {'scenes_checked': s, 'max_err_over_1_plus_abs_ref': max_rel, 'ade_oracle': ao, 'ade_hip': ah,
+        out['parity'] = {'scenes_checked': min(s, sb.n_scenes), 'max_err_over_1_plus_abs_ref': max_rel, 'ade_oracle': ao, 'ade_hip': ah,
                          'ade_abs_diff': abs(ao - ah)}
         out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
     if rank == 0:
