@@ -203,6 +203,31 @@ class ODEGDecoder(nn.Module):
         return F.relu(tgt + self.time * x)
 
 
+def ode_integrate_ref(f, y0, t1, method='euler', steps=1):
+    """Fixed-grid integration of y' = f(y) on a uniform grid of ``steps`` steps over [0, t1]: Euler, torchdiffeq's fixed-grid
+    'rk4' (the 3/8-rule ``rk4_alt_step_func``) and the classical RK4.  Only the single Euler step is ever run by the reference
+    (ode_demo.py:186-190); the others have no reference pin (torchdiffeq absent, SURVEY.md §8c: "parity unpinned")."""
+    h = float(t1) / steps
+    y = y0
+    for _ in range(steps):
+        k1 = f(y)
+        if method == 'euler':
+            y = y + h * k1
+        elif method == 'rk4':
+            k2 = f(y + h * k1 / 3)
+            k3 = f(y + h * (k2 - k1 / 3))
+            k4 = f(y + h * (k1 - k2 + k3))
+            y = y + h * (k1 + 3 * (k2 + k3) + k4) / 8
+        elif method == 'rk4_classic':
+            k2 = f(y + h * k1 / 2)
+            k3 = f(y + h * k2 / 2)
+            k4 = f(y + h * k3)
+            y = y + h * (k1 + 2 * k2 + 2 * k3 + k4) / 6
+        else:
+            raise ValueError(method)
+    return y
+
+
 def sinusoid_table(max_len, d_model):
     """model/STTODE.py:149-155."""
     pe = torch.zeros(max_len, d_model)

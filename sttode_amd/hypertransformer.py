@@ -119,6 +119,51 @@ def _euler_relu(x, y, time):
     return out
 
 
+def _axpy(y, a, x):
+    """y += a * x (in place, HIP element kernel)."""
+    capi.call('sttode_train_ewise', 1, y, x.contiguous(), None, None, None, y.numel(), 0, float(a), capi.stream_ptr())
+    return y
+
+
+def _relu_(x):
+    z = torch.zeros_like(x)
+    out = torch.empty_like(x)
+    capi.call('sttode_train_ewise', 3, out, x.contiguous(), z, None, None, out.numel(), 0, 0.0, capi.stream_ptr())
+    return out
+
+
+def ode_integrate(f, y0, t1, method='euler', steps=1):
+    """Fixed-grid integration of the autonomous system y' = f(y) over [0, t1] in ``steps`` equal steps (what torchdiffeq's
+    fixed-grid solvers do on a uniform grid).  The reference only ever takes ONE Euler step (ode_demo.py:186-190 with t = [0, time]
+    and no step_size); the multi-step / Runge-Kutta variants are provided because the north star names them and are checked
+    against the CPU oracle only (the reference never runs them, torchdiffeq is not installed: parity unpinned).
+      'euler'   y += h f(y)
+      'rk4'     the 3/8-rule step torchdiffeq's fixed-grid 'rk4' uses (rk4_alt_step_func)
+      'rk4_classic'  the classical 1/6 (k1 + 2 k2 + 2 k3 + k4) step"""
+    h = float(t1) / steps
+    y = y0.contiguous().clone()
+    for _ in range(steps):
+        k1 = f(y)
+        if method == 'euler':
+            _axpy(y, h, k1)
+            continue
+        if method == 'rk4':
+            k2 = f(_axpy(y.clone(), h / 3, k1))
+            y3 = _axpy(_axpy(y.clone(), h, k2), -h / 3, k1)
+            k3 = f(y3)
+            y4 = _axpy(_axpy(_axpy(y.clone(), h, k1), -h, k2), h, k3)
+            k4 = f(y4)
+            _axpy(_axpy(_axpy(_axpy(y, h / 8, k1), 3 * h / 8, k2), 3 * h / 8, k3), h / 8, k4)
+        elif method == 'rk4_classic':
+            k2 = f(_axpy(y.clone(), h / 2, k1))
+            k3 = f(_axpy(y.clone(), h / 2, k2))
+            k4 = f(_axpy(y.clone(), h, k3))
+            _axpy(_axpy(_axpy(_axpy(y, h / 6, k1), h / 3, k2), h / 3, k3), h / 6, k4)
+        else:
+            raise ValueError(f'unknown ODE method {method!r}')
+    return y
+
+
 class ODEG(nn.Module):
     """relu(tgt + time * DecoderStack(tgt, memory)): torchdiffeq's fixed-grid Euler on t = [0, time] is ONE step (ode_demo.py:151-166)."""
 
@@ -139,14 +184,20 @@ class ODEG(nn.Module):
 
 
 class ODEG_Encoder(nn.Module):
-    def __init__(self, encoder_layer, nlayer, time):
+    """ode_demo.py:217-231.  ``method`` / ``steps`` default to the reference's single Euler step; see ``ode_integrate``."""
+
+    def __init__(self, encoder_layer, nlayer, time, method='euler', steps=1):
         super().__init__()
         self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(nlayer)])
-        self.time = float(time)
+        self.time, self.method, self.steps = float(time), method, int(steps)
+
+    def _rhs(self, x):
+        for m in self.layers:
+            x = m(x)
+        return x
 
     @torch.no_grad()
     def forward(self, src, mask=None, src_key_padding_mask=None, num_agent=1):
-        x = src
-        for m in self.layers:
-            x = m(x)
-        return _euler_relu(src, x, self.time)
+        if self.method == 'euler' and self.steps == 1:
+            return _euler_relu(src, self._rhs(src), self.time)
+        return _relu_(ode_integrate(self._rhs, src, self.time, self.method, self.steps))

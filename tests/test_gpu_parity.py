@@ -925,3 +925,27 @@ def test_pmath_autograd_functions_vs_reference_golden(golden):
         y.backward(torch.from_numpy(g['gr']).to(dev))
         assert_close(xr.grad.cpu().numpy(), g[f'riem_c{c}_grad'], rtol=1e-5, atol=1e-6, what='riemannian gradient')
     pmath.RiemannianGradient.c = 1
+
+
+@pytest.mark.parametrize('method,steps', [('euler', 1), ('euler', 4), ('rk4', 3), ('rk4_classic', 2)])
+def test_ode_encoder_integrators_vs_oracle(method, steps):
+    """ODEG_Encoder as an op with multi-step Euler / RK4 right-hand-side evaluations on the HIP layer kernels vs the CPU oracle
+    (the reference itself only ever takes one Euler step; these variants are oracle-checked only: no reference pin exists)."""
+    from oracle.sttode_ref import EncoderLayer, ode_integrate_ref
+    from sttode_amd.hypertransformer import ODEG_Encoder, TransformerEncoderLayer
+    from sttode_amd.weights import make_decoder_layer_weights, to_torch_state_dict
+    dev = _gpu()
+    sd = {k: v for k, v in to_torch_state_dict(make_decoder_layer_weights(71, d=64, ff=256)).items()
+          if not k.startswith('cross_attn') and not k.startswith('norm3')}
+    sd = {k: (v * 0.3 if k.endswith('weight') and 'norm' not in k else v) for k, v in sd.items()}     # keep the RHS mild
+    layer = TransformerEncoderLayer(64, 8, 256)
+    layer.load_state_dict(sd, strict=True)
+    ora = EncoderLayer(64, 8, 256).eval()
+    ora.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((5, 7, 1, 64)).astype(np.float32))
+    enc = ODEG_Encoder(layer, 1, 0.9, method=method, steps=steps).to(dev)
+    out = enc(x.to(dev))
+    with torch.no_grad():
+        ref = torch.relu(ode_integrate_ref(ora, x, 0.9, method, steps))
+    assert_close(out.cpu().numpy(), ref.numpy(), what=f'ODEG_Encoder {method} x{steps}')
