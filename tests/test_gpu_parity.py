@@ -949,3 +949,19 @@ def test_ode_encoder_integrators_vs_oracle(method, steps):
     with torch.no_grad():
         ref = torch.relu(ode_integrate_ref(ora, x, 0.9, method, steps))
     assert_close(out.cpu().numpy(), ref.numpy(), what=f'ODEG_Encoder {method} x{steps}')
+
+
+@pytest.mark.parametrize('N', [1, 3, 17])
+def test_single_small_scene_inference_vs_oracle(N):
+    """One scene on its own (the reference's call pattern, test.py:182-184) at sizes below one 16-column tile per agent stage and
+    20 .. 340 trajectories in the decoder (partial 64-column work items everywhere)."""
+    from sttode_amd import scenes
+    _gpu()
+    o, p = scenes.eth_scene(8200 + N, n_min=N, n_max=N)
+    z = scenes.latents(300 + N, N)
+    m = hip_model('eth', 8, 12)
+    m.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(N, 8), torch.ones(N, 12))
+    out = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+    ref = oracle_scene_inference(oracle_model('eth', 8, 12), o, p, z)
+    assert out.shape == (20, N, 12, 2)
+    assert_close(out, ref, what=f'single scene N={N}')
