@@ -135,6 +135,11 @@ int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw,
  * partials in scratch (scratch_floats capacity; NULL = single split). */
 int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,
                   int K, float* scratch, long scratch_floats, void* stream);
+/* Backward of one nn.Linear: dX[c, 0:Kdx] = mask(sum_n dY[c, n] W[n, 0:Kdx] (+ dX)) and dW += dY^T X, db += sum_c dY, in ONE
+ * launch when cols <= 1024 (the launch-bound training regime; dX must not alias dY or X), otherwise sttode_tlinear + sttode_twgrad. */
+int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, long ldw, const float* mask, long ldm, float* dX, long lddx,
+                       int Kdx, int accumulate, const float* X, long ldx, int xdiv, float* dW, long ldgw, float* db, int cols, int N,
+                       int K, float* scratch, long scratch_floats, void* stream);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
 /* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */
@@ -145,7 +150,7 @@ int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int row
  * 7 p0=f0 | 8 rsample backward (dz p0, params p1, eps p2 -> dparams p3 +=) | 9 p0[c,d] += p1[c / K, d % 2] (row length i0,
  * K = f0: "+ cur_location", model/STTODE.py:343-344) | 10 p0=p1*(1-p2^2) (tanh backward from its output) | 11 stage-2 latent
  * backward (sampler.py:51-53): dz p0, dlogvar p1, A p2, eps p3 -> dA p4 = dz*eps + dlogvar*2A/(A^2+1e-8); i0 = nz*4 + eps_mode,
- * f0 = K*nz. */
+ * f0 = K*nz | 12 p0[c,d] = p1 + p2 (+ p3[c / K, d % 2]) (row length i0, K = f0: sum of the blocks' outputs + cur_location). */
 int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0,
                        void* stream);
 /* y = LayerNorm(x + r) over 64 features (hypertransformer.py:146,151); saves xhat [rows,64], rstd [rows]. */
@@ -162,11 +167,12 @@ int sttode_gru_cell_bwd(const float* dh, const float* tape, const float* hprev, 
                         int m, void* stream);
 /* The same over the WHOLE sequence in one launch (columns are independent): gi [m*Tp,288] (row = col*Tp + t), H [(Tp+1),m,96]
  * with H[0] = 0 on entry (H[t+1] = h_t written), tapes [Tp,m,384].  W_hh fragments stay in registers across the steps. */
-int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, int m, int Tp, void* stream);
+int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, float* hfinal, long ldhf, int m,
+                       int Tp, void* stream);   /* hfinal (optional): the final state also goes to rows of ldhf floats */
 /* Whole BPTT in one launch: dh_last [m,96] = grad wrt the final state -> dgi [m*Tp,288], dgh [Tp,m,288]
  * (dh_{t-1} = dh_t * z_t + dgh_t W_hh is carried in registers / LDS). */
-int sttode_gru_seq_bwd(const float* dh_last, const float* tapes, const float* H, const float* Whh, float* dgi, float* dgh, int m,
-                       int Tp, void* stream);
+int sttode_gru_seq_bwd(const float* dh_last, long lddh, const float* tapes, const float* H, const float* Whh, float* dgi, float* dgh,
+                       int m, int Tp, void* stream);
 /* conv1d(2->32,k3,pad1)+relu (model/STTODE.py:65) on x = xa[c / adiv] - xb[c] ([m,T,2], xb optional); saves x; e [m,T,32]. */
 int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m, int T,
                     void* stream);

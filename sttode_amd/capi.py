@@ -35,6 +35,7 @@ SIGNATURES = {
     # training step (csrc/train.hip)
     'sttode_tlinear': [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
+    'sttode_tlinear_bwd': [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
     'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_train_ewise': [_I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -42,8 +43,8 @@ SIGNATURES = {
     'sttode_ln_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
     'sttode_gru_cell_fwd': [_P, _L, _P, _P, _P, _P, _I, _P],
     'sttode_gru_cell_bwd': [_P, _P, _P, _P, _L, _P, _P, _I, _P],
-    'sttode_gru_seq_fwd': [_P, _P, _P, _P, _P, _I, _I, _P],
-    'sttode_gru_seq_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'sttode_gru_seq_fwd': [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    'sttode_gru_seq_bwd': [_P, _L, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _P],

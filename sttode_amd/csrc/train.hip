@@ -45,11 +45,10 @@ static __device__ __forceinline__ float act_apply(float v, int act) {
 //   <1,1,8>  latency mode (few columns: 32 .. 1024): 16 x 16 block per WG, 4-way K split -> one or two round trips per launch;
 //   <4,4,2>  throughput mode (NBA / long batches): 64 columns x 64 outputs per wave, weight fragments reused over 4 column tiles.
 template <int RT, int CT, int U>
-__global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
-    __shared__ f32x4 part[3][RT * CT][64];
+static __device__ __forceinline__ void tlinear_body(const TLin& a, int ksplit, int bx, int by, f32x4 (*part)[RT * CT][64]) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int blocks_per_wg = 4 / ksplit;
-    const int oblock = blockIdx.y * blocks_per_wg + wave / ksplit, ksub = wave % ksplit;
+    const int oblock = by * blocks_per_wg + wave / ksplit, ksub = wave % ksplit;
     const int it0 = oblock * RT;
     const bool active = it0 * 16 < a.I;
     int col[CT];
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
     const float* xrow[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-        col[t] = (blockIdx.x * CT + t) * 16 + c;
+        col[t] = (bx * CT + t) * 16 + c;
         colok[t] = col[t] < a.cols;
         xrow[t] = a.X + (long)((colok[t] ? col[t] : 0) / a.xdiv) * a.ldx;
     }
@@ -143,6 +142,12 @@ __global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
     }
 }
 
+template <int RT, int CT, int U>
+__global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
+    __shared__ f32x4 part[3][RT * CT][64];
+    tlinear_body<RT, CT, U>(a, ksplit, blockIdx.x, blockIdx.y, part);
+}
+
 static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
 
 extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
@@ -189,10 +194,9 @@ struct TWg {
     int cols, N, K, xdiv, S, chunks_per_split;
 };
 
-__global__ __launch_bounds__(256) void twgrad_kernel(TWg a) {
-    __shared__ float red[4][32][33];
+static __device__ __forceinline__ void twgrad_body(const TWg& a, int bx, int by, int bz, float (*red)[32][33]) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32, s = blockIdx.z;
+    const int n0 = bx * 32, k0 = by * 32, s = bz;
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -238,6 +242,24 @@ __global__ __launch_bounds__(256) void twgrad_kernel(TWg a) {
     }
 }
 
+__global__ __launch_bounds__(256) void twgrad_kernel(TWg a) {
+    __shared__ float red[4][32][33];
+    twgrad_body(a, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
+// One launch for a layer's backward at training-scene sizes: blocks [0, nA) compute the input gradient (tlinear latency mode),
+// the remaining blocks the weight / bias gradient.  The two halves are independent (dX must not alias dY or X).
+__global__ __launch_bounds__(256) void tbwd_kernel(TLin a, int ksplit, int gxA, int nA, TWg w, int gxW, int gyW) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 33 * 4];
+    int id = blockIdx.x;
+    if (id < nA) {
+        tlinear_body<1, 1, 8>(a, ksplit, id % gxA, id / gxA, reinterpret_cast<f32x4(*)[1][64]>(sm));
+    } else {
+        id -= nA;
+        twgrad_body(w, id % gxW, (id / gxW) % gyW, id / (gxW * gyW), reinterpret_cast<float(*)[32][33]>(sm));
+    }
+}
+
 __global__ void twgrad_reduce_kernel(TWg a) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)a.N * (a.K + 1);
@@ -268,6 +290,44 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     dim3 grid((N + 31) / 32, (K + 1 + 31) / 32, S);
     hipLaunchKernelGGL(twgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (S > 1) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Backward of one nn.Linear in (at most) two launches: dX = mask(dY W[:, :Kdx] (+ dX)) and dW += dY^T X, db += sum dY.
+// Small column counts (the launch-bound regime) take the fused kernel; otherwise the two stand-alone entry points run.
+extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, long ldw, const float* mask, long ldm, float* dX,
+                                  long lddx, int Kdx, int accumulate, const float* X, long ldx, int xdiv, float* dW, long ldgw,
+                                  float* db, int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(dY && W && dX && X && dW, "sttode_tlinear_bwd: null pointer");
+    STT_REQUIRE(cols > 0 && N > 0 && K > 0 && Kdx > 0 && Kdx <= K && xdiv > 0, "sttode_tlinear_bwd: bad sizes");
+    if (cols > 1024 || xdiv != 1) {
+        if (int rc = sttode_tlinear(dY, ldy, 1, W, ldw, 1, nullptr, mask, ldm, dX, lddx, cols, N, Kdx, 0, accumulate, stream)) return rc;
+        return sttode_twgrad(dY, ldy, X, ldx, xdiv, dW, ldgw, db, cols, N, K, scratch, scratch_floats, stream);
+    }
+    STT_REQUIRE(ldy >= N && ldx >= K && ldgw >= K && ldw >= K && lddx >= Kdx, "sttode_tlinear_bwd: leading dimension smaller than the row length");
+    TLin a;
+    a.X = dY; a.W = W; a.bias = nullptr; a.mask = mask; a.Y = dX;
+    a.ldx = ldy; a.ldw = ldw; a.ldy = lddx; a.ldm = ldm;
+    a.cols = cols; a.J = N; a.I = Kdx; a.trans = 1; a.act = 0; a.accumulate = accumulate; a.xdiv = 1;
+    a.xvec = aligned16(dY, ldy); a.wvec = aligned16(W, ldw); a.yvec = aligned16(dX, lddx);
+    const int ksplit = N > 256 ? 4 : (N > 128 ? 2 : 1);
+    const int blocks_per_wg = 4 / ksplit;
+    const int gxA = (cols + 15) / 16, gyA = ((Kdx + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg;
+    TWg w;
+    w.dY = dY; w.X = X; w.dW = dW; w.db = db; w.scratch = scratch;
+    w.ldy = ldy; w.ldx = ldx; w.ldw = ldgw; w.cols = cols; w.N = N; w.K = K; w.xdiv = 1;
+    const int chunks = (cols + 15) / 16;
+    const long per = (long)N * (K + 1);
+    int S = (chunks + 31) / 32;
+    if (!scratch || per * S > scratch_floats) S = scratch && scratch_floats >= 2 * per ? (int)(scratch_floats / per) : 1;
+    if (S < 1) S = 1;
+    w.S = S;
+    w.chunks_per_split = (chunks + S - 1) / S;
+    const int gxW = (N + 31) / 32, gyW = (K + 1 + 31) / 32;
+    const int nA = gxA * gyA, nB = gxW * gyW * S;
+    hipLaunchKernelGGL(tbwd_kernel, dim3(nA + nB), dim3(256), 0, (hipStream_t)stream, a, ksplit, gxA, nA, w, gxW, gyW);
+    if (S > 1) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -322,6 +382,7 @@ enum {
     EW_CUR_ADD = 9,    // p0[c, d] += p1[c / K, d % 2] with row length i0, K = (int)f0   ("+ cur_location", model/STTODE.py:343-344)
     EW_TANH_BWD = 10,  // p0[i] = p1[i] * (1 - p2[i]^2)      (p2 = tanh output)
     EW_LATENT_BWD = 11,  // sampler.py:51-53: dz=p0, dlogvar=p1, A=p2, eps p3 (mode i0: 0 none | 1 shared [nz] | 2 per agent) -> dA=p4
+    EW_SUM_CUR = 12,   // p0[c, d] = p1 + p2 (+ p3[c / K, d % 2] if p3)   row length i0, K = (int)f0  (Decoder.forward :336-344)
     EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
 };
 
@@ -359,6 +420,11 @@ __global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2
             else if (mode == 2) e = p3[(i / (long)f0) * nz + i % nz];
             p4[i] = p0[i] * e + p1[i] * 2.0f * a / (a * a + 1e-8f);
         } break;
+        case EW_SUM_CUR: {
+            float v = p1[i] + p2[i];
+            if (p3) v += p3[((i / i0) / (int)f0) * 2 + (i % i0) % 2];
+            p0[i] = v;
+        } break;
         case EW_CUR_ADD: {
             const long c = i / i0;
             p0[i] += p1[(c / (int)f0) * 2 + (i % i0) % 2];
@@ -374,7 +440,7 @@ __global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2
 
 extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
                                   float f0, void* stream) {
-    STT_REQUIRE(op >= 0 && op <= EW_LATENT_BWD && p0 && count > 0, "sttode_train_ewise: bad argument");
+    STT_REQUIRE(op >= 0 && op <= EW_SUM_CUR && p0 && count > 0, "sttode_train_ewise: bad argument");
     hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, p0, p1, p2, p3, p4, count, i0, f0);
     STT_HIP(hipGetLastError());
     return 0;
@@ -524,7 +590,8 @@ extern "C" int sttode_gru_cell_bwd(const float* dh, const float* tape, const flo
 
 __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ Whh,
                                                           const float* __restrict__ bhh, float* __restrict__ H,
-                                                          float* __restrict__ tapes, int m, int Tp) {
+                                                          float* __restrict__ tapes, float* __restrict__ hfinal, long ldhf, int m,
+                                                          int Tp) {
     __shared__ float sH[16 * GSEQ_LDH];
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, j = threadIdx.x >> 6;
     const int col = blockIdx.x * 16 + c;
@@ -563,6 +630,7 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
             float* tp = tapes + ((long)t * m + col) * 384;
             st4(tp + f, r); st4(tp + 96 + f, z); st4(tp + 192 + f, n); st4(tp + 288 + f, acc[2]);
             st4(H + ((long)(t + 1) * m + col) * 96 + f, hn);
+            if (hfinal && t == Tp - 1) st4(hfinal + (long)col * ldhf + f, hn);
         }
         __syncthreads();                                // every wave has read h_{t-1}
         st4(sH + c * GSEQ_LDH + f, hn);
@@ -570,7 +638,7 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restrict__ dh_last, const float* __restrict__ tapes,
+__global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restrict__ dh_last, long lddh, const float* __restrict__ tapes,
                                                           const float* __restrict__ H, const float* __restrict__ Whh,
                                                           float* __restrict__ dgi, float* __restrict__ dgh, int m, int Tp) {
     __shared__ float sG[16 * GSEQ_LDG];
@@ -584,7 +652,7 @@ __global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restric
     for (int T = 0; T < 18; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[T][r] = Whh[(long)(16 * T + 4 * q + r) * 96 + 16 * j + c];
-    f32x4 dh = ok ? ld4(dh_last + (long)col * 96 + f) : splat4(0.f);
+    f32x4 dh = ok ? ld4(dh_last + (long)col * lddh + f) : splat4(0.f);
     for (int t = Tp - 1; t >= 0; --t) {
         f32x4 dr = splat4(0.f), dz = dr, dn = dr, dhn = dr, dhz = dr;
         if (ok) {
@@ -618,18 +686,20 @@ __global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
-extern "C" int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, int m, int Tp,
-                                  void* stream) {
+extern "C" int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, float* hfinal,
+                                  long ldhf, int m, int Tp, void* stream) {
     STT_REQUIRE(gi && Whh && bhh && H && tapes && m > 0 && Tp > 0, "sttode_gru_seq_fwd: bad argument");
     STT_REQUIRE(((size_t)Whh) % 16 == 0 && ((size_t)gi) % 16 == 0, "sttode_gru_seq_fwd: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, m, Tp);
+    STT_REQUIRE(!hfinal || (((size_t)hfinal) % 16 == 0 && ldhf % 4 == 0 && ldhf >= 96), "sttode_gru_seq_fwd: hfinal must be 16-byte aligned rows of >= 96 floats");
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, hfinal, ldhf, m, Tp);
     STT_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int sttode_gru_seq_bwd(const float* dh_last, const float* tapes, const float* H, const float* Whh, float* dgi, float* dgh,
-                                  int m, int Tp, void* stream) {
+extern "C" int sttode_gru_seq_bwd(const float* dh_last, long lddh, const float* tapes, const float* H, const float* Whh, float* dgi,
+                                  float* dgh, int m, int Tp, void* stream) {
     STT_REQUIRE(dh_last && tapes && H && Whh && dgi && dgh && m > 0 && Tp > 0, "sttode_gru_seq_bwd: bad argument");
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, dh_last, tapes, H, Whh, dgi, dgh, m, Tp);
+    STT_REQUIRE(((size_t)dh_last) % 16 == 0 && lddh % 4 == 0 && lddh >= 96, "sttode_gru_seq_bwd: dh_last must be 16-byte aligned rows of >= 96 floats");
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, dh_last, lddh, tapes, H, Whh, dgi, dgh, m, Tp);
     STT_HIP(hipGetLastError());
     return 0;
 }

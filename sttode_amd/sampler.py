@@ -156,15 +156,12 @@ class _SamplerFn(torch.autograd.Function):
         if g_mu is not None:
             eng.ew(EW_AXPY, db, g_mu.contiguous(), f0=1.0)
         G = {k: torch.zeros_like(p) for k, p in smp.named_parameters() if not k.startswith('q_c.')}
-        eng.wgrad(dA, hs[-1], G['q_A.weight'], G['q_A.bias'])
-        eng.wgrad(db, hs[-1], G['q_b.weight'], G['q_b.bias'])
-        dh = eng.lin_dx(dA, smp.q_A.weight)
-        eng.lin_dx(db, smp.q_b.weight, out=dh, accumulate=True)
+        dh = eng.lin_bwd(dA, smp.q_A.weight, hs[-1], G['q_A.weight'], G['q_A.bias'])
+        eng.lin_bwd(db, smp.q_b.weight, hs[-1], G['q_b.weight'], G['q_b.bias'], out=dh, accumulate=True)
         for i in range(len(smp.q_mlp.affine_layers) - 1, -1, -1):
             lin = smp.q_mlp.affine_layers[i]
             eng.ew(EW_TANH_BWD, dh, dh, hs[i + 1])
-            eng.wgrad(dh, hs[i], G[f'q_mlp.affine_layers.{i}.weight'], G[f'q_mlp.affine_layers.{i}.bias'])
-            dh = eng.lin_dx(dh, lin.weight)
+            dh = eng.lin_bwd(dh, lin.weight, hs[i], G[f'q_mlp.affine_layers.{i}.weight'], G[f'q_mlp.affine_layers.{i}.bias'])
         eng.wgrad(dh, ctx.pf, G['linear.weight'], G['linear.bias'])
         return (None, None, None, None) + tuple(G.get(k) for k, _ in smp.named_parameters())
 

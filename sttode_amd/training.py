@@ -16,7 +16,7 @@ import torch
 from . import capi
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
-EW_TANH_BWD, EW_LATENT_BWD = 10, 11
+EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR = 10, 11, 12
 ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
@@ -67,6 +67,20 @@ class Engine:
         K = X.shape[1]
         assert gW.shape[0] == N and gW.shape[1] == K, (gW.shape, N, K)
         capi.call('sttode_twgrad', dY, _ld(dY), X, _ld(X), xdiv, gW, _ld(gW), gb, cols, N, K, self.scratch, self.scratch.numel(), self.st)
+
+    def lin_bwd(self, dY, W, X, gW, gb, mask=None, out=None, accumulate=False, in_features=None):
+        """One layer's backward: returns dX = (dY W[:, :in_features]) (* (mask > 0)) (+ out) and accumulates gW += dY^T X,
+        gb += sum dY -- one launch at scene sizes (sttode_tlinear_bwd)."""
+        if not self.param_grads:
+            return self.lin_dx(dY, W, mask=mask, out=out, accumulate=accumulate, in_features=in_features)
+        cols, N = dY.shape
+        K = W.shape[1]
+        Kdx = K if in_features is None else in_features
+        out = self.new(cols, Kdx) if out is None else out
+        assert X.shape[1] == K and gW.shape[0] == N and gW.shape[1] == K
+        capi.call('sttode_tlinear_bwd', dY, _ld(dY), W, _ld(W), mask, _ld(mask) if mask is not None else 0, out, _ld(out), Kdx,
+                  int(accumulate), X, _ld(X), 1, gW, _ld(gW), gb, cols, N, K, self.scratch, self.scratch.numel(), self.st)
+        return out
 
     def ew(self, op, p0, p1=None, p2=None, p3=None, p4=None, i0=0, f0=0.0, count=None):
         capi.call('sttode_train_ewise', op, p0, p1, p2, p3, p4, p0.numel() if count is None else count, i0, float(f0), self.st)
@@ -149,37 +163,33 @@ class Engine:
         dsum2 = self.new(n, 64)
         capi.call('sttode_ln_bwd', dy, t['xh2'], t['rs2'], P[a + 'norm2.weight'], dsum2, g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
                   self.scratch, self.scratch.numel(), self.st)
-        self.wgrad(dsum2, t['f1'], g(a + 'linear2.weight'), g(a + 'linear2.bias'))
-        df1 = self.lin_dx(dsum2, P[a + 'linear2.weight'], mask=t['f1'])
-        self.wgrad(df1, t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'))
+        df1 = self.lin_bwd(dsum2, P[a + 'linear2.weight'], t['f1'], g(a + 'linear2.weight'), g(a + 'linear2.bias'), mask=t['f1'])
         dh = dsum2                                           # residual branch of LN2(h + f)
-        self.lin_dx(df1, P[a + 'linear1.weight'], out=dh, accumulate=True)
+        self.lin_bwd(df1, P[a + 'linear1.weight'], t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'), out=dh, accumulate=True)
         dsum1 = self.new(n, 64)
         capi.call('sttode_ln_bwd', dh, t['xh1'], t['rs1'], P[a + 'norm1.weight'], dsum1, g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
                   self.scratch, self.scratch.numel(), self.st)
         self.ew(EW_AXPY, dx, dsum1, f0=1.0)                  # residual branch of LN1(x + gated)
         du, dv = self.new(n, 64), self.new(n, 64)
         self.ew(EW_GATE_BWD, dsum1, t['tt'], t['ss'], du, dv)
-        self.wgrad(du, t['ao'], g(a + 'self_attn.temporal_info.weight'), g(a + 'self_attn.temporal_info.bias'))
-        self.wgrad(dv, t['ao'], g(a + 'self_attn.temporal_gate.weight'), g(a + 'self_attn.temporal_gate.bias'))
-        dao = self.lin_dx(du, P[a + 'self_attn.temporal_info.weight'])
-        self.lin_dx(dv, P[a + 'self_attn.temporal_gate.weight'], out=dao, accumulate=True)
+        dao = self.lin_bwd(du, P[a + 'self_attn.temporal_info.weight'], t['ao'], g(a + 'self_attn.temporal_info.weight'),
+                           g(a + 'self_attn.temporal_info.bias'))
+        self.lin_bwd(dv, P[a + 'self_attn.temporal_gate.weight'], t['ao'], g(a + 'self_attn.temporal_gate.weight'),
+                     g(a + 'self_attn.temporal_gate.bias'), out=dao, accumulate=True)
         op = a + 'self_attn.temporal_attention_before.'
-        self.wgrad(dao, t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
-        dattn = self.lin_dx(dao, P[op + 'out_proj.weight'])
+        dattn = self.lin_bwd(dao, P[op + 'out_proj.weight'], t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
         dqkv = self.new(n, 192)
         capi.call('sttode_mhgsa_attn_bwd', t['qkv'], dattn, dqkv, t['L'], t['Nb'], self.st)
-        self.wgrad(dqkv, t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'))
-        self.lin_dx(dqkv, P[op + 'in_proj_weight'], out=dx, accumulate=True)
+        self.lin_bwd(dqkv, P[op + 'in_proj_weight'], t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'), out=dx, accumulate=True)
         # dx is now the gradient wrt ftraj_input
-        self.wgrad(dx, t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'))
-        dh2 = self.lin_dx(dx, P[pre + 'input_fc3.weight'], in_features=64)
-        self.wgrad(dh2, t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'), g(pre + 'input_fc2.bias'))
-        dtp = self.lin_dx(dh2, P[pre + 'input_fc2.weight']).view(n * T, 64)
+        dh2 = self.lin_bwd(dx, P[pre + 'input_fc3.weight'], t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'),
+                           in_features=64)
+        dtp = self.lin_bwd(dh2, P[pre + 'input_fc2.weight'], t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'),
+                           g(pre + 'input_fc2.bias')).view(n * T, 64)
         if t['drop'] is not None:
             self.ew(EW_MUL, dtp, dtp, t['drop'])
-        self.wgrad(dtp, t['posin'], g(pre + 'pos_encoder.fc.weight'), g(pre + 'pos_encoder.fc.bias'))
-        dtf = self.lin_dx(dtp, P[pre + 'pos_encoder.fc.weight'], in_features=64)
+        dtf = self.lin_bwd(dtp, P[pre + 'pos_encoder.fc.weight'], t['posin'], g(pre + 'pos_encoder.fc.weight'),
+                           g(pre + 'pos_encoder.fc.bias'), in_features=64)
         self.wgrad(dtf, t['X0'], g(pre + 'input_fc.weight'), g(pre + 'input_fc.bias'))
 
     # ---------------------------------------------------------------- decoder (Decoder.forward, model/STTODE.py:320-347)
@@ -193,12 +203,10 @@ class Engine:
     def mlp_bwd(self, pre, inp, saved, dout, din, accumulate):
         P, g = self.P, self.grad
         a1, a2 = saved
-        self.wgrad(dout, a2, g(pre + 'layers.2.weight'), g(pre + 'layers.2.bias'))
-        da2 = self.lin_dx(dout, P[pre + 'layers.2.weight'], mask=a2)
-        self.wgrad(da2, a1, g(pre + 'layers.1.weight'), g(pre + 'layers.1.bias'))
-        da1 = self.lin_dx(da2, P[pre + 'layers.1.weight'], mask=a1)
-        self.wgrad(da1, inp, g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias'))
-        self.lin_dx(da1, P[pre + 'layers.0.weight'], out=din, accumulate=accumulate)
+        da2 = self.lin_bwd(dout, P[pre + 'layers.2.weight'], a2, g(pre + 'layers.2.weight'), g(pre + 'layers.2.bias'), mask=a2)
+        da1 = self.lin_bwd(da2, P[pre + 'layers.1.weight'], a1, g(pre + 'layers.1.weight'), g(pre + 'layers.1.bias'), mask=a1)
+        self.lin_bwd(da1, P[pre + 'layers.0.weight'], inp, g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias'), out=din,
+                     accumulate=accumulate)
 
     def block_fwd(self, i, past, K, xhat_prev, pf, z, want_x):
         P = self.P
@@ -210,12 +218,11 @@ class Engine:
         gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [m*Tp, 288], row c*Tp + t
         H = self.zeros(Tp + 1, m, 96)                                                                    # H[0] = 0, H[t+1] = h_t
         tapes = self.new(Tp, m, 384)
-        capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes, m, Tp,
-                  self.st)                                                                               # all Tp steps, one launch
-        inp = self.new(m, 256)
+        inp = self.new(m, 256)                                                                           # cat(pf_rep, z, state)
+        capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
+                  inp[:, 160:], 256, m, Tp, self.st)                                                     # all Tp steps, one launch
         capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
-        inp[:, 128:160] = z
-        inp[:, 160:] = H[Tp]
+        capi.call('sttode_rows_copy', inp[:, 128:], 256, z, _ld(z), m, 32, 1, m, self.st)
         yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp)
         xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp) if want_x else (None, None)
         return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx)
@@ -228,13 +235,12 @@ class Engine:
         self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, accumulate=False)
         if dxh is not None:
             self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
-        dh = din[:, 160:].contiguous()
         dgi = self.new(m * Tp, 288)
         dgh = self.new(Tp, m, 288)
-        capi.call('sttode_gru_seq_bwd', dh, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
+        capi.call('sttode_gru_seq_bwd', din[:, 160:], 256, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
         self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
-        self.wgrad(dgi, b['e'], g(pre + 'encoder_past.weight_ih_l0'), g(pre + 'encoder_past.bias_ih_l0'))
-        de = self.lin_dx(dgi, P[pre + 'encoder_past.weight_ih_l0'], mask=b['e'])
+        de = self.lin_bwd(dgi, P[pre + 'encoder_past.weight_ih_l0'], b['e'], g(pre + 'encoder_past.weight_ih_l0'),
+                          g(pre + 'encoder_past.bias_ih_l0'), mask=b['e'])
         dx = self.new(m, Tp, 2) if need_dx else None
         capi.call('sttode_conv_bwd', de, b['x'], P[pre + 'conv_past.weight'], dx, g(pre + 'conv_past.weight'), g(pre + 'conv_past.bias'),
                   m, Tp, self.st)
@@ -246,13 +252,12 @@ class Engine:
         m = n * K
         b0 = self.block_fwd(0, past, K, None, pf, z, True)
         b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover)
-        pred = b0['yh'].clone()
-        self.ew(EW_AXPY, pred, b1['yh'], f0=1.0)
-        self.ew(EW_CUR_ADD, pred, cur, i0=2 * Tf, f0=K)
+        pred = self.new(m, 2 * Tf)
+        self.ew(EW_SUM_CUR, pred, b0['yh'], b1['yh'], cur, i0=2 * Tf, f0=K)
         rec = None
         if want_recover:
-            rec = b0['xh'].clone()
-            self.ew(EW_AXPY, rec, b1['xh'], f0=1.0)
+            rec = self.new(m, 2 * Tp)
+            self.ew(EW_SUM_CUR, rec, b0['xh'], b1['xh'], None, i0=2 * Tp, f0=K)
         return dict(b0=b0, b1=b1, n=n, K=K, m=m, pred=pred, rec=rec)
 
     def decoder_bwd(self, d, dpred, drec, dpf, dz):
@@ -326,10 +331,10 @@ class Engine:
         self.decoder_bwd(T['d1'], T['dpred1'], T['drec1'], dpf, dqz)
         dqzp = T['dqzp']                                            # starts as the KL gradient
         self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
-        self.wgrad(dqzp, T['hq'], g('future_encoder.qz_layer.weight'), g('future_encoder.qz_layer.bias'))
-        dhq = self.lin_dx(dqzp, P['future_encoder.qz_layer.weight'], mask=T['hq'])
-        self.wgrad(dhq, T['hcat'], g('future_encoder.out_mlp.affine_layers.0.weight'), g('future_encoder.out_mlp.affine_layers.0.bias'))
-        dhcat = self.lin_dx(dhq, P['future_encoder.out_mlp.affine_layers.0.weight'])
+        dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
+                           g('future_encoder.qz_layer.bias'), mask=T['hq'])
+        dhcat = self.lin_bwd(dhq, P['future_encoder.out_mlp.affine_layers.0.weight'], T['hcat'],
+                             g('future_encoder.out_mlp.affine_layers.0.weight'), g('future_encoder.out_mlp.affine_layers.0.bias'))
         self.ew(EW_AXPY, dpf, dhcat[:, :128].contiguous(), f0=1.0)
         self.trunk_bwd(T['tf'], dhcat[:, 128:])
         self.trunk_bwd(T['tp'], dpf)
