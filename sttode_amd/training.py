@@ -444,7 +444,8 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     params = [p for _, p in net.named_parameters()]
     ready = None
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
-           params[0].data_ptr(), params[-1].data_ptr())     # graphs hold raw parameter pointers
+           params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
+           float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
     # launch-bound regime only (one scene, <= ~100 agents): at NBA batch sizes the kernels dominate and replay is no faster
     if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= 100:
         if key in net._graphs or key in net._graph_seen:
