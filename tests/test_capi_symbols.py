@@ -70,6 +70,32 @@ def test_calls_fail_loudly_without_gpu_or_with_bad_arguments():
         capi.call('sttode_linear_cols', None, 0, 0, None, 0, 0, None, None, None, 0, 0, 0, 0, None)
 
 
+def test_every_entry_point_rejects_null_arguments():
+    """Every compute entry point validates its arguments before touching the device: called with all-zero / NULL arguments it
+    must return a non-zero status with a message naming itself (no crash, no launch) -- runs without a GPU."""
+    from sttode_amd import capi
+    L = capi.lib()
+    skip = {'sttode_abi_version', 'sttode_last_error', 'sttode_model_destroy', 'sttode_timing_enable', 'sttode_diag_mfma_peak'}
+    checked = 0
+    for name, argtypes in capi.SIGNATURES.items():
+        if name in skip:
+            continue
+        args = []
+        for t in argtypes:
+            if t in (ctypes.c_int, ctypes.c_long):
+                args.append(0)
+            elif t is ctypes.c_float:
+                args.append(0.0)
+            else:
+                args.append(None)
+        rc = getattr(L, name)(*args)
+        assert rc != 0, name
+        msg = L.sttode_last_error().decode()
+        assert name.replace('_async', '') in msg or 'sttode_' in msg, (name, msg)
+        checked += 1
+    assert checked >= 40
+
+
 def test_pk16_layout_and_mlp_stream_roundtrip():
     """PK16[it, T, lane, r] == W[16 it + (lane & 15), 16 T + 4 (lane >> 4) + r]; chunk stream holds every weight once."""
     from sttode_amd import packing
