@@ -144,7 +144,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('STTODE_BENCH_FORCE_DIST'):   # the env switch lets a 1-rank launch exercise the RCCL code path
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
