@@ -120,6 +120,27 @@ def _f32(t, device):
     return torch.as_tensor(t, dtype=torch.float32).to(device).contiguous()
 
 
+class _LazyViews(dict):
+    """name -> workspace view, materialised on first access (a per-scene inference() call should not pay for ten tensor views
+    nobody reads)."""
+
+    def __init__(self, makers):
+        super().__init__()
+        self._makers = makers
+
+    def __missing__(self, key):
+        if key not in self._makers:
+            raise KeyError(key)
+        v = self[key] = self._makers[key]()
+        return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
 class STTODENet(nn.Module):
     ODE_TIME = 12.0  # ODEG_Encoder(encoder_layers, nlayer, 12): model/STTODE.py:195 -> one Euler step of size 12
 
@@ -147,9 +168,22 @@ class STTODENet(nn.Module):
         self._mode = None
         self._async_calls = 0
         self._async_bufs = {}
+        self._ptr_cache = {}
+        self._pf = self._pf_thunk = None
         self.to(self.device)
 
     # ------------------------------------------------------------------ plumbing
+    @property
+    def past_feature(self):
+        """[n, 128] encoder output (model/STTODE.py:496); after inference() it is a view into the workspace, made on first read."""
+        if self._pf is None and self._pf_thunk is not None:
+            self._pf, self._pf_thunk = self._pf_thunk(), None
+        return self._pf
+
+    @past_feature.setter
+    def past_feature(self, value):
+        self._pf, self._pf_thunk = value, None
+
     def set_device(self, device):
         self.device = torch.device(device)
         self.to(self.device)
@@ -220,8 +254,12 @@ class STTODENet(nn.Module):
         scene about ``scene_orig`` (``theta`` may be injected; otherwise torch.rand(1)*2pi, or a multiple of pi/12 when
         ``discrete_rot``).  This is data preparation on a [N, T, 2] track, done with torch ops before the kernels run."""
         dev = self.device
-        past = _f32(pre_motion, dev).permute(0, 2, 1).contiguous()
-        fut = _f32(fut_motion, dev).permute(0, 2, 1).contiguous() if fut_motion is not None else None
+
+        def to_dev(x):      # [N, 2, T] loader layout -> [N, T, 2]; a host tensor is transposed on the host (one H2D copy, no kernel)
+            x = torch.as_tensor(x, dtype=torch.float32)
+            return x.permute(0, 2, 1).contiguous().to(dev)
+        past = to_dev(pre_motion)
+        fut = to_dev(fut_motion) if fut_motion is not None else None
         if self.training and past.shape[0] > self.max_train_agent:
             ind = torch.tensor(np.random.choice(past.shape[0], self.max_train_agent).tolist(), device=dev)
             past = past.index_select(0, ind).contiguous()
@@ -239,7 +277,12 @@ class STTODENet(nn.Module):
             past = rot(past)
             fut = rot(fut) if fut is not None else None
         N = past.shape[0]
-        self.set_scene_batch(past, fut, torch.tensor([0, N], dtype=torch.int32))
+        if N == 0:
+            raise ValueError('empty scene')
+        ptr = self._ptr_cache.get(N)                             # device-resident [0, N] CSR, built once per scene size
+        if ptr is None or ptr.device != torch.device(dev):
+            ptr = self._ptr_cache[N] = torch.tensor([0, N], dtype=torch.int32).to(dev)
+        self.set_scene_batch(past, fut, ptr)
         self.batch_size = 1
         self.pre_motion_mask, self.fut_motion_mask = pre_motion_mask, fut_motion_mask
 
@@ -490,11 +533,11 @@ class STTODENet(nn.Module):
         else:
             capi.call('sttode_inference_nba', nat.h, self._past, self.batch_size, self._N, z, buf, pred, st)
         m = n * K
-        self.past_feature = self._view(buf, off, 'pf', n, 128)
-        self._ws = {'xpad': self._view(buf, off, 'xpad', n, 16 * TPX), 'enc_in': self._view(buf, off, 'enc_in', n, Tp, 4),
-                    'cur': self._view(buf, off, 'cur', n, 2), 'orig': self._view(buf, off, 'orig', n, 2)}
-        self._dbg = {'state0': self._view(buf, off, 'state0', n, 96), 'dbuf': self._view(buf, off, 'dbuf', m, 16 * TPX),
-                     'ybuf': self._view(buf, off, 'ybuf', m, 16 * NOY), 'state1': self._view(buf, off, 'state1', m, 96)}
+        self._pf, self._pf_thunk = None, (lambda: self._view(buf, off, 'pf', n, 128))
+        self._ws = _LazyViews({'xpad': lambda: self._view(buf, off, 'xpad', n, 16 * TPX), 'enc_in': lambda: self._view(buf, off, 'enc_in', n, Tp, 4),
+                               'cur': lambda: self._view(buf, off, 'cur', n, 2), 'orig': lambda: self._view(buf, off, 'orig', n, 2)})
+        self._dbg = _LazyViews({'state0': lambda: self._view(buf, off, 'state0', n, 96), 'dbuf': lambda: self._view(buf, off, 'dbuf', m, 16 * TPX),
+                                'ybuf': lambda: self._view(buf, off, 'ybuf', m, 16 * NOY), 'state1': lambda: self._view(buf, off, 'state1', m, 96)})
         self.diverse_pred = pred
         return pred.permute(1, 0, 2, 3)
 
