@@ -965,3 +965,32 @@ def test_single_small_scene_inference_vs_oracle(N):
     ref = oracle_scene_inference(oracle_model('eth', 8, 12), o, p, z)
     assert out.shape == (20, N, 12, 2)
     assert_close(out, ref, what=f'single scene N={N}')
+
+
+def test_sampler_training_loop_reduces_the_objective():
+    """trainsampler.py:171-185 loop (frozen prediction net, Adam over sampler.parameters()) for a few iterations on one scene:
+    the stage-2 objective goes down and only the sampler's parameters move."""
+    from sttode_amd import Sampler, samplerloss, scenes
+    dev = _gpu()
+    net = hip_model('eth', 8, 12)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    torch.manual_seed(3)
+    smp = Sampler(sampler_args('eth', 8, 12))
+    smp.set_device(dev)
+    smp.train()
+    opt = torch.optim.Adam(smp.parameters(), lr=1e-3)
+    o, p = scenes.eth_scene(4242, n_min=9, n_max=9)
+    fut = torch.from_numpy(np.ascontiguousarray(p.transpose(0, 2, 1))).to(dev)
+    cfg = samplerloss.get_diversity_config('eth')
+    losses = []
+    for it in range(12):
+        net.set_data(None, torch.from_numpy(o), torch.from_numpy(p), torch.ones(9, 8), torch.ones(9, 12))
+        dec, sd, vd, _ = smp.forward(net, mean=False, eps=torch.zeros(1, 32))          # deterministic codes: z = b
+        tot, ld, _ = samplerloss.compute_sampler_loss(smp.args, fut, dec, 1, None, vd, sd, cfg)
+        opt.zero_grad()
+        tot.backward()
+        opt.step()
+        losses.append(float(tot.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert all(torch.equal(before[k], v) for k, v in net.state_dict().items())
+    assert smp.q_c.weight.grad is None                                                  # never on the loss path (sampler.py:52)
