@@ -64,9 +64,23 @@ def train_bench(args, rank, world, dev, dist):
     data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]
     agents = sum(o.shape[0] for o, _ in data) / nsc
 
+    TB = max(1, args.train_batch)
+    if TB > 1:                                                       # batched steps: TB consecutive scenes as one CSR batch
+        import numpy as _np
+        batches = []
+        for b0 in range(0, nsc, TB):
+            grp = data[b0:b0 + TB]
+            ptr = torch.tensor(_np.concatenate([[0], _np.cumsum([o.shape[0] for o, _ in grp])]).astype('int32'), device=dev)
+            batches.append((torch.cat([o.permute(0, 2, 1) for o, _ in grp]).contiguous(), torch.cat([p.permute(0, 2, 1) for _, p in grp]).contiguous(), ptr))
+
     def step(i):
-        o, p = data[i % nsc]
-        model.set_data(None, o, p, None, None)
+        if TB > 1:
+            past, fut, ptr = batches[i % len(batches)]
+            model.set_scene_batch(past, fut, ptr)                    # (no augmentation in the batched form)
+            o = past
+        else:
+            o, p = data[i % nsc]
+            model.set_data(None, o, p, None, None)
         tot = model.forward()[0]
         opt.zero_grad()
         tot.backward()
@@ -90,8 +104,9 @@ def train_bench(args, rank, world, dev, dist):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
-    out = {'metric': 'training-steps/sec (one scene per step, forward + backward + Adam)', 'value': world * args.steps / dt,
-           'unit': 'steps/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': max(args.warmup, 2 * nsc),
+    out = {'metric': 'training-steps/sec (one scene per step, forward + backward + Adam)' if TB == 1 else
+                     f'training-scenes/sec ({TB} scenes per step, forward + backward + Adam)', 'value': world * args.steps * TB / dt,
+           'unit': 'steps/s' if TB == 1 else 'scenes/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': max(args.warmup, 2 * nsc),
            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
            'data': 'synthetic', 'config': {'workload': f'train.py:72-95 loop over {nsc} synthetic ETH-shaped scenes per GPU (2..32 '
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
@@ -136,6 +151,8 @@ def main():
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
+    ap.add_argument('--train-batch', type=int, default=1, help='with --train: scenes per optimizer step (1 = the reference loop; '
+                                                                '>1 = one batched step whose gradient is the sum of the per-scene gradients)')
     ap.add_argument('--train', action='store_true', help='secondary metric: training steps/s (train.py:72-95 loop, one scene per step); '
                                                          'the default run and the headline metric stay the inference path')
     args = ap.parse_args()

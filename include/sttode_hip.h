@@ -183,12 +183,15 @@ int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, 
 int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream);
 /* out[0] = scale * sum (pred - target)^2 (calculate_loss_pred / _recover, :372-376,384-388); dpred optional. */
 int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream);
-/* out[0] = clamp_min(sum KL(N(mu,logvar) || N(0,I)) / denom, min_clip) (:378-382, utils/dist.py:26-29); params [rows,2*zd]. */
-int sttode_loss_kl(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams, void* stream);
-/* out[0] = mean_a min_k sum (target_a - pred_ak)^2 (calculate_loss_diverse :390-395); pred [n,K,D], target [n,D], K <= 64;
- * scratch >= n floats (per-agent minima). */
-int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred, float* scratch,
-                        void* stream);
+/* KL term (:378-382, utils/dist.py:26-29), params [rows,2*zd].  scene_ptr NULL: out[0] = clamp_min(sum KL / denom, min_clip).
+ * scene_ptr [S+1] (a batch of independent scenes in one step): out[0] = sum_s clamp_min(sum_{a in s} KL_a / N_s, min_clip), i.e. the
+ * sum of the per-scene objectives (what accumulating S reference steps gives).  scratch >= max(S, 1) floats. */
+int sttode_loss_kl(const float* params, const int* scene_ptr, int S, int rows, int zd, float denom, float min_clip, float* out,
+                   float* dparams, float* scratch, void* stream);
+/* Best-of-K term (calculate_loss_diverse :390-395); pred [n,K,D], target [n,D], K <= 64.  scene_ptr NULL: mean over the n agents;
+ * with scene_ptr / agent_scene: sum over scenes of the per-scene means.  scratch >= n floats. */
+int sttode_loss_diverse(const float* pred, const float* target, const int* scene_ptr, const int* agent_scene, int n, int K, int D,
+                        float* out, float* dpred, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).

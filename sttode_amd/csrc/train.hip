@@ -925,11 +925,16 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* pred, const flo
 }
 // KL(q || N(0, I)) in the two-distribution form (utils/dist.py:26-29 with p.sigma = 1), sum / denom, clamp_min(min_clip).
 // dparams [rows, 2*zd] = gradient of the CLAMPED value (zero when the clamp is active).
-__global__ __launch_bounds__(256) void kl_kernel(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams) {
+// one WG per scene (scene_ptr NULL: one WG over all rows with the given denominator).  vals[s] = clamp_min(KL_s / denom_s, min_clip),
+// denom_s = agents of the scene (B = 1 per scene, model/STTODE.py:378-382); dparams carries the gradient of the clamped value.
+__global__ __launch_bounds__(256) void kl_kernel(const float* params, const int* scene_ptr, int rows, int zd, float denom, float min_clip,
+                                                 float* vals, float* dparams) {
     __shared__ float red[256];
     const float ps = 1.0f + 1e-8f;
+    const long r0 = scene_ptr ? scene_ptr[blockIdx.x] : 0, r1 = scene_ptr ? scene_ptr[blockIdx.x + 1] : rows;
+    if (scene_ptr) denom = (float)(r1 - r0);
     float acc = 0.f;
-    for (long i = threadIdx.x; i < (long)rows * zd; i += 256) {
+    for (long i = r0 * zd + threadIdx.x; i < r1 * zd; i += 256) {
         const long r = i / zd;
         const int d = (int)(i % zd);
         const float mu = params[r * 2 * zd + d], lv = params[r * 2 * zd + zd + d];
@@ -938,9 +943,9 @@ __global__ __launch_bounds__(256) void kl_kernel(const float* params, int rows, 
     }
     const float s = block_sum(acc, red) / denom;
     const bool live = s >= min_clip;   // clamp_min_: gradient passes where input >= min (torch convention)
-    if (threadIdx.x == 0) out[0] = live ? s : min_clip;
+    if (threadIdx.x == 0) vals[blockIdx.x] = live ? s : min_clip;
     if (dparams) {
-        for (long i = threadIdx.x; i < (long)rows * zd; i += 256) {
+        for (long i = r0 * zd + threadIdx.x; i < r1 * zd; i += 256) {
             const long r = i / zd;
             const int d = (int)(i % zd);
             const float mu = params[r * 2 * zd + d], lv = params[r * 2 * zd + zd + d];
@@ -952,9 +957,12 @@ __global__ __launch_bounds__(256) void kl_kernel(const float* params, int rows, 
 }
 // best-of-K: per agent min_k sum_{t,xy} (target - pred)^2 (first minimum, like torch.min), mean over agents.
 // one wave per agent (lane = sample k, K <= 64), then a single-WG mean over the per-agent minima (fixed order).
-__global__ __launch_bounds__(64) void diverse_agent_kernel(const float* pred, const float* target, int n, int K, int D, float* best,
-                                                           float* dpred) {
+__global__ __launch_bounds__(64) void diverse_agent_kernel(const float* pred, const float* target, const int* scene_ptr,
+                                                           const int* agent_scene, int n, int K, int D, float* best, float* dpred) {
     const int a = blockIdx.x, lane = threadIdx.x;
+    // weight of this agent in the objective: 1 / (agents of its scene) (mean over the scene, :390-395); one scene: 1 / n
+    float wgt = 1.0f / (float)n;
+    if (scene_ptr) { const int sc = agent_scene[a]; wgt = 1.0f / (float)(scene_ptr[sc + 1] - scene_ptr[sc]); }
     float s = 3.4e38f;
     if (lane < K) {
         s = 0.f;
@@ -971,20 +979,20 @@ __global__ __launch_bounds__(64) void diverse_agent_kernel(const float* pred, co
         const int ok = __shfl_xor(bk, o, 64);
         if (os < bs || (os == bs && ok < bk)) { bs = os; bk = ok; }
     }
-    if (lane == 0) best[a] = bs;
+    if (lane == 0) best[a] = bs * wgt;
     if (dpred)
         for (int i = lane; i < K * D; i += 64) {
             const int k = i / D, d = i % D;
             const long idx = ((long)a * K + k) * D + d;
-            dpred[idx] = k == bk ? 2.0f * (pred[idx] - target[(long)a * D + d]) / (float)n : 0.f;
+            dpred[idx] = k == bk ? 2.0f * (pred[idx] - target[(long)a * D + d]) * wgt : 0.f;
         }
 }
-__global__ __launch_bounds__(256) void mean_kernel(const float* v, int n, float* out) {
+__global__ __launch_bounds__(256) void sum_kernel(const float* v, int n, float* out) {
     __shared__ float red[256];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) out[0] = s / (float)n;
+    if (threadIdx.x == 0) out[0] = s;
 }
 extern "C" int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream) {
     STT_REQUIRE(pred && target && out && count > 0, "sttode_loss_sqerr: bad argument");
@@ -992,17 +1000,22 @@ extern "C" int sttode_loss_sqerr(const float* pred, const float* target, long co
     STT_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int sttode_loss_kl(const float* params, int rows, int zd, float denom, float min_clip, float* out, float* dparams, void* stream) {
-    STT_REQUIRE(params && out && rows > 0 && zd > 0 && denom > 0.f, "sttode_loss_kl: bad argument");
-    hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, params, rows, zd, denom, min_clip, out, dparams);
+extern "C" int sttode_loss_kl(const float* params, const int* scene_ptr, int S, int rows, int zd, float denom, float min_clip, float* out,
+                              float* dparams, float* scratch, void* stream) {
+    STT_REQUIRE(params && out && scratch && rows > 0 && zd > 0, "sttode_loss_kl: bad argument");
+    STT_REQUIRE(scene_ptr ? S > 0 : denom > 0.f, "sttode_loss_kl: scene_ptr needs S > 0, otherwise denom > 0");
+    const int nb = scene_ptr ? S : 1;
+    hipLaunchKernelGGL(kl_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, scene_ptr, rows, zd, denom, min_clip, scratch, dparams);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, out);
     STT_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int sttode_loss_diverse(const float* pred, const float* target, int n, int K, int D, float* out, float* dpred,
-                                   float* scratch, void* stream) {
+extern "C" int sttode_loss_diverse(const float* pred, const float* target, const int* scene_ptr, const int* agent_scene, int n, int K,
+                                   int D, float* out, float* dpred, float* scratch, void* stream) {
     STT_REQUIRE(pred && target && out && scratch && n > 0 && K > 0 && K <= 64 && D > 0, "sttode_loss_diverse: bad argument (K <= 64, scratch >= n floats)");
-    hipLaunchKernelGGL(diverse_agent_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, pred, target, n, K, D, scratch, dpred);
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, out);
+    STT_REQUIRE(!scene_ptr || agent_scene, "sttode_loss_diverse: scene_ptr needs agent_scene");
+    hipLaunchKernelGGL(diverse_agent_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, pred, target, scene_ptr, agent_scene, n, K, D, scratch, dpred);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, out);
     STT_HIP(hipGetLastError());
     return 0;
 }

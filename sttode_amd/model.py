@@ -492,9 +492,12 @@ class STTODENet(nn.Module):
         # calculate_loss_pred / _recover / _kl (model/STTODE.py:372-388), on the loss kernels of csrc/train.hip
         capi.call('sttode_loss_sqerr', pred1, fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], None, st)
         capi.call('sttode_loss_sqerr', rec1, past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], None, st)
-        capi.call('sttode_loss_kl', self.qz_param, n, a.zdim, float(B * N), float(a.min_clip), losses[2:], None, st)
+        seg = self._mode == 'scenes' and self._S > 1          # batch of scenes: sum of the per-scene objectives (see training.py)
+        sp, ags, S = (self._scene_ptr, self._ws['agent_scene'], self._S) if seg else (None, None, 0)
+        scratch = self._f(max(n, S, 1))
+        capi.call('sttode_loss_kl', self.qz_param, sp, S, n, a.zdim, float(B * N), float(a.min_clip), losses[2:], None, scratch, st)
         self.decoder_future_1(self.pz_sampled)
-        capi.call('sttode_loss_diverse', self.diverse_pred_traj.contiguous(), fut, n, 20, 2 * Tf, losses[3:], None, scratch, st)   # :390-395
+        capi.call('sttode_loss_diverse', self.diverse_pred_traj.contiguous(), fut, sp, ags, n, 20, 2 * Tf, losses[3:], None, scratch, st)   # :390-395
         lv = losses.tolist()
         return losses.sum(), lv[0], lv[1], lv[2], lv[3]
 

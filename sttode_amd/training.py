@@ -306,8 +306,12 @@ class Engine:
         dpred1, drec1, dqzp, dpred20 = self.new(n, 2 * Tf), self.new(n, 2 * Tp), self.new(n, 2 * zd), self.new(n * 20, 2 * Tf)
         capi.call('sttode_loss_sqerr', d1['pred'], fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], dpred1, self.st)
         capi.call('sttode_loss_sqerr', d1['rec'], past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], drec1, self.st)
-        capi.call('sttode_loss_kl', qzp, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.st)
-        capi.call('sttode_loss_diverse', d20['pred'], fut, n, 20, 2 * Tf, losses[3:], dpred20, self.scratch, self.st)
+        # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
+        # gradient equals what S reference steps would accumulate (per-scene KL clamp and per-scene mean of the best-of-20 term)
+        seg = net._mode == 'scenes' and net._S > 1
+        sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
+        capi.call('sttode_loss_kl', qzp, sp, S, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.scratch, self.st)
+        capi.call('sttode_loss_diverse', d20['pred'], fut, sp, ags, n, 20, 2 * Tf, losses[3:], dpred20, self.scratch, self.st)
         self.tape = dict(tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
                          dpred20=dpred20, n=n, zd=zd)
         # attributes the reference sets (read by callers)

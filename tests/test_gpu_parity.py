@@ -994,3 +994,43 @@ def test_sampler_training_loop_reduces_the_objective():
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert all(torch.equal(before[k], v) for k, v in net.state_dict().items())
     assert smp.q_c.weight.grad is None                                                  # never on the loss path (sampler.py:52)
+
+
+def test_batched_scene_training_step_equals_sum_of_per_scene_steps():
+    """set_scene_batch + forward() + backward() over several independent scenes in ONE step: the objective is the sum of the
+    per-scene objectives (per-scene KL clamp, per-scene mean of the best-of-20 term), so loss and gradients must equal the sum
+    over the reference-style one-scene-per-step runs (which are pinned against the reference / oracle above)."""
+    from sttode_amd import scenes
+    dev = _gpu()
+    m = hip_model('eth', 8, 12)
+    m.eval()
+    sizes = (5, 9, 3, 17)
+    rng = np.random.default_rng(44)
+    sc = [scenes.eth_scene(660000 + i, n_min=n, n_max=n) for i, n in enumerate(sizes)]
+    eps = [[rng.standard_normal(s).astype(np.float32) for s in ((n, 32), (n, 32), (n * 20, 32))] for n in sizes]
+    tot_sum, parts_sum, grad_sum = 0.0, np.zeros(4), None
+    for (o, p), e in zip(sc, eps):
+        m.zero_grad()
+        m.set_data(None, torch.from_numpy(o), torch.from_numpy(p), None, None)
+        out = m.forward(*[torch.from_numpy(x) for x in e])
+        out[0].backward()
+        tot_sum += float(out[0].detach())
+        parts_sum += np.array(out[1:])
+        g = {k: (q.grad.detach().double().cpu() if q.grad is not None else None) for k, q in m.named_parameters()}
+        grad_sum = g if grad_sum is None else {k: (None if v is None else v + g[k]) for k, v in grad_sum.items()}
+    past = np.concatenate([o.transpose(0, 2, 1) for o, _ in sc])
+    fut = np.concatenate([p.transpose(0, 2, 1) for _, p in sc])
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    m.zero_grad()
+    m.set_scene_batch(torch.from_numpy(past), torch.from_numpy(fut), torch.from_numpy(ptr))
+    cat = [torch.from_numpy(np.concatenate([e[i] for e in eps])) for i in range(3)]
+    out = m.forward(*cat)
+    out[0].backward()
+    np.testing.assert_allclose(float(out[0].detach()), tot_sum, rtol=2e-5)
+    np.testing.assert_allclose(np.array(out[1:]), parts_sum, rtol=2e-5)
+    got = {k: (q.grad.detach().cpu() if q.grad is not None else None) for k, q in m.named_parameters()}
+    _compare_grads(got, grad_sum, rtol=2e-4)
+    m.zero_grad()
+    with torch.no_grad():                                       # the value path agrees on the batched objective
+        v = m.forward(*cat)
+    np.testing.assert_allclose([float(v[0])] + list(v[1:]), [tot_sum] + list(parts_sum), rtol=1e-4)
