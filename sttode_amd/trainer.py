@@ -48,3 +48,22 @@ def save_checkpoint(path, args, model, optimizer, scheduler, epoch):
     """train.py:208-213 layout: test.py:675-678 loads ``model_cfg`` / ``model_dict`` from it."""
     torch.save({'model_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
                 'scheduler': scheduler.state_dict() if scheduler is not None else None, 'epoch': epoch + 1, 'model_cfg': args}, path)
+
+
+def rotate_scene_batch(past, future, scene_ptr, theta):
+    """Train-mode augmentation of model/STTODE.py:419-426 for a CSR batch of scenes (``STTODENet.set_scene_batch``): scene s is
+    rotated by ``theta[s]`` about its own origin (the mean of its agents' last observed positions).  past [n,Tp,2],
+    future [n,Tf,2], scene_ptr [S+1], theta [S]; data preparation with torch ops on whatever device the tensors live on."""
+    ptr = torch.as_tensor(scene_ptr, dtype=torch.long, device=past.device)
+    counts = ptr[1:] - ptr[:-1]
+    S = counts.numel()
+    sid = torch.repeat_interleave(torch.arange(S, device=past.device), counts)
+    orig = torch.zeros(S, 2, dtype=past.dtype, device=past.device).index_add_(0, sid, past[:, -1]) / counts[:, None].to(past.dtype)
+    th = torch.as_tensor(theta, dtype=past.dtype, device=past.device)
+    c, s = torch.cos(th)[sid], torch.sin(th)[sid]                     # per agent
+    o = orig[sid][:, None, :]
+
+    def rot(x):
+        d = x - o
+        return torch.stack((d[..., 0] * c[:, None] - d[..., 1] * s[:, None], d[..., 0] * s[:, None] + d[..., 1] * c[:, None]), dim=-1) + o
+    return rot(past), (rot(future) if future is not None else None)
