@@ -180,3 +180,22 @@ def test_input_validation_on_host():
     m2.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 5], np.int32))
     with pytest.raises((NotImplementedError, capi.SttodeError)):
         m2.inference(None)
+
+
+def test_no_cpu_fallback_anywhere():
+    """Every compute entry of the package refuses CPU tensors / CPU devices instead of falling back (training step, stage-2
+    sampler, op-level transformer blocks, manifold ops, stand-alone operators)."""
+    import torch
+    from helpers import make_args, sampler_args
+    from sttode_amd import STTODENet, Sampler, capi, ops, pmath
+    from sttode_amd.hypertransformer import TransformerDecoderLayer
+    m = STTODENet(make_args(), 'cpu')
+    m.set_data(None, torch.zeros(3, 2, 8), torch.zeros(3, 2, 12))
+    for call in (lambda: m.forward(), lambda: m.inference(None), lambda: m.encode_history(),
+                 lambda: Sampler(sampler_args()).forward(m),
+                 lambda: TransformerDecoderLayer(64, 8, 64)(torch.zeros(2, 3, 1, 64), torch.zeros(4, 3, 1, 64)),
+                 lambda: pmath.mobius_add(torch.zeros(2, 4), torch.zeros(2, 4)), lambda: pmath.artanh(torch.zeros(3)),
+                 lambda: ops.mhgsa(torch.zeros(2, 3, 64), torch.zeros(2, 3, 64), torch.zeros(2, 3, 64), torch.zeros(192, 64),
+                                   torch.zeros(192), torch.zeros(64, 64), torch.zeros(64))):
+        with pytest.raises(capi.SttodeError):
+            call()
