@@ -176,8 +176,10 @@ int sttode_gru_seq_bwd(const float* dh_last, long lddh, const float* tapes, cons
 /* conv1d(2->32,k3,pad1)+relu (model/STTODE.py:65) on x = xa[c / adiv] - xb[c] ([m,T,2], xb optional); saves x; e [m,T,32]. */
 int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m, int T,
                     void* stream);
-/* de (already relu-masked) -> dx [m,T,2] (optional), dw [32,2,3] +=, db [32] +=. */
-int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T, void* stream);
+/* de (already relu-masked) -> dx [m,T,2] (optional), dw [32,2,3] +=, db [32] += (deterministic: per-WG partials in scratch,
+ * >= 256*224 floats, then one ordered pass). */
+int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T, float* scratch,
+                    long scratch_floats, void* stream);
 /* Backward of the geodesic self-attention (hyptransformerlib.py:191-300, scores untransposed :261-265): qkv [L*Nb,192] (q|k|v,
  * row = l*Nb + slot), dO [L*Nb,64] (grad wrt the merged-head output before out_proj) -> dqkv [L*Nb,192].  L <= 1024. */
 int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream);

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
     tlinear_body<RT, CT, U>(a, ksplit, blockIdx.x, blockIdx.y, part);
 }
 
+#ifndef TLIN_MEDIUM_BELOW
+#define TLIN_MEDIUM_BELOW 4096   // throughput-mode wave count below which the 32 x 32 tiling is used instead
+#endif
+
 static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
 
 extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
@@ -168,7 +172,7 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         const int blocks_per_wg = 4 / ksplit;
         dim3 grid((cols + 15) / 16, ((I + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg);
         hipLaunchKernelGGL((tlinear_kernel<1, 1, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
-    } else if ((long)((cols + 63) / 64) * ((I + 63) / 64) < 4096) {
+    } else if ((long)((cols + 63) / 64) * ((I + 63) / 64) < TLIN_MEDIUM_BELOW) {
         // medium mode: 32 columns x 32 outputs per wave -- 4x the waves of the throughput tiling, for launches that would
         // otherwise leave most SIMDs empty (e.g. 7040 columns x 512 outputs = 880 throughput-mode waves on 1024 SIMDs)
         const int ksplit = (I <= 32 && J > 64) ? 4 : ((I <= 64 && J > 64) ? 2 : 1);
@@ -741,33 +745,46 @@ __global__ void conv_bwd_x_kernel(const float* de, const float* w, float* dx, in
     }
     dx[id] = acc;
 }
-// one WG per (oc, ic, k) and one for each bias: dW += sum_{c,t} de[c,t,oc] * x[c,t+k-1,ic]
-__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const float* x, float* dw, float* db, int m, int T) {
-    __shared__ float red[256];
-    const int j = blockIdx.x;  // 0..191 weights, 192..223 biases
-    float acc = 0.f;
-    if (j < 192) {
-        const int k = j % 3, ic = (j / 3) % 2, oc = j / 6;
-        for (long i = threadIdx.x; i < (long)m * T; i += 256) {
-            const int t = (int)(i % T);
+// dW[oc,ic,k] += sum_{c,t} de[c,t,oc] * x[c,t+k-1,ic], db[oc] += sum de.  A WG walks a contiguous slab of (c,t) rows: thread
+// (row lane 0..7, oc 0..31) reads de[row][oc] (one 128-byte line per row across the 32 oc threads) and the row's 3 x 2 inputs,
+// keeps its 6 weight partials + 1 bias partial in registers, the 8 row lanes are combined through LDS and every WG writes one
+// partial vector [224]; a second single-WG pass adds the partials in order (deterministic).
+__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const float* x, float* part, int m, int T, int rows_per_wg) {
+    __shared__ float red[8][224];
+    const int oc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const long rows = (long)m * T;
+    const long r0 = (long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, rows);
+    float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b = 0.f;
+    for (long r = r0 + rl; r < r1; r += 8) {
+        const int t = (int)(r % T);
+        const float d = de[r * 32 + oc];
+        b += d;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
             const int tt = t + k - 1;
             if (tt < 0 || tt >= T) continue;
-            acc += de[i * 32 + oc] * x[(i - t + tt) * 2 + ic];
+            const float* xr = x + (r - t + tt) * 2;
+            w[0 * 3 + k] += d * xr[0];
+            w[1 * 3 + k] += d * xr[1];
         }
-    } else {
-        const int oc = j - 192;
-        for (long i = threadIdx.x; i < (long)m * T; i += 256) acc += de[i * 32 + oc];
     }
-    red[threadIdx.x] = acc;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[rl][oc * 6 + j] = w[j];      // dw index = (oc*2 + ic)*3 + k = oc*6 + ic*3 + k
+    red[rl][192 + oc] = b;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
+    if (threadIdx.x < 224) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][threadIdx.x];
+        part[(long)blockIdx.x * 224 + threadIdx.x] = s;
     }
-    if (threadIdx.x == 0) {
-        if (j < 192) dw[j] += red[0];
-        else db[j - 192] += red[0];
-    }
+}
+__global__ void conv_bwd_w_reduce_kernel(const float* part, int G, float* dw, float* db) {
+    const int j = threadIdx.x;  // 224 threads
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(long)g * 224 + j];
+    if (j < 192) dw[j] += s;
+    else db[j - 192] += s;
 }
 extern "C" int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m,
                                int T, void* stream) {
@@ -778,13 +795,19 @@ extern "C" int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const
     return 0;
 }
 extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T,
-                               void* stream) {
-    STT_REQUIRE(de && x && w && dw && db && m > 0 && T > 0, "sttode_conv_bwd: bad argument");
+                               float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(de && x && w && dw && db && scratch && m > 0 && T > 0, "sttode_conv_bwd: bad argument");
     if (dx) {
         const long tot = (long)m * T * 2;
         hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, de, w, dx, m, T);
     }
-    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(224), dim3(256), 0, (hipStream_t)stream, de, x, dw, db, m, T);
+    const long rows = (long)m * T;
+    int G = (int)((rows + 511) / 512);
+    if (G > 256) G = 256;
+    STT_REQUIRE(scratch_floats >= (long)G * 224, "sttode_conv_bwd: scratch too small");
+    const int rpw = (int)((rows + G - 1) / G);
+    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, de, x, scratch, m, T, rpw);
+    hipLaunchKernelGGL(conv_bwd_w_reduce_kernel, dim3(1), dim3(224), 0, (hipStream_t)stream, scratch, G, dw, db);
     STT_HIP(hipGetLastError());
     return 0;
 }

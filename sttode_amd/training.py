@@ -243,7 +243,7 @@ class Engine:
                           g(pre + 'encoder_past.bias_ih_l0'), mask=b['e'])
         dx = self.new(m, Tp, 2) if need_dx else None
         capi.call('sttode_conv_bwd', de, b['x'], P[pre + 'conv_past.weight'], dx, g(pre + 'conv_past.weight'), g(pre + 'conv_past.bias'),
-                  m, Tp, self.st)
+                  m, Tp, self.scratch, self.scratch.numel(), self.st)
         return din, dx
 
     def decoder_fwd(self, pf, z, K, past, cur, want_recover):
