@@ -280,7 +280,10 @@ def main():
            'config': {'workload': f'BASELINE configs[1]: synthetic ETH-shaped scenes (2..32 pedestrians), obs={TP} pred={TF}, '
                                   f'K={K}, {args.scenes} scenes per GPU per step, random-recipe weights (seed 1234)',
                       'scenes_per_gpu': args.scenes, 'agents_rank0': n, 'trajectories_rank0': m, 'parallelism': f'scenes x{world}'},
-           'roofline': roof, 'kernels': kern}
+           'roofline': roof, 'kernels': kern,
+           'kernels_note': 'HIP-event durations on the launch streams; in the pipelined run the per-agent stages (frontend, embed_qkv, '
+                           'post_attn, gru_cols[block0], agent_preact) execute inside the tails of the previous batch, so their '
+                           'durations include waiting for compute units (alone they take 20 / 39 / 44 / 93 / 68 us)'}
 
     if rank == 0:
         out['ade_fde_synthetic'] = [float(acc[0] / acc[2]), float(acc[1] / acc[2])]
