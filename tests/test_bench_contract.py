@@ -1,0 +1,30 @@
+"""CPU check of the bench.py output contract on the committed round-1 line (profiles/r01/final_bench.json): the keys the driver
+and the judge read must be there with sane values, and the roofline numbers must be self-consistent."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_honours_the_contract():
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'final_bench.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert 'BASELINE configs[1]' in d['config']['workload'] and d['config']['scenes_per_gpu'] == 512
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert abs(r['achieved'] * 1e12 - r['flop_per_launch'] / r['mean_launch_s']) / (r['achieved'] * 1e12) < 1e-6
+    assert 0.3 < r['frac'] < 1.0 and r['traffic'] is not None
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['unit'] == d['unit'] and c['cores'] >= 1
+    # throughput and step time describe the same run
+    traj = d['config']['trajectories_rank0']
+    assert abs(d['value'] - traj / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    assert d['parity']['max_err_over_1_plus_abs_ref'] < 1e-4 and d['parity']['ade_abs_diff'] < 1e-4
