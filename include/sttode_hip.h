@@ -270,14 +270,6 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
 
-/* Diagnostic (not on the product path): sustained TFLOP/s of a register-only v_mfma_f32_16x16x4_f32 loop on every CU
- * (waves_per_cu in {4, 8, 16}; negative: the same with one ds_read_b128 A fragment per MFMA quad, the operand traffic of the
- * real kernels); scratch: >= 256*1024 floats.  Synchronises. */
-int sttode_diag_mfma_peak(int waves_per_cu, int iters, int repeats, float* scratch, double* tflops, void* stream);
-/* Same probe for four operand/instruction shapes: kind 0 16x16x4 registers | 1 16x16x4 + LDS fragment reads | 2 32x32x2
- * registers | 3 32x32x2 + LDS fragment reads; waves_per_cu in {4, 8, 12, 16}. */
-int sttode_diag_mfma_kinds(int kind, int waves_per_cu, int iters, int repeats, float* scratch, double* tflops, void* stream);
-
 /* Pipelined forms: the per-agent stage runs on an internal stream beside the per-trajectory stage of the PREVIOUS call
  * (its kernels fill the grid tails of the big kernels).  Two workspace/pred slots alternate (slot = call index & 1);
  * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream.

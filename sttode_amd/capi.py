@@ -71,8 +71,6 @@ SIGNATURES = {
     'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_wait': [_P, _I, _P],
-    'sttode_diag_mfma_peak': [_I, _I, _I, _P, ctypes.POINTER(ctypes.c_double), _P],
-    'sttode_diag_mfma_kinds': [_I, _I, _I, _I, _P, ctypes.POINTER(ctypes.c_double), _P],
 }
 
 # enum SttodeWeight / SttodeBuffer / SttodeStage of include/sttode_hip.h (order is ABI)
