@@ -2,75 +2,389 @@
 """Headline benchmark: predicted-trajectories/sec (K=20 best-of-K) of the STTODE forward path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path (scene front-end -> MHGSA/ODE encoder -> K=20 decomposition decoder ->
-device-side best-of-K ADE/FDE) over one batch of synthetic ETH-shaped scenes that is already resident in HBM.
-Workload = BASELINE.json configs[1]: 512 scenes per GPU (<= 32 pedestrians, obs 8 / pred 12, K = 20); weak scaling
-(each rank owns its own 512 scenes, no data-path collective; one 3-scalar all-reduce per step aggregates ADE/FDE).
+N > 1: either launched by ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`` (one rank
+per GPU, RCCL), or -- when WORLD_SIZE is not in the environment -- bench.py starts exactly that launcher itself as a child
+process BEFORE anything touches the GPU and exits with its status.  It never runs fewer ranks than ``--gpus`` asks for: fewer
+visible GPUs than N is an error (non-zero exit, no JSON line).  ``n_gpus`` in the line is the world size the process group saw.
+
+A step = one pass of the hot path (H2D of the scene batch from pinned host memory -> scene front-end -> MHGSA/ODE encoder ->
+K=20 decomposition decoder -> device-side best-of-K ADE/FDE) over one batch of synthetic scenes (SURVEY.md §8d metric).
+Headline workload = BASELINE.json configs[1]: 512 ETH-shaped scenes per GPU (<= 32 pedestrians, obs 8 / pred 12, K = 20);
+weak scaling (each rank owns its own scenes, no data-path collective; one 3-scalar all-reduce of ADE/FDE sums at the end).
 
 The JSON line carries
   roofline     : dominant kernel's algorithmic FLOP / its mean duration (HIP events on the launch stream, inside the
                  timed region) vs the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
   cpu_baseline : the CPU oracle (PyTorch-eager port of the reference path, per-scene loop as test.py:171-184) timed on
-                 this box's host cores over a bounded sample of the same scenes (rank 0, N = 1 only);
-  parity       : HIP vs oracle on the sampled scenes with injected latents (max relative coordinate error, ADE/FDE).
+                 this box's host cores over a bounded sample of the same scenes (rank 0, N = 1 only), 16 threads and 1 thread;
+  parity       : HIP vs oracle on the sampled scenes with injected latents (max relative coordinate error, ADE/FDE);
+  configs      : secondary legs for BASELINE configs 2-5 at the per-GPU share each config implies (UCY-mixed 2048/8 = 256 scenes,
+                 SDD 1024/4 = 256 scenes, NBA B=128 x 11 agents (test.py:616-622), NBA long horizon 4096/8 = 512 scenes x 10 agents,
+                 obs 10 / pred 40), each with ms_per_step, trajectories/s, its dominant kernel's roofline and a short CPU sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA = 157.3e12  # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md
-TP, TF, K = 8, 12, 20
+K = 20
+F_TRAJ_SURVEY = 2254214   # SURVEY.md §8d figure for ETH shapes, written before the per-agent / per-trajectory layer-1 split
+
 
 # Algorithmic FLOP per unit (multiply-add = 2), stated in DESIGN.md §4.
-F_GRU = TP * (2 * 32 * 6 + 2 * 32 * 288 + 2 * 96 * 288)                        # conv + GRU per column
-F_MLP0 = 2 * (2 * 32 * 512 + 2 * 512 * 256) + 2 * 256 * (2 * TP + 2 * TF)        # block-0 x,y MLPs per trajectory
-F_MLP1 = 2 * 128 * 512 + 2 * 512 * 256 + 2 * 256 * 2 * TF                       # block-1 y MLP per trajectory
-F_LIN = {'A0': 2 * 224 * 512, 'A1': 2 * 128 * 512}
-F_ENC = 512 * TP + 8192 * TP + 8192 * TP + 8576 + 24576 + 24576 + 262144 + 256  # per agent, pe part folded (G = 1)
-F_TRAJ_SURVEY = 2254214                                                         # SURVEY.md §8d official figure
+def flops(Tp, Tf, G=1):
+    f = {'gru': Tp * (2 * 32 * 6 + 2 * 32 * 288 + 2 * 96 * 288),                                # conv + GRU per column
+         'mlp0': 2 * (2 * 32 * 512 + 2 * 512 * 256) + 2 * 256 * (2 * Tp + 2 * Tf),               # block-0 x,y MLPs per trajectory
+         'mlp1': 2 * 128 * 512 + 2 * 512 * 256 + 2 * 256 * 2 * Tf,                               # block-1 y MLP per trajectory
+         'A0': 2 * 224 * 512, 'A1': 2 * 128 * 512,
+         'enc': 512 * Tp + 8192 * Tp + 8192 * Tp + 8576 + 24576 + 24576 + 262144 + 256 * G,     # per agent, pe part folded
+         'attn': 4 * G * 64}                                                                      # scores + PV per agent (VALU)
+    f['path_per_traj'] = f['gru'] + f['mlp0'] + f['mlp1'] + (f['enc'] + f['gru'] + 2 * f['A0'] + f['A1']) / K
+    return f
 
 
-def kernel_flops(tag, n, m):
-    return {'gru_cols[block0,agents]': F_GRU * n, 'gru_cols[block1,trajectories]': F_GRU * m,
-            'mlp_block0': F_MLP0 * m, 'mlp_block1': F_MLP1 * m, 'agent_preact': (2 * F_LIN['A0'] + F_LIN['A1']) * n,
-            'embed_qkv+post_attn': F_ENC * n}.get(tag)
+def kernel_flops(tag, n, m, F):
+    return {'gru_cols[block0,agents]': F['gru'] * n, 'gru_cols[block1,trajectories]': F['gru'] * m,
+            'mlp_block0': F['mlp0'] * m, 'mlp_block1': F['mlp1'] * m, 'agent_preact': (2 * F['A0'] + F['A1']) * n,
+            'trajectory_chain': (F['mlp0'] + F['gru'] + F['mlp1']) * m}.get(tag)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launch: self-spawn of the ranks (no GPU call in this process), or failure
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start ``torch.distributed.run`` with N ranks as a child and exit with its status.
+    Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise HIP on this image)."""
+    import torch
+    backend_cpu = bool(args.selftest_dist)
+    have = torch.cuda.device_count()
+    if not backend_cpu and have < args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run fewer ranks '
+                         f'than requested (no JSON line is printed)\n')
+        return 2
+    port = 29400 + os.getpid() % 500
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), STTODE_BENCH_SELF_LAUNCHED='1')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_dist(args):
+    """-> (rank, world, local, dist | None).  A WORLD_SIZE that disagrees with --gpus is an error, never a relabelled run."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.stderr.write(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node == --gpus\n')
+        sys.exit(2)
+    dist = None
+    if world > 1 or os.environ.get('STTODE_BENCH_FORCE_DIST'):   # the env switch lets a 1-rank launch exercise the RCCL code path
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.selftest_dist:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write(f'bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}\n')
+            sys.exit(2)
+    return rank, world, local, dist
+
+
+def selftest_dist(args):
+    """CPU rehearsal of the launch / timing / reduction plumbing (gloo, no GPU, no kernels): every rank 'processes' a fixed number of
+    units per step; the line it prints has the same launch-related keys as the real one.  Used by tests/test_bench_contract.py."""
+    import torch
+    rank, world, local, dist = init_dist(args)
+    units = 1000 * (rank + 1)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(units)], dtype=torch.float64)
+    total = float(units)
+    if dist is not None:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt, total = float(tmax[0]), float(tt[1])
+    if rank == 0:
+        print(json.dumps({'metric': 'selftest units/sec', 'value': total * args.steps / dt, 'n_gpus': world,
+                          'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'backend': 'gloo (selftest, no GPU)',
+                          'self_launched': bool(os.environ.get('STTODE_BENCH_SELF_LAUNCHED')), 'steps': args.steps}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one workload ("leg"): inputs in pinned host memory, two device input slots, pipelined steps
+# ------------------------------------------------------------------------------------------------------------------
+LEGS = {
+    # name: (kind, dataset, Tp, Tf, per-GPU size, description)
+    'eth_512': ('scenes', 'eth', 8, 12, 512, 'BASELINE configs[1]: synthetic ETH-shaped scenes (2..32 pedestrians)'),
+    'ucy_2048': ('scenes', 'ucy', 8, 12, 256, 'BASELINE configs[2]: UCY-mixed (zara1/zara2 2..20, univ 20..60 pedestrians), 2048 scenes / 8 GPUs'),
+    'sdd_1024': ('scenes', 'sdd', 8, 12, 256, 'BASELINE configs[3]: SDD ragged scenes (1..40 agents, pixels/50), 1024 scenes / 4 GPUs'),
+    'nba_128': ('nba', 'nba', 5, 10, 128, 'reference NBA test batch: one attention group of B=128 scenes x 11 agents (test.py:616-622)'),
+    'nba_long_4096': ('nba', 'nba', 10, 40, 512, 'BASELINE configs[4]: NBA long horizon, 10 agents, obs 10 / pred 40, 4096 scenes / 8 GPUs = one '
+                                                  'attention group of 512 scenes per GPU (groups -> ranks, SURVEY.md §8e)'),
+}
+
+
+class Leg:
+    def __init__(self, name, rank, dev, size=None):
+        import torch
+        from helpers import make_args
+        from sttode_amd import STTODENet, scenes
+        from sttode_amd.weights import make_weights, to_torch_state_dict
+        self.name = name
+        self.kind, self.dataset, self.Tp, self.Tf, dsize, self.desc = LEGS[name]
+        self.size = size or dsize
+        self.dev = dev
+        self.model = STTODENet(make_args('nba' if self.kind == 'nba' else 'eth', self.Tp, self.Tf), dev).eval()
+        self.model.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=self.Tp, future_length=self.Tf)), strict=True)
+        if self.kind == 'scenes':
+            base = {'eth': 0, 'ucy': 0, 'sdd': 0}[self.dataset]
+            self.sb = scenes.make_scene_batch(range(base + rank * self.size, base + (rank + 1) * self.size), self.dataset)
+            self.n = self.sb.n_agents
+            host = [torch.from_numpy(self.sb.past), torch.from_numpy(self.sb.future), torch.from_numpy(self.sb.scene_ptr)]
+            self.G = 1
+        else:
+            self.N = 11 if name == 'nba_128' else 10
+            self.batch = scenes.nba_batch(7000 + rank, self.size, N=self.N, obs_len=self.Tp, pred_len=self.Tf)
+            self.n = self.size * self.N
+            host = [torch.from_numpy(self.batch['past_traj']), torch.from_numpy(self.batch['future_traj'])]
+            self.G = self.size
+        self.m = self.n * K
+        self.F = flops(self.Tp, self.Tf, self.G)
+        self.host = [t.pin_memory() for t in host]
+        self.h2d_bytes = sum(t.numel() * t.element_size() for t in self.host)
+        self.slots = [[torch.empty_like(t, device=dev) for t in self.host] for _ in range(2)]
+        self.n_dev = torch.tensor(float(self.n), dtype=torch.float32, device=dev)
+        self.calls = 0
+        self.pending = []
+        self.model.packed()
+
+    def _load(self):
+        """H2D of this step's inputs (pinned -> one of two device slots, on the caller's stream) + the data-entry call."""
+        slot = self.slots[self.calls & 1]
+        self.calls += 1
+        for d, h in zip(slot, self.host):
+            d.copy_(h, non_blocking=True)
+        if self.kind == 'scenes':
+            self.model.set_scene_batch(slot[0], slot[1], slot[2])
+        else:
+            self.model.set_data_nba({'past_traj': slot[0], 'future_traj': slot[1]})
+
+    def _finish(self, h):
+        import torch
+        pred = self.model.wait(h)                               # [K, n, Tf, 2]
+        self.last_pred = pred
+        ade, fde = self.model.best_of_k(pred.permute(1, 0, 2, 3), gt=h['gt'])
+        return torch.stack((ade.sum(), fde.sum(), self.n_dev))   # local sums; ONE all-reduce after the last step
+
+    def step(self, serial=False):
+        import torch
+        self._load()
+        if serial:
+            pred = self.model.inference(None)
+            self.last_pred = pred
+            ade, fde = self.model.best_of_k(pred.permute(1, 0, 2, 3))
+            return torch.stack((ade.sum(), fde.sum(), self.n_dev))
+        h = self.model.inference_async()                        # z is drawn on device exactly like Normal.rsample in the reference
+        h['gt'] = self.model._future
+        self.pending.append(h)
+        return self._finish(self.pending.pop(0)) if len(self.pending) > 1 else None
+
+    def drain(self):
+        out = None
+        while self.pending:
+            out = self._finish(self.pending.pop(0))
+        return out
+
+    def timed(self, steps, warmup, dist, time_every, serial=False, d2h=False):
+        """W untimed + exactly `steps` timed steps, barrier + synchronize on both sides, MAX over ranks.
+        d2h: additionally copy every step's futures to pinned host memory inside the timed region."""
+        import torch
+        dev = self.dev
+        hostbuf = torch.empty((K, self.n, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None
+        acc = None
+        for _ in range(warmup):
+            self.step(serial)
+        self.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        self.model.native().timing(time_every)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = self.step(serial)
+            if r is not None:
+                acc = r
+                if d2h:
+                    hostbuf.copy_(self.last_pred, non_blocking=True)
+        r = self.drain()                                          # every one of the K steps completes inside the timed region
+        if r is not None:
+            acc = r
+            if d2h:
+                hostbuf.copy_(self.last_pred, non_blocking=True)
+        if dist is not None:
+            dist.all_reduce(acc)                                  # metrics of the last step over all ranks: sum ADE, sum FDE, agents
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stage_ms = self.model.native().read_timing()
+        self.model.native().timing(0)
+        tt = torch.tensor([dt, float(self.m)], dtype=torch.float64, device=dev)
+        total = float(self.m)
+        if dist is not None:
+            tmax = tt.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            dt, total = float(tmax[0]), float(tt[1])
+        return {'dt': dt, 'total_traj': total, 'value': total * steps / dt, 'ms_per_step': 1e3 * dt / steps, 'stage_ms': stage_ms,
+                'metrics': acc}
+
+    def roofline(self, stage_ms, value_per_gpu, time_every):
+        kern, dom = {}, None
+        for t, (ms, cnt) in stage_ms.items():
+            mean_s = ms * 1e-3 / cnt
+            kern[t] = {'mean_us': 1e6 * mean_s, 'launches_sampled': cnt}
+            fl = kernel_flops(t, self.n, self.m, self.F)
+            if fl is None:
+                continue
+            kern[t]['tflops'] = fl / mean_s / 1e12
+            if dom is None or ms > dom[1]:
+                dom = (t, ms, fl, mean_s)
+        roof = None
+        if dom:
+            traffic = None
+            tp = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get(self.name, {}).get(dom[0])
+            roof = {'kernel': dom[0], 'bound': 'mfma', 'achieved': dom[2] / dom[3] / 1e12, 'peak': PEAK_F32_MFMA / 1e12,
+                    'unit': 'TFLOP/s', 'frac': dom[2] / dom[3] / PEAK_F32_MFMA, 'traffic': traffic,
+                    'flop_per_launch': dom[2], 'mean_launch_s': dom[3], 'events_every_nth_step': time_every,
+                    # whole-path figure: executed (de-duplicated, layer-1 split) FLOP per trajectory x throughput / peak
+                    'path_frac_executed': value_per_gpu * self.F['path_per_traj'] / PEAK_F32_MFMA,
+                    'path_flop_per_trajectory': self.F['path_per_traj']}
+        return roof, kern
+
+    # ---- CPU oracle sample + parity (rank 0, N = 1 only; outside every timed region) ----
+    def cpu_sample(self, seconds, threads):
+        import torch
+        from helpers import oracle_model, oracle_scene_inference
+        from oracle.metrics_ref import best_of_k_ade_fde
+        from sttode_amd import scenes
+        torch.set_num_threads(threads)
+        ora = oracle_model('nba' if self.kind == 'nba' else 'eth', self.Tp, self.Tf)
+        out = {'cores': torch.get_num_threads(), 'unit': 'trajectories/s', 'kind': 'port'}
+        if self.kind == 'scenes':
+            sb = self.sb
+            z_all = scenes.latents(99, self.n)
+            self.model.set_scene_batch(torch.from_numpy(sb.past).to(self.dev), torch.from_numpy(sb.future).to(self.dev), torch.from_numpy(sb.scene_ptr).to(self.dev))
+            hip = self.model.inference(None, z=torch.from_numpy(z_all)).cpu().numpy()
+            max_rel, traj_cpu, t_cpu, s = 0.0, 0, 0.0, 0
+            ade_o, ade_h = [], []
+            while t_cpu < seconds or s < 2:                       # bounded sample: scenes of this workload, cycled
+                i = s % sb.n_scenes
+                a, b = int(sb.scene_ptr[i]), int(sb.scene_ptr[i + 1])
+                obs, pr = sb.scene(i)
+                tc = time.perf_counter()
+                ref = oracle_scene_inference(ora, obs, pr, z_all[a * K:b * K])
+                t_cpu += time.perf_counter() - tc
+                traj_cpu += (b - a) * K
+                if s < sb.n_scenes:                                # parity of every sampled scene once
+                    err = np.abs(hip[:, a:b] - ref) / (np.abs(ref) + 1.0)
+                    max_rel = max(max_rel, float(err.max()))
+                    gt = sb.future[a:b]
+                    ade_o.append(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0])
+                    ade_h.append(best_of_k_ade_fde(hip[:, a:b].transpose(1, 0, 2, 3), gt)[0])
+                s += 1
+            ao, ah = float(np.concatenate(ade_o).mean()), float(np.concatenate(ade_h).mean())
+            out.update(value=traj_cpu / t_cpu, sample=f'{s} scene evaluations cycling over the {sb.n_scenes} scenes of this workload, per-scene '
+                       f'set_data+inference loop (test.py:171-184 structure), PyTorch-eager fp32 oracle, {t_cpu:.1f} s of CPU time')
+            par = {'scenes_checked': min(s, sb.n_scenes), 'max_err_over_1_plus_abs_ref': max_rel, 'ade_oracle': ao, 'ade_hip': ah,
+                   'ade_abs_diff': abs(ao - ah)}
+            return out, par
+        # NBA: one forward call on a reduced batch (the attention group is the batch, so HIP runs the SAME reduced batch for parity)
+        Bs = min(self.size, 16 if self.Tf > 12 else 32)
+        d = {k: (v[:Bs] if isinstance(v, np.ndarray) else v) for k, v in self.batch.items()}
+        nn_ = Bs * self.N
+        z = scenes.latents(98, nn_)
+        self.model.set_data_nba({k: (torch.from_numpy(v).to(self.dev) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+        hip = self.model.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+        t_cpu, reps = 0.0, 0
+        while t_cpu < seconds or reps < 1:
+            tc = time.perf_counter()
+            with torch.no_grad():
+                ora.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+                ref = ora.inference(None, z=torch.from_numpy(z)).numpy()
+            t_cpu += time.perf_counter() - tc
+            reps += 1
+        err = np.abs(hip - ref) / (np.abs(ref) + 1.0)
+        gt = d['future_traj'].reshape(nn_, self.Tf, 2)
+        ao = float(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0].mean())
+        ah = float(best_of_k_ade_fde(hip.transpose(1, 0, 2, 3), gt)[0].mean())
+        out.update(value=reps * nn_ * K / t_cpu, sample=f'{reps} forward call(s) of a reduced batch (B={Bs} of {self.size} scenes x {self.N} agents: the attention '
+                   f'group is the batch, so the CPU cost per trajectory is a lower bound for the full group), PyTorch-eager fp32 oracle, {t_cpu:.1f} s')
+        par = {'batch_checked': Bs, 'max_err_over_1_plus_abs_ref': float(err.max()), 'ade_oracle': ao, 'ade_hip': ah, 'ade_abs_diff': abs(ao - ah)}
+        return out, par
+
+    def config(self, world):
+        c = {'workload': f'{self.desc}, obs={self.Tp} pred={self.Tf}, K={K}, {self.size} scenes per GPU per step, random-recipe weights (seed 1234)',
+             'scenes_per_gpu': self.size, 'agents_rank0': self.n, 'trajectories_rank0': self.m, 'h2d_bytes_per_step': self.h2d_bytes,
+             'parallelism': ('scenes' if self.kind == 'scenes' else 'attention groups') + f' x{world}'}
+        if self.kind == 'nba':
+            c['attention_group'] = self.G
+        return c
 
 
 def train_bench(args, rank, world, dev, dist):
     """Training steps/s: the reference's per-scene loop (train.py:72-95: set_data with augmentation, forward, zero_grad, backward,
     Adam step) over this rank's synthetic ETH scenes; with several ranks the gradients are averaged by one flat all-reduce per
-    step (sttode_amd.parallel.average_gradients).  One JSON line, same conventions as the headline bench."""
+    step (sttode_amd.parallel.average_gradients).  Returns the dict (same conventions as the headline bench)."""
+    import torch
     from helpers import make_args
     from sttode_amd import STTODENet, parallel, scenes
     from sttode_amd.weights import make_weights, to_torch_state_dict
+    TP, TF = 8, 12
     sd = to_torch_state_dict(make_weights(1234))
     model = STTODENet(make_args('eth', TP, TF), dev)
     model.load_state_dict(sd, strict=True)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    nsc = 64
+    nsc = args.train_scenes
     data = [scenes.eth_scene(100000 + rank * nsc + i) for i in range(nsc)]
     data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]
     agents = sum(o.shape[0] for o, _ in data) / nsc
 
     TB = max(1, args.train_batch)
     if TB > 1:                                                       # batched steps: TB consecutive scenes as one CSR batch
-        import numpy as _np
         batches = []
         for b0 in range(0, nsc, TB):
             grp = data[b0:b0 + TB]
-            ptr = torch.tensor(_np.concatenate([[0], _np.cumsum([o.shape[0] for o, _ in grp])]).astype('int32'), device=dev)
+            ptr = torch.tensor(np.concatenate([[0], np.cumsum([o.shape[0] for o, _ in grp])]).astype('int32'), device=dev)
             batches.append((torch.cat([o.permute(0, 2, 1) for o, _ in grp]).contiguous(), torch.cat([p.permute(0, 2, 1) for _, p in grp]).contiguous(), ptr))
 
     def step(i):
@@ -88,13 +402,14 @@ def train_bench(args, rank, world, dev, dist):
             parallel.average_gradients(model.parameters(), weight=float(o.shape[0]))
         opt.step()
 
-    for i in range(max(args.warmup, 2 * nsc)):                     # every scene size is seen twice: hipGraphs captured
+    steps = args.train_steps
+    for i in range(2 * nsc):                                       # every scene size is seen twice: hipGraphs captured
         step(i)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     if dist is not None:
         dist.barrier()
@@ -105,9 +420,9 @@ def train_bench(args, rank, world, dev, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     out = {'metric': 'training-steps/sec (one scene per step, forward + backward + Adam)' if TB == 1 else
-                     f'training-scenes/sec ({TB} scenes per step, forward + backward + Adam)', 'value': world * args.steps * TB / dt,
-           'unit': 'steps/s' if TB == 1 else 'scenes/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': max(args.warmup, 2 * nsc),
-           'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                     f'training-scenes/sec ({TB} scenes per step, forward + backward + Adam)', 'value': world * steps * TB / dt,
+           'unit': 'steps/s' if TB == 1 else 'scenes/s', 'steps_per_s': world * steps / dt, 'n_gpus': world, 'steps': steps, 'warmup': 2 * nsc,
+           'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
            'data': 'synthetic', 'config': {'workload': f'train.py:72-95 loop over {nsc} synthetic ETH-shaped scenes per GPU (2..32 '
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
                                                        '(rotation + positional dropout), Adam lr 1e-4',
@@ -120,7 +435,7 @@ def train_bench(args, rank, world, dev, dist):
         ora.load_state_dict(sd, strict=True)
         oo = torch.optim.Adam(ora.parameters(), lr=1e-4)
         t_cpu, k = 0.0, 0
-        while t_cpu < args.cpu_seconds or k < 2:
+        while t_cpu < args.train_cpu_seconds or k < 2:
             o, p = data[k % nsc]
             nn_ = o.shape[0]
             tc = time.perf_counter()
@@ -133,11 +448,8 @@ def train_bench(args, rank, world, dev, dist):
             k += 1
         out['cpu_baseline'] = {'value': k / t_cpu, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                'sample': f'{k} steps of the same loop on the PyTorch-eager fp32 oracle (torch autograd), {t_cpu:.1f} s'}
-        out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        out['speedup_vs_cpu_baseline'] = out['steps_per_s'] / out['cpu_baseline']['value']
+    return out
 
 
 def main():
@@ -145,189 +457,109 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU per step')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU-baseline sample')
+    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU per step of the headline workload')
+    ap.add_argument('--cpu-seconds', type=float, default=8.0, help='budget of the headline CPU-baseline sample at 16 threads (half of it again at 1 thread)')
+    ap.add_argument('--leg-cpu-seconds', type=float, default=1.5, help='CPU-baseline budget of each secondary leg')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
-    ap.add_argument('--train-batch', type=int, default=1, help='with --train: scenes per optimizer step (1 = the reference loop; '
-                                                                '>1 = one batched step whose gradient is the sum of the per-scene gradients)')
-    ap.add_argument('--train', action='store_true', help='secondary metric: training steps/s (train.py:72-95 loop, one scene per step); '
-                                                         'the default run and the headline metric stay the inference path')
+    ap.add_argument('--legs', default='all', help="secondary legs: 'all', 'none' or a comma list of " + ','.join(k for k in LEGS if k != 'eth_512'))
+    ap.add_argument('--leg-steps', type=int, default=10)
+    ap.add_argument('--train', action='store_true', help='print ONLY the training line (secondary metric: train.py:72-95 loop)')
+    ap.add_argument('--no-train', action='store_true', help='skip the "train" object of the default line')
+    ap.add_argument('--train-batch', type=int, default=1, help='scenes per optimizer step (1 = the reference loop)')
+    ap.add_argument('--train-scenes', type=int, default=64)
+    ap.add_argument('--train-steps', type=int, default=200)
+    ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--selftest-dist', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    dist = None
-    if world > 1 or os.environ.get('STTODE_BENCH_FORCE_DIST'):   # the env switch lets a 1-rank launch exercise the RCCL code path
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        return 2
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)            # before any GPU call in this process
+    if args.selftest_dist:
+        return selftest_dist(args)
+
+    import torch
+    rank, world, local, dist = init_dist(args)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    from helpers import make_args
-    from sttode_amd import STTODENet, capi, scenes
-    from sttode_amd.weights import make_weights, to_torch_state_dict
-
     if args.train:
-        return train_bench(args, rank, world, dev, dist)
-    model = STTODENet(make_args('eth', TP, TF), dev).eval()
-    model.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
-    sb = scenes.make_scene_batch(range(rank * args.scenes, (rank + 1) * args.scenes), 'eth')
-    n, m = sb.n_agents, sb.n_agents * K
-    past, fut = torch.from_numpy(sb.past).to(dev), torch.from_numpy(sb.future).to(dev)
-    ptr = torch.from_numpy(sb.scene_ptr).to(dev)
-    model.set_scene_batch(past, fut, ptr)
-    model.packed()
+        out = train_bench(args, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    head = Leg('eth_512', rank, dev, size=args.scenes)
     if args.col_parts:
-        model.native().set_col_parts(args.col_parts)
-    n_dev = torch.tensor(float(n), dtype=torch.float32, device=dev)
-    acc = None
-
-    # Steps are software-pipelined (depth 2): step i's per-agent stage overlaps step i-1's per-trajectory kernels
-    # (sttode_inference_scenes_async); the metrics of step i-1 are taken while step i is in flight.  --serial disables it.
-    pending = []
-
-    def finish(h):
-        pred = model.wait(h)                               # [K, n, Tf, 2]
-        ade, fde = model.best_of_k(pred.permute(1, 0, 2, 3))
-        return torch.stack((ade.sum(), fde.sum(), n_dev))   # local sums; ONE 3-scalar all-reduce after the last step (no per-step rank coupling)
-
-    def step():
-        # inputs are resident; z is drawn on device by inference() exactly like Normal.rsample in the reference
-        model.set_scene_batch(past, fut, ptr)
-        if args.serial:
-            pred = model.inference(None)
-            ade, fde = model.best_of_k(pred.permute(1, 0, 2, 3))
-            return torch.stack((ade.sum(), fde.sum(), n_dev))
-        pending.append(model.inference_async())
-        return finish(pending.pop(0)) if len(pending) > 1 else None
-
-    def drain():
-        out = None
-        while pending:
-            out = finish(pending.pop(0))
-        return out
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # per-stage hipEvents recorded on the launch streams by csrc/pipeline.hip, on every 4th step of the timed region
-    # (bracketing every step costs 2 % of throughput; measured 67.9 -> 69.2 M traj/s without any brackets)
-    model.native().timing(args.time_every)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-        acc = r if r is not None else acc
-    r = drain()                                            # every one of the K steps completes inside the timed region
-    acc = r if r is not None else acc
-    if dist is not None:
-        dist.all_reduce(acc)                               # metrics of the last step over all ranks: sum ADE, sum FDE, agents
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stage_ms = model.native().read_timing()
-    model.native().timing(0)
-
-    tt = torch.tensor([dt, float(m)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        dt, total_traj = float(tmax[0]), float(tt[1])
-    else:
-        total_traj = float(m)
-    value = total_traj * args.steps / dt
-
-    # per-kernel durations from the events recorded inside the timed region (this rank)
-    kern, dom = {}, None
-    for t, (ms, cnt) in stage_ms.items():
-        mean_s = ms * 1e-3 / cnt
-        kern[t] = {'mean_us': 1e6 * mean_s, 'launches_sampled': cnt}
-        fl = kernel_flops(t, n, m)
-        if fl is None:
-            continue
-        kern[t]['tflops'] = fl / mean_s / 1e12
-        if dom is None or ms > dom[1]:
-            dom = (t, ms, fl, mean_s)
-    roof = None
-    if dom:
-        traffic = None
-        tp = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get(dom[0])
-        roof = {'kernel': dom[0], 'bound': 'mfma', 'achieved': dom[2] / dom[3] / 1e12, 'peak': PEAK_F32_MFMA / 1e12,
-                'unit': 'TFLOP/s', 'frac': dom[2] / dom[3] / PEAK_F32_MFMA, 'traffic': traffic,
-                'flop_per_launch': dom[2], 'mean_launch_s': dom[3], 'events_every_nth_step': args.time_every,
-                'path_frac_executed': value / world * (F_GRU + F_MLP0 + F_MLP1 + (F_ENC + F_GRU + 2 * F_LIN['A0'] + F_LIN['A1']) / K) / PEAK_F32_MFMA,
-                'path_frac_survey_flops': value / world * F_TRAJ_SURVEY / PEAK_F32_MFMA}
-
-    out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': value, 'unit': 'trajectories/s',
-           'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'BASELINE configs[1]: synthetic ETH-shaped scenes (2..32 pedestrians), obs={TP} pred={TF}, '
-                                  f'K={K}, {args.scenes} scenes per GPU per step, random-recipe weights (seed 1234)',
-                      'scenes_per_gpu': args.scenes, 'agents_rank0': n, 'trajectories_rank0': m, 'parallelism': f'scenes x{world}'},
-           'roofline': roof, 'kernels': kern,
-           'kernels_note': 'HIP-event durations on the launch streams; in the pipelined run the per-agent stages (frontend, embed_qkv, '
-                           'post_attn, gru_cols[block0], agent_preact) execute inside the tails of the previous batch, so their '
-                           'durations include waiting for compute units (alone they take 20 / 39 / 44 / 93 / 68 us)'}
-
+        head.model.native().set_col_parts(args.col_parts)
+    r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial)
+    roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every)
+    if roof:
+        roof['path_frac_survey_flops_superseded'] = r['value'] / world * F_TRAJ_SURVEY / PEAK_F32_MFMA
+    acc = r['metrics']
+    out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
+           'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': head.config(world), 'roofline': roof, 'kernels': kern,
+           'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
+                           'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
+           'kernels_note': 'HIP-event durations on the launch streams; in the pipelined run the per-agent stages execute beside the previous '
+                           "batch's per-trajectory kernels, so their durations include waiting for compute units"}
     if rank == 0:
         out['ade_fde_synthetic'] = [float(acc[0] / acc[2]), float(acc[1] / acc[2])]
-    if rank == 0 and world == 1 and not args.no_cpu:
-        from helpers import oracle_model, oracle_scene_inference
-        ora = oracle_model('eth', TP, TF)
-        # threads: the box's usable cores, but never more than 16 -- the per-scene ops are tiny and PyTorch-CPU gets
-        # SLOWER beyond that (256 threads measured 100x slower than 8); the count actually used is reported.
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        torch.set_num_threads(max(1, min(16, ncpu)))
-        z_all = scenes.latents(99, n)
-        # parity sample first (not timed): HIP with injected z vs oracle
-        model.set_scene_batch(past, fut, ptr)
-        hip = model.inference(None, z=torch.from_numpy(z_all)).cpu().numpy()
-        max_rel, traj_cpu, t_cpu, s = 0.0, 0, 0.0, 0
-        ade_o, ade_h = [], []
-        from oracle.metrics_ref import best_of_k_ade_fde
-        while t_cpu < args.cpu_seconds or s < 2:                  # bounded sample: whole passes over the workload's scenes, cycled
-            i = s % sb.n_scenes
-            a, b = int(sb.scene_ptr[i]), int(sb.scene_ptr[i + 1])
-            obs, pr = sb.scene(i)
-            tc = time.perf_counter()
-            ref = oracle_scene_inference(ora, obs, pr, z_all[a * K:b * K])
-            t_cpu += time.perf_counter() - tc
-            traj_cpu += (b - a) * K
-            if s < sb.n_scenes:                                    # parity of every scene once (first pass)
-                err = np.abs(hip[:, a:b] - ref) / (np.abs(ref) + 1.0)
-                max_rel = max(max_rel, float(err.max()))
-                gt = sb.future[a:b]
-                ade_o.append(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0])
-                ade_h.append(best_of_k_ade_fde(hip[:, a:b].transpose(1, 0, 2, 3), gt)[0])
-            s += 1
-        ao, ah = float(np.concatenate(ade_o).mean()), float(np.concatenate(ade_h).mean())
-        out['cpu_baseline'] = {'value': traj_cpu / t_cpu, 'unit': 'trajectories/s', 'cores': torch.get_num_threads(), 'host_cpus_visible': ncpu, 'kind': 'port',
-                               'sample': f'{s} scene evaluations cycling over the {sb.n_scenes} scenes of this workload, per-scene set_data+inference loop '
-                                         f'(test.py:171-184 structure), PyTorch-eager fp32 oracle, {t_cpu:.1f} s of CPU time'}
-        out['parity'] = {'scenes_checked': min(s, sb.n_scenes), 'max_err_over_1_plus_abs_ref': max_rel, 'ade_oracle': ao, 'ade_hip': ah,
-                         'ade_abs_diff': abs(ao - ah)}
-        out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+    # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
+    r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
+    out['value_incl_d2h'] = r2['value']
+    out['ms_per_step_incl_d2h'] = r2['ms_per_step']
+
+    want = [k for k in LEGS if k != 'eth_512'] if args.legs == 'all' else [] if args.legs == 'none' else args.legs.split(',')
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    # threads: the box's usable cores, but never more than 16 -- the per-scene ops are tiny and PyTorch-CPU gets SLOWER beyond
+    # that (256 threads measured 100x slower than 8); the count actually used is reported, and a 1-thread figure beside it.
+    nthr = max(1, min(16, ncpu))
+    if do_cpu:
+        cb, par = head.cpu_sample(args.cpu_seconds, nthr)
+        cb['host_cpus_visible'] = ncpu
+        cb1, _ = head.cpu_sample(args.cpu_seconds / 2, 1)
+        cb['value_1_thread'] = cb1['value']
+        cb['sample_1_thread'] = cb1['sample']
+        out['cpu_baseline'], out['parity'] = cb, par
+        out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
+    del head
+    legs = {}
+    for name in want:
+        if name not in LEGS or name == 'eth_512':
+            sys.stderr.write(f'bench.py: unknown leg {name!r}\n')
+            return 2
+        leg = Leg(name, rank, dev)
+        lr = leg.timed(args.leg_steps, 2, dist, 2)
+        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2)
+        e = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'], 'steps': args.leg_steps, 'config': leg.config(world),
+             'roofline': lroof, 'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}
+        if do_cpu:
+            e['cpu_baseline'], e['parity'] = leg.cpu_sample(args.leg_cpu_seconds, nthr)
+        legs[name] = e
+        del leg
+        torch.cuda.empty_cache()
+    if legs:
+        out['configs'] = legs
+    if not args.no_train and args.legs == 'all':
+        t = train_bench(args, rank, world, dev, dist)
+        out['train'] = {k: t[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'steps', 'config', 'cpu_baseline', 'speedup_vs_cpu_baseline') if k in t}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

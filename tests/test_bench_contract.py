@@ -28,3 +28,40 @@ def test_committed_bench_line_honours_the_contract():
     traj = d['config']['trajectories_rank0']
     assert abs(d['value'] - traj / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     assert d['parity']['max_err_over_1_plus_abs_ref'] < 1e-4 and d['parity']['ade_abs_diff'] < 1e-4
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], capture_output=True, text=True, timeout=240, env=e)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_requested():
+    """`python bench.py --gpus N` with fewer than N visible GPUs (0 in the CPU container, 1 on the 1-GPU box) must exit non-zero
+    and print NO JSON line -- never a single-rank number labelled n_gpus = N (round-1 advisor finding)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('needs a host with fewer than 2 GPUs')
+    r = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0')
+    assert r.returncode != 0
+    assert '{' not in r.stdout and 'refusing to run fewer ranks' in r.stderr
+    # a launcher-provided world size that disagrees with --gpus is an error too
+    r = _run_bench('--gpus', '2', '--steps', '1', '--selftest-dist', env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and '{' not in r.stdout and 'WORLD_SIZE=1 but --gpus 2' in r.stderr
+
+
+def test_bench_self_launch_spawns_the_ranks():
+    """--gpus 2 without a launcher: bench.py starts torch.distributed.run itself (before any GPU call) and the line reports the world
+    size the process group saw.  Rehearsed on CPU with gloo (--selftest-dist: same launch / barrier / MAX-over-ranks plumbing)."""
+    r = _run_bench('--gpus', '2', '--steps', '3', '--selftest-dist')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['self_launched'] is True and d['steps'] == 3
+    assert d['value'] > 0 and d['backend'].startswith('gloo')
