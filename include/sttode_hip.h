@@ -102,6 +102,18 @@ int sttode_mlp_block1(const float* A1y, const float* stream, int total_chunks, c
 int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, const float* z,
                     const float* state, float* out, int ncols, int K, int NO, void* stream_);
 
+/* Fused per-trajectory chain of Decoder.forward for all K samples (model/STTODE.py:320-347 with DecomposeBlock.forward :51-77
+ * twice and the "+ scene_orig" of :621-622): block-0 decoder_x -> d = x_true - x_hat0 -> block-0 decoder_y -> block-1 conv + GRU
+ * -> block-1 decoder_y -> pred [m,Tf,2] = ((y_hat0 + y_hat1) + cur) + orig, ONE persistent kernel, intermediates in registers
+ * (replaces sttode_mlp_block0 + sttode_gru_cols + sttode_mlp_block1 on the inference path; csrc/chain32.hip).
+ * A0x/A0y/A1y [n,512] as above; pool/prog/consts: packing.chain_stream (PK32 tile pool, per-group chunk program of
+ * sttode_chain_prog_len(Tp,Tf) int32 pairs, bias block); xpad [n,ldx] (ldx = 16 or 32); counter: one int32 of scratch
+ * (work queue, zeroed by the call on `stream`). */
+int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
+                      const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
+                      float* pred, int* counter, int ncols, int K, int Tp, int Tf, void* stream);
+int sttode_chain_prog_len(int Tp, int Tf);
+
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
 
@@ -234,19 +246,20 @@ enum SttodeWeight {
     STT_W_B0_CONVP, STT_W_B0_CONVB, STT_W_B0_WIHP, STT_W_B0_WHHP, STT_W_B0_GBIAS, STT_W_B0_XWA, STT_W_B0_XB1, STT_W_B0_YWA,
     STT_W_B0_YB1, STT_W_B0_STREAM,
     STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
+    STT_W_CHAIN_POOL, STT_W_CHAIN_PROG, STT_W_CHAIN_CONSTS,
     STT_W_COUNT
 };
 
 /* workspace buffers (offsets in floats from sttode_workspace_layout) */
 enum SttodeBuffer {
     STT_B_SCENE_ORIG, STT_B_AGENT_SCENE, STT_B_XPAD, STT_B_ENC_IN, STT_B_CUR, STT_B_ORIG, STT_B_LAST, STT_B_G, STT_B_QKV,
-    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_COUNT
+    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_QUEUE, STT_B_COUNT
 };
 
 /* pipeline stages reported by sttode_timing_read */
 enum SttodeStage {
     STT_STAGE_FRONTEND, STT_STAGE_EMBED, STT_STAGE_ATTN, STT_STAGE_POST, STT_STAGE_GRU0, STT_STAGE_LINEAR, STT_STAGE_MLP0,
-    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_COUNT
+    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_COUNT
 };
 
 /* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366). */
@@ -257,6 +270,9 @@ int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*
 /* number of column parts (1..8) the per-trajectory kernels are pipelined over on separate streams (default 1,
  * or env STTODE_COL_PARTS); results are bitwise independent of it. */
 int sttode_set_col_parts(SttodeModel* m, int parts);
+/* per-trajectory stage: 1 = fused chain kernel (sttode_traj_chain), 0 = the three-kernel form (mlp_block0 -> gru_cols -> mlp_block1),
+ * -1 = automatic (fused when the batch has >= 128 trajectories per workgroup slot to fill; default, or env STTODE_CHAIN). */
+int sttode_set_chain(SttodeModel* m, int mode);
 /* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams */
 int sttode_timing_enable(SttodeModel* m, int every);
 int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);

@@ -27,6 +27,8 @@ SIGNATURES = {
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    'sttode_traj_chain': [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_chain_prog_len': [_I, _I],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     # stage-2 sampler (csrc/sampler.hip)
     'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
@@ -64,6 +66,7 @@ SIGNATURES = {
     'sttode_model_destroy': [_P],
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
     'sttode_set_col_parts': [_P, _I],
+    'sttode_set_chain': [_P, _I],
     'sttode_timing_enable': [_P, _I],
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
@@ -78,11 +81,12 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                                        'outb', 'infoP', 'infob', 'gateP', 'gateb', 'ln1w', 'ln1b', 'l1P', 'l1b', 'l2P', 'l2b', 'ln2w',
                                        'ln2b')]
                 + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream')]
-                + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')])
+                + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')]
+                + [('chain', k) for k in ('pool', 'prog', 'consts')])
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
-           'A1y', 'dbuf', 'ybuf', 'state1')
+           'A1y', 'dbuf', 'ybuf', 'state1', 'queue')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',
-          'gru_cols[block1,trajectories]', 'mlp_block1')
+          'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain')
 
 
 class NativeModel:
@@ -113,6 +117,11 @@ class NativeModel:
     def set_col_parts(self, parts):
         if lib().sttode_set_col_parts(self.h, int(parts)) != 0:
             raise SttodeError('sttode_set_col_parts failed: ' + lib().sttode_last_error().decode())
+
+    def set_chain(self, mode):
+        """1: fused per-trajectory chain kernel, 0: three-kernel form, -1: automatic."""
+        if lib().sttode_set_chain(self.h, int(mode)) != 0:
+            raise SttodeError('sttode_set_chain failed: ' + lib().sttode_last_error().decode())
 
     def timing(self, every):
         """0/False: off; n: bracket every n-th forward call (True == every call)."""

@@ -1,0 +1,444 @@
+// Fused per-trajectory decoder chain (round 2): ONE persistent kernel runs, for a group of 128 trajectories,
+//     decoder_x MLP (block 0) -> d = x_true - x_hat0 -> decoder_y MLP (block 0) -> conv + GRU (block 1)
+//     -> decoder_y MLP (block 1) -> pred = ((y_hat0 + y_hat1) + cur) + orig
+// (model/STTODE.py:51-77 DecomposeBlock.forward x2, :320-347 Decoder.forward, :621-622), with every intermediate
+// (d, state, the 512/256-wide hidden activations) in REGISTERS.  Round 1 ran this as three kernels (mlp_block0 ->
+// gru_cols -> mlp_block1, csrc/decoder.hip) that exchanged dbuf / ybuf / state1 through HBM and each paid a grid tail.
+//
+// CDNA4 design:
+//   * v_mfma_f32_32x32x2_f32: a wave owns 32 trajectories ("columns") on the 32 MFMA columns, features in registers.
+//     One 32-feature x 32-column tile is a f32x16 per lane:  lane l: column l & 31, half h = l >> 5;
+//     register j  <->  feature 8*(j/4) + 4*h + (j%4).  That accumulator layout IS the B-operand layout of the next
+//     layer (MFMA step j consumes k-pair (8*(j/4) + j%4, +4)), so the whole chain needs no transpose and no LDS round trip.
+//     Versus the 16x16x4 chain of round 1: half the MFMA instructions and half the A-operand LDS bytes per FLOP, no
+//     dependent-accumulator stall (64-cycle issue = 64-cycle latency); measured 143.6 vs 135.2 TFLOP/s in the
+//     weight-stream probe (profiles/r02/diag_probe.json).
+//   * ALL weights (both MLPs of block 0, conv + GRU of block 1, the MLP of block 1: 3.2 MB per group) stream L2 -> LDS
+//     by LDS-DMA (global_load_lds_dwordx4) in chunks of <= 3 "PK32" tiles of 4 KiB (tile = A operand of 16 MFMAs:
+//     32 rows x 32 k), double buffered, one workgroup barrier per chunk; the chunk order is a host-built PROGRAM
+//     (packing.chain_stream), so the kernel only consumes tiles in order.  The GRU's recurrent weights are streamed per
+//     step like everything else (66 FLOP per streamed byte, the same intensity as the MLP layers), which frees the
+//     144 KiB of LDS round 1 pinned for them: LDS per workgroup is 24 KiB ring + 16 KiB gather slots + 6 KiB biases.
+//   * workgroup = 4 waves x 32 columns = 128 trajectories, 2 workgroups per CU (<= 256 VGPRs per wave); groups are
+//     handed out by an atomic work counter (one tail for the whole chain instead of three, and a later launch on
+//     another stream fills it: the kernel holds no chip-wide resource).
+#include "chain.hpp"
+#include "api_util.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define C32_TILE 256                        // f32x4 per tile (4 KiB)
+#define C32_CMAX 3                          // tiles per chunk
+#define C32_RING (2 * C32_CMAX * C32_TILE)  // f32x4 in the double buffer (24 KiB)
+#define C32_SLOT 256                        // f32x4 per wave gather slot (4 KiB)
+
+struct ChainArgs {
+    const float* A0x; const float* A0y; const float* A1y;  // [nagents][512] per-agent layer-1 pre-activations (b1 included)
+    const f32x4* pool;                                      // PK32 tile pool
+    const int2* prog; int prog_len;                         // chunk program of ONE group: (first tile, tiles <= 3)
+    const float* consts;                                    // biases, layout below
+    const float* z;                                         // [ncols][32]
+    const float* xpad; int ldx;                             // [nagents][ldx] normalised past, flattened (t,c), zero padded
+    const float* cur; const float* orig;                    // [nagents][2]
+    float* pred;                                            // [ncols][Tf2]
+    int* counter;                                           // work queue (zeroed before the launch)
+    int ncols, K, Tp, Tf2;
+};
+
+// consts layout (floats): b2x[256] b3x[32] | b2y[256] b3y[32*NY] | gbias[4][96] convb[32] | b2m[256] b3m[32*NY]
+template <int NY> struct C32Const {
+    static constexpr int b2x = 0, b3x = 256, b2y = 288, b3y = 544, gb = 544 + 32 * NY, cb = gb + 384, b2m = cb + 32,
+                         b3m = b2m + 256, total = b3m + 32 * NY;
+};
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r[e] = v;
+    return r;
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    return v;
+}
+// 32 consecutive features starting at p (LDS or global), in accumulator layout: register 4a+b <- p[8a + 4h + b]
+__device__ __forceinline__ f32x16 ldrows(const float* p, int h) {
+    f32x16 r;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const f32x4 v = ld4(p + 8 * a + 4 * h);
+        r[4 * a + 0] = v[0]; r[4 * a + 1] = v[1]; r[4 * a + 2] = v[2]; r[4 * a + 3] = v[3];
+    }
+    return r;
+}
+
+struct ChainStream {
+    const f32x4* pool; const int2* prog; f32x4* ring;
+    int len, p, par, lane, wave;
+    int2 nxt;  // program entry of the chunk after the one in flight
+    static __device__ __forceinline__ void glds16(const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    __device__ __forceinline__ void dma(int2 e, int buf) {
+        // a chunk of nt tiles = 4*nt pieces of 1 KiB; wave w moves pieces w, w+4, w+8
+        const f32x4* src = pool + (size_t)e.x * C32_TILE + lane;
+        f32x4* dst = ring + buf * (C32_CMAX * C32_TILE);
+#pragma unroll
+        for (int i = 0; i < C32_CMAX; ++i) {
+            const int idx = 4 * i + wave;
+            if (i < e.y) glds16(src + idx * 64, dst + idx * 64);
+        }
+    }
+    __device__ __forceinline__ int2 entry(int q) const {
+        int2 e = prog[q];
+        e.x = __builtin_amdgcn_readfirstlane(e.x);
+        e.y = __builtin_amdgcn_readfirstlane(e.y);
+        return e;
+    }
+    __device__ __forceinline__ void init(const f32x4* pool_, const int2* prog_, int len_, f32x4* ring_) {
+        pool = pool_; prog = prog_; len = len_; ring = ring_;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        p = 0; par = 0;
+        dma(entry(0), 0);
+        nxt = entry(1 % len);
+    }
+    // start of a chunk step: prefetch the next chunk into the other buffer (its readers passed the previous barrier)
+    __device__ __forceinline__ void begin() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma(nxt, par ^ 1);
+        int q = p + 2;
+        q = q >= len ? q - len : q;
+        nxt = entry(q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ const f32x4* cur() const { return ring + par * (C32_CMAX * C32_TILE) + lane; }
+    // end of a chunk step: the barrier's fence waits vmcnt(0) first -- exactly the wait this wave's DMA pieces need
+    __device__ __forceinline__ void end() {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        p = p + 1 >= len ? 0 : p + 1;
+        par ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+// acc += Atile (32 rows x 32 k, PK32) * B (32 k x 32 columns in accumulator layout)
+__device__ __forceinline__ void tile_mma(f32x16& acc, const f32x4* __restrict__ t, const f32x16& B) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 a = t[g * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], B[4 * g + r], acc, 0, 0, 0);
+    }
+}
+
+// Layers 1+2 of one MLP for this wave's 32 columns: acc2 (256 rows = 8 tiles) += W2 relu(A0[agent] + W1v B).
+// Per 32-row hidden tile: KT1 layer-1 tiles then 8 layer-2 tiles, a chunk boundary every 3 tiles ((KT1 + 8) % 3 == 0).
+// The per-agent pre-activation rows arrive through the wave's gather slot (4 x 16 B per lane per hidden tile, LDS-DMA):
+// a0 points at this lane's A0 row; a0_next at the row the NEXT phase starts with.
+template <int KT1>
+__device__ __forceinline__ void mlp_l12(ChainStream& st, f32x4* slot, const f32x16 (&B)[KT1], const float* __restrict__ a0,
+                                        const float* __restrict__ a0_next, f32x16 (&acc2)[8], int lane, int h) {
+    static_assert((KT1 + 8) % 3 == 0, "hidden tile must be a whole number of chunks");
+#pragma unroll
+    for (int R = 0; R < 8; ++R) acc2[R] = splat16(0.f);
+#pragma unroll 1
+    for (int ht = 0; ht < 16; ++ht) {
+        f32x16 h1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 v = slot[a * 64 + lane];
+            h1[4 * a + 0] = v[0]; h1[4 * a + 1] = v[1]; h1[4 * a + 2] = v[2]; h1[4 * a + 3] = v[3];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the gather issued next
+        __builtin_amdgcn_sched_barrier(0);
+        const float* nx = (ht + 1 < 16) ? a0 + 32 * (ht + 1) : a0_next;
+        st.begin();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ChainStream::glds16(nx + 8 * a + 4 * h, slot + a * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KT1 + 8; ++i) {
+            if (i > 0 && i % 3 == 0) { st.end(); st.begin(); }
+            const f32x4* t = st.cur() + (i % 3) * C32_TILE;
+            if (i < KT1) {
+                tile_mma(h1, t, B[i]);
+            } else {
+                if (i == KT1) h1 = relu16(h1);
+                tile_mma(acc2[i - KT1], t, h1);
+            }
+        }
+        st.end();
+    }
+}
+
+// Layer 3: out[o] = b3 + W3[o] relu(acc2 + b2), NO output tiles of 32 rows; 8 k-tiles per output tile, chunks of 3 tiles.
+template <int NO>
+__device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const float* __restrict__ b2, const float* __restrict__ b3,
+                                       f32x16 (&out)[NO], int h) {
+#pragma unroll
+    for (int R = 0; R < 8; ++R) {
+        STT_FENCE();  // keep the bias reads next to their use (hoisted as a block they spill)
+        const f32x16 b = ldrows(b2 + 32 * R, h);
+        acc2[R] = relu16(acc2[R] + b);
+    }
+    STT_FENCE();
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[o] = ldrows(b3 + 32 * o, h);
+    st.begin();
+#pragma unroll
+    for (int i = 0; i < 8 * NO; ++i) {
+        if (i > 0 && i % 3 == 0) { st.end(); st.begin(); }
+        tile_mma(out[i / 8], st.cur() + (i % 3) * C32_TILE, acc2[i % 8]);
+    }
+    st.end();
+}
+
+template <int NY>
+__global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* ring = reinterpret_cast<f32x4*>(smem);
+    f32x4* slots = ring + C32_RING;
+    float* cst = reinterpret_cast<float*>(slots + 4 * C32_SLOT);
+    int* sq = reinterpret_cast<int*>(cst + C32Const<NY>::total);  // [2]: group handed to this workgroup, parity-indexed
+    typedef C32Const<NY> CO;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x4* slot = slots + wave * C32_SLOT;
+    const int ngroups = (A.ncols + 127) >> 7;
+
+    for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
+    if (threadIdx.x == 0) {
+        sq[0] = atomicAdd(A.counter, 1);
+        sq[1] = atomicAdd(A.counter, 1);
+    }
+    ChainStream st;
+    st.init(A.pool, A.prog, A.prog_len, ring);
+    __syncthreads();
+    int g = sq[0], gn = sq[1], qpar = 0;
+    if (g >= ngroups) return;  // (uniform) more workgroups than groups; the DMA issued by init() has landed (barrier above)
+
+    auto col_of = [&](int gg) { int col = gg * 128 + wave * 32 + c; return col < A.ncols ? col : A.ncols - 1; };
+    {   // first gather: A0x rows of hidden tile 0
+        const float* a0 = A.A0x + (size_t)(col_of(g) / A.K) * 512;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ChainStream::glds16(a0 + 8 * a + 4 * h, slot + a * 64);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    while (true) {
+        const int col = g * 128 + wave * 32 + c;
+        const int colc = col < A.ncols ? col : A.ncols - 1;
+        const int agent = colc / A.K;
+        const bool live = col < A.ncols;
+        // the group after the next one is requested now; it is read after the many barriers of this group
+        __syncthreads();  // every wave has read sq[qpar] (previous hand-over) before it is overwritten
+        if (threadIdx.x == 0) sq[qpar] = atomicAdd(A.counter, 1);
+
+        f32x16 acc2[8];
+        f32x16 d;
+        {   // ---- block 0, decoder_x: x_hat0, d = x_true - x_hat0
+            f32x16 B[1];
+            B[0] = ldrows(A.z + (size_t)colc * 32, h);
+            mlp_l12<1>(st, slot, B, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
+            f32x16 xo[1];
+            mlp_l3<1>(st, acc2, cst + CO::b2x, cst + CO::b3x, xo, h);
+            const float* xp = A.xpad + (size_t)agent * A.ldx;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 v = splat4(0.f);
+                if (8 * a + 4 * h < A.ldx) v = ld4(xp + 8 * a + 4 * h);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) d[4 * a + b] = v[b] - xo[0][4 * a + b];
+            }
+        }
+        {   // ---- block 0, decoder_y: y_hat0 parked in pred (re-read by the epilogue)
+            f32x16 B[1];
+            B[0] = ldrows(A.z + (size_t)colc * 32, h);
+            mlp_l12<1>(st, slot, B, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
+            f32x16 yo[NY];
+            mlp_l3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
+            if (live) {
+#pragma unroll
+                for (int o = 0; o < NY; ++o)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int row0 = 32 * o + 8 * a + 4 * h;
+                        float* p = A.pred + (size_t)col * A.Tf2 + row0;
+                        if (row0 + 3 < A.Tf2 && (A.Tf2 & 3) == 0) {
+                            f32x4 v = {yo[o][4 * a], yo[o][4 * a + 1], yo[o][4 * a + 2], yo[o][4 * a + 3]};
+                            st4(p, v);
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                if (row0 + b < A.Tf2) p[b] = yo[o][4 * a + b];
+                        }
+                    }
+            }
+        }
+        f32x16 hs[3];
+        {   // ---- block 1: conv1d + relu + GRU over Tp steps, weights streamed per step (gate rows pre-scaled, chain.hpp)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hs[j] = splat16(0.f);
+            const float* gb = cst + CO::gb;
+#pragma unroll 1
+            for (int t = 0; t < A.Tp; ++t) {
+                f32x16 e = ldrows(cst + CO::cb, h);
+                st.begin();
+                tile_mma(e, st.cur(), d);
+                e = relu16(e);
+                st.end();
+                f32x16 hn[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    // 12 tiles: r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2] n_i:[e]; chunk boundary every 3 tiles.
+                    // One gate accumulator is live at a time (finished gates shrink to their 16 outputs).
+                    STT_FENCE();
+                    f32x16 ar = ldrows(gb + 0 * 96 + 32 * j, h);
+                    st.begin();
+                    tile_mma(ar, st.cur() + 0 * C32_TILE, e);
+                    tile_mma(ar, st.cur() + 1 * C32_TILE, hs[0]);
+                    tile_mma(ar, st.cur() + 2 * C32_TILE, hs[1]);
+                    st.end(); st.begin();
+                    tile_mma(ar, st.cur() + 0 * C32_TILE, hs[2]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ar[r] = sigmoid_prescaled(ar[r]);          // r gate
+                    STT_FENCE();
+                    f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
+                    tile_mma(az, st.cur() + 1 * C32_TILE, e);
+                    tile_mma(az, st.cur() + 2 * C32_TILE, hs[0]);
+                    st.end(); st.begin();
+                    tile_mma(az, st.cur() + 0 * C32_TILE, hs[1]);
+                    tile_mma(az, st.cur() + 1 * C32_TILE, hs[2]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) az[r] = sigmoid_prescaled(az[r]);          // z gate
+                    STT_FENCE();
+                    f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
+                    tile_mma(an, st.cur() + 2 * C32_TILE, hs[0]);
+                    st.end(); st.begin();
+                    tile_mma(an, st.cur() + 0 * C32_TILE, hs[1]);
+                    tile_mma(an, st.cur() + 1 * C32_TILE, hs[2]);
+                    {
+                        const f32x16 bi = ldrows(gb + 2 * 96 + 32 * j, h);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) an[r] = fmaf(ar[r], an[r], bi[r]);     // b_in + r * (W_hn h + b_hn)
+                    }
+                    STT_FENCE();
+                    tile_mma(an, st.cur() + 2 * C32_TILE, e);                               // + W_in e
+                    st.end();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float ng = tanh_prescaled(an[r]);
+                        hn[j][r] = fmaf(az[r], hs[j][r] - ng, ng);  // (1-z) n + z h
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) hs[j] = hn[j];
+            }
+        }
+        // next group's first gather pointer (A0x of its first hidden tile); sq[qpar] was written at the top of this group
+        const int g2 = sq[qpar];
+        qpar ^= 1;
+        const int gnext = gn;
+        {   // ---- block 1, decoder_y + epilogue
+            f32x16 B[4];
+            B[0] = ldrows(A.z + (size_t)colc * 32, h);
+            B[1] = hs[0]; B[2] = hs[1]; B[3] = hs[2];
+            const int agent_nx = col_of(gnext < ngroups ? gnext : g) / A.K;
+            mlp_l12<4>(st, slot, B, A.A1y + (size_t)agent * 512, A.A0x + (size_t)agent_nx * 512, acc2, lane, h);
+            f32x16 yo[NY];
+            mlp_l3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
+            if (live) {
+                const float cx = A.cur[2 * agent], cy = A.cur[2 * agent + 1];
+                const float ox = A.orig[2 * agent], oy = A.orig[2 * agent + 1];
+#pragma unroll
+                for (int o = 0; o < NY; ++o)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int row0 = 32 * o + 8 * a + 4 * h;
+                        float* p = A.pred + (size_t)col * A.Tf2 + row0;
+                        if (row0 + 3 < A.Tf2 && (A.Tf2 & 3) == 0) {
+                            const f32x4 y0 = ld4(p);
+                            f32x4 v;
+                            v[0] = ((y0[0] + yo[o][4 * a + 0]) + cx) + ox;
+                            v[1] = ((y0[1] + yo[o][4 * a + 1]) + cy) + oy;
+                            v[2] = ((y0[2] + yo[o][4 * a + 2]) + cx) + ox;
+                            v[3] = ((y0[3] + yo[o][4 * a + 3]) + cy) + oy;
+                            st4(p, v);
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                if (row0 + b < A.Tf2) p[b] = ((p[b] + yo[o][4 * a + b]) + ((b & 1) ? cy : cx)) + ((b & 1) ? oy : ox);
+                        }
+                    }
+            }
+        }
+        g = gnext;
+        gn = g2;
+        if (g >= ngroups) break;  // uniform: every wave read the same sq words
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+static int chain_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+template <int NY> static int chain_lds() { return (C32_RING + 4 * C32_SLOT) * 16 + C32Const<NY>::total * 4 + 16; }
+
+template <int NY> static int chain_launch(const ChainArgs& a, hipStream_t s) {
+    static bool attr_set = false;  // once per instantiation (hipFuncSetAttribute is a driver call)
+    if (!attr_set) {
+        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds<NY>()));
+        attr_set = true;
+    }
+    const int ngroups = (a.ncols + 127) / 128;
+    int grid = 2 * chain_cus();
+    if (grid > ngroups) grid = ngroups;
+    STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), chain_lds<NY>(), s, a);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
+    const int NY = (2 * Tf + 31) / 32;
+    const int l3y = (8 * NY + 2) / 3;
+    return (48 + 3) + (48 + l3y) + 13 * Tp + (64 + l3y);
+}
+
+// Fused per-trajectory chain of Decoder.forward (model/STTODE.py:320-347) for K samples per agent; see the file header.
+extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
+                                 const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
+                                 float* pred, int* counter, int ncols, int K, int Tp, int Tf, void* stream) {
+    STT_REQUIRE(A0x && A0y && A1y && pool && prog && consts && z && xpad && cur && orig && pred && counter, "sttode_traj_chain: null pointer");
+    STT_REQUIRE(ncols > 0 && K > 0 && Tp >= 1 && 2 * Tp <= 32 && Tf >= 1, "sttode_traj_chain: bad ncols/K/Tp/Tf");
+    STT_REQUIRE(ldx == 16 || ldx == 32, "sttode_traj_chain: ldx must be 16 or 32");
+    STT_REQUIRE(2 * Tp <= ldx, "sttode_traj_chain: xpad rows shorter than 2*Tp");
+    STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "sttode_traj_chain: chunk program length does not match (Tp, Tf)");
+    ChainArgs a;
+    a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
+    a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
+    a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
+    const int NY = (2 * Tf + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    switch (NY) {
+        case 1: return chain_launch<1>(a, s);
+        case 2: return chain_launch<2>(a, s);
+        case 3: return chain_launch<3>(a, s);
+        default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
+    }
+    return 0;
+}

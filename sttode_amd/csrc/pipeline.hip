@@ -26,6 +26,8 @@ struct SttodeModel {
     // column-part pipelining of the per-trajectory kernels: part p runs mlp_block0 -> gru_cols -> mlp_block1 on its own
     // stream, so the grid tail of one part's kernel is filled by the next part's kernel (columns are independent).
     int col_parts;
+    int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
+    int prog_len;
     hipStream_t part_stream[STT_MAX_PARTS];
     hipEvent_t ev_agents, ev_part[STT_MAX_PARTS];
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
@@ -59,6 +61,9 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->calls = 0;
     m->b_streams = 1;
     if (const char* e = getenv("STTODE_B_STREAMS")) m->b_streams = atoi(e) == 2 ? 2 : 1;
+    m->chain_mode = -1;
+    if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
+    m->prog_len = sttode_chain_prog_len(Tp, Tf);
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
     if (const char* e = getenv("STTODE_COL_PARTS")) m->col_parts = atoi(e);
     if (m->col_parts < 1) m->col_parts = 1;
@@ -127,7 +132,15 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_DBUF, mm * 16 * m->TPX);
     put(STT_B_YBUF, mm * 16 * m->NOY);
     put(STT_B_STATE1, mm * 96);
+    put(STT_B_QUEUE, 64);
     *total_floats = (long)o;
+    return 0;
+}
+
+extern "C" int sttode_set_chain(SttodeModel* m, int mode) {
+    STT_REQUIRE(m, "sttode_set_chain: null model");
+    STT_REQUIRE(mode >= -1 && mode <= 1, "sttode_set_chain: mode must be -1 (auto), 0 or 1");
+    m->chain_mode = mode;
     return 0;
 }
 
@@ -242,6 +255,18 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
     const float* xpad = ws + off[STT_B_XPAD];
     const float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
     float *dbuf = ws + off[STT_B_DBUF], *ybuf = ws + off[STT_B_YBUF], *state1 = ws + off[STT_B_STATE1];
+    // Fused chain: one persistent kernel for the whole per-trajectory stage (csrc/chain32.hip).  Its work item is a group of
+    // 128 trajectories on one workgroup, so automatic mode uses it once the batch fills the chip's 512 workgroup slots at least
+    // ~once (small batches keep the 16-column kernels, whose items spread over more CUs).
+    const long ncols_all = (long)n * K;
+    const bool fused = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 32768);
+    if (fused) {
+        RUN(STT_STAGE_CHAIN, s,
+            sttode_traj_chain(A0x, A0y, A1y, W[STT_W_CHAIN_POOL], (const int*)W[STT_W_CHAIN_PROG], m->prog_len, W[STT_W_CHAIN_CONSTS], z,
+                              xpad, 16 * TPX, ws + off[STT_B_CUR], ws + off[STT_B_ORIG], pred, (int*)(ws + off[STT_B_QUEUE]), (int)ncols_all, K,
+                              Tp, Tf, s));
+        return 0;
+    }
     // optional split into column parts at agent boundaries (pointers are simply offset)
     int P = m->col_parts;
     if (P > n) P = n;

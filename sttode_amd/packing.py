@@ -174,6 +174,98 @@ def pack_block(sd, i, Tp, Tf, first):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# PK32 / fused trajectory chain (csrc/chain32.hip)
+# ---------------------------------------------------------------------------------------------------
+def pk32_tile(Wb):
+    """[32, 32] block (rows = output features, columns = k) -> 1024 floats in v_mfma_f32_32x32x2_f32 A-operand order:
+    T[g, lane, r] = Wb[lane & 31, 8*g + 4*(lane >> 5) + r]  (four ds_read_b128 per lane feed 16 MFMAs; MFMA step 4g+r
+    consumes the k-pair (8g + r, 8g + 4 + r), which is where the 32x32 accumulator layout keeps those features)."""
+    Wb = np.asarray(Wb, np.float32)
+    assert Wb.shape == (32, 32)
+    X = Wb.reshape(32, 4, 2, 4).transpose(1, 2, 0, 3)     # i, g, h, r -> g, h, i, r   (lane = 32*h + i)
+    return np.ascontiguousarray(X).reshape(-1)
+
+
+def pk32_tiles(W):
+    """[N, K] (zero padded to multiples of 32) -> [N/32, K/32, 1024]."""
+    W = np.asarray(W, np.float32)
+    N, K = W.shape
+    Np, Kp = (N + 31) // 32 * 32, (K + 31) // 32 * 32
+    Wp = np.zeros((Np, Kp), np.float32)
+    Wp[:N, :K] = W
+    return np.stack([np.stack([pk32_tile(Wp[32 * i:32 * i + 32, 32 * j:32 * j + 32]) for j in range(Kp // 32)]) for i in range(Np // 32)])
+
+
+def tiles_y32(Tf):
+    return (2 * Tf + 31) // 32
+
+
+def chain_prog_len(Tp, Tf):
+    l3y = (8 * tiles_y32(Tf) + 2) // 3
+    return (48 + 3) + (48 + l3y) + 13 * Tp + (64 + l3y)
+
+
+def chain_stream(sd, Tp, Tf):
+    """Weight stream of the fused per-trajectory chain (csrc/chain32.hip): block-0 decoder_x, block-0 decoder_y, block-1
+    conv + GRU, block-1 decoder_y.  Returns
+      pool   float32 [n_tiles, 1024]  PK32 tiles
+      prog   int32   [n_chunks, 2]    (first tile, tile count <= 3) in the order the kernel consumes them for ONE group
+      consts float32 [1216 + 64*NY]   b2x b3x | b2y b3y | GRU gate biases (pre-scaled) conv bias | b2 b3 of block-1 decoder_y
+    The kernel's consumption order is fixed (chain32.hip); this function is its single source of truth on the host."""
+    NY = tiles_y32(Tf)
+    g = lambda k: np.asarray(sd[k], np.float32)
+    tiles, prog = [], []
+
+    def add(ts):                     # append tiles, cut into chunks of <= 3 consecutive tiles
+        base = len(tiles)
+        tiles.extend(ts)
+        for o in range(0, len(ts), 3):
+            prog.append((base + o, min(3, len(ts) - o)))
+
+    def mlp(prefix, kcols, NO, n_out):
+        W1, W2, W3 = g(prefix + 'layers.0.weight'), g(prefix + 'layers.1.weight'), g(prefix + 'layers.2.weight')
+        P1 = pk32_tiles(W1[:, kcols])                     # [16, KT1, 1024]
+        P2 = pk32_tiles(W2)                               # [8, 16, 1024]
+        W3p = np.zeros((32 * NO, 256), np.float32)
+        W3p[:n_out] = W3
+        P3 = pk32_tiles(W3p)                              # [NO, 8, 1024]
+        for ht in range(16):                              # per hidden tile: KT1 layer-1 tiles, then the 8 layer-2 row tiles
+            add(list(P1[ht]) + [P2[R, ht] for R in range(8)])
+        add([P3[o, T] for o in range(NO) for T in range(8)])
+        b3 = np.zeros(32 * NO, np.float32)
+        b3[:n_out] = g(prefix + 'layers.2.bias')
+        return g(prefix + 'layers.1.bias'), b3
+
+    b2x, b3x = mlp('decoder.decompose.0.decoder_x.', slice(128, 160), 1, 2 * Tp)
+    b2y, b3y = mlp('decoder.decompose.0.decoder_y.', slice(128, 160), NY, 2 * Tf)
+    # block-1 conv + GRU: gate rows pre-scaled as in pack_block (sigmoid / tanh without a multiply, csrc/chain.hpp)
+    p = 'decoder.decompose.1.'
+    L2E = np.float32(1.4426950408889634)
+    sc = np.concatenate([np.full(192, -L2E, np.float32), np.full(96, 2 * L2E, np.float32)])
+    wih = g(p + 'encoder_past.weight_ih_l0') * sc[:, None]
+    whh = g(p + 'encoder_past.weight_hh_l0') * sc[:, None]
+    bih, bhh = g(p + 'encoder_past.bias_ih_l0'), g(p + 'encoder_past.bias_hh_l0')
+    Pih, Phh = pk32_tiles(wih), pk32_tiles(whh)           # [9, 1, 1024], [9, 3, 1024]; row tiles r0..2 z0..2 n0..2
+    gru = []
+    for j in range(3):                                    # r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2] n_i:[e]
+        gru += [Pih[j, 0], Phh[j, 0], Phh[j, 1], Phh[j, 2], Pih[3 + j, 0], Phh[3 + j, 0], Phh[3 + j, 1], Phh[3 + j, 2],
+                Phh[6 + j, 0], Phh[6 + j, 1], Phh[6 + j, 2], Pih[6 + j, 0]]
+    conv = pk32_tiles(toeplitz_conv(g(p + 'conv_past.weight'), Tp, 2))   # [Tp, 1, 1024]: step t = rows 32t..32t+31
+    gru_base, conv_base = len(tiles), len(tiles) + 36
+    tiles.extend(gru)
+    tiles.extend(conv[t, 0] for t in range(Tp))
+    for t in range(Tp):
+        prog.append((conv_base + t, 1))
+        prog.extend((gru_base + 3 * c, 3) for c in range(12))
+    gbias = np.concatenate([(bih[:96] + bhh[:96]) * -L2E, (bih[96:192] + bhh[96:192]) * -L2E, bih[192:] * (2 * L2E), bhh[192:] * (2 * L2E)])
+    b2m, b3m = mlp(p + 'decoder_y.', slice(128, 256), NY, 2 * Tf)
+    consts = np.concatenate([b2x, b3x, b2y, b3y, gbias, g(p + 'conv_past.bias'), b2m, b3m]).astype(np.float32)
+    assert consts.size == 1216 + 64 * NY and len(prog) == chain_prog_len(Tp, Tf), (consts.size, len(prog))
+    return {'pool': np.ascontiguousarray(np.stack(tiles)), 'prog': np.ascontiguousarray(np.asarray(prog, np.int32)),
+            'consts': np.ascontiguousarray(consts), 'prog_len': len(prog)}
+
+
 def pack_posterior(sd):
     """FutureEncoder head (model/STTODE.py:258-261,297-299): out_mlp 256->128 relu, qz_layer 128->2*zdim."""
     g = lambda k: np.asarray(sd['future_encoder.' + k], np.float32)

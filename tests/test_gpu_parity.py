@@ -187,33 +187,96 @@ def test_best_of_k_vs_reference_golden(golden):
 def test_batched_scenes_full_size_properties():
     """BASELINE config[1] size: 512 ETH-shaped scenes, K=20, one call.
     (1) a sample of scenes equals the CPU oracle run scene by scene (test.py:171-184 structure);
-    (2) scene independence: the batched result equals per-scene HIP calls bit for bit;
+    (2) scene independence: the batched result equals per-scene HIP calls bit for bit, for BOTH forms of the per-trajectory
+        stage (fused chain kernel, csrc/chain32.hip; three-kernel form, csrc/decoder.hip) -- the two forms use different MFMA
+        shapes, i.e. different summation orders, so across forms the results agree to rounding (checked at 2e-5), not bitwise;
     (3) determinism: two runs are bitwise identical;  (4) device ADE/FDE equal the NumPy oracle."""
     from oracle.metrics_ref import best_of_k_ade_fde
     from sttode_amd import scenes
     m = hip_model('eth', 8, 12)
     sb = scenes.make_scene_batch(range(512), 'eth')
     z = scenes.latents(99, sb.n_agents)
-    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
-    out = m.inference(None, z=torch.from_numpy(z))
-    out2 = m.inference(None, z=torch.from_numpy(z))
-    assert torch.equal(out, out2)
-    o = out.cpu().numpy()
-    assert np.isfinite(o).all()
     ora = oracle_model('eth', 8, 12)
-    for s in (0, 1, 17, 255, 511):
-        a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
-        obs, pred = sb.scene(s)
-        ref = oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20])
-        assert_close(o[:, a:b], ref, what=f'scene {s} vs oracle')
-        m.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred))
-        single = m.inference(None, z=torch.from_numpy(z[a * 20:b * 20])).cpu().numpy()
-        assert np.array_equal(single, o[:, a:b]), f'scene {s}: batched != per-scene'
+    per_form = {}
+    try:
+        for form in (1, 0):
+            m.native().set_chain(form)
+            m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+            out = m.inference(None, z=torch.from_numpy(z))
+            out2 = m.inference(None, z=torch.from_numpy(z))
+            assert torch.equal(out, out2)
+            o = out.cpu().numpy()
+            assert np.isfinite(o).all()
+            per_form[form] = o
+            for s in (0, 1, 17, 255, 511):
+                a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+                obs, pred = sb.scene(s)
+                ref = oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20])
+                assert_close(o[:, a:b], ref, what=f'form {form} scene {s} vs oracle')
+                m.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred))
+                single = m.inference(None, z=torch.from_numpy(z[a * 20:b * 20])).cpu().numpy()
+                assert np.array_equal(single, o[:, a:b]), f'form {form} scene {s}: batched != per-scene'
+        assert_close(per_form[1], per_form[0], rtol=2e-5, atol=2e-5, what='fused chain vs three-kernel form')
+    finally:
+        m.native().set_chain(-1)
     m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    out = m.inference(None, z=torch.from_numpy(z))     # automatic mode picks the fused chain at this size
+    assert np.array_equal(out.cpu().numpy(), per_form[1])
+    o = per_form[1]
     ade, fde = m.best_of_k(out.permute(1, 0, 2, 3))
     ra, rf = best_of_k_ade_fde(o.transpose(1, 0, 2, 3), sb.future)
     assert_close(ade.cpu().numpy(), ra, rtol=1e-5, atol=1e-5, what='ade')
     assert_close(fde.cpu().numpy(), rf, rtol=1e-5, atol=1e-5, what='fde')
+
+
+@pytest.mark.parametrize('case', ['eth_ragged', 'tiny', 'nba', 'nba_long', 'k_not_20'])
+def test_fused_trajectory_chain_vs_three_kernel_form_and_oracle(case):
+    """sttode_traj_chain (one persistent kernel: decoder_x -> d -> decoder_y -> conv+GRU -> decoder_y -> epilogue, 32x32x2 MFMA,
+    all weights streamed) against the three-kernel form on identical inputs and against the CPU oracle: ragged column counts
+    (not a multiple of the 128-trajectory group), fewer columns than one group, the NBA shapes (Tp 5 / Tf 10) and the
+    long-horizon shapes (Tp 10 / Tf 40: ldx = 32, three output tiles)."""
+    from sttode_amd import scenes
+    if case in ('eth_ragged', 'tiny', 'k_not_20'):
+        m, ora = hip_model('eth', 8, 12), oracle_model('eth', 8, 12)
+        sb = scenes.make_scene_batch(range(900, 900 + (1 if case == 'tiny' else 61)), 'eth')
+        z = scenes.latents(31, sb.n_agents)
+        if case == 'k_not_20':      # K = 7 samples per agent (the kernels take K as an argument; the reference hard-codes 20)
+            from sttode_amd import STTODENet
+            a7 = make_args('eth', 8, 12)
+            a7.sample_k = 7
+            m7 = STTODENet(a7, _gpu()).eval()
+            m7.load_state_dict(m.state_dict(), strict=True)
+            m, z = m7, scenes.latents(31, sb.n_agents, K=7)
+        feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    else:
+        Tp, Tf, B, N = (5, 10, 24, 11) if case == 'nba' else (10, 40, 12, 10)
+        m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+        d = scenes.nba_batch(41, B, N=N, obs_len=Tp, pred_len=Tf)
+        z = scenes.latents(32, B * N)
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        feed = lambda: m.set_data_nba(data)
+    outs = {}
+    try:
+        for form in (0, 1):
+            m.native().set_chain(form)
+            feed()
+            outs[form] = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+            feed()
+            assert np.array_equal(m.inference(None, z=torch.from_numpy(z)).cpu().numpy(), outs[form])
+    finally:
+        m.native().set_chain(-1)
+    assert np.isfinite(outs[1]).all()
+    assert_close(outs[1], outs[0], rtol=2e-5, atol=2e-5, what=f'{case}: fused chain vs three-kernel form')
+    if case in ('eth_ragged', 'tiny'):
+        for s in range(0, sb.n_scenes, 9):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            assert_close(outs[1][:, a:b], oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20]), what=f'{case} scene {s} vs oracle')
+    elif case != 'k_not_20':
+        with torch.no_grad():
+            ora.set_data_nba(data)
+            ref = ora.inference(None, z=torch.from_numpy(z)).numpy()
+        assert_close(outs[1], ref, what=f'{case} vs oracle')
 
 
 def test_pmath_op_library_vs_reference_golden(golden):
