@@ -338,8 +338,9 @@ class Leg:
         while t_cpu < seconds or reps < 1:
             tc = time.perf_counter()
             with torch.no_grad():
-                ora.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
-                ref = ora.inference(None, z=torch.from_numpy(z)).numpy()
+                dt_ = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+                ora.set_data_nba(dt_)
+                ref = ora.inference(dt_, z=torch.from_numpy(z)).numpy()
             t_cpu += time.perf_counter() - tc
             reps += 1
         err = np.abs(hip - ref) / (np.abs(ref) + 1.0)

@@ -74,43 +74,40 @@ __device__ __forceinline__ f32x16 ldrows(const float* p, int h) {
 }
 
 struct ChainStream {
-    const f32x4* pool; const int2* prog; f32x4* ring;
+    const f32x4* pool; const int2* lprog; f32x4* ring;  // lprog: the chunk program, copied to LDS at kernel start
     int len, p, par, lane, wave;
-    int2 nxt;  // program entry of the chunk after the one in flight
+    int2 nxt_v;  // program entry of the chunk after the one in flight: issued as an LDS read one step early, consumed
+                 // (readfirstlane) at the next begin().  It must NOT be a global load: with an LDS-DMA in flight hipcc waits
+                 // vmcnt(0) before the first use of any register-destination global load, i.e. for the DMA itself.
     static __device__ __forceinline__ void glds16(const void* g, void* l) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
-    __device__ __forceinline__ void dma(int2 e, int buf) {
+    __device__ __forceinline__ void dma(int2 ev, int buf) {
         // a chunk of nt tiles = 4*nt pieces of 1 KiB; wave w moves pieces w, w+4, w+8
-        const f32x4* src = pool + (size_t)e.x * C32_TILE + lane;
+        const int off = __builtin_amdgcn_readfirstlane(ev.x), nt = __builtin_amdgcn_readfirstlane(ev.y);
+        const f32x4* src = pool + (size_t)off * C32_TILE + lane;
         f32x4* dst = ring + buf * (C32_CMAX * C32_TILE);
 #pragma unroll
         for (int i = 0; i < C32_CMAX; ++i) {
             const int idx = 4 * i + wave;
-            if (i < e.y) glds16(src + idx * 64, dst + idx * 64);
+            if (i < nt) glds16(src + idx * 64, dst + idx * 64);
         }
     }
-    __device__ __forceinline__ int2 entry(int q) const {
-        int2 e = prog[q];
-        e.x = __builtin_amdgcn_readfirstlane(e.x);
-        e.y = __builtin_amdgcn_readfirstlane(e.y);
-        return e;
-    }
-    __device__ __forceinline__ void init(const f32x4* pool_, const int2* prog_, int len_, f32x4* ring_) {
-        pool = pool_; prog = prog_; len = len_; ring = ring_;
+    __device__ __forceinline__ void init(const f32x4* pool_, const int2* lprog_, int len_, f32x4* ring_) {
+        pool = pool_; lprog = lprog_; len = len_; ring = ring_;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         p = 0; par = 0;
-        dma(entry(0), 0);
-        nxt = entry(1 % len);
+        dma(lprog[0], 0);
+        nxt_v = lprog[1 % len];
     }
     // start of a chunk step: prefetch the next chunk into the other buffer (its readers passed the previous barrier)
     __device__ __forceinline__ void begin() {
         __builtin_amdgcn_sched_barrier(0);
-        dma(nxt, par ^ 1);
+        dma(nxt_v, par ^ 1);
         int q = p + 2;
         q = q >= len ? q - len : q;
-        nxt = entry(q);
+        nxt_v = lprog[q];
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ const f32x4* cur() const { return ring + par * (C32_CMAX * C32_TILE) + lane; }
@@ -202,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
     f32x4* slots = ring + C32_RING;
     float* cst = reinterpret_cast<float*>(slots + 4 * C32_SLOT);
-    int* sq = reinterpret_cast<int*>(cst + C32Const<NY>::total);  // [2]: group handed to this workgroup, parity-indexed
+    int2* lprog = reinterpret_cast<int2*>(cst + C32Const<NY>::total);
+    int* sq = reinterpret_cast<int*>(lprog + A.prog_len);  // [2]: this workgroup's first group / the group after the current one
     typedef C32Const<NY> CO;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
@@ -211,15 +209,13 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     const int ngroups = (A.ncols + 127) >> 7;
 
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
-    if (threadIdx.x == 0) {
-        sq[0] = atomicAdd(A.counter, 1);
-        sq[1] = atomicAdd(A.counter, 1);
-    }
-    ChainStream st;
-    st.init(A.pool, A.prog, A.prog_len, ring);
+    for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
+    if (threadIdx.x == 0) sq[0] = atomicAdd(A.counter, 1);
     __syncthreads();
-    int g = sq[0], gn = sq[1], qpar = 0;
-    if (g >= ngroups) return;  // (uniform) more workgroups than groups; the DMA issued by init() has landed (barrier above)
+    int g = sq[0];
+    if (g >= ngroups) return;  // (uniform) cannot happen with grid <= ngroups; nothing is in flight yet
+    ChainStream st;
+    st.init(A.pool, lprog, A.prog_len, ring);
 
     auto col_of = [&](int gg) { int col = gg * 128 + wave * 32 + c; return col < A.ncols ? col : A.ncols - 1; };
     {   // first gather: A0x rows of hidden tile 0
@@ -235,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         const int colc = col < A.ncols ? col : A.ncols - 1;
         const int agent = colc / A.K;
         const bool live = col < A.ncols;
-        // the group after the next one is requested now; it is read after the many barriers of this group
-        __syncthreads();  // every wave has read sq[qpar] (previous hand-over) before it is overwritten
-        if (threadIdx.x == 0) sq[qpar] = atomicAdd(A.counter, 1);
+        // the NEXT group is requested now (one ticket of look-ahead: the last MLP prefetches its first gather); every wave reads
+        // it after the many barriers of this group
+        __syncthreads();  // every wave has read sq[1] of the previous hand-over before it is overwritten
+        if (threadIdx.x == 0) sq[1] = atomicAdd(A.counter, 1);
 
         f32x16 acc2[8];
         f32x16 d;
@@ -340,10 +337,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                 for (int j = 0; j < 3; ++j) hs[j] = hn[j];
             }
         }
-        // next group's first gather pointer (A0x of its first hidden tile); sq[qpar] was written at the top of this group
-        const int g2 = sq[qpar];
-        qpar ^= 1;
-        const int gnext = gn;
+        const int gnext = sq[1];  // written at the top of this group
         {   // ---- block 1, decoder_y + epilogue
             f32x16 B[4];
             B[0] = ldrows(A.z + (size_t)colc * 32, h);
@@ -378,7 +372,6 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
             }
         }
         g = gnext;
-        gn = g2;
         if (g >= ngroups) break;  // uniform: every wave read the same sq words
     }
 }
@@ -396,19 +389,19 @@ static int chain_cus() {
     }
     return n;
 }
-template <int NY> static int chain_lds() { return (C32_RING + 4 * C32_SLOT) * 16 + C32Const<NY>::total * 4 + 16; }
+static int chain_lds(int NY, int prog_len) { return (C32_RING + 4 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
 template <int NY> static int chain_launch(const ChainArgs& a, hipStream_t s) {
     static bool attr_set = false;  // once per instantiation (hipFuncSetAttribute is a driver call)
     if (!attr_set) {
-        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds<NY>()));
+        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_set = true;
     }
     const int ngroups = (a.ncols + 127) / 128;
     int grid = 2 * chain_cus();
     if (grid > ngroups) grid = ngroups;
     STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), chain_lds<NY>(), s, a);
+    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), chain_lds(NY, a.prog_len), s, a);
     STT_HIP(hipGetLastError());
     return 0;
 }

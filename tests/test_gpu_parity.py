@@ -275,7 +275,7 @@ def test_fused_trajectory_chain_vs_three_kernel_form_and_oracle(case):
     elif case != 'k_not_20':
         with torch.no_grad():
             ora.set_data_nba(data)
-            ref = ora.inference(None, z=torch.from_numpy(z)).numpy()
+            ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
         assert_close(outs[1], ref, what=f'{case} vs oracle')
 
 
