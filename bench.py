@@ -149,6 +149,8 @@ LEGS = {
 
 
 class Leg:
+    DEPTH = 3
+
     def __init__(self, name, rank, dev, size=None):
         import torch
         from helpers import make_args
@@ -176,7 +178,9 @@ class Leg:
         self.F = flops(self.Tp, self.Tf, self.G)
         self.host = [t.pin_memory() for t in host]
         self.h2d_bytes = sum(t.numel() * t.element_size() for t in self.host)
-        self.slots = [[torch.empty_like(t, device=dev) for t in self.host] for _ in range(2)]
+        self.depth = Leg.DEPTH                                    # calls in flight (= model.async_depth): device input slots
+        self.model.async_depth = self.depth
+        self.slots = [[torch.empty_like(t, device=dev) for t in self.host] for _ in range(self.depth)]
         self.n_dev = torch.tensor(float(self.n), dtype=torch.float32, device=dev)
         self.calls = 0
         self.pending = []
@@ -184,7 +188,7 @@ class Leg:
 
     def _load(self):
         """H2D of this step's inputs (pinned -> one of two device slots, on the caller's stream) + the data-entry call."""
-        slot = self.slots[self.calls & 1]
+        slot = self.slots[self.calls % self.depth]
         self.calls += 1
         for d, h in zip(slot, self.host):
             d.copy_(h, non_blocking=True)
@@ -211,7 +215,7 @@ class Leg:
         h = self.model.inference_async()                        # z is drawn on device exactly like Normal.rsample in the reference
         h['gt'] = self.model._future
         self.pending.append(h)
-        return self._finish(self.pending.pop(0)) if len(self.pending) > 1 else None
+        return self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
 
     def drain(self):
         out = None
@@ -464,6 +468,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
+    ap.add_argument('--depth', type=int, default=3, help='calls in flight of the software pipeline (2..4)')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
     ap.add_argument('--legs', default='all', help="secondary legs: 'all', 'none' or a comma list of " + ','.join(k for k in LEGS if k != 'eth_512'))
     ap.add_argument('--leg-steps', type=int, default=10)
@@ -497,6 +502,7 @@ def main():
             dist.destroy_process_group()
         return 0
 
+    Leg.DEPTH = max(2, min(4, args.depth))
     head = Leg('eth_512', rank, dev, size=args.scenes)
     if args.col_parts:
         head.model.native().set_col_parts(args.col_parts)

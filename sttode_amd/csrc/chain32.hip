@@ -18,14 +18,24 @@
 //     32 rows x 32 k), double buffered, one workgroup barrier per chunk; the chunk order is a host-built PROGRAM
 //     (packing.chain_stream), so the kernel only consumes tiles in order.  The GRU's recurrent weights are streamed per
 //     step like everything else (66 FLOP per streamed byte, the same intensity as the MLP layers), which frees the
-//     144 KiB of LDS round 1 pinned for them: LDS per workgroup is 24 KiB ring + 16 KiB gather slots + 6 KiB biases.
+//     144 KiB of LDS round 1 pinned for them: LDS per workgroup is 24 KiB ring + 32 KiB gather / z slots + 8 KiB biases + program.
 //   * workgroup = 4 waves x 32 columns = 128 trajectories, 2 workgroups per CU (<= 256 VGPRs per wave); groups are
 //     handed out by an atomic work counter (one tail for the whole chain instead of three, and a later launch on
 //     another stream fills it: the kernel holds no chip-wide resource).
 #include "chain.hpp"
 #include "api_util.hpp"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// diagnostic builds (profiles/exp_chain_variants.sh; never shipped): -DC32_DIAG_NODMA / _NOGATHER / _NOBARRIER / _NOGATES
+#ifdef C32_DIAG_NOGATES
+#define C32_SIG(x) ((x) * 1e-3f)
+#define C32_TANH(x) ((x) * 1e-3f)
+#else
+#define C32_SIG(x) sigmoid_prescaled(x)
+#define C32_TANH(x) tanh_prescaled(x)
+#endif
 
 #define C32_TILE 256                        // f32x4 per tile (4 KiB)
 #define C32_CMAX 3                          // tiles per chunk
@@ -43,6 +53,8 @@ struct ChainArgs {
     float* pred;                                            // [ncols][Tf2]
     int* counter;                                           // work queue (zeroed before the launch)
     int ncols, K, Tp, Tf2;
+    int persistent;  // 1: workgroups pull groups from the work queue until it is empty; 0: one group per workgroup (grid = groups)
+    long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS): per-workgroup phase stamps
 };
 
 // consts layout (floats): b2x[256] b3x[32] | b2y[256] b3y[32*NY] | gbias[4][96] convb[32] | b2m[256] b3m[32*NY]
@@ -73,28 +85,40 @@ __device__ __forceinline__ f32x16 ldrows(const float* p, int h) {
     return r;
 }
 
+// LDS byte address of a pointer into shared memory (generic -> address space 3)
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// LDS-DMA issued from inline asm, so hipcc does NOT track it: with the builtin form it inserts s_waitcnt vmcnt(0) in front of
+// later LDS reads it cannot prove disjoint from the DMA's destination (here: every tile read of the other ring buffer), which
+// serialises DMA and MFMA -- measured 3.4x the MFMA time per chunk.  The completion is counted by hand: ChainStream::end() waits
+// vmcnt(0) before the workgroup barrier (the guide's recipe: cdna_hip_programming.md §5.7, glds16_asm).  `lds_dst` is the
+// wave-uniform destination byte address; the hardware adds lane * 16.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 struct ChainStream {
     const f32x4* pool; const int2* lprog; f32x4* ring;  // lprog: the chunk program, copied to LDS at kernel start
+    unsigned ring_addr;
     int len, p, par, lane, wave;
-    int2 nxt_v;  // program entry of the chunk after the one in flight: issued as an LDS read one step early, consumed
-                 // (readfirstlane) at the next begin().  It must NOT be a global load: with an LDS-DMA in flight hipcc waits
-                 // vmcnt(0) before the first use of any register-destination global load, i.e. for the DMA itself.
-    static __device__ __forceinline__ void glds16(const void* g, void* l) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    }
+    int2 nxt_v;  // program entry of the chunk after the one in flight: read from LDS one step early, consumed at the next begin()
     __device__ __forceinline__ void dma(int2 ev, int buf) {
         // a chunk of nt tiles = 4*nt pieces of 1 KiB; wave w moves pieces w, w+4, w+8
         const int off = __builtin_amdgcn_readfirstlane(ev.x), nt = __builtin_amdgcn_readfirstlane(ev.y);
         const f32x4* src = pool + (size_t)off * C32_TILE + lane;
-        f32x4* dst = ring + buf * (C32_CMAX * C32_TILE);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)buf * (C32_CMAX * C32_TILE * 16) + (unsigned)wave * 1024);
+#ifndef C32_DIAG_NODMA
 #pragma unroll
-        for (int i = 0; i < C32_CMAX; ++i) {
-            const int idx = 4 * i + wave;
-            if (i < nt) glds16(src + idx * 64, dst + idx * 64);
-        }
+        for (int i = 0; i < C32_CMAX; ++i)
+            if (i < nt) glds16_asm(src + (4 * i + wave) * 64, dst + i * 4096);
+#endif
     }
     __device__ __forceinline__ void init(const f32x4* pool_, const int2* lprog_, int len_, f32x4* ring_) {
         pool = pool_; lprog = lprog_; len = len_; ring = ring_;
+        ring_addr = lds_addr(ring_);
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         p = 0; par = 0;
@@ -111,10 +135,13 @@ struct ChainStream {
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ const f32x4* cur() const { return ring + par * (C32_CMAX * C32_TILE) + lane; }
-    // end of a chunk step: the barrier's fence waits vmcnt(0) first -- exactly the wait this wave's DMA pieces need
+    // end of a chunk step: this wave's DMA pieces have landed (vmcnt), then everybody's (barrier)
     __device__ __forceinline__ void end() {
         __builtin_amdgcn_sched_barrier(0);
+#ifndef C32_DIAG_NOBARRIER
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
         p = p + 1 >= len ? 0 : p + 1;
         par ^= 1;
         __builtin_amdgcn_sched_barrier(0);
@@ -131,37 +158,50 @@ __device__ __forceinline__ void tile_mma(f32x16& acc, const f32x4* __restrict__ 
     }
 }
 
-// Layers 1+2 of one MLP for this wave's 32 columns: acc2 (256 rows = 8 tiles) += W2 relu(A0[agent] + W1v B).
-// Per 32-row hidden tile: KT1 layer-1 tiles then 8 layer-2 tiles, a chunk boundary every 3 tiles ((KT1 + 8) % 3 == 0).
+// Layers 1+2 of one MLP for this wave's 32 columns: acc2 (256 rows = 8 tiles) += W2 relu(A0[agent] + W1v [z | Bh]).
+// Per 32-row hidden tile: 1 + KH layer-1 tiles then 8 layer-2 tiles, a chunk boundary every 3 tiles ((1 + KH + 8) % 3 == 0).
+// z (the first layer-1 k-tile's B operand) is read from the wave's LDS z slot every hidden tile (it would cost 16 VGPRs for the
+// whole group otherwise; the kernel has 256 and must not spill: a kernel with ANY scratch pays a scratch set-up per dispatch).
 // The per-agent pre-activation rows arrive through the wave's gather slot (4 x 16 B per lane per hidden tile, LDS-DMA):
 // a0 points at this lane's A0 row; a0_next at the row the NEXT phase starts with.
-template <int KT1>
-__device__ __forceinline__ void mlp_l12(ChainStream& st, f32x4* slot, const f32x16 (&B)[KT1], const float* __restrict__ a0,
-                                        const float* __restrict__ a0_next, f32x16 (&acc2)[8], int lane, int h) {
+template <int KH>
+__device__ __forceinline__ void mlp_l12(ChainStream& st, const f32x4* slot, const f32x4* zslot, const f32x16* Bh,
+                                        const float* __restrict__ a0, const float* __restrict__ a0_next, f32x16 (&acc2)[8], int lane, int h) {
+    const unsigned slot_addr = __builtin_amdgcn_readfirstlane(lds_addr(slot));
+    constexpr int KT1 = 1 + KH;
     static_assert((KT1 + 8) % 3 == 0, "hidden tile must be a whole number of chunks");
 #pragma unroll
     for (int R = 0; R < 8; ++R) acc2[R] = splat16(0.f);
 #pragma unroll 1
     for (int ht = 0; ht < 16; ++ht) {
-        f32x16 h1;
+        f32x16 h1, zb;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const f32x4 v = slot[a * 64 + lane];
             h1[4 * a + 0] = v[0]; h1[4 * a + 1] = v[1]; h1[4 * a + 2] = v[2]; h1[4 * a + 3] = v[3];
         }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 v = zslot[a * 64 + lane];
+            zb[4 * a + 0] = v[0]; zb[4 * a + 1] = v[1]; zb[4 * a + 2] = v[2]; zb[4 * a + 3] = v[3];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the gather issued next
         __builtin_amdgcn_sched_barrier(0);
         const float* nx = (ht + 1 < 16) ? a0 + 32 * (ht + 1) : a0_next;
         st.begin();
+#ifndef C32_DIAG_NOGATHER
 #pragma unroll
-        for (int a = 0; a < 4; ++a) ChainStream::glds16(nx + 8 * a + 4 * h, slot + a * 64);
+        for (int a = 0; a < 4; ++a) glds16_asm(nx + 8 * a + 4 * h, slot_addr + a * 1024);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < KT1 + 8; ++i) {
             if (i > 0 && i % 3 == 0) { st.end(); st.begin(); }
             const f32x4* t = st.cur() + (i % 3) * C32_TILE;
-            if (i < KT1) {
-                tile_mma(h1, t, B[i]);
+            if (i == 0) {
+                tile_mma(h1, t, zb);
+            } else if (i < KT1) {
+                tile_mma(h1, t, Bh[i - 1]);
             } else {
                 if (i == KT1) h1 = relu16(h1);
                 tile_mma(acc2[i - KT1], t, h1);
@@ -180,6 +220,7 @@ __device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const
         STT_FENCE();  // keep the bias reads next to their use (hoisted as a block they spill)
         const f32x16 b = ldrows(b2 + 32 * R, h);
         acc2[R] = relu16(acc2[R] + b);
+        asm volatile("" : "+v"(acc2[R]));  // ... and the add right behind its read (8 bias tiles in flight = 128 VGPRs otherwise)
     }
     STT_FENCE();
 #pragma unroll
@@ -193,24 +234,39 @@ __device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const
     st.end();
 }
 
+// makes a per-lane integer opaque to the optimiser: address arithmetic derived from it is redone where it is used instead of
+// being computed once at the top of the group and kept live (64-bit pointers held across phases were what spilled)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+#ifdef C32_DIAG_STAMPS
+#define C32_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && gi < 4) { A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k)] = __builtin_amdgcn_s_memtime(); \
+                                                                    A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define C32_STAMP(k) do { } while (0)
+#endif
+
 template <int NY>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
     f32x4* slots = ring + C32_RING;
-    float* cst = reinterpret_cast<float*>(slots + 4 * C32_SLOT);
+    f32x4* zslots = slots + 4 * C32_SLOT;
+    float* cst = reinterpret_cast<float*>(zslots + 4 * C32_SLOT);
     int2* lprog = reinterpret_cast<int2*>(cst + C32Const<NY>::total);
     int* sq = reinterpret_cast<int*>(lprog + A.prog_len);  // [2]: this workgroup's first group / the group after the current one
     typedef C32Const<NY> CO;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x4* slot = slots + wave * C32_SLOT;
+    const f32x4* slot = slots + wave * C32_SLOT;
+    const f32x4* zslot = zslots + wave * C32_SLOT;
+    const unsigned slot_addr = __builtin_amdgcn_readfirstlane(lds_addr(slot));
+    const unsigned zslot_addr = __builtin_amdgcn_readfirstlane(lds_addr(zslot));
     const int ngroups = (A.ncols + 127) >> 7;
 
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
     for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
-    if (threadIdx.x == 0) sq[0] = atomicAdd(A.counter, 1);
+    if (threadIdx.x == 0) sq[0] = A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
     __syncthreads();
     int g = sq[0];
     if (g >= ngroups) return;  // (uniform) cannot happen with grid <= ngroups; nothing is in flight yet
@@ -218,32 +274,38 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     st.init(A.pool, lprog, A.prog_len, ring);
 
     auto col_of = [&](int gg) { int col = gg * 128 + wave * 32 + c; return col < A.ncols ? col : A.ncols - 1; };
-    {   // first gather: A0x rows of hidden tile 0
-        const float* a0 = A.A0x + (size_t)(col_of(g) / A.K) * 512;
+    {   // first gathers: A0x rows of hidden tile 0, and z of this group
+        const int c0 = col_of(g);
+        const float* a0 = A.A0x + (size_t)(c0 / A.K) * 512;
+        const float* zp = A.z + (size_t)c0 * 32;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) ChainStream::glds16(a0 + 8 * a + 4 * h, slot + a * 64);
+        for (int a = 0; a < 4; ++a) glds16_asm(a0 + 8 * a + 4 * h, slot_addr + a * 1024);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) glds16_asm(zp + 8 * a + 4 * h, zslot_addr + a * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int gi = 0;
     while (true) {
+        C32_STAMP(0);
         const int col = g * 128 + wave * 32 + c;
-        const int colc = col < A.ncols ? col : A.ncols - 1;
-        const int agent = colc / A.K;
+        int colc = col < A.ncols ? col : A.ncols - 1;
+        int agent = colc / A.K;
         const bool live = col < A.ncols;
         // the NEXT group is requested now (one ticket of look-ahead: the last MLP prefetches its first gather); every wave reads
         // it after the many barriers of this group
         __syncthreads();  // every wave has read sq[1] of the previous hand-over before it is overwritten
-        if (threadIdx.x == 0) sq[1] = atomicAdd(A.counter, 1);
+        if (threadIdx.x == 0) sq[1] = A.persistent ? atomicAdd(A.counter, 1) : ngroups;
 
         f32x16 acc2[8];
         f32x16 d;
         {   // ---- block 0, decoder_x: x_hat0, d = x_true - x_hat0
-            f32x16 B[1];
-            B[0] = ldrows(A.z + (size_t)colc * 32, h);
-            mlp_l12<1>(st, slot, B, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
+            agent = opaque(agent);
+            mlp_l12<0>(st, slot, zslot, nullptr, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
             f32x16 xo[1];
             mlp_l3<1>(st, acc2, cst + CO::b2x, cst + CO::b3x, xo, h);
+            agent = opaque(agent);
             const float* xp = A.xpad + (size_t)agent * A.ldx;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -253,19 +315,21 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                 for (int b = 0; b < 4; ++b) d[4 * a + b] = v[b] - xo[0][4 * a + b];
             }
         }
+        STT_FENCE();
+        C32_STAMP(1);
         {   // ---- block 0, decoder_y: y_hat0 parked in pred (re-read by the epilogue)
-            f32x16 B[1];
-            B[0] = ldrows(A.z + (size_t)colc * 32, h);
-            mlp_l12<1>(st, slot, B, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
+            agent = opaque(agent);
+            mlp_l12<0>(st, slot, zslot, nullptr, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
             f32x16 yo[NY];
             mlp_l3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
             if (live) {
+                float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
 #pragma unroll
                 for (int o = 0; o < NY; ++o)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const int row0 = 32 * o + 8 * a + 4 * h;
-                        float* p = A.pred + (size_t)col * A.Tf2 + row0;
+                        float* p = prow + row0;
                         if (row0 + 3 < A.Tf2 && (A.Tf2 & 3) == 0) {
                             f32x4 v = {yo[o][4 * a], yo[o][4 * a + 1], yo[o][4 * a + 2], yo[o][4 * a + 3]};
                             st4(p, v);
@@ -277,6 +341,8 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     }
             }
         }
+        STT_FENCE();
+        C32_STAMP(2);
         f32x16 hs[3];
         {   // ---- block 1: conv1d + relu + GRU over Tp steps, weights streamed per step (gate rows pre-scaled, chain.hpp)
 #pragma unroll
@@ -303,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     st.end(); st.begin();
                     tile_mma(ar, st.cur() + 0 * C32_TILE, hs[2]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ar[r] = sigmoid_prescaled(ar[r]);          // r gate
+                    for (int r = 0; r < 16; ++r) ar[r] = C32_SIG(ar[r]);          // r gate
                     STT_FENCE();
                     f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
                     tile_mma(az, st.cur() + 1 * C32_TILE, e);
@@ -312,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     tile_mma(az, st.cur() + 0 * C32_TILE, hs[1]);
                     tile_mma(az, st.cur() + 1 * C32_TILE, hs[2]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) az[r] = sigmoid_prescaled(az[r]);          // z gate
+                    for (int r = 0; r < 16; ++r) az[r] = C32_SIG(az[r]);          // z gate
                     STT_FENCE();
                     f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
                     tile_mma(an, st.cur() + 2 * C32_TILE, hs[0]);
@@ -329,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     st.end();
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float ng = tanh_prescaled(an[r]);
+                        const float ng = C32_TANH(an[r]);
                         hn[j][r] = fmaf(az[r], hs[j][r] - ng, ng);  // (1-z) n + z h
                     }
                 }
@@ -337,24 +403,31 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                 for (int j = 0; j < 3; ++j) hs[j] = hn[j];
             }
         }
+        STT_FENCE();
+        C32_STAMP(3);
         const int gnext = sq[1];  // written at the top of this group
         {   // ---- block 1, decoder_y + epilogue
-            f32x16 B[4];
-            B[0] = ldrows(A.z + (size_t)colc * 32, h);
-            B[1] = hs[0]; B[2] = hs[1]; B[3] = hs[2];
-            const int agent_nx = col_of(gnext < ngroups ? gnext : g) / A.K;
-            mlp_l12<4>(st, slot, B, A.A1y + (size_t)agent * 512, A.A0x + (size_t)agent_nx * 512, acc2, lane, h);
+            agent = opaque(agent);
+            const int cnx = col_of(gnext < ngroups ? gnext : g);
+            mlp_l12<3>(st, slot, zslot, hs, A.A1y + (size_t)agent * 512, A.A0x + (size_t)(cnx / A.K) * 512, acc2, lane, h);
+            {   // z of the NEXT group into the z slot (this group's last read of it is behind us); lands during layer 3
+                const float* zp = A.z + (size_t)opaque(cnx) * 32;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) glds16_asm(zp + 8 * a + 4 * h, zslot_addr + a * 1024);
+            }
             f32x16 yo[NY];
             mlp_l3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
             if (live) {
+                agent = opaque(agent);
                 const float cx = A.cur[2 * agent], cy = A.cur[2 * agent + 1];
                 const float ox = A.orig[2 * agent], oy = A.orig[2 * agent + 1];
+                float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
 #pragma unroll
                 for (int o = 0; o < NY; ++o)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const int row0 = 32 * o + 8 * a + 4 * h;
-                        float* p = A.pred + (size_t)col * A.Tf2 + row0;
+                        float* p = prow + row0;
                         if (row0 + 3 < A.Tf2 && (A.Tf2 & 3) == 0) {
                             const f32x4 y0 = ld4(p);
                             f32x4 v;
@@ -371,8 +444,10 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     }
             }
         }
+        C32_STAMP(4);
+        ++gi;
         g = gnext;
-        if (g >= ngroups) break;  // uniform: every wave read the same sq words
+        if (g >= ngroups) break;  // uniform: every wave read the same sq word
     }
 }
 
@@ -389,22 +464,31 @@ static int chain_cus() {
     }
     return n;
 }
-static int chain_lds(int NY, int prog_len) { return (C32_RING + 4 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
+static int chain_lds(int NY, int prog_len) { return (C32_RING + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
 template <int NY> static int chain_launch(const ChainArgs& a, hipStream_t s) {
     static bool attr_set = false;  // once per instantiation (hipFuncSetAttribute is a driver call)
     if (!attr_set) {
-        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         attr_set = true;
     }
     const int ngroups = (a.ncols + 127) / 128;
-    int grid = 2 * chain_cus();
-    if (grid > ngroups) grid = ngroups;
+    // STTODE_CHAIN_RESERVE=r leaves r of the chip's 2-per-CU workgroup slots to concurrently running kernels (the per-agent stage
+    // of the next call in the pipelined form); the work queue makes the remaining workgroups absorb the groups
+    static int reserve = -1;
+    if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
+    int grid = 2 * chain_cus() - reserve;
+    if (grid > ngroups || !a.persistent) grid = ngroups;
     STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));
     hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), chain_lds(NY, a.prog_len), s, a);
     STT_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef C32_DIAG_STAMPS
+static long long* g_chain_dbg = nullptr;
+extern "C" int sttode_chain_debug_buffer(void* p) { g_chain_dbg = (long long*)p; return 0; }  // >= grid * 4 * 16 int64, zeroed
+#endif
 
 extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
     const int NY = (2 * Tf + 31) / 32;
@@ -425,6 +509,17 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
     a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
     a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
     a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
+    a.dbg = nullptr;
+    {
+        static int pers = -1;   // default 0: one group per workgroup (slots free up continuously, so kernels of other streams -- the next
+                                // call's per-agent stage, the next chain -- interleave at group granularity; measured 1.38 vs 1.87 ms per
+                                // 256-scene step); STTODE_CHAIN_PERSISTENT=1: workgroups pull groups from the atomic work queue
+        if (pers < 0) { const char* e = getenv("STTODE_CHAIN_PERSISTENT"); pers = e ? (atoi(e) != 0) : 0; }
+        a.persistent = pers;
+    }
+#ifdef C32_DIAG_STAMPS
+    a.dbg = g_chain_dbg;
+#endif
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {

@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #define STT_MAX_PARTS 8
+#define STT_MAX_SLOTS 4   // workspace / prediction slots of the cross-call pipeline (sttode_inference_*_async)
 struct TimRec { int stage; hipEvent_t e0, e1; };
 
 struct SttodeModel {
@@ -33,8 +34,9 @@ struct SttodeModel {
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB, sB2;
-    int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate slots between sB and sB2
-    hipEvent_t ev_call, evA_done[2], evB_done[2];
+    int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate calls between sB and sB2
+    long acalls;
+    hipEvent_t ev_call, evA_done[STT_MAX_SLOTS], evB_done[STT_MAX_SLOTS];
     bool timing;        // brackets active for the CURRENT call
     int timing_every;   // 0 = off, n = bracket every n-th forward call
     long calls;
@@ -59,7 +61,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->timing = false;
     m->timing_every = 0;
     m->calls = 0;
-    m->b_streams = 1;
+    m->b_streams = 2;
+    m->acalls = 0;
     if (const char* e = getenv("STTODE_B_STREAMS")) m->b_streams = atoi(e) == 2 ? 2 : 1;
     m->chain_mode = -1;
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
@@ -70,20 +73,28 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     if (m->col_parts > STT_MAX_PARTS) m->col_parts = STT_MAX_PARTS;
     // All internal streams run at normal priority.  Measured on MI355X: high priority for the per-agent streams makes the
     // cross-call pipeline slower (61.6 M traj/s with sA+side raised, 65.6 M with only side raised, 66.9 M with neither).
-    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess &&
+    // STTODE_A_PRIORITY=1: the per-agent streams (sA, side) get the highest stream priority, so their small kernels are dispatched
+    // first whenever a running per-trajectory kernel frees workgroup slots
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const bool a_prio = getenv("STTODE_A_PRIORITY") && atoi(getenv("STTODE_A_PRIORITY")) > 0;
+    auto mk_stream = [&](hipStream_t* st, bool high) {
+        return (high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+    };
+    m->side = nullptr;   // created on the first serial call
+    bool ok =              hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&m->ev_agents, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < STT_MAX_PARTS && ok; ++p) {
         m->part_stream[p] = nullptr;
         ok = hipEventCreateWithFlags(&m->ev_part[p], hipEventDisableTiming) == hipSuccess &&
-             (p == 0 || hipStreamCreateWithFlags(&m->part_stream[p], hipStreamNonBlocking) == hipSuccess);
+             true;   // part streams are created on first use (every stream takes a share of the 4 hardware queues)
     }
-    ok = ok && hipStreamCreateWithFlags(&m->sA, hipStreamNonBlocking) == hipSuccess &&
+    ok = ok && mk_stream(&m->sA, a_prio) &&
          hipStreamCreateWithFlags(&m->sB, hipStreamNonBlocking) == hipSuccess &&
          hipStreamCreateWithFlags(&m->sB2, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
-    for (int p = 0; p < 2 && ok; ++p)
+    for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evB_done[p], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -100,10 +111,11 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     for (auto& r : m->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : m->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); (void)hipEventDestroy(m->ev_agents);
-    for (int p = 0; p < STT_MAX_PARTS; ++p) { (void)hipEventDestroy(m->ev_part[p]); if (p) (void)hipStreamDestroy(m->part_stream[p]); }
-    (void)hipStreamDestroy(m->side); (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB); (void)hipStreamDestroy(m->sB2);
+    for (int p = 0; p < STT_MAX_PARTS; ++p) { (void)hipEventDestroy(m->ev_part[p]); if (p && m->part_stream[p]) (void)hipStreamDestroy(m->part_stream[p]); }
+    if (m->side) (void)hipStreamDestroy(m->side);
+    (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB); (void)hipStreamDestroy(m->sB2);
     (void)hipEventDestroy(m->ev_call);
-    for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
+    for (int p = 0; p < STT_MAX_SLOTS; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
     delete m;
     return 0;
 }
@@ -203,7 +215,7 @@ struct StageTimer {
     } while (0)
 
 // stage A: everything per AGENT (encoder, block-0 GRU on the side stream, layer-1 pre-activations), on stream s
-static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, hipStream_t s) {
+static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, hipStream_t s, bool use_side) {
     const float* const* W = m->w;
     const int Tp = m->Tp, TPX = m->TPX;
     float* xpad = ws + off[STT_B_XPAD];
@@ -215,12 +227,18 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
 
     // fork: block-0 conv+GRU (per agent) only needs the front-end output; it runs beside the encoder
-    STT_HIP(hipEventRecord(m->ev_fork, s));
-    STT_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    RUN(STT_STAGE_GRU0, m->side,
+    // (pipelined form: no side stream -- the stage already runs beside the previous calls' per-trajectory kernels, and every
+    // extra stream shares one of the 4 hardware queues with the streams that must overlap)
+    if (use_side && !m->side) STT_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    hipStream_t gs = use_side ? m->side : s;
+    if (use_side) {
+        STT_HIP(hipEventRecord(m->ev_fork, s));
+        STT_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    }
+    RUN(STT_STAGE_GRU0, gs,
         sttode_gru_cols(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
-                        Tp, TPX, m->side));
-    STT_HIP(hipEventRecord(m->ev_join, m->side));
+                        Tp, TPX, gs));
+    if (use_side) STT_HIP(hipEventRecord(m->ev_join, m->side));
 
     RUN(STT_STAGE_EMBED, s,
         sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
@@ -241,7 +259,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         sttode_post_attn(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
                          W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], g,
                          attn_src, ld_attn, pf, n, 12.0f, s));
-    STT_HIP(hipStreamWaitEvent(s, m->ev_join, 0));  // join
+    if (use_side) STT_HIP(hipStreamWaitEvent(s, m->ev_join, 0));  // join
     RUN(STT_STAGE_LINEAR, s,
         sttode_agent_preact(pf, state0, W[STT_W_B0_XWA], W[STT_W_B0_XB1], W[STT_W_B0_YWA], W[STT_W_B0_YB1], W[STT_W_B1_YWA], W[STT_W_B1_YB1],
                             A0x, A0y, A1y, n, s));
@@ -277,6 +295,7 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
         const long a0 = (long)n * p / P, a1 = (long)n * (p + 1) / P;
         const int na = (int)(a1 - a0), nc = na * K;
         const long c0 = a0 * K;
+        if (p > 0 && !m->part_stream[p]) STT_HIP(hipStreamCreateWithFlags(&m->part_stream[p], hipStreamNonBlocking));
         hipStream_t ps = p == 0 ? s : m->part_stream[p];
         if (p > 0) STT_HIP(hipStreamWaitEvent(ps, m->ev_agents, 0));
         RUN(STT_STAGE_MLP0, ps,
@@ -321,14 +340,14 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
-    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s)) return rc;
+    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
     return stage_trajectories(m, ws, off, n, z, pred, s);
 }
 
 // pipelined form: stage A on sA, stage B on sB, two workspace slots; the caller later waits with sttode_wait(slot)
 static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
                      float* pred, int slot, hipStream_t s) {
-    STT_REQUIRE(slot == 0 || slot == 1, "sttode_inference_*_async: slot must be 0 or 1");
+    STT_REQUIRE(slot >= 0 && slot < STT_MAX_SLOTS, "sttode_inference_*_async: slot must be in [0, 4)");
     arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
@@ -336,9 +355,11 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     STT_HIP(hipStreamWaitEvent(m->sA, m->ev_call, 0));
     STT_HIP(hipStreamWaitEvent(m->sA, m->evB_done[slot], 0));    // the slot's previous user (call i-2) has drained
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, m->sA)) return rc;
-    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA)) return rc;
+    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA, false)) return rc;
     STT_HIP(hipEventRecord(m->evA_done[slot], m->sA));
-    hipStream_t sb = (m->b_streams == 2 && slot == 1) ? m->sB2 : m->sB;
+    // per-trajectory stages of consecutive calls alternate between two streams (b_streams == 2): the persistent chain kernel of
+    // call i+1 then starts on the compute units its predecessor's last workgroups leave (no chip-wide resource is held)
+    hipStream_t sb = (m->b_streams == 2 && (m->acalls++ & 1)) ? m->sB2 : m->sB;
     STT_HIP(hipStreamWaitEvent(sb, m->ev_call, 0));
     STT_HIP(hipStreamWaitEvent(sb, m->evA_done[slot], 0));
     if (int rc = stage_trajectories(m, ws, off, n, z, pred, sb)) return rc;
@@ -376,7 +397,7 @@ extern "C" int sttode_inference_nba_async(SttodeModel* m, const float* past, int
 
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
-    STT_REQUIRE(m && (slot == 0 || slot == 1), "sttode_wait: bad arguments");
+    STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");
     STT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->evB_done[slot], 0));
     return 0;
 }

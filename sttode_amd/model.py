@@ -167,6 +167,7 @@ class STTODENet(nn.Module):
         self._packed_key = None
         self._mode = None
         self._async_calls = 0
+        self.async_depth = 3     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
         self._ptr_cache = {}
         self._pf = self._pf_thunk = None
@@ -584,8 +585,9 @@ class STTODENet(nn.Module):
     @torch.no_grad()
     def inference_async(self, z=None):
         """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  The per-agent stage
-        runs on an internal stream beside the per-trajectory kernels of the previous call; two slots alternate, so at most
-        two calls may be in flight: call ``wait(handle)`` (which returns the [K, n, Tf, 2] view) before the second-next call.
+        runs on an internal stream beside the per-trajectory kernels of the previous calls; ``async_depth`` (default 3) slots rotate,
+        so at most that many calls may be in flight: call ``wait(handle)`` (which returns the [K, n, Tf, 2] view) before the
+        ``async_depth``-th next call.
         Inputs set by set_data / set_scene_batch / set_data_nba must stay unmodified until then.  Bitwise identical to inference()."""
         self._require_gpu()
         a = self.args
@@ -600,7 +602,7 @@ class STTODENet(nn.Module):
         if tuple(z.shape) != (n * K, a.zdim):
             raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
         S = self._S if self._mode == 'scenes' else 0
-        slot = self._async_calls & 1
+        slot = self._async_calls % max(2, min(4, int(self.async_depth)))
         self._async_calls += 1
         key = (n, S, slot)
         if key not in self._async_bufs:
