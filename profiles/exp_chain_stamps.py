@@ -17,14 +17,15 @@ for S in [int(a) for a in sys.argv[1:]] or [128]:
     m.native().set_chain(1)
     for _ in range(3):
         m.inference(None)
-    dbg = torch.zeros(512 * 4 * 16, dtype=torch.int64, device=dev)
+    ngroups = (sb.n_agents * 20 + 127) // 128
+    nwg = max(512, ngroups)                      # non-persistent launches use one workgroup per group
+    dbg = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=dev)
     L.sttode_chain_debug_buffer.argtypes = [ctypes.c_void_p]
     L.sttode_chain_debug_buffer(dbg.data_ptr())
     m.inference(None)
     torch.cuda.synchronize()
     L.sttode_chain_debug_buffer(None)
-    d = dbg.cpu().numpy().reshape(512, 4, 8, 2)
-    ngroups = (sb.n_agents * 20 + 127) // 128
+    d = dbg.cpu().numpy().reshape(nwg, 4, 8, 2)
     valid = d[:, :, 0, 0] > 0
     cyc = d[..., 0].astype(np.float64); ns = d[..., 1].astype(np.float64) * 10.0
     names = ['mlp0x', 'mlp0y', 'gru', 'mlp1']
