@@ -66,6 +66,16 @@ int sttode_post_attn(const float* outP, const float* outb, const float* infoP, c
                      const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* g, const float* attn,
                      int ld_attn, float* pf, int n, float ode_time, void* stream);
 
+/* The same layer with the integrator as a kernel parameter (the north star names RK4 / multi-step updates; the reference itself only ever
+ * runs ONE Euler step, ode_demo.py:186-190, so anything else is checked against the CPU oracle only: parity unpinned).
+ * method 0 Euler | 1 torchdiffeq fixed-grid "rk4" (3/8 rule) | 2 classical RK4; `steps` uniform steps over [0, ode_time].  Attention
+ * length 1 only (ETH/UCY/SDD path: the attention output of a stage's state is W_v y + b_v, taken from the packed in-projection
+ * inP/inb and evaluated inside the kernel); (method 0, steps 1) equals sttode_post_attn. */
+int sttode_post_attn_ode(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                         const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                         const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* inP, const float* inb,
+                         const float* g, float* pf, int n, float ode_time, int method, int steps, void* stream);
+
 /* DecomposeBlock front half (model/STTODE.py:62-69): conv1d(2->32,k3,pad1)+relu, GRU(32->96) final state.
  * xin [ncols,16*TPX] = flattened (x_true - x_hat) -> state [ncols,96]. */
 int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
@@ -273,6 +283,9 @@ int sttode_set_col_parts(SttodeModel* m, int parts);
 /* per-trajectory stage: 1 = fused chain kernel (sttode_traj_chain), 0 = the three-kernel form (mlp_block0 -> gru_cols -> mlp_block1),
  * -1 = automatic (fused when the batch has >= 128 trajectories per workgroup slot to fill; default, or env STTODE_CHAIN). */
 int sttode_set_chain(SttodeModel* m, int mode);
+/* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
+ * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */
+int sttode_set_ode(SttodeModel* m, int method, int steps);
 /* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams */
 int sttode_timing_enable(SttodeModel* m, int every);
 int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);

@@ -21,6 +21,7 @@ SIGNATURES = {
     'sttode_embed_qkv': [_P] * 11 + [_P, _P, _P, _P, _I, _I, _P],
     'sttode_mhgsa_attn': [_P, _P, _P, _P, _P, _P, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
+    'sttode_post_attn_ode': [_P] * 16 + [_P, _P, _I, _F, _I, _I, _P],
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_agent_preact': [_P] * 11 + [_I, _P],
@@ -67,6 +68,7 @@ SIGNATURES = {
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
+    'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
@@ -122,6 +124,10 @@ class NativeModel:
         """1: fused per-trajectory chain kernel, 0: three-kernel form, -1: automatic."""
         if lib().sttode_set_chain(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_chain failed: ' + lib().sttode_last_error().decode())
+
+    def set_ode(self, method, steps):
+        if lib().sttode_set_ode(self.h, int(method), int(steps)) != 0:
+            raise SttodeError('sttode_set_ode failed: ' + lib().sttode_last_error().decode())
 
     def timing(self, every):
         """0/False: off; n: bracket every n-th forward call (True == every call)."""

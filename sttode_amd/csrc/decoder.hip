@@ -532,6 +532,15 @@ static int nonpersistent() {
     if (v < 0) { const char* e = getenv("STTODE_NONPERSISTENT"); v = (e && e[0] == '1') ? 1 : 0; }
     return v;
 }
+// hipFuncSetAttribute is a driver call: once per kernel instantiation, not once per launch
+#define STT_SET_LDS_ONCE(kernel, bytes)                                                                        \
+    do {                                                                                                       \
+        static bool _done = false;                                                                             \
+        if (!_done) {                                                                                          \
+            STT_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            _done = true;                                                                                      \
+        }                                                                                                      \
+    } while (0)
 static int g_num_cu = 0;
 static int num_cus() {
     if (!g_num_cu) {
@@ -559,11 +568,11 @@ extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float
     int grid = (ntiles + nw - 1) / nw;
     if (grid > num_cus()) grid = num_cus();
     if (TPX == 1) {
-        STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
+        STT_SET_LDS_ONCE(gru_cols_kernel<1>, GRU_LDS_BYTES);
         hipLaunchKernelGGL(gru_cols_kernel<1>, dim3(grid), dim3(threads), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     } else {
-        STT_HIP(hipFuncSetAttribute((const void*)gru_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GRU_LDS_BYTES));
+        STT_SET_LDS_ONCE(gru_cols_kernel<2>, GRU_LDS_BYTES);
         hipLaunchKernelGGL(gru_cols_kernel<2>, dim3(grid), dim3(threads), GRU_LDS_BYTES, s, xin, (const f32x4*)convP, convB,
                            (const f32x4*)wihP, (const f32x4*)whhP, gbias, state, ncols, Tp);
     }
@@ -639,7 +648,7 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     hipStream_t s = (hipStream_t)stream_;
 #define L0(TX, NY)                                                                                                              \
     do {                                                                                                                        \
-        STT_HIP(hipFuncSetAttribute((const void*)mlp_block0_kernel<TX, NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP0_LDS(TX, NY))); \
+        STT_SET_LDS_ONCE((mlp_block0_kernel<TX, NY>), MLP0_LDS(TX, NY));                                                        \
         hipLaunchKernelGGL((mlp_block0_kernel<TX, NY>), dim3(grid), dim3(256), MLP0_LDS(TX, NY), s, A0x, A0y, (const f32x4*)stream, \
                            total_chunks, z, xpad, dbuf, ybuf, ncols, K);                                                \
     } while (0)
@@ -667,7 +676,7 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
     hipStream_t s = (hipStream_t)stream_;
 #define L1(NY)                                                                                                              \
     do {                                                                                                                    \
-        STT_HIP(hipFuncSetAttribute((const void*)mlp_block1_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
+        STT_SET_LDS_ONCE(mlp_block1_kernel<NY>, MLP1_LDS(NY));                                                              \
         hipLaunchKernelGGL((mlp_block1_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A1y, (const f32x4*)stream, total_chunks, \
                            z, state1, ybuf, cur, orig, pred, ncols, K, 2 * Tf);                                      \
     } while (0)
@@ -695,7 +704,7 @@ extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_c
     hipStream_t s = (hipStream_t)stream_;
 #define LC(NY)                                                                                                              \
     do {                                                                                                                    \
-        STT_HIP(hipFuncSetAttribute((const void*)mlp_cols_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP1_LDS(NY))); \
+        STT_SET_LDS_ONCE(mlp_cols_kernel<NY>, MLP1_LDS(NY));                                                                \
         hipLaunchKernelGGL((mlp_cols_kernel<NY>), dim3(grid), dim3(256), MLP1_LDS(NY), s, A0, (const f32x4*)stream, total_chunks, z, \
                            state, out, ncols, K);                                                                           \
     } while (0)

@@ -235,21 +235,11 @@ struct PostW {
 //                            the four partials are summed through LDS;
 //   LayerNorms / Euler     : recomputed by every wave on the full 64 features (cheap VALU), wave w stores tile w.
 // The serial MFMA chain per wave drops from ~2200 to ~560 instructions (this kernel is latency-bound: 541 tiles only).
-__global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g,  // [n][64]
-                                                        const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
-                                                        float* __restrict__ pf,                       // [n][128]
-                                                        int n, float ode_time) {
-    __shared__ f32x4 sX[4][4][64];  // [slot][tile][lane] exchange buffer (16 KiB)
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wv = threadIdx.x >> 6;
-    const int col = blockIdx.x * 16 + c;
-    const int colc = col < n ? col : n - 1;
-    f32x4 a[4], gg[4], x[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-        a[T] = ld4(attn + (size_t)colc * ld_attn + 16 * T + 4 * q);
-        gg[T] = ld4(g + (size_t)colc * 64 + 16 * T + 4 * q);
-    }
+// Right-hand side of the tensor ODE for 16 columns held by this workgroup: f(y) = LN2(h + FFN(h)), h = LN1(y + gate(out_proj(a)))
+// (hypertransformer.py:134-153, :81-83), `a` = attention output for state y.  Every wave enters with the full a[4], y[4] tiles and
+// leaves with the full result in x[4]; sX is the 16 KiB exchange buffer.  Ends with a barrier-protected sX, so calls can be chained.
+__device__ __forceinline__ void ode_rhs(const PostW& w, f32x4 (*sX)[4][64], const f32x4 (&a)[4], const f32x4 (&y)[4], f32x4 (&x)[4],
+                                        int lane, int q, int wv) {
     // FFN fragments of this wave's first hidden tile: issue early
     f32x4 wn1[4], wn2[4];
 #pragma unroll
@@ -266,7 +256,7 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
     f32x4 o[4];
 #pragma unroll
     for (int T = 0; T < 4; ++T) o[T] = sX[0][T][lane];
-    // info / gate, row tile wv  ->  x = g + tanh(info) * sigmoid(gate)
+    // info / gate, row tile wv  ->  x = y + tanh(info) * sigmoid(gate)
     {
         f32x4 vi = ld4(w.infob + 16 * wv + 4 * q), vg = ld4(w.gateb + 16 * wv + 4 * q);
 #pragma unroll
@@ -275,7 +265,7 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
             vg = mfma_k16(vg, w.gateP[(wv * 4 + T) * 64 + lane], o[T]);
         }
         f32x4 xr;
-        const f32x4 gw = ld4(g + (size_t)colc * 64 + 16 * wv + 4 * q);
+        const f32x4 gw = wv == 0 ? y[0] : wv == 1 ? y[1] : wv == 2 ? y[2] : y[3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) xr[r] = gw[r] + tanhf(vi[r]) * sigmoidf_(vg[r]);
         sX[1][wv][lane] = xr;
@@ -317,12 +307,92 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
         x[it] = x[it] + (t + ld4(w.l2b + 16 * it + 4 * q));
     }
     layernorm64(x, w.ln2w, w.ln2b, q);
+}
+
+// ODE = false: the reference's integrator -- ONE explicit Euler step of size ode_time (ode_demo.py:186-190) with the attention output
+// given (any attention length).  ODE = true: `steps` steps of `method` (0 Euler, 1 torchdiffeq's fixed-grid rk4 = 3/8 rule,
+// 2 classical RK4) over [0, ode_time]; every stage needs the attention output of ITS state, which for attention length 1 (the
+// ETH/UCY/SDD path: softmax over one element) is just v(y) = W_v y + b_v and is computed here (vP, vb = value rows of the packed
+// in-projection).  With attention length > 1 a stage needs a pass over the whole group: op level (hypertransformer.ODEG_Encoder).
+template <bool ODE>
+__global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g,  // [n][64]
+                                                        const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
+                                                        float* __restrict__ pf,                       // [n][128]
+                                                        int n, float ode_time, int method, int steps, const f32x4* __restrict__ vP,
+                                                        const float* __restrict__ vb) {
+    __shared__ f32x4 sX[4][4][64];  // [slot][tile][lane] exchange buffer (16 KiB)
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 a[4], gg[4], x[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) gg[T] = ld4(g + (size_t)colc * 64 + 16 * T + 4 * q);
+    f32x4 yo[4];  // integrated state
+    if (!ODE) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a[T] = ld4(attn + (size_t)colc * ld_attn + 16 * T + 4 * q);
+        ode_rhs(w, sX, a, gg, x, lane, q, wv);
+        // torchdiffeq fixed-grid euler on t=[0,T]: y1 = y0 + T*f(y0) (ode_demo.py:188)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) yo[T] = gg[T] + x[T] * ode_time;
+    } else {
+        auto F = [&](const f32x4 (&y)[4], f32x4 (&k)[4]) {
+            __syncthreads();  // previous stage's sX reads are done
+            {   // attention output for state y at attention length 1: v(y), row tile wv, exchanged through sX[2]
+                f32x4 v = ld4(vb + 16 * wv + 4 * q);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) v = mfma_k16(v, vP[(wv * 4 + T) * 64 + lane], y[T]);
+                sX[2][wv][lane] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) a[T] = sX[2][T][lane];
+            __syncthreads();
+            ode_rhs(w, sX, a, y, k, lane, q, wv);
+        };
+        const float hstep = ode_time / (float)steps;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) yo[T] = gg[T];
+        for (int s = 0; s < steps; ++s) {
+            f32x4 k1[4], k2[4], k3[4], k4[4], t[4];
+            F(yo, k1);
+            if (method == 0) {
+#pragma unroll
+                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + k1[T] * hstep;
+            } else if (method == 1) {   // 3/8 rule (torchdiffeq rk4_alt_step_func)
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k1[T] * (hstep / 3.f);
+                F(t, k2);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + (k2[T] - k1[T] * (1.f / 3.f)) * hstep;
+                F(t, k3);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + (k1[T] - k2[T] + k3[T]) * hstep;
+                F(t, k4);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + (k1[T] + (k2[T] + k3[T]) * 3.f + k4[T]) * (hstep / 8.f);
+            } else {                    // classical RK4
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k1[T] * (hstep / 2.f);
+                F(t, k2);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k2[T] * (hstep / 2.f);
+                F(t, k3);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k3[T] * hstep;
+                F(t, k4);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + (k1[T] + k2[T] * 2.f + k3[T] * 2.f + k4[T]) * (hstep / 6.f);
+            }
+        }
+    }
     if (col < n) {
-        // torchdiffeq fixed-grid euler on t=[0,T]: y1 = y0 + T*f(y0); then relu (ode_demo.py:188,231); wave wv stores tile wv
-        st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, gg[wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 3]);
-        f32x4 go = wv == 0 ? gg[0] : wv == 1 ? gg[1] : wv == 2 ? gg[2] : gg[3];
-        f32x4 xo = wv == 0 ? x[0] : wv == 1 ? x[1] : wv == 2 ? x[2] : x[3];
-        st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(go + xo * ode_time));
+        // pf = cat(ftraj_input, relu(ODE state at t = ode_time)) (ode_demo.py:231, model/STTODE.py:233-235); wave wv stores tile wv
+        const f32x4 go = wv == 0 ? gg[0] : wv == 1 ? gg[1] : wv == 2 ? gg[2] : gg[3];
+        const f32x4 xo = wv == 0 ? yo[0] : wv == 1 ? yo[1] : wv == 2 ? yo[2] : yo[3];
+        st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
+        st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
     }
 }
 
@@ -374,7 +444,29 @@ extern "C" int sttode_post_attn(const float* outP, const float* outb, const floa
     w.outP = (const f32x4*)outP; w.outb = outb; w.infoP = (const f32x4*)infoP; w.infob = infob; w.gateP = (const f32x4*)gateP;
     w.gateb = gateb; w.ln1w = ln1w; w.ln1b = ln1b; w.l1P = (const f32x4*)l1P; w.l1b = l1b; w.l2P = (const f32x4*)l2P; w.l2b = l2b;
     w.ln2w = ln2w; w.ln2b = ln2b;
-    hipLaunchKernelGGL(post_attn_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, g, attn, ld_attn, pf, n, ode_time);
+    hipLaunchKernelGGL(post_attn_kernel<false>, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, g, attn, ld_attn, pf, n, ode_time, 0,
+                       1, (const f32x4*)nullptr, (const float*)nullptr);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Same layer with the integrator as a kernel parameter, attention length 1: method 0 Euler | 1 rk4 (3/8 rule, torchdiffeq's fixed-grid
+// "rk4") | 2 classical RK4, `steps` uniform steps over [0, ode_time]; inP / inb: the packed in-projection (PK16 [12][4]) and its bias
+// (the value rows 128..191 give the attention output of a state).  (method 0, steps 1) computes what sttode_post_attn computes.
+extern "C" int sttode_post_attn_ode(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                                    const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                                    const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* inP,
+                                    const float* inb, const float* g, float* pf, int n, float ode_time, int method, int steps,
+                                    void* stream) {
+    STT_REQUIRE(outP && outb && infoP && infob && gateP && gateb && ln1w && ln1b && l1P && l1b && l2P && l2b && ln2w && ln2b && inP && inb && g && pf,
+                "sttode_post_attn_ode: null pointer");
+    STT_REQUIRE(n > 0 && method >= 0 && method <= 2 && steps >= 1 && steps <= 1024, "sttode_post_attn_ode: n > 0, method in {0,1,2}, 1 <= steps <= 1024");
+    PostW w;
+    w.outP = (const f32x4*)outP; w.outb = outb; w.infoP = (const f32x4*)infoP; w.infob = infob; w.gateP = (const f32x4*)gateP;
+    w.gateb = gateb; w.ln1w = ln1w; w.ln1b = ln1b; w.l1P = (const f32x4*)l1P; w.l1b = l1b; w.l2P = (const f32x4*)l2P; w.l2b = l2b;
+    w.ln2w = ln2w; w.ln2b = ln2b;
+    hipLaunchKernelGGL(post_attn_kernel<true>, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, g, (const float*)nullptr, 64, pf, n,
+                       ode_time, method, steps, (const f32x4*)inP + 8 * 4 * 64, inb + 128);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,7 @@ struct SttodeModel {
     // stream, so the grid tail of one part's kernel is filled by the next part's kernel (columns are independent).
     int col_parts;
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
+    int ode_method, ode_steps;  // integrator of the encoder ODE (0, 1 = one Euler step = the reference)
     int prog_len;
     hipStream_t part_stream[STT_MAX_PARTS];
     hipEvent_t ev_agents, ev_part[STT_MAX_PARTS];
@@ -65,6 +66,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->acalls = 0;
     if (const char* e = getenv("STTODE_B_STREAMS")) m->b_streams = atoi(e) == 2 ? 2 : 1;
     m->chain_mode = -1;
+    m->ode_method = 0; m->ode_steps = 1;
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
     m->prog_len = sttode_chain_prog_len(Tp, Tf);
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
@@ -153,6 +155,13 @@ extern "C" int sttode_set_chain(SttodeModel* m, int mode) {
     STT_REQUIRE(m, "sttode_set_chain: null model");
     STT_REQUIRE(mode >= -1 && mode <= 1, "sttode_set_chain: mode must be -1 (auto), 0 or 1");
     m->chain_mode = mode;
+    return 0;
+}
+
+extern "C" int sttode_set_ode(SttodeModel* m, int method, int steps) {
+    STT_REQUIRE(m, "sttode_set_ode: null model");
+    STT_REQUIRE(method >= 0 && method <= 2 && steps >= 1 && steps <= 1024, "sttode_set_ode: method in {0,1,2}, 1 <= steps <= 1024");
+    m->ode_method = method; m->ode_steps = steps;
     return 0;
 }
 
@@ -255,6 +264,14 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         attn_src = attn;
         ld_attn = 64;
     }
+    if (m->ode_method != 0 || m->ode_steps != 1) {
+        STT_REQUIRE(attn_len == 1, "sttode_inference_nba: a non-default ODE integrator needs attention length 1 (every stage of an attention group > 1 "
+                                   "is a pass over the whole group: use the op-level hypertransformer.ODEG_Encoder)");
+        RUN(STT_STAGE_POST, s,
+            sttode_post_attn_ode(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
+                                 W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B],
+                                 W[STT_W_INP], W[STT_W_INB], g, pf, n, 12.0f, m->ode_method, m->ode_steps, s));
+    } else
     RUN(STT_STAGE_POST, s,
         sttode_post_attn(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
                          W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], g,

@@ -126,12 +126,17 @@ __global__ __launch_bounds__(256) void pmath_row_kernel(int op, const float* __r
             }
         } break;
         case OP_PMEAN_PREP: {  // pmath.py:472-476 : xk = p2k(x); lam = lorenz(xk); out = lam * xk, out2[r] = lam
-            const float den = 1.0f + c * x2;
-            float k2 = 0.f;
-            for (int i = lane; i < d; i += 64) { const float v = 2.0f * xr[i] / den; k2 += v * v; }
-            const float lam = 1.0f / sqrtf(1.0f - c * wsum(k2));
-            for (int i = lane; i < d; i += 64) o[i] = lam * (2.0f * xr[i] / den);
-            if (lane == 0) out2[r] = lam;
+            // 1 - c|xk|^2 = ((1 - c|x|^2) / (1 + c|x|^2))^2 is ~1e-6 for rows on the ball boundary: formed from fp32 Klein coordinates
+            // it is only good to a few percent (the reference's own fp32 result is ~1e-3..6e-3 off the exact value there).  The Lorenz
+            // factor is therefore taken in closed form, lam = (1 + c|x|^2) / (1 - c|x|^2), from a float64 sum of squares.
+            double x2d = 0.;
+            for (int i = lane; i < d; i += 64) { const double a = xr[i]; x2d += a * a; }
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) x2d += __shfl_xor(x2d, ofs, 64);
+            const double dend = 1.0 + (double)c * x2d;
+            const double lamd = dend / (1.0 - (double)c * x2d);
+            for (int i = lane; i < d; i += 64) o[i] = (float)(lamd * (2.0 * (double)xr[i] / dend));
+            if (lane == 0) out2[r] = (float)lamd;
         } break;
     }
 }
@@ -213,30 +218,39 @@ __global__ void pmath_pair_kernel(int which, const float* __restrict__ x, const 
     const float* xr = x + (size_t)p * d;
     const float* yr = y + (size_t)q * d;
     const float sgn = (which == 1) ? 1.0f : -1.0f;  // dist_matrix / hyperbolic_softmax call batch(-x, y)
-    float x2 = 0.f, y2 = 0.f, xy = 0.f;
-    for (int i = 0; i < d; ++i) { const float a = sgn * xr[i], b = yr[i]; x2 += a * a; y2 += b * b; xy += a * b; }
-    const MobCoef m = mob_coef(x2, y2, xy, c);  // pmath.py:416-427
+    // Row scalars and the Moebius sum are formed in float64 and rounded once: 1 - c|x|^2 cancels catastrophically for rows on the ball
+    // boundary (|x|^2 -> (1-1e-3)^2 / c), where a 1-ulp error of an fp32 sum of squares becomes 5e-5 relative in the coefficient and
+    // is amplified again by artanh's slope (~500).  The fp32 result of the reference is only defined to that level there; the
+    // float64 path keeps this kernel within 1e-6 of the exact value of the same fp32 inputs (tests: float64 yardstick).
+    double x2 = 0., y2 = 0., xy = 0.;
+    for (int i = 0; i < d; ++i) { const double a = sgn * xr[i], b = yr[i]; x2 += a * a; y2 += b * b; xy += a * b; }
+    const double cd = c;
+    const double ca = 1.0 + 2.0 * cd * xy + cd * y2, cb = 1.0 - cd * x2;                 // pmath.py:416-427
+    const double den = 1.0 + 2.0 * cd * xy + cd * cd * x2 * y2 + (double)1e-5f;
     if (which == 1) {
-        for (int i = 0; i < d; ++i) out[idx * d + i] = (m.ca * xr[i] + m.cb * yr[i]) / m.den;
+        for (int i = 0; i < d; ++i) out[idx * d + i] = (float)((ca * (double)(sgn * xr[i]) + cb * (double)yr[i]) / den);
         return;
     }
-    float s2 = 0.f, sa = 0.f, a2 = 0.f;
+    double s2 = 0., sa = 0., a2 = 0.;
     for (int i = 0; i < d; ++i) {
-        const float v = (m.ca * (-xr[i]) + m.cb * yr[i]) / m.den;
+        const double v = (ca * (double)(-xr[i]) + cb * (double)yr[i]) / den;
         s2 += v * v;
-        if (which == 2) { const float av = A[(size_t)p * d + i]; sa += v * av; a2 += av * av; }
+        if (which == 2) { const double av = A[(size_t)p * d + i]; sa += v * av; a2 += av * av; }
     }
-    const float sc = sqrtf(c);
+    const double sc = sqrt(cd);
     if (which == 0) {
-        out[idx] = 2.0f / sc * artanh_(sc * sqrtf(s2));  // pmath.py:482-493
+        double u = sc * sqrt(s2);
+        u = fmin(fmax(u, -1.0 + (double)1e-5f), 1.0 - (double)1e-5f);                     // Artanh clamp, pmath.py:19
+        out[idx] = (float)(2.0 / sc * 0.5 * (log1p(u) - log1p(-u)));                     // pmath.py:482-493
     } else {
         // _hyperbolic_softmax (pmath.py:430-437): x = P (classes, rows p), y = X (batch, rows q); result [B, C] = out[q][p]
-        const float an = sqrtf(a2);
-        const float lam = 2.0f / (1.0f - c * x2);
-        const float k = lam * an / sc;
-        const float num = 2.0f * sc * sa;
-        const float den = an * (1.0f - c * s2);
-        out[(size_t)q * P + p] = k * arsinh_(num / den);
+        const double an = sqrt(a2);
+        const double lam = 2.0 / (1.0 - cd * x2);
+        const double k = lam * an / sc;
+        const double num = 2.0 * sc * sa;
+        const double dn = an * (1.0 - cd * s2);
+        const double t = num / dn;
+        out[(size_t)q * P + p] = (float)(k * log(fmax(t + sqrt(1.0 + t * t), (double)1e-5f)));
     }
 }
 

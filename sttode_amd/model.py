@@ -12,6 +12,8 @@ Build-defined extension (the batched scene front-end):
 All compute runs in hand-written HIP kernels (sttode_amd/csrc); PyTorch only owns device memory and the
 stream.  There is no eager / CPU fallback: a missing library or a CPU tensor raises.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -19,6 +21,8 @@ from torch import nn
 from .dist import Normal
 from . import capi, packing
 from .weights import sinusoid_table_np
+
+_DEBUG = os.environ.get('STTODE_DEBUG', '0') not in ('', '0')   # debug mode: validate device-resident inputs too (costs a D2H sync per call)
 
 
 class _HypMHSA(nn.Module):
@@ -143,6 +147,7 @@ class _LazyViews(dict):
 
 class STTODENet(nn.Module):
     ODE_TIME = 12.0  # ODEG_Encoder(encoder_layers, nlayer, 12): model/STTODE.py:195 -> one Euler step of size 12
+    ODE_METHODS = {'euler': 0, 'rk4': 1, 'rk4_classic': 2}
 
     def __init__(self, args, device):
         super().__init__()
@@ -167,6 +172,9 @@ class STTODENet(nn.Module):
         self._packed_key = None
         self._mode = None
         self._async_calls = 0
+        # integrator of the tensor-ODE encoder: the reference runs ONE Euler step (ode_demo.py:186-190) = ('euler', 1); 'rk4' is
+        # torchdiffeq's fixed-grid rk4 (3/8 rule), 'rk4_classic' the classical one; steps = uniform steps over [0, 12] (oracle-checked only)
+        self.ode_method, self.ode_steps = 'euler', 1
         self.async_depth = 3     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
         self._ptr_cache = {}
@@ -224,6 +232,10 @@ class STTODENet(nn.Module):
 
     def native(self):
         self.packed()
+        ode = (self.ODE_METHODS[self.ode_method], int(self.ode_steps))
+        if self._native is not None and getattr(self._native, '_ode', (0, 1)) != ode:
+            self._native.set_ode(*ode)
+            self._native._ode = ode
         return self._native
 
     def _workspace(self, n, S):
@@ -299,10 +311,10 @@ class STTODENet(nn.Module):
             raise ValueError(f'past must be [n, {a.past_length}, 2], got {tuple(self._past.shape)}')
         if self._past.shape[0] == 0 or self._scene_ptr.numel() < 2:
             raise ValueError('empty batch: need at least one scene with at least one agent')
-        if not (isinstance(scene_ptr, torch.Tensor) and scene_ptr.is_cuda):
+        if not (isinstance(scene_ptr, torch.Tensor) and scene_ptr.is_cuda) or _DEBUG:
             # host-side CSR is validated here; a device-resident CSR is trusted (validating it would force a D2H sync
-            # per call -- callers on the hot loop keep their batches resident, bench.py)
-            sp = torch.as_tensor(scene_ptr)
+            # per call -- callers on the hot loop keep their batches resident, bench.py) unless STTODE_DEBUG=1
+            sp = torch.as_tensor(scene_ptr).cpu()
             if int(sp[0]) != 0 or int(sp[-1]) != self._past.shape[0] or bool((sp[1:] <= sp[:-1]).any()):
                 raise ValueError('scene_ptr must start at 0, end at n and be strictly increasing (no empty scenes)')
         self._mode = 'scenes'
@@ -365,8 +377,16 @@ class STTODENet(nn.Module):
         else:
             attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192  # softmax over one element == 1  =>  output == v
         pf = self._f(n, 128)
-        capi.call('sttode_post_attn', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
-                  W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], g, attn_ptr, ld, pf, n, self.ODE_TIME, st)
+        if (self.ode_method, self.ode_steps) != ('euler', 1):
+            if L > 1:
+                raise NotImplementedError('a non-default ODE integrator with an attention group > 1 needs a pass over the group per stage: '
+                                          'use the op-level sttode_amd.hypertransformer.ODEG_Encoder(method, steps)')
+            capi.call('sttode_post_attn_ode', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
+                      W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], W['inP'], W['inb'], g, pf, n, self.ODE_TIME,
+                      self.ODE_METHODS[self.ode_method], int(self.ode_steps), st)
+        else:
+            capi.call('sttode_post_attn', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
+                      W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], g, attn_ptr, ld, pf, n, self.ODE_TIME, st)
         self._keep = (g, qkv)
         return pf
 

@@ -28,21 +28,57 @@ def shard_groups(n_groups, rank, world):
     return (n_groups * rank) // world, (n_groups * (rank + 1)) // world
 
 
+def _coll_device(t, group=None):
+    """Device the collective runs on: RCCL ("nccl") takes device tensors; gloo (CPU rehearsals, also with the compute on a GPU)
+    gets host copies."""
+    return torch.device('cpu') if dist.get_backend(group) == 'gloo' else t.device
+
+
 def gather_futures(pred_local, group=None):
-    """All-gather of per-rank futures [n_r, K, Tf, 2] (n_r differs per rank) -> [sum n_r, K, Tf, 2] in rank order."""
+    """All-gather of per-rank rows [n_r, ...] (n_r differs per rank, may be 0) -> [sum n_r, ...] in rank order, on the caller's device."""
     world = dist.get_world_size(group)
     if world == 1:
         return pred_local
-    n_local = torch.tensor([pred_local.shape[0]], dtype=torch.int64, device=pred_local.device)
+    cdev = _coll_device(pred_local, group)
+    n_local = torch.tensor([pred_local.shape[0]], dtype=torch.int64, device=cdev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c) for c in counts]
-    nmax = max(counts)
-    pad = pred_local.new_zeros((nmax,) + tuple(pred_local.shape[1:]))
-    pad[: pred_local.shape[0]] = pred_local
+    nmax = max(max(counts), 1)
+    pad = torch.zeros((nmax,) + tuple(pred_local.shape[1:]), dtype=pred_local.dtype, device=cdev)
+    pad[: pred_local.shape[0]] = pred_local.to(cdev)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(pred_local.device)
+
+
+def infer_sharded(model, sb, rank, world, z=None, group=None, gather=True):
+    """Scenes of ``sb`` sharded over the ranks of ``group`` (contiguous ranges balanced by agent count), the hot path run locally,
+    results combined: returns (futures [K, n_total, Tf, 2] in scene order if ``gather`` else this rank's [K, n_r, Tf, 2],
+    (ADE, FDE, agents) over all ranks).  ``z`` [n_total*K, zdim] (optional) is the latent of the WHOLE batch: every rank takes its rows.
+    A rank whose range is empty (fewer scenes than ranks) runs no kernel and contributes zero rows / zero sums, so the
+    collectives below are entered by every rank."""
+    a = model.args
+    K, Tf = a.sample_k, a.future_length
+    local, (s0, s1) = shard_scene_batch(sb, rank, world)
+    dev = model.device
+    if local.n_agents > 0:
+        a0 = int(sb.scene_ptr[s0])
+        zl = None if z is None else torch.as_tensor(z)[a0 * K:(a0 + local.n_agents) * K]
+        model.set_scene_batch(local.past, local.future, local.scene_ptr)
+        pred = model.inference(None, z=zl)                                   # [K, n_r, Tf, 2]
+        ade, fde = model.best_of_k(pred.permute(1, 0, 2, 3))
+        sums = (ade.sum().double(), fde.sum().double())
+    else:
+        pred = torch.zeros(K, 0, Tf, 2, dtype=torch.float32, device=dev)
+        sums = (torch.zeros((), dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev))
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi and dist.get_backend(group) == 'gloo':
+        sums = tuple(t.cpu() for t in sums)
+    metrics = reduce_metrics(sums[0], sums[1], local.n_agents, group=group)
+    if gather and multi:
+        pred = gather_futures(pred.permute(1, 0, 2, 3).contiguous(), group=group).permute(1, 0, 2, 3)
+    return pred, metrics
 
 
 def reduce_metrics(ade_sum, fde_sum, count, group=None):

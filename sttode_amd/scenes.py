@@ -109,12 +109,18 @@ def make_scene_batch(scene_ids, kind='eth', obs_len=8, pred_len=12):
 
 
 def shard_scenes(scene_ptr, world_size):
-    """Contiguous scene ranges balanced by agent count: returns [(s0, s1)] * world_size."""
+    """Contiguous scene ranges balanced by agent count: returns [(s0, s1)] * world_size.
+    Every rank gets at least one scene whenever there are at least ``world_size`` scenes (a skewed agent distribution must not
+    leave a rank empty: an empty rank would skip the collectives its peers wait in); with fewer scenes than ranks the
+    trailing ranks get empty ranges (s0 == s1), which ``parallel.infer_sharded`` turns into zero-row contributions."""
     ptr = np.asarray(scene_ptr, np.int64)
     S, total = len(ptr) - 1, int(ptr[-1])
     cuts = [0]
     for r in range(1, world_size):
         target = total * r / world_size
-        cuts.append(int(np.clip(np.searchsorted(ptr, target, side='left'), cuts[-1], S)))
+        c = int(np.searchsorted(ptr, target, side='left'))
+        lo = min(cuts[-1] + 1, S)                    # previous rank keeps >= 1 scene (while scenes remain)
+        hi = max(S - (world_size - r), lo) if S >= world_size else S   # leave >= 1 scene for every later rank
+        cuts.append(int(np.clip(c, lo, hi)))
     cuts.append(S)
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]

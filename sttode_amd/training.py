@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import capi
+from .capi import SttodeError
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
 EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR = 10, 11, 12
@@ -312,7 +313,8 @@ class Engine:
         sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
         capi.call('sttode_loss_kl', qzp, sp, S, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.scratch, self.st)
         capi.call('sttode_loss_diverse', d20['pred'], fut, sp, ags, n, 20, 2 * Tf, losses[3:], dpred20, self.scratch, self.st)
-        self.tape = dict(tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
+        self.step_id = getattr(self, 'step_id', 0) + 1
+        self.tape = dict(step_id=self.step_id, tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
                          dpred20=dpred20, n=n, zd=zd)
         # attributes the reference sets (read by callers)
         net.past_feature = pf
@@ -324,8 +326,16 @@ class Engine:
         net.past_traj, net.future_traj, net.cur_location = past, fut, past[:, -1:]
         return losses
 
-    def run_backward(self, gout=None):
+    def run_backward(self, gout=None, step_id=None):
         T = self.tape
+        # The tape (and the flat gradient buffer it fills) belongs to the MOST RECENT eager forward().  backward() of an older loss, or
+        # a second backward() of the same loss, would silently differentiate the wrong step: refuse instead.
+        if T is None:
+            raise SttodeError('training backward: the tape of this forward() was already consumed (backward() called twice, or '
+                              'retain_graph reuse); run forward() again')
+        if step_id is not None and T.get('step_id') != step_id:
+            raise SttodeError('training backward: this loss belongs to an earlier forward(); only the most recent forward() of a model '
+                              'can be differentiated (its tape was overwritten by the newer forward())')
         self._grad_views()
         n, zd = T['n'], T['zd']
         P, g = self.P, self.grad
@@ -354,6 +364,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, total, engine, names, ready, *params):
         ctx.engine, ctx.names, ctx.ready, ctx.params = engine, names, ready, params
+        ctx.step_id = engine.tape['step_id'] if (ready is None and engine.tape is not None) else None
         return total.clone()
 
     @staticmethod
@@ -363,7 +374,7 @@ class _LossFn(torch.autograd.Function):
             flat.mul_(gout)
             G = views
         else:
-            G = ctx.engine.run_backward(gout)
+            G = ctx.engine.run_backward(gout, ctx.step_id)
         # Hand the gradients over directly instead of returning them: autograd's AccumulateGrad would copy each of the 88 views
         # of the flat buffer into a fresh tensor (88 extra kernels per step).  The flat buffer is private to this step, so the
         # views can BE the .grad tensors; an existing .grad (gradient accumulation) is added to in place.

@@ -298,32 +298,63 @@ def test_pmath_op_library_vs_reference_golden(golden):
             'mobius_addition_batch': pm._mobius_addition_batch(xb[:6], yb[:5], c),
             'hyperbolic_softmax': pm._hyperbolic_softmax(xb, mat * 0.5, pm.project(mat * 0.3, c=c), c),
         }
-        # Rows that project() clipped to the ball boundary (|x| = (1-1e-3)/sqrt(c): x row 2 by construction plus any random
-        # row that happened to fall outside) are ILL-CONDITIONED for every op that forms 1 - c|x|^2 or artanh(|.|) near 1:
-        # the result is only defined to ~1e-3..1e-1 relative in fp32 (summation order alone moves it; the reference is
-        # equally sensitive to its BLAS).  Those entries get a loose sanity bound; all others keep the 1e-4 bar.
+        # Rows that project() clipped to the ball boundary (|x| = (1-1e-3)/sqrt(c): x row 2 by construction plus any random row
+        # that happened to fall outside) are ILL-CONDITIONED for every op that forms 1 - c|x|^2 or artanh(|.|) near 1: a 1-ulp
+        # change of the input moves the fp32 result by 1e-3..1e-1 relative, so two correct fp32 implementations disagree there.
+        # Yardstick for those entries: the same op evaluated in FLOAT64 (oracle/pmath_ref.py is dtype-generic) on the very fp32
+        # inputs each implementation used.  Required: HIP's error against that truth is no more than twice the error of the
+        # reference's own fp32 result against ITS truth (or 1e-4 relative, whichever is larger).  All other entries: 1e-4.
+        import oracle.pmath_ref as pref
         maxn = (1 - 1e-3) / np.sqrt(c)
         bx = (xb.norm(dim=-1) > 0.99 * maxn).cpu().numpy()
         by = (yb.norm(dim=-1) > 0.99 * maxn).cpu().numpy()
+        D = lambda a: torch.from_numpy(np.asarray(a)).double()
+        u64, m64 = D(g[t + 'u']), D(g[t + 'm'])
+
+        def truth(xq, yq, kq):                # every op in float64 on the fp32 values each op actually received: projected points
+            xq, yq, k = D(xq), D(yq), D(kq)   # xq, yq [33,16]; kq = the fp32 Klein coordinates fed to k2p / lorenz_factor
+            return {'project': xq, 'lambda_x': pref.lambda_x(xq, c), 'mobius_add': pref.mobius_add(xq, yq, c), 'dist': pref.dist(xq, yq, c),
+                    'dist0': pref.dist0(xq, c), 'expmap': pref.expmap(xq, u64, c), 'expmap0': pref.expmap0(u64, c),
+                    'logmap': pref.logmap(xq, yq, c), 'logmap0': pref.logmap0(xq, c), 'mobius_matvec': pref.mobius_matvec(m64, xq, c),
+                    'p2k': pref.p2k(xq, c), 'k2p': pref.k2p(k, c), 'lorenz': pref.lorenz_factor(k, c), 'poincare_mean': pref.poincare_mean(xq, c),
+                    'dist_matrix': pref.dist_matrix(xq, yq[:9], c), 'mobius_addition_batch': pref.mobius_addition_batch(xq[:6], yq[:5], c),
+                    'hyperbolic_softmax': pref.hyperbolic_softmax(xq, m64 * 0.5, pref.project(m64 * 0.3, c), c)}
+        t_hip = {k: v.numpy() for k, v in truth(xb.cpu().numpy(), yb.cpu().numpy(), checks['p2k'].cpu().numpy()).items()}
+        t_ref = {k: v.numpy() for k, v in truth(g[t + 'project'], pref.project(torch.from_numpy(g[t + 'y']), c).numpy(), g[t + 'p2k']).items()}
+
+        def rel_rows(a, tr):                  # per leading-index relative error (max over the trailing axes), float64
+            a, tr = np.asarray(a, np.float64), np.asarray(tr, np.float64)
+            a, tr = a.reshape(a.shape[0], -1) if a.ndim > 1 else a[:, None], tr.reshape(tr.shape[0], -1) if tr.ndim > 1 else tr[:, None]
+            return np.abs(a - tr).max(1) / (np.abs(tr).max(1) + 1e-6)
+
         for k, v in checks.items():
             got, ref = v.cpu().numpy(), g[t + k]
-            if k in ('dist_matrix', 'mobius_addition_batch'):
-                bad = bx[:ref.shape[0], None] | by[None, :ref.shape[1]]
-            elif k in ('poincare_mean',):
+            if k == 'poincare_mean':
                 # the Lorenz factors of the boundary rows (~20x the others, themselves ill-conditioned) weight the whole mean
-                np.testing.assert_allclose(got, ref, rtol=3e-2, atol=1e-3, err_msg=f'{k} c={c} (contains boundary rows)')
-                import oracle.pmath_ref as pref
+                e_hip = np.abs(got - t_hip[k]).max() / np.abs(t_hip[k]).max()
+                e_ref = np.abs(ref - t_ref[k]).max() / np.abs(t_ref[k]).max()
+                assert e_hip <= max(2 * e_ref, 1e-4), (k, c, e_hip, e_ref)
                 inner = xb[torch.from_numpy(~bx).to(xb.device)]
                 np.testing.assert_allclose(pm.poincare_mean(inner, dim=0, c=c).cpu().numpy(), pref.poincare_mean(inner.cpu(), c).numpy(),
                                            rtol=1e-4, atol=2e-6, err_msg=f'{k} c={c} (interior rows vs oracle)')
                 continue
-            elif k in ('expmap0',):
+            if k in ('dist_matrix', 'mobius_addition_batch'):
+                bad = bx[:ref.shape[0], None] | by[None, :ref.shape[1]]
+            elif k == 'expmap0':
                 bad = np.zeros(ref.shape[0], bool)
             else:
                 bad = bx | by if k in ('mobius_add', 'dist', 'logmap') else bx
-            if bad.any():
-                np.testing.assert_allclose(got[bad], ref[bad], rtol=0.25, atol=1e-3, err_msg=f'{k} c={c} (boundary entries)')
             np.testing.assert_allclose(got[~bad], ref[~bad], rtol=1e-4, atol=2e-6, err_msg=f'{k} c={c}', equal_nan=True)
+            if bad.any():
+                if bad.ndim == 2:             # pairwise ops: entry-wise (flatten the [P, R] index)
+                    sel = bad.reshape(-1)
+                    shp = (-1,) + got.shape[2:]
+                    e_hip = rel_rows(got.reshape(shp)[sel], t_hip[k].reshape(shp)[sel])
+                    e_ref = rel_rows(ref.reshape(shp)[sel], t_ref[k].reshape(shp)[sel])
+                else:
+                    e_hip, e_ref = rel_rows(got[bad], t_hip[k][bad]), rel_rows(ref[bad], t_ref[k][bad])
+                ok = e_hip <= np.maximum(2 * e_ref, 1e-4)
+                assert ok.all(), f'{k} c={c} boundary entries: HIP error vs float64 {e_hip[~ok]} > 2 x reference fp32 error {e_ref[~ok]}'
     s = T(g['scalar_in'])
     np.testing.assert_allclose(pm.tanh(s).cpu().numpy(), g['tanh'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(pm.artanh(s).cpu().numpy(), g['artanh'], rtol=1e-4, atol=1e-6)
@@ -427,6 +458,162 @@ def test_nba_group_spanning_two_ranks_matches_single_rank():
         loc = {'past_traj': torch.from_numpy(d['past_traj'][b0:b1]), 'future_traj': torch.from_numpy(d['future_traj'][b0:b1])}
         out = m.inference_nba_sharded(loc, z=z[b0 * N * 20:b1 * N * 20], gather=lambda q: qkv_full)
         assert_close(out.cpu().numpy(), full[:, b0 * N:b1 * N].cpu().numpy(), rtol=1e-6, atol=1e-6, what=f'rank slice {b0}:{b1}')
+
+
+def _chunked_oracle_mhgsa(query, key, value, num_heads, in_w, in_b, out_w, out_b, slots=2):
+    """oracle.sttode_ref.mhgsa evaluated a few batch slots at a time: attention never mixes batch slots (dim 1), and at L = 4096 the
+    un-chunked score tensor [Nb*H, S, L] is 5.4 GB in fp32.  Same function, same arithmetic; returns (out, None)."""
+    import oracle.sttode_ref as R
+    outs = []
+    for b0 in range(0, query.shape[1], slots):
+        sl = slice(b0, b0 + slots)
+        outs.append(R._mhgsa_unchunked(query[:, sl], key[:, sl], value[:, sl], num_heads, in_w, in_b, out_w, out_b)[0])
+    return torch.cat(outs, dim=1), None
+
+
+def test_attention_at_config5_length_vs_oracle(monkeypatch):
+    """BASELINE config 5 read literally: ONE attention group of 4096 scenes x 10 agents (obs 10 / pred 40).  The flash-style column
+    tiling of mhgsa_attn (32 tiles of 128 columns, 4096-term un-normalised softmax sums, the acos polynomial) is compared with the
+    CPU oracle at that length: (1) the stand-alone op; (2) the NBA branch of inference(): past_feature of all 40 960 agents against
+    the oracle encoder, and the predictions of a sample of agents against the oracle decoder fed with the oracle's own
+    past_feature; (3) the same group split over two simulated ranks (all-gather of q|k|v injected) equals the single-rank call."""
+    import oracle.sttode_ref as R
+    from sttode_amd import scenes
+    from sttode_amd.ops import mhgsa
+    dev = _gpu()
+    if not hasattr(R, '_mhgsa_unchunked'):
+        R._mhgsa_unchunked = R.mhgsa
+    monkeypatch.setattr(R, 'mhgsa', _chunked_oracle_mhgsa)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    L, N, Tp, Tf = 4096, 10, 10, 40
+    m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+    # (1) op level, self-attention L = S = 4096 (the untransposed-score quirk applies)
+    att = ora.past_encoder.ODE_Encoder.odeblock.odefunc.layers[0].self_attn.temporal_attention_before
+    W = [att.in_proj_weight.detach(), att.in_proj_bias.detach(), att.out_proj.weight.detach(), att.out_proj.bias.detach()]
+    x = torch.from_numpy(np.random.default_rng(4096).standard_normal((L, N, 64)).astype(np.float32))
+    o, _ = mhgsa(x.to(dev), x.to(dev), x.to(dev), *[w.to(dev) for w in W])
+    with torch.no_grad():
+        ref, _ = _chunked_oracle_mhgsa(x, x, x, 8, *W)
+    assert_close(o.cpu().numpy(), ref.numpy(), what='mhgsa self-attention L=4096')
+    # (2) inference(), NBA branch
+    d = scenes.nba_batch(4096, L, N=N, obs_len=Tp, pred_len=Tf)
+    z = scenes.latents(4097, L * N)
+    data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+    m.set_data_nba(data)
+    out = m.inference(data, z=torch.from_numpy(z))
+    pf = m.past_feature.cpu().numpy()
+    with torch.no_grad():
+        past = data['past_traj'].reshape(L * N, Tp, 2)
+        inputs = torch.cat((past, R.first_diff_dup(past)), dim=-1)
+        pf_ref = ora.past_encoder(inputs, L, N)
+        err = np.abs(pf - pf_ref.numpy())
+        if (err > ATOL + RTOL * np.abs(pf_ref.numpy())).any():
+            # The encoder output is 12 x the layer output (one Euler step of size 12) on values up to ~60, and every row of the layer
+            # is a 4096-term softmax sum: two fp32 evaluations differ by a few 1e-4 on a handful of the 5.2 M entries.  Yardstick:
+            # the same encoder in FLOAT64 (same oracle code, .double()); HIP must be no further from it than twice the fp32 oracle is.
+            import copy
+            enc64 = copy.deepcopy(ora.past_encoder).double()
+            t64 = enc64(inputs.double(), L, N).numpy()
+            e_hip = (np.abs(pf - t64) / (1.0 + np.abs(t64))).max()
+            e_ref = (np.abs(pf_ref.numpy() - t64) / (1.0 + np.abs(t64))).max()
+            assert e_hip <= max(2 * e_ref, 1e-4), f'past_feature at L=4096: HIP {e_hip:.3e} vs float64, fp32 oracle {e_ref:.3e}'
+        idx = np.sort(np.random.default_rng(7).choice(L * N, 96, replace=False))
+        ti = torch.from_numpy(idx)
+        zs = torch.from_numpy(z).view(L * N, 20, 32)[ti].reshape(-1, 32)
+        dec, _ = ora.decoder(pf_ref[ti].repeat_interleave(20, dim=0), zs, past[ti], past[ti][:, -1:], sample_num=20, mode='inference')
+    assert_close(out[:, ti.to(dev)].cpu().numpy(), dec.permute(1, 0, 2, 3).numpy(), what='inference() at L=4096, sampled agents')
+    # (3) two simulated ranks: 1500 + 2596 scenes
+    qkv_full = m._view(*m._workspace(L * N, 0), 'qkv', L * N, 192).clone()
+    full = out.clone()
+    zt = torch.from_numpy(z).to(dev)
+    for b0, b1 in ((0, 1500), (1500, L)):
+        loc = {'past_traj': data['past_traj'][b0:b1], 'future_traj': data['future_traj'][b0:b1]}
+        part = m.inference_nba_sharded(loc, z=zt[b0 * N * 20:b1 * N * 20], gather=lambda q: qkv_full)
+        assert_close(part.cpu().numpy(), full[:, b0 * N:b1 * N].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'rank slice {b0}:{b1} of the 4096 group')
+
+
+def _two_process_worker(rank, world, port, q):
+    """One of two processes sharing cuda:0; collectives over gloo (host copies), compute on the GPU through the C ABI."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sttode_amd import parallel, scenes
+    m = hip_model('nba', 5, 10)
+    B, N, split = 24, 11, 10
+    d = scenes.nba_batch(321, B, N=N)
+    z = torch.from_numpy(scenes.latents(322, B * N)).to(m.device)
+    b0, b1 = (0, split) if rank == 0 else (split, B)
+    loc = {'past_traj': torch.from_numpy(d['past_traj'][b0:b1]), 'future_traj': torch.from_numpy(d['future_traj'][b0:b1])}
+    part = m.inference_nba_sharded(loc, z=z[b0 * N * 20:b1 * N * 20])           # gather=None: the real parallel.gather_futures
+    allp = parallel.gather_futures(part.permute(1, 0, 2, 3).contiguous())         # [B*N, K, Tf, 2] in rank order
+    # ETH path: scenes sharded over the two processes through parallel.infer_sharded
+    me = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(700, 745), 'eth')
+    ze = scenes.latents(71, sb.n_agents)
+    pe, metrics = parallel.infer_sharded(me, sb, rank, world, z=ze)
+    if rank == 0:
+        q.put((allp.cpu().numpy(), pe.cpu().numpy(), metrics))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_real_collectives_match_single_process():
+    """The non-injected multi-rank code paths: inference_nba_sharded's all-gather of q|k|v through parallel.gather_futures, the
+    gather of the futures, and parallel.infer_sharded (scene sharding + gather + metric all-reduce), run by TWO processes (both on
+    cuda:0, gloo collectives over host copies -- RCCL itself needs two GPUs) and compared with the single-process results."""
+    import os
+    import torch.multiprocessing as mp
+    from sttode_amd import scenes
+    _gpu()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allp, pe, (ade, fde, cnt) = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m = hip_model('nba', 5, 10)
+    d = scenes.nba_batch(321, 24, N=11)
+    data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+    m.set_data_nba(data)
+    full = m.inference(data, z=torch.from_numpy(scenes.latents(322, 24 * 11))).permute(1, 0, 2, 3).cpu().numpy()
+    assert_close(allp, full, rtol=1e-6, atol=1e-6, what='two-process NBA group vs single process')
+    me = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(700, 745), 'eth')
+    me.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    ref = me.inference(None, z=torch.from_numpy(scenes.latents(71, sb.n_agents)))
+    assert np.array_equal(pe, ref.cpu().numpy())                 # scene independence: bitwise
+    a, f = me.best_of_k(ref.permute(1, 0, 2, 3))
+    assert cnt == sb.n_agents and abs(ade - float(a.double().mean())) < 1e-5 and abs(fde - float(f.double().mean())) < 1e-5
+
+
+def test_stale_training_tape_is_refused(golden):
+    """Eager training steps keep ONE tape per model (the most recent forward()).  backward() of an older loss, or a second backward()
+    of the same loss, must raise instead of differentiating the wrong step (round-1 advisor finding)."""
+    import os
+    from sttode_amd import STTODENet, capi
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    g = golden('eth_forward_losses')
+    try:
+        m = STTODENet(make_args('eth', 8, 12), _gpu()).train()
+        m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+        m.rand_rot_scene = False
+        m.train_graphs = False                     # eager steps (the hipGraph replay path keeps its gradients per call)
+        m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
+        first = m.forward()[0]
+        second = m.forward()[0]
+        with pytest.raises(capi.SttodeError, match='earlier forward'):
+            first.backward()
+        second.backward()
+        assert all(p.grad is not None for p in m.decoder.parameters())
+        with pytest.raises((capi.SttodeError, RuntimeError)):
+            second.backward()
+    finally:
+        pass
 
 
 def test_evaluation_loops_vs_oracle_metrics(tmp_path):
@@ -1012,6 +1199,50 @@ def test_ode_encoder_integrators_vs_oracle(method, steps):
     with torch.no_grad():
         ref = torch.relu(ode_integrate_ref(ora, x, 0.9, method, steps))
     assert_close(out.cpu().numpy(), ref.numpy(), what=f'ODEG_Encoder {method} x{steps}')
+
+
+@pytest.mark.parametrize('method,steps', [('euler', 3), ('rk4', 1), ('rk4', 2), ('rk4_classic', 2)])
+def test_model_path_ode_integrator_parameter_vs_oracle(method, steps):
+    """method / n_steps as parameters of the fused encoder kernel (post_attn_kernel<true>, attention length 1): inference() and the
+    staged encode_history() with multi-step Euler / RK4 against the oracle model whose ODE block is integrated by
+    oracle.ode_integrate_ref.  The reference only ever takes one Euler step (ode_demo.py:186-190), so these variants have no
+    reference pin (parity unpinned, like the op-level test above); the default ('euler', 1) stays on the reference-pinned kernel."""
+    from oracle.sttode_ref import ode_integrate_ref
+    from sttode_amd import STTODENet, capi, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    m = STTODENet(make_args('eth', 8, 12), _gpu()).eval()
+    m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+    m.ode_method, m.ode_steps = method, steps
+    ora = oracle_model('eth', 8, 12)
+    blk = ora.past_encoder.ODE_Encoder.odeblock
+    orig = blk.forward
+    blk.forward = lambda x: ode_integrate_ref(lambda y: blk.odefunc(0.0, y), x, blk.t1, method, steps)
+    try:
+        sb = scenes.make_scene_batch(range(60, 66), 'eth')
+        z = scenes.latents(61, sb.n_agents)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        out = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+        pf = m.past_feature.cpu().numpy()
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        pf_staged = m.encode_history().cpu().numpy()
+        for s in range(sb.n_scenes):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            tr = {}
+            ref = oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20], trace=tr)
+            assert_close(pf[a:b], tr['past_feature'].numpy(), what=f'{method} x{steps}: past_feature scene {s}')
+            assert_close(out[:, a:b], ref, what=f'{method} x{steps}: inference scene {s}')
+        # staged API: same integrator (its velocities come from the un-normalised track: equal up to rounding of a - b vs (a-o) - (b-o))
+        np.testing.assert_allclose(pf_staged[:, 64:], pf[:, 64:], rtol=2e-3, atol=2e-3)
+        # an attention group > 1 cannot take a non-default integrator inside the fused path: loud failure, not a silent Euler step
+        d = scenes.nba_batch(5, 4)
+        mn = STTODENet(make_args('nba', 5, 10), _gpu()).eval()
+        mn.ode_method, mn.ode_steps = method, steps
+        mn.set_data_nba({'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])})
+        with pytest.raises(capi.SttodeError, match='attention length 1'):
+            mn.inference(None)
+    finally:
+        blk.forward = orig
 
 
 @pytest.mark.parametrize('N', [1, 3, 17])

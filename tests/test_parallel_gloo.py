@@ -73,6 +73,75 @@ def test_shard_scenes_balanced_and_complete():
         assert sum(loads) == sb.n_agents and max(loads) - min(loads) <= 64
 
 
+class _OracleAsModel:
+    """The CPU oracle behind the few methods parallel.infer_sharded calls on a model (test infrastructure: the product model needs a GPU;
+    the code under test here is the sharding / empty-rank / collective logic)."""
+
+    def __init__(self):
+        from helpers import make_args
+        self.args, self.device = make_args('eth', 8, 12), torch.device('cpu')
+
+    def set_scene_batch(self, past, future, ptr):
+        from sttode_amd import scenes
+        self.sb = scenes.SceneBatch(np.asarray(past), np.asarray(future), np.asarray(ptr))
+
+    def inference(self, data=None, z=None):
+        return torch.from_numpy(_local_predictions(self.sb, np.asarray(z))).permute(1, 0, 2, 3)   # [K, n, Tf, 2]
+
+    def best_of_k(self, pred_nk):
+        from oracle.metrics_ref import best_of_k_ade_fde
+        a, f = best_of_k_ade_fde(pred_nk.numpy(), self.sb.future)
+        return torch.from_numpy(np.asarray(a)), torch.from_numpy(np.asarray(f))
+
+
+def _empty_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sttode_amd import parallel, scenes
+    torch.set_num_threads(2)
+    sb = scenes.make_scene_batch(range(40, 42), 'sdd')            # 2 scenes, 3 ranks: rank 2 is empty
+    z = scenes.latents(6, sb.n_agents)
+    pred, metrics = parallel.infer_sharded(_OracleAsModel(), sb, rank, world, z=z)
+    if rank == 0:
+        q.put((pred.numpy(), metrics, [parallel.shard_scene_batch(sb, r, world)[0].n_agents for r in range(world)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_more_ranks_than_scenes_does_not_hang():
+    """world_size 3 over 2 scenes: the empty rank must enter every collective with zero rows / zero sums (round-1 advisor finding:
+    it used to raise 'empty batch' locally while its peers waited in the all-gather)."""
+    from oracle.metrics_ref import best_of_k_ade_fde
+    from sttode_amd import scenes
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    full, (ade, fde, cnt), loads = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sb = scenes.make_scene_batch(range(40, 42), 'sdd')
+    assert loads[2] == 0 and loads[0] > 0 and loads[1] > 0 and sum(loads) == sb.n_agents
+    ref = _local_predictions(sb, scenes.latents(6, sb.n_agents))
+    assert np.array_equal(full, ref.transpose(1, 0, 2, 3))
+    ra, rf = best_of_k_ade_fde(ref, sb.future)
+    assert cnt == sb.n_agents and abs(ade - ra.mean()) < 1e-6 and abs(fde - rf.mean()) < 1e-6
+
+
+def test_every_rank_gets_a_scene_when_there_are_enough():
+    from sttode_amd import scenes
+    ptr = np.array([0, 1000] + [1000 + i for i in range(1, 8)])     # one huge scene, then seven single-agent scenes
+    for world in (2, 3, 8):
+        parts = scenes.shard_scenes(ptr, world)
+        assert all(b > a for a, b in parts) and parts[0][0] == 0 and parts[-1][1] == 8
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    parts = scenes.shard_scenes(ptr, 12)
+    assert sum(b > a for a, b in parts) == 8 and all(b == a == 8 for a, b in parts[8:])
+
+
 def _grad_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
