@@ -158,6 +158,28 @@ __device__ __forceinline__ void tile_mma(f32x16& acc, const f32x4* __restrict__ 
     }
 }
 
+// Software-pipelined form.  A lone wave per SIMD issues in order: with the fragment reads placed right in front of their MFMAs
+// (what hipcc does with tile_mma) every pair of reads costs ~40 idle matrix-pipe cycles (LDS latency ~100 vs the 64-cycle shadow of
+// the previous MFMA), and the first reads of a chunk sit behind the DMA issue.  Here the fragments of a tile are registers handed
+// in (`cur`), the next tile's fragments of the same chunk are requested halfway through this tile, and the first tile of a chunk is
+// read BEFORE the chunk's DMA pieces are issued (ChainStream::begin), so its latency overlaps that issue.
+struct Frag { f32x4 a[4]; };
+__device__ __forceinline__ void ldfrag(Frag& f, const f32x4* __restrict__ t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) f.a[g] = t[g * 64];
+}
+__device__ __forceinline__ void tile_mma2(f32x16& acc, const Frag& cur, const f32x16& B, Frag& nxt, const f32x4* __restrict__ tn) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g == 2 && tn) {
+            ldfrag(nxt, tn);
+            __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks these reads back in front of their first use
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[g][r], B[4 * g + r], acc, 0, 0, 0);
+    }
+}
+
 // Layers 1+2 of one MLP for this wave's 32 columns: acc2 (256 rows = 8 tiles) += W2 relu(A0[agent] + W1v [z | Bh]).
 // Per 32-row hidden tile: 1 + KH layer-1 tiles then 8 layer-2 tiles, a chunk boundary every 3 tiles ((1 + KH + 8) % 3 == 0).
 // z (the first layer-1 k-tile's B operand) is read from the wave's LDS z slot every hidden tile (it would cost 16 VGPRs for the
@@ -188,23 +210,29 @@ __device__ __forceinline__ void mlp_l12(ChainStream& st, const f32x4* slot, cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the gather issued next
         __builtin_amdgcn_sched_barrier(0);
         const float* nx = (ht + 1 < 16) ? a0 + 32 * (ht + 1) : a0_next;
-        st.begin();
-#ifndef C32_DIAG_NOGATHER
-#pragma unroll
-        for (int a = 0; a < 4; ++a) glds16_asm(nx + 8 * a + 4 * h, slot_addr + a * 1024);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        Frag fr[2];
 #pragma unroll
         for (int i = 0; i < KT1 + 8; ++i) {
-            if (i > 0 && i % 3 == 0) { st.end(); st.begin(); }
-            const f32x4* t = st.cur() + (i % 3) * C32_TILE;
+            if (i % 3 == 0) {
+                if (i > 0) st.end();
+                ldfrag(fr[i & 1], st.cur());       // first tile of the chunk: its read latency overlaps the DMA issue below
+                st.begin();
+                if (i == 0) {
+#ifndef C32_DIAG_NOGATHER
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) glds16_asm(nx + 8 * a + 4 * h, slot_addr + a * 1024);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const f32x4* tn = (i % 3 < 2) ? st.cur() + (i % 3 + 1) * C32_TILE : nullptr;
             if (i == 0) {
-                tile_mma(h1, t, zb);
+                tile_mma2(h1, fr[i & 1], zb, fr[(i + 1) & 1], tn);
             } else if (i < KT1) {
-                tile_mma(h1, t, Bh[i - 1]);
+                tile_mma2(h1, fr[i & 1], Bh[i - 1], fr[(i + 1) & 1], tn);
             } else {
                 if (i == KT1) h1 = relu16(h1);
-                tile_mma(acc2[i - KT1], t, h1);
+                tile_mma2(acc2[i - KT1], fr[i & 1], h1, fr[(i + 1) & 1], tn);
             }
         }
         st.end();
@@ -225,11 +253,16 @@ __device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const
     STT_FENCE();
 #pragma unroll
     for (int o = 0; o < NO; ++o) out[o] = ldrows(b3 + 32 * o, h);
-    st.begin();
+    Frag fr[2];
 #pragma unroll
     for (int i = 0; i < 8 * NO; ++i) {
-        if (i > 0 && i % 3 == 0) { st.end(); st.begin(); }
-        tile_mma(out[i / 8], st.cur() + (i % 3) * C32_TILE, acc2[i % 8]);
+        if (i % 3 == 0) {
+            if (i > 0) st.end();
+            ldfrag(fr[i & 1], st.cur());
+            st.begin();
+        }
+        const f32x4* tn = (i % 3 < 2 && i + 1 < 8 * NO) ? st.cur() + (i % 3 + 1) * C32_TILE : nullptr;
+        tile_mma2(out[i / 8], fr[i & 1], acc2[i % 8], fr[(i + 1) & 1], tn);
     }
     st.end();
 }
@@ -287,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     __syncthreads();
 
     int gi = 0;
+    (void)gi;
     while (true) {
         C32_STAMP(0);
         const int col = g * 128 + wave * 32 + c;
@@ -351,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
 #pragma unroll 1
             for (int t = 0; t < A.Tp; ++t) {
                 f32x16 e = ldrows(cst + CO::cb, h);
+                Frag fa, fb;
+                ldfrag(fa, st.cur());
                 st.begin();
-                tile_mma(e, st.cur(), d);
+                tile_mma2(e, fa, d, fb, nullptr);
                 e = relu16(e);
                 st.end();
                 f32x16 hn[3];
@@ -362,36 +398,36 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                     // One gate accumulator is live at a time (finished gates shrink to their 16 outputs).
                     STT_FENCE();
                     f32x16 ar = ldrows(gb + 0 * 96 + 32 * j, h);
-                    st.begin();
-                    tile_mma(ar, st.cur() + 0 * C32_TILE, e);
-                    tile_mma(ar, st.cur() + 1 * C32_TILE, hs[0]);
-                    tile_mma(ar, st.cur() + 2 * C32_TILE, hs[1]);
-                    st.end(); st.begin();
-                    tile_mma(ar, st.cur() + 0 * C32_TILE, hs[2]);
+                    ldfrag(fa, st.cur()); st.begin();
+                    tile_mma2(ar, fa, e, fb, st.cur() + 1 * C32_TILE);
+                    tile_mma2(ar, fb, hs[0], fa, st.cur() + 2 * C32_TILE);
+                    tile_mma2(ar, fa, hs[1], fb, nullptr);
+                    st.end(); ldfrag(fa, st.cur()); st.begin();
+                    tile_mma2(ar, fa, hs[2], fb, st.cur() + 1 * C32_TILE);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ar[r] = C32_SIG(ar[r]);          // r gate
                     STT_FENCE();
                     f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
-                    tile_mma(az, st.cur() + 1 * C32_TILE, e);
-                    tile_mma(az, st.cur() + 2 * C32_TILE, hs[0]);
-                    st.end(); st.begin();
-                    tile_mma(az, st.cur() + 0 * C32_TILE, hs[1]);
-                    tile_mma(az, st.cur() + 1 * C32_TILE, hs[2]);
+                    tile_mma2(az, fb, e, fa, st.cur() + 2 * C32_TILE);
+                    tile_mma2(az, fa, hs[0], fb, nullptr);
+                    st.end(); ldfrag(fa, st.cur()); st.begin();
+                    tile_mma2(az, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
+                    tile_mma2(az, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) az[r] = C32_SIG(az[r]);          // z gate
                     STT_FENCE();
                     f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
-                    tile_mma(an, st.cur() + 2 * C32_TILE, hs[0]);
-                    st.end(); st.begin();
-                    tile_mma(an, st.cur() + 0 * C32_TILE, hs[1]);
-                    tile_mma(an, st.cur() + 1 * C32_TILE, hs[2]);
+                    tile_mma2(an, fa, hs[0], fb, nullptr);
+                    st.end(); ldfrag(fa, st.cur()); st.begin();
+                    tile_mma2(an, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
+                    tile_mma2(an, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
                     {
                         const f32x16 bi = ldrows(gb + 2 * 96 + 32 * j, h);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) an[r] = fmaf(ar[r], an[r], bi[r]);     // b_in + r * (W_hn h + b_hn)
                     }
                     STT_FENCE();
-                    tile_mma(an, st.cur() + 2 * C32_TILE, e);                               // + W_in e
+                    tile_mma2(an, fa, e, fb, nullptr);                                       // + W_in e
                     st.end();
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

@@ -291,10 +291,10 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
     const float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
     float *dbuf = ws + off[STT_B_DBUF], *ybuf = ws + off[STT_B_YBUF], *state1 = ws + off[STT_B_STATE1];
     // Fused chain: one persistent kernel for the whole per-trajectory stage (csrc/chain32.hip).  Its work item is a group of
-    // 128 trajectories on one workgroup, so automatic mode uses it once the batch fills the chip's 512 workgroup slots at least
-    // ~once (small batches keep the 16-column kernels, whose items spread over more CUs).
+    // 128 trajectories on one workgroup, so automatic mode uses it from 128 groups on (measured: +4..5 % at 20-28 k trajectories, the SDD
+    // and NBA-128 legs; smaller batches keep the 16-column kernels, whose items spread over more CUs).
     const long ncols_all = (long)n * K;
-    const bool fused = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 32768);
+    const bool fused = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
     if (fused) {
         RUN(STT_STAGE_CHAIN, s,
             sttode_traj_chain(A0x, A0y, A1y, W[STT_W_CHAIN_POOL], (const int*)W[STT_W_CHAIN_PROG], m->prog_len, W[STT_W_CHAIN_CONSTS], z,
