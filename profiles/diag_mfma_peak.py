@@ -39,7 +39,8 @@ for w in (4, 8, 12, 16):
         print(f'waves/CU {w:2d}  {KN[k]:32s} median {np.median(vals[k]):6.1f}  best {max(vals[k]):6.1f} TFLOP/s', flush=True)
 
 SN = {0: '16x16x4 stream, 18 KiB chunks (round-1 mlp_block0 shape)', 1: '32x32x2 stream, 12 KiB chunks', 2: '32x32x2 stream, 12 KiB chunks, fragment prefetch',
-      3: '32x32x2 stream, 36 KiB chunks', 4: '32x32x2 stream, 36 KiB chunks, fragment prefetch'}
+      3: '32x32x2 stream, 36 KiB chunks', 4: '32x32x2 stream, 36 KiB chunks, fragment prefetch',
+      5: '32x32x2 stream, 36 KiB chunks, two interleaved accumulator chains'}
 for wg in (1, 2, 3):
     vals = {k: [] for k in SN}
     for _ in range(ROUNDS):

@@ -3,6 +3,7 @@
 
   python profiles/summarize_pmc.py gpurun_out profiles/r01
 
+Round 2: python profiles/summarize_pmc.py gpurun_out/r02c profiles/r02   (also copies the bench lines / sweep / text artefacts)
 Reads  <in>/pmc_*/**/_counter_collection.csv (+ kernel_trace.csv for durations) and <in>/prof*/**/_kernel_stats.csv.
 Writes <out>/pmc_summary.json (per kernel: mean duration, counters, derived MFMA utilisation and clock) and
        profiles/traffic.json (HBM bytes per launch per pipeline stage; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -15,7 +16,7 @@ import json
 import os
 import sys
 
-STAGE_OF = {'mlp_block0_kernel': 'mlp_block0', 'mlp_block1_kernel': 'mlp_block1', 'post_attn_kernel': 'post_attn',
+STAGE_OF = {'traj_chain_kernel': 'trajectory_chain', 'mlp_block0_kernel': 'mlp_block0', 'mlp_block1_kernel': 'mlp_block1', 'post_attn_kernel': 'post_attn',
             'embed_qkv_kernel': 'embed_qkv', 'linear_cols_kernel': 'agent_preact', 'gru_cols_kernel': 'gru_cols'}
 
 
@@ -65,7 +66,13 @@ def main(src, dst):
             st = 'gru_cols[block1,trajectories]' if 'trajectories' in name else 'gru_cols[block0,agents]'
         if st:
             traffic[st] = e['hbm_bytes_per_launch']
-    json.dump(traffic, open(os.path.join(os.path.dirname(dst.rstrip('/')), 'traffic.json'), 'w'), indent=1, sort_keys=True)
+    # bench.py looks the dominant kernel's traffic up as traffic.json[leg][stage]; the PMC passes run the headline leg
+    tp = os.path.join(os.path.dirname(dst.rstrip('/')), 'traffic.json')
+    allt = json.load(open(tp)) if os.path.exists(tp) else {}
+    if allt and not all(isinstance(v, dict) for v in allt.values()):
+        allt = {'round1_three_kernel_form': allt}
+    allt['eth_512'] = traffic
+    json.dump(allt, open(tp, 'w'), indent=1, sort_keys=True)
     for f in glob.glob(os.path.join(src, 'prof*', '*', '*_kernel_stats.csv')):
         tag = f.split(os.sep)[-3]
         rows = list(csv.DictReader(open(f)))[:14]
@@ -77,5 +84,28 @@ def main(src, dst):
                       for k, v in out.items()}, indent=1))
 
 
+def copy_lines(src, dst):
+    import shutil
+    sweep = {}
+    for f in sorted(glob.glob(os.path.join(src, '*.json'))):
+        name = os.path.basename(f)
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if name.startswith('sweep_s'):
+            r = d.get('roofline') or {}
+            sweep[name[len('sweep_s'):-5]] = {'scenes': d['config']['scenes_per_gpu'], 'trajectories': d['config']['trajectories_rank0'],
+                                              'ms_per_step': d['ms_per_step'], 'M_traj_per_s': d['value'] / 1e6, 'dominant_kernel': r.get('kernel'),
+                                              'frac': r.get('frac'), 'tflops': {k: v.get('tflops') for k, v in d['kernels'].items() if 'tflops' in v}}
+        else:
+            shutil.copy(f, os.path.join(dst, name))
+    if sweep:
+        json.dump(dict(sorted(sweep.items(), key=lambda kv: int(kv[0]))), open(os.path.join(dst, 'batch_sweep.json'), 'w'), indent=1)
+    for f in glob.glob(os.path.join(src, '*.txt')):
+        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+
+
 if __name__ == '__main__':
     main(sys.argv[1], sys.argv[2])
+    copy_lines(sys.argv[1], sys.argv[2])

@@ -308,6 +308,73 @@ __global__ __launch_bounds__(256, 2) void diag_stream32_kernel(const f32x4* __re
     if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// shape 5: as shape 3 (36 KiB chunks = one hidden tile: 1 layer-1 tile + 8 layer-2 row tiles), but the layer-2 MFMAs of two row tiles
+// ALTERNATE (acc2[2p], acc2[2p+1]): two independent accumulator chains instead of 16 back-to-back dependent MFMAs on one.
+__global__ __launch_bounds__(256, 2) void diag_stream32i_kernel(const f32x4* __restrict__ blob, int total_tiles, float* __restrict__ out,
+                                                                int ngroups, float seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* lds = reinterpret_cast<f32x4*>(smem);
+    constexpr int TILE = 256, C = 9;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto dma = [&](int chunk, int buf) {
+        const f32x4* src = blob + ((size_t)chunk * C % total_tiles) * TILE + lane;
+        f32x4* dst = lds + buf * (C * TILE);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int idx = i * 4 + wave;
+            glds16(src + idx * 64, dst + idx * 64);
+        }
+    };
+    f32x16 acc2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = seed * (float)(i + 1);
+    f32x16 Bz;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Bz[e] = 1.0f - 0.002f * (float)(lane + e);
+    f32x16 h1;
+    dma(blockIdx.x, 0);
+    __syncthreads();
+    int chunk = 0;
+    for (int grp = 0; grp < ngroups * 9; ++grp) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma(blockIdx.x + chunk + 1, (chunk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4* buf = lds + (chunk & 1) * (C * TILE) + lane;
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = buf[g * 64];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) h1[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j >> 2][j & 3], Bz[j], h1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) h1[e] = fmaxf(h1[e], 0.f);
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { a[g] = buf[(1 + 2 * p2) * TILE + g * 64]; b[g] = buf[(2 + 2 * p2) * TILE + g * 64]; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                acc2[2 * p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j >> 2][j & 3], h1[j], acc2[2 * p2], 0, 0, 0);
+                acc2[2 * p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j >> 2][j & 3], h1[j], acc2[2 * p2 + 1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        ++chunk;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc2[i][e];
+    if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 struct StreamCtx { int shape, grid, lds, n, total; const f32x4* blob; float* scratch; hipStream_t s; };
 static void stream_go(void* p) {
     StreamCtx* c = (StreamCtx*)p;
@@ -317,16 +384,18 @@ static void stream_go(void* p) {
         case 1: hipLaunchKernelGGL((diag_stream32_kernel<3, 0>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
         case 2: hipLaunchKernelGGL((diag_stream32_kernel<3, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
         case 3: hipLaunchKernelGGL((diag_stream32_kernel<9, 0>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
-        default: hipLaunchKernelGGL((diag_stream32_kernel<9, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
+        case 4: hipLaunchKernelGGL((diag_stream32_kernel<9, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
+        default: hipLaunchKernelGGL(diag_stream32i_kernel, g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
     }
 }
 
-// shape: 0 16x16x4 stream (3 WG/CU) | 1 32x32x2 C=3 | 2 32x32x2 C=3 prefetched | 3 32x32x2 C=9 | 4 32x32x2 C=9 prefetched
+// shape: 0 16x16x4 stream (3 WG/CU) | 1 32x32x2 C=3 | 2 32x32x2 C=3 prefetched | 3 32x32x2 C=9 | 4 32x32x2 C=9 prefetched | 5 C=9, two
+// interleaved accumulator chains
 // (2 WG/CU).  wgs_per_cu <= 3 (shape 0) / 2 (others); blob: >= 2 MiB of random weights (L2 resident); n: chunks (shape 0) or
 // 9-chunk groups (others) per workgroup.
 extern "C" int sttode_diag_stream(int shape, int wgs_per_cu, int n, int repeats, const float* blob, long blob_floats, float* scratch,
                                   double* tflops, void* stream) {
-    DIAG_REQUIRE(blob && scratch && tflops && n > 0 && repeats > 0 && shape >= 0 && shape <= 4, "sttode_diag_stream: bad arguments");
+    DIAG_REQUIRE(blob && scratch && tflops && n > 0 && repeats > 0 && shape >= 0 && shape <= 5, "sttode_diag_stream: bad arguments");
     DIAG_REQUIRE(wgs_per_cu >= 1 && wgs_per_cu <= (shape == 0 ? 3 : 2), "sttode_diag_stream: too many workgroups per CU");
     DIAG_REQUIRE(blob_floats >= 512 * 1024, "sttode_diag_stream: blob must hold >= 2 MiB");
     StreamCtx c;
@@ -341,7 +410,8 @@ extern "C" int sttode_diag_stream(int shape, int wgs_per_cu, int n, int repeats,
         c.lds = 2 * C * 4096; c.total = (int)(blob_floats / 4 / 256) / C * C;
         flop_per_wg = 4.0 * n * 9.0 * C * 16.0 * 4096.0;
         const void* f = shape == 1 ? (const void*)diag_stream32_kernel<3, 0> : shape == 2 ? (const void*)diag_stream32_kernel<3, 1>
-                      : shape == 3 ? (const void*)diag_stream32_kernel<9, 0> : (const void*)diag_stream32_kernel<9, 1>;
+                      : shape == 3 ? (const void*)diag_stream32_kernel<9, 0> : shape == 4 ? (const void*)diag_stream32_kernel<9, 1>
+                      : (const void*)diag_stream32i_kernel;
         DIAG_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
     }
     double ms = 0;
