@@ -118,11 +118,17 @@ int sttode_mlp_cols(const float* A0, const float* stream, int total_chunks, cons
  * (replaces sttode_mlp_block0 + sttode_gru_cols + sttode_mlp_block1 on the inference path; csrc/chain32.hip).
  * A0x/A0y/A1y [n,512] as above; pool/prog/consts: packing.chain_stream (PK32 tile pool, per-group chunk program of
  * sttode_chain_prog_len(Tp,Tf) int32 pairs, bias block); xpad [n,ldx] (ldx = 16 or 32); counter: one int32 of scratch
- * (work queue, zeroed by the call on `stream`). */
+ * (work queue, zeroed by the call on `stream`); wgs_per_cu: resident workgroups per CU, 2 for a stand-alone call, 1 when kernels of
+ * other streams should run beside it (the pipelined forms use 1). */
 int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                       const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
-                      float* pred, int* counter, int ncols, int K, int Tp, int Tf, void* stream);
+                      float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream);
 int sttode_chain_prog_len(int Tp, int Tf);
+/* sttode_gru_cols in streaming form (same function: DecomposeBlock front half, model/STTODE.py:62-69): 32-column MFMA tiles, every
+ * weight tile streamed per step, 24 KiB of LDS -- its workgroups co-reside with a running sttode_traj_chain of another stream, which
+ * the resident-weights kernel (144 KiB of LDS) cannot.  pool / prog / consts: packing.gru32_stream; prog_len = 13 * Tp; ldx = 16 | 32. */
+int sttode_gru_cols32(const float* xin, int ldx, const float* pool, const int* prog, int prog_len, const float* consts, float* state,
+                      int ncols, int Tp, void* stream);
 
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
@@ -256,7 +262,7 @@ enum SttodeWeight {
     STT_W_B0_CONVP, STT_W_B0_CONVB, STT_W_B0_WIHP, STT_W_B0_WHHP, STT_W_B0_GBIAS, STT_W_B0_XWA, STT_W_B0_XB1, STT_W_B0_YWA,
     STT_W_B0_YB1, STT_W_B0_STREAM,
     STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
-    STT_W_CHAIN_POOL, STT_W_CHAIN_PROG, STT_W_CHAIN_CONSTS,
+    STT_W_CHAIN_POOL, STT_W_CHAIN_PROG, STT_W_CHAIN_CONSTS, STT_W_G0_POOL, STT_W_G0_PROG, STT_W_G0_CONSTS,
     STT_W_COUNT
 };
 

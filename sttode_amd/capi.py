@@ -28,8 +28,9 @@ SIGNATURES = {
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_block1': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_mlp_cols': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
-    'sttode_traj_chain': [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'sttode_traj_chain': [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'sttode_chain_prog_len': [_I, _I],
+    'sttode_gru_cols32': [_P, _I, _P, _P, _I, _P, _P, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     # stage-2 sampler (csrc/sampler.hip)
     'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
@@ -84,7 +85,7 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                                        'ln2b')]
                 + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream')]
                 + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')]
-                + [('chain', k) for k in ('pool', 'prog', 'consts')])
+                + [('chain', k) for k in ('pool', 'prog', 'consts')] + [('gru0s', k) for k in ('pool', 'prog', 'consts')])
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
            'A1y', 'dbuf', 'ybuf', 'state1', 'queue')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',

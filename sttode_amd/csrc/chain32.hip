@@ -267,6 +267,70 @@ __device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const
     st.end();
 }
 
+// conv1d(k=3) + relu + GRU(32 -> 96) over Tp steps for this wave's 32 columns, every weight tile streamed per step
+// (model/STTODE.py:62-69; gate rows pre-scaled, chain.hpp): d = the flattened (t, c) input rows in accumulator layout, hs = h (in/out),
+// gb = gate biases [4][96] (r, z, b_in, b_hn), cb = conv bias [32], both in LDS.  Per step: 1 conv tile (a chunk of its own) and 36
+// gate tiles = 12 chunks.  Shared by the fused chain (block 1, per trajectory) and gru32_kernel (block 0, per agent).
+__device__ __forceinline__ void gru32_steps(ChainStream& st, const float* gb, const float* cb, const f32x16& d, f32x16 (&hs)[3], int Tp, int h) {
+#pragma unroll 1
+    for (int t = 0; t < Tp; ++t) {
+        f32x16 e = ldrows(cb, h);
+        Frag fa, fb;
+        ldfrag(fa, st.cur());
+        st.begin();
+        tile_mma2(e, fa, d, fb, nullptr);
+        e = relu16(e);
+        st.end();
+        f32x16 hn[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // 12 tiles: r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2] n_i:[e]; chunk boundary every 3 tiles.
+            // One gate accumulator is live at a time (finished gates shrink to their 16 outputs).
+            STT_FENCE();
+            f32x16 ar = ldrows(gb + 0 * 96 + 32 * j, h);
+            ldfrag(fa, st.cur()); st.begin();
+            tile_mma2(ar, fa, e, fb, st.cur() + 1 * C32_TILE);
+            tile_mma2(ar, fb, hs[0], fa, st.cur() + 2 * C32_TILE);
+            tile_mma2(ar, fa, hs[1], fb, nullptr);
+            st.end(); ldfrag(fa, st.cur()); st.begin();
+            tile_mma2(ar, fa, hs[2], fb, st.cur() + 1 * C32_TILE);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ar[r] = C32_SIG(ar[r]);          // r gate
+            STT_FENCE();
+            f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
+            tile_mma2(az, fb, e, fa, st.cur() + 2 * C32_TILE);
+            tile_mma2(az, fa, hs[0], fb, nullptr);
+            st.end(); ldfrag(fa, st.cur()); st.begin();
+            tile_mma2(az, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
+            tile_mma2(az, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) az[r] = C32_SIG(az[r]);          // z gate
+            STT_FENCE();
+            f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
+            tile_mma2(an, fa, hs[0], fb, nullptr);
+            st.end(); ldfrag(fa, st.cur()); st.begin();
+            tile_mma2(an, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
+            tile_mma2(an, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
+            {
+                const f32x16 bi = ldrows(gb + 2 * 96 + 32 * j, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) an[r] = fmaf(ar[r], an[r], bi[r]);     // b_in + r * (W_hn h + b_hn)
+            }
+            STT_FENCE();
+            tile_mma2(an, fa, e, fb, nullptr);                                       // + W_in e
+            st.end();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ng = C32_TANH(an[r]);
+                hn[j][r] = fmaf(az[r], hs[j][r] - ng, ng);  // (1-z) n + z h
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hs[j] = hn[j];
+    }
+
+}
+
 // makes a per-lane integer opaque to the optimiser: address arithmetic derived from it is redone where it is used instead of
 // being computed once at the top of the group and kept live (64-bit pointers held across phases were what spilled)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -378,66 +442,10 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         STT_FENCE();
         C32_STAMP(2);
         f32x16 hs[3];
-        {   // ---- block 1: conv1d + relu + GRU over Tp steps, weights streamed per step (gate rows pre-scaled, chain.hpp)
+        {   // ---- block 1: conv1d + relu + GRU over Tp steps, weights streamed per step
 #pragma unroll
             for (int j = 0; j < 3; ++j) hs[j] = splat16(0.f);
-            const float* gb = cst + CO::gb;
-#pragma unroll 1
-            for (int t = 0; t < A.Tp; ++t) {
-                f32x16 e = ldrows(cst + CO::cb, h);
-                Frag fa, fb;
-                ldfrag(fa, st.cur());
-                st.begin();
-                tile_mma2(e, fa, d, fb, nullptr);
-                e = relu16(e);
-                st.end();
-                f32x16 hn[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    // 12 tiles: r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2] n_i:[e]; chunk boundary every 3 tiles.
-                    // One gate accumulator is live at a time (finished gates shrink to their 16 outputs).
-                    STT_FENCE();
-                    f32x16 ar = ldrows(gb + 0 * 96 + 32 * j, h);
-                    ldfrag(fa, st.cur()); st.begin();
-                    tile_mma2(ar, fa, e, fb, st.cur() + 1 * C32_TILE);
-                    tile_mma2(ar, fb, hs[0], fa, st.cur() + 2 * C32_TILE);
-                    tile_mma2(ar, fa, hs[1], fb, nullptr);
-                    st.end(); ldfrag(fa, st.cur()); st.begin();
-                    tile_mma2(ar, fa, hs[2], fb, st.cur() + 1 * C32_TILE);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ar[r] = C32_SIG(ar[r]);          // r gate
-                    STT_FENCE();
-                    f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
-                    tile_mma2(az, fb, e, fa, st.cur() + 2 * C32_TILE);
-                    tile_mma2(az, fa, hs[0], fb, nullptr);
-                    st.end(); ldfrag(fa, st.cur()); st.begin();
-                    tile_mma2(az, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
-                    tile_mma2(az, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) az[r] = C32_SIG(az[r]);          // z gate
-                    STT_FENCE();
-                    f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
-                    tile_mma2(an, fa, hs[0], fb, nullptr);
-                    st.end(); ldfrag(fa, st.cur()); st.begin();
-                    tile_mma2(an, fa, hs[1], fb, st.cur() + 1 * C32_TILE);
-                    tile_mma2(an, fb, hs[2], fa, st.cur() + 2 * C32_TILE);
-                    {
-                        const f32x16 bi = ldrows(gb + 2 * 96 + 32 * j, h);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) an[r] = fmaf(ar[r], an[r], bi[r]);     // b_in + r * (W_hn h + b_hn)
-                    }
-                    STT_FENCE();
-                    tile_mma2(an, fa, e, fb, nullptr);                                       // + W_in e
-                    st.end();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float ng = C32_TANH(an[r]);
-                        hn[j][r] = fmaf(az[r], hs[j][r] - ng, ng);  // (1-z) n + z h
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) hs[j] = hn[j];
-            }
+            gru32_steps(st, cst + CO::gb, cst + CO::cb, d, hs, A.Tp, h);
         }
         STT_FENCE();
         C32_STAMP(3);
@@ -487,6 +495,58 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     }
 }
 
+// Stand-alone streaming GRU over columns (block 0: one column per AGENT): the same 32-column MFMA tiles and weight stream as the
+// fused chain, 24 KiB of LDS and <= 256 VGPRs per wave, so its workgroups co-reside with a chain workgroup of another stream.  The
+// resident-weights gru_cols kernel (144 KiB of LDS) cannot: in the pipelined form it had to wait for the running chain's tail.
+struct Gru32Args {
+    const float* xin; int ldx;                    // [ncols][ldx] flattened (t, c) input rows, zero padded
+    const f32x4* pool; const int2* prog; int prog_len;
+    const float* consts;                          // gbias[4][96] convb[32]
+    float* state;                                 // [ncols][96]
+    int ncols, Tp;
+};
+__global__ __launch_bounds__(256, 2) void gru32_kernel(Gru32Args A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* ring = reinterpret_cast<f32x4*>(smem);
+    float* cst = reinterpret_cast<float*>(ring + C32_RING);
+    int2* lprog = reinterpret_cast<int2*>(cst + 416);
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 416; i += blockDim.x) cst[i] = A.consts[i];
+    for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
+    __syncthreads();
+    ChainStream st;
+    st.init(A.pool, lprog, A.prog_len, ring);
+    const int col = blockIdx.x * 128 + wave * 32 + c;
+    const int colc = col < A.ncols ? col : A.ncols - 1;
+    f32x16 d;
+    {
+        const float* xp = A.xin + (size_t)colc * A.ldx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 v = splat4(0.f);
+            if (8 * a + 4 * h < A.ldx) v = ld4(xp + 8 * a + 4 * h);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[4 * a + b] = v[b];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 hs[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hs[j] = splat16(0.f);
+    gru32_steps(st, cst, cst + 384, d, hs, A.Tp, h);
+    if (col < A.ncols) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = {hs[j][4 * a], hs[j][4 * a + 1], hs[j][4 * a + 2], hs[j][4 * a + 3]};
+                st4(A.state + (size_t)col * 96 + 32 * j + 8 * a + 4 * h, v);
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
@@ -502,10 +562,10 @@ static int chain_cus() {
 }
 static int chain_lds(int NY, int prog_len) { return (C32_RING + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
-template <int NY> static int chain_launch(const ChainArgs& a, hipStream_t s) {
+template <int NY> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
     static bool attr_set = false;  // once per instantiation (hipFuncSetAttribute is a driver call)
     if (!attr_set) {
-        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int ngroups = (a.ncols + 127) / 128;
@@ -516,7 +576,33 @@ template <int NY> static int chain_launch(const ChainArgs& a, hipStream_t s) {
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
     STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), chain_lds(NY, a.prog_len), s, a);
+    // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
+    // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
+    // of LDS stay free for kernels of OTHER streams: the per-agent stage of the next call and the next call's chain run beside this
+    // one instead of waiting for its tail (pipelined callers: 72.9 vs 62.4 M trajectories/s at 512 scenes on one box).  A single
+    // serial call is ~4 % faster with two resident workgroups.
+    static int wgs_env = -1;   // STTODE_CHAIN_WGS=1|2 overrides the caller's choice (experiments)
+    if (wgs_env < 0) { const char* e = getenv("STTODE_CHAIN_WGS"); wgs_env = e ? atoi(e) : 0; }
+    const int wgs = wgs_env > 0 ? wgs_env : wgs_per_cu;
+    int lds = chain_lds(NY, a.prog_len);
+    if (wgs == 1 && lds < 84 * 1024) lds = 84 * 1024;
+    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), lds, s, a);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// DecomposeBlock front half over columns, streaming form (same function as sttode_gru_cols: model/STTODE.py:62-69).  pool / prog /
+// consts: packing.gru32_stream (36 gate tiles + Tp conv tiles; 13*Tp chunk entries; gate biases [4][96] + conv bias [32]).
+extern "C" int sttode_gru_cols32(const float* xin, int ldx, const float* pool, const int* prog, int prog_len, const float* consts,
+                                 float* state, int ncols, int Tp, void* stream) {
+    STT_REQUIRE(xin && pool && prog && consts && state, "sttode_gru_cols32: null pointer");
+    STT_REQUIRE(ncols > 0 && Tp >= 1 && (ldx == 16 || ldx == 32) && 2 * Tp <= ldx, "sttode_gru_cols32: bad ncols/Tp/ldx");
+    STT_REQUIRE(prog_len == 13 * Tp, "sttode_gru_cols32: chunk program must hold 13 entries per step");
+    Gru32Args a;
+    a.xin = xin; a.ldx = ldx; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len; a.consts = consts;
+    a.state = state; a.ncols = ncols; a.Tp = Tp;
+    const int lds = C32_RING * 16 + 416 * 4 + prog_len * 8 + 16;
+    hipLaunchKernelGGL(gru32_kernel, dim3((ncols + 127) / 128), dim3(256), lds, (hipStream_t)stream, a);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -535,10 +621,11 @@ extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
 // Fused per-trajectory chain of Decoder.forward (model/STTODE.py:320-347) for K samples per agent; see the file header.
 extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                                  const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
-                                 float* pred, int* counter, int ncols, int K, int Tp, int Tf, void* stream) {
+                                 float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream) {
     STT_REQUIRE(A0x && A0y && A1y && pool && prog && consts && z && xpad && cur && orig && pred && counter, "sttode_traj_chain: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && Tp >= 1 && 2 * Tp <= 32 && Tf >= 1, "sttode_traj_chain: bad ncols/K/Tp/Tf");
     STT_REQUIRE(ldx == 16 || ldx == 32, "sttode_traj_chain: ldx must be 16 or 32");
+    STT_REQUIRE(wgs_per_cu == 1 || wgs_per_cu == 2, "sttode_traj_chain: wgs_per_cu must be 1 or 2");
     STT_REQUIRE(2 * Tp <= ldx, "sttode_traj_chain: xpad rows shorter than 2*Tp");
     STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "sttode_traj_chain: chunk program length does not match (Tp, Tf)");
     ChainArgs a;
@@ -559,9 +646,9 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {
-        case 1: return chain_launch<1>(a, s);
-        case 2: return chain_launch<2>(a, s);
-        case 3: return chain_launch<3>(a, s);
+        case 1: return chain_launch<1>(a, wgs_per_cu, s);
+        case 2: return chain_launch<2>(a, wgs_per_cu, s);
+        case 3: return chain_launch<3>(a, wgs_per_cu, s);
         default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;

@@ -244,6 +244,14 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         STT_HIP(hipEventRecord(m->ev_fork, s));
         STT_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     }
+    // STTODE_GRU0_STREAM=1 (default off): same-box A/Bs showed no gain over the resident-weights kernel once the chain keeps one
+    // workgroup per CU (63.7 vs 65.7 / 64.3 M trajectories/s), so the streaming form stays an option, not the default
+    static const bool gru0_stream = getenv("STTODE_GRU0_STREAM") && atoi(getenv("STTODE_GRU0_STREAM")) != 0;
+    if (!use_side && gru0_stream && (long)n * m->K >= 16384) {
+        // streaming GRU (24 KiB of LDS): co-resides with the previous calls' chain workgroups
+        RUN(STT_STAGE_GRU0, gs,
+            sttode_gru_cols32(xpad, 16 * TPX, W[STT_W_G0_POOL], (const int*)W[STT_W_G0_PROG], 13 * Tp, W[STT_W_G0_CONSTS], state0, n, Tp, gs));
+    } else
     RUN(STT_STAGE_GRU0, gs,
         sttode_gru_cols(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
                         Tp, TPX, gs));
@@ -284,7 +292,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
 }
 
 // stage B: everything per TRAJECTORY (block-0 MLPs, block-1 GRU, block-1 MLP + epilogue), on stream s
-static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n, const float* z, float* pred, hipStream_t s) {
+static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n, const float* z, float* pred, hipStream_t s, bool pipelined) {
     const float* const* W = m->w;
     const int K = m->K, Tp = m->Tp, Tf = m->Tf, TPX = m->TPX, NOY = m->NOY;
     const float* xpad = ws + off[STT_B_XPAD];
@@ -299,7 +307,7 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
         RUN(STT_STAGE_CHAIN, s,
             sttode_traj_chain(A0x, A0y, A1y, W[STT_W_CHAIN_POOL], (const int*)W[STT_W_CHAIN_PROG], m->prog_len, W[STT_W_CHAIN_CONSTS], z,
                               xpad, 16 * TPX, ws + off[STT_B_CUR], ws + off[STT_B_ORIG], pred, (int*)(ws + off[STT_B_QUEUE]), (int)ncols_all, K,
-                              Tp, Tf, s));
+                              Tp, Tf, pipelined ? 1 : 2, s));
         return 0;
     }
     // optional split into column parts at agent boundaries (pointers are simply offset)
@@ -358,7 +366,7 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
     if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
-    return stage_trajectories(m, ws, off, n, z, pred, s);
+    return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
 
 // pipelined form: stage A on sA, stage B on sB, two workspace slots; the caller later waits with sttode_wait(slot)
@@ -379,7 +387,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     hipStream_t sb = (m->b_streams == 2 && (m->acalls++ & 1)) ? m->sB2 : m->sB;
     STT_HIP(hipStreamWaitEvent(sb, m->ev_call, 0));
     STT_HIP(hipStreamWaitEvent(sb, m->evA_done[slot], 0));
-    if (int rc = stage_trajectories(m, ws, off, n, z, pred, sb)) return rc;
+    if (int rc = stage_trajectories(m, ws, off, n, z, pred, sb, true)) return rc;
     STT_HIP(hipEventRecord(m->evB_done[slot], sb));
     return 0;
 }

@@ -221,7 +221,8 @@ class STTODENet(nn.Module):
                     'blk1': packing.pack_block(sd, 1, a.past_length, a.future_length, first=False),
                     'future': packing.pack_trunk(sd, 'future_encoder.', a.future_length),
                     'post': packing.pack_posterior(sd),
-                    'chain': packing.chain_stream(sd, a.past_length, a.future_length)}
+                    'chain': packing.chain_stream(sd, a.past_length, a.future_length),
+                    'gru0s': packing.gru32_stream(sd, 0, a.past_length)}
             self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
                                 for k, v in d.items()} for g, d in host.items()}
             self._packed_key = key

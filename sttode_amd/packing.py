@@ -266,6 +266,33 @@ def chain_stream(sd, Tp, Tf):
             'consts': np.ascontiguousarray(consts), 'prog_len': len(prog)}
 
 
+def gru32_stream(sd, block, Tp):
+    """Weight stream of the stand-alone streaming GRU (csrc/chain32.hip gru32_kernel) for DecomposeBlock ``block``: the same tile order
+    as the GRU phase of chain_stream.  Returns pool [36 + Tp, 1024], prog [13*Tp, 2], consts [416] (gate biases [4][96], conv bias)."""
+    p = f'decoder.decompose.{block}.'
+    g = lambda k: np.asarray(sd[p + k], np.float32)
+    L2E = np.float32(1.4426950408889634)
+    sc = np.concatenate([np.full(192, -L2E, np.float32), np.full(96, 2 * L2E, np.float32)])
+    wih, whh = g('encoder_past.weight_ih_l0') * sc[:, None], g('encoder_past.weight_hh_l0') * sc[:, None]
+    bih, bhh = g('encoder_past.bias_ih_l0'), g('encoder_past.bias_hh_l0')
+    Pih, Phh = pk32_tiles(wih), pk32_tiles(whh)
+    tiles = []
+    for j in range(3):                                    # r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2] n_i:[e]
+        tiles += [Pih[j, 0], Phh[j, 0], Phh[j, 1], Phh[j, 2], Pih[3 + j, 0], Phh[3 + j, 0], Phh[3 + j, 1], Phh[3 + j, 2],
+                  Phh[6 + j, 0], Phh[6 + j, 1], Phh[6 + j, 2], Pih[6 + j, 0]]
+    conv = pk32_tiles(toeplitz_conv(g('conv_past.weight'), Tp, 2))
+    tiles.extend(conv[t, 0] for t in range(Tp))
+    prog = []
+    for t in range(Tp):
+        prog.append((36 + t, 1))
+        prog.extend((3 * c, 3) for c in range(12))
+    gbias = np.concatenate([(bih[:96] + bhh[:96]) * -L2E, (bih[96:192] + bhh[96:192]) * -L2E, bih[192:] * (2 * L2E), bhh[192:] * (2 * L2E)])
+    consts = np.concatenate([gbias, g('conv_past.bias')]).astype(np.float32)
+    assert consts.size == 416 and len(prog) == 13 * Tp
+    return {'pool': np.ascontiguousarray(np.stack(tiles)), 'prog': np.ascontiguousarray(np.asarray(prog, np.int32)),
+            'consts': np.ascontiguousarray(consts), 'prog_len': len(prog)}
+
+
 def pack_posterior(sd):
     """FutureEncoder head (model/STTODE.py:258-261,297-299): out_mlp 256->128 relu, qz_layer 128->2*zdim."""
     g = lambda k: np.asarray(sd['future_encoder.' + k], np.float32)

@@ -92,6 +92,28 @@ def test_gru_cols_vs_torch(Tp, ncols):
     assert_close(state.cpu().numpy(), ref, rtol=1e-4, atol=2e-5, what='gru state')
 
 
+@pytest.mark.parametrize('Tp,ncols', [(8, 300), (5, 129), (10, 31)])
+def test_streaming_gru_cols32_vs_resident_form(Tp, ncols):
+    """sttode_gru_cols32 (32-column tiles, weights streamed per step) == sttode_gru_cols (16-column tiles, weights resident in LDS) on
+    the same inputs: ragged column counts, Tp 5 / 8 / 10 (ldx 16 and 32)."""
+    from sttode_amd import capi, packing
+    from sttode_amd.weights import make_weights
+    dev = _gpu()
+    sd = make_weights(1234, past_length=Tp, future_length=12)
+    P = packing.pack_block(sd, 0, Tp, 12, first=True)
+    G = packing.gru32_stream(sd, 0, Tp)
+    TPX = packing.tiles_x(Tp)
+    rng = np.random.default_rng(100 + Tp)
+    xin = np.zeros((ncols, 16 * TPX), np.float32)
+    xin[:, :2 * Tp] = rng.standard_normal((ncols, 2 * Tp)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = t(xin)
+    ref, got = torch.zeros(ncols, 96, device=dev), torch.zeros(ncols, 96, device=dev)
+    capi.call('sttode_gru_cols', x, t(P['convP']), t(P['convB']), t(P['wihP']), t(P['whhP']), t(P['gbias']), ref, ncols, Tp, TPX, capi.stream_ptr())
+    capi.call('sttode_gru_cols32', x, 16 * TPX, t(G['pool']), t(G['prog']), G['prog_len'], t(G['consts']), got, ncols, Tp, capi.stream_ptr())
+    assert_close(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'gru_cols32 Tp={Tp}')
+
+
 @pytest.mark.parametrize('N', [2, 7, 32])
 def test_eth_scene_vs_reference_golden(golden, N):
     g = golden(f'eth_N{N}')
@@ -549,6 +571,7 @@ def _two_process_worker(rank, world, port, q):
     allp = parallel.gather_futures(part.permute(1, 0, 2, 3).contiguous())         # [B*N, K, Tf, 2] in rank order
     # ETH path: scenes sharded over the two processes through parallel.infer_sharded
     me = hip_model('eth', 8, 12)
+    me.native().set_chain(0)        # one form of the per-trajectory stage on every shard size, so the comparison below can be bitwise
     sb = scenes.make_scene_batch(range(700, 745), 'eth')
     ze = scenes.latents(71, sb.n_agents)
     pe, metrics = parallel.infer_sharded(me, sb, rank, world, z=ze)
@@ -585,7 +608,11 @@ def test_two_processes_real_collectives_match_single_process():
     me = hip_model('eth', 8, 12)
     sb = scenes.make_scene_batch(range(700, 745), 'eth')
     me.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
-    ref = me.inference(None, z=torch.from_numpy(scenes.latents(71, sb.n_agents)))
+    me.native().set_chain(0)
+    try:
+        ref = me.inference(None, z=torch.from_numpy(scenes.latents(71, sb.n_agents)))
+    finally:
+        me.native().set_chain(-1)
     assert np.array_equal(pe, ref.cpu().numpy())                 # scene independence: bitwise
     a, f = me.best_of_k(ref.permute(1, 0, 2, 3))
     assert cnt == sb.n_agents and abs(ade - float(a.double().mean())) < 1e-5 and abs(fde - float(f.double().mean())) < 1e-5
