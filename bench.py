@@ -258,6 +258,7 @@ class Leg:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         stage_ms = self.model.native().read_timing()
+        self.busy_ms = dict(getattr(self.model.native(), 'busy_ms', {}))
         self.model.native().timing(0)
         tt = torch.tensor([dt, float(self.m)], dtype=torch.float64, device=dev)
         total = float(self.m)
@@ -270,25 +271,36 @@ class Leg:
                 'metrics': acc}
 
     def roofline(self, stage_ms, value_per_gpu, time_every):
+        """Dominant kernel's rate.  Launches of consecutive pipelined steps run CONCURRENTLY (two streams, one workgroup per CU each), so
+        the rate is  (algorithmic FLOP per launch x launches) / busy time,  busy time = length of the union of the launches' [start, end]
+        HIP-event intervals; FLOP / mean launch duration would count the shared time once per launch in flight.  The raw mean launch
+        duration (what rocprofv3 --stats averages) and the mean number of launches in flight are reported next to it."""
         kern, dom = {}, None
         for t, (ms, cnt) in stage_ms.items():
             mean_s = ms * 1e-3 / cnt
-            kern[t] = {'mean_us': 1e6 * mean_s, 'launches_sampled': cnt}
+            busy_s = max(self.busy_ms.get(t, ms), 1e-9) * 1e-3
+            kern[t] = {'mean_us': 1e6 * mean_s, 'launches_sampled': cnt, 'busy_ms': 1e3 * busy_s}
             fl = kernel_flops(t, self.n, self.m, self.F)
             if fl is None:
                 continue
-            kern[t]['tflops'] = fl / mean_s / 1e12
+            kern[t]['tflops'] = fl * cnt / busy_s / 1e12
             if dom is None or ms > dom[1]:
-                dom = (t, ms, fl, mean_s)
+                dom = (t, ms, fl, mean_s, cnt, busy_s)
         roof = None
         if dom:
             traffic = None
             tp = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get(self.name, {}).get(dom[0])
-            roof = {'kernel': dom[0], 'bound': 'mfma', 'achieved': dom[2] / dom[3] / 1e12, 'peak': PEAK_F32_MFMA / 1e12,
-                    'unit': 'TFLOP/s', 'frac': dom[2] / dom[3] / PEAK_F32_MFMA, 'traffic': traffic,
-                    'flop_per_launch': dom[2], 'mean_launch_s': dom[3], 'events_every_nth_step': time_every,
+            ach = dom[2] * dom[4] / dom[5]
+            roof = {'kernel': dom[0], 'bound': 'mfma', 'achieved': ach / 1e12, 'peak': PEAK_F32_MFMA / 1e12,
+                    'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA, 'traffic': traffic,
+                    'flop_per_launch': dom[2], 'launches': dom[4], 'busy_time_s': dom[5], 'mean_launch_s': dom[3],
+                    'launches_in_flight': dom[3] * dom[4] / dom[5],
+                    'achieved_definition': 'flop_per_launch * launches / busy_time_s (union of the launch intervals); with launches_in_flight = 1 '
+                                           'this is flop_per_launch / mean_launch_s',
+                    'frac_per_launch_latency': dom[2] / dom[3] / PEAK_F32_MFMA,
+                    'events_every_nth_step': time_every,
                     # whole-path figure: executed (de-duplicated, layer-1 split) FLOP per trajectory x throughput / peak
                     'path_frac_executed': value_per_gpu * self.F['path_per_traj'] / PEAK_F32_MFMA,
                     'path_flop_per_trajectory': self.F['path_per_traj']}

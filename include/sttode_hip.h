@@ -292,9 +292,13 @@ int sttode_set_chain(SttodeModel* m, int mode);
 /* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
  * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */
 int sttode_set_ode(SttodeModel* m, int method, int steps);
-/* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams */
+/* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams (the
+ * per-trajectory stages are bracketed on every call while n > 0) */
 int sttode_timing_enable(SttodeModel* m, int every);
-int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/);
+/* total_ms: sum of the launches' durations; busy_ms (optional): length of the union of their [start, end] intervals -- launches of
+ * consecutive pipelined calls overlap, so a stage's rate is work / busy time, not work / mean launch duration. */
+int sttode_timing_read(SttodeModel* m, double* total_ms /*[STT_STAGE_COUNT]*/, int* launches /*[STT_STAGE_COUNT]*/,
+                       double* busy_ms /*[STT_STAGE_COUNT] or NULL*/);
 
 /* set_data (batched over scenes) + inference (model/STTODE.py:397-461,574-623; caller loop test.py:171-184).
  * past [n,Tp,2] world coords, scene_ptr [S+1], z [n*K,32] -> pred [n,K,Tf,2] world coords. */

@@ -71,7 +71,7 @@ SIGNATURES = {
     'sttode_set_chain': [_P, _I],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
-    'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
+    'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     'sttode_inference_nba': [_P, _P, _I, _I, _P, _P, _P, _P],
     'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
@@ -137,9 +137,11 @@ class NativeModel:
     def read_timing(self):
         ms = (ctypes.c_double * len(STAGES))()
         cnt = (ctypes.c_int * len(STAGES))()
-        rc = lib().sttode_timing_read(self.h, ms, cnt)
+        busy = (ctypes.c_double * len(STAGES))()
+        rc = lib().sttode_timing_read(self.h, ms, cnt, busy)
         if rc != 0:
             raise SttodeError('sttode_timing_read failed: ' + lib().sttode_last_error().decode())
+        self.busy_ms = {STAGES[i]: busy[i] for i in range(len(STAGES)) if cnt[i]}     # union of the launches' intervals per stage
         return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES)) if cnt[i]}
 
     def __del__(self):

@@ -11,6 +11,8 @@
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include <cstring>
 
 #include <cstdlib>
@@ -190,29 +192,52 @@ static hipEvent_t get_event(SttodeModel* m) {
 }
 
 // Reads (and clears) the per-stage totals accumulated since the last read.  Synchronises on the recorded events.
-extern "C" int sttode_timing_read(SttodeModel* m, double* total_ms, int* launches) {
+extern "C" int sttode_timing_read(SttodeModel* m, double* total_ms, int* launches, double* busy_ms) {
     STT_REQUIRE(m && total_ms && launches, "sttode_timing_read: null pointer");
-    for (int i = 0; i < STT_STAGE_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (int i = 0; i < STT_STAGE_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; if (busy_ms) busy_ms[i] = 0.0; }
+    // busy time of a stage = length of the UNION of its launches' [start, end] intervals (launches of consecutive pipelined calls run
+    // concurrently on two streams: their durations add up to more than the time the stage kept the device busy)
+    std::vector<std::pair<double, double>> iv[STT_STAGE_COUNT];
+    hipEvent_t ref = m->recs.empty() ? nullptr : m->recs.front().e0;
     for (auto& r : m->recs) {
         STT_HIP(hipEventSynchronize(r.e1));
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         STT_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
         total_ms[r.stage] += ms;
         launches[r.stage] += 1;
-        m->pool.push_back(r.e0);
-        m->pool.push_back(r.e1);
+        if (busy_ms && r.e0 != ref) {
+            STT_HIP(hipEventSynchronize(r.e0));
+            STT_HIP(hipEventElapsedTime(&t0, ref, r.e0));   // may be negative: `ref` is merely the first record made on the host
+        }
+        iv[r.stage].push_back({(double)t0, (double)t0 + (double)ms});
     }
+    if (busy_ms)
+        for (int st = 0; st < STT_STAGE_COUNT; ++st) {
+            std::sort(iv[st].begin(), iv[st].end());
+            double cur0 = 0, cur1 = 0;
+            bool open = false;
+            for (auto& p : iv[st]) {
+                if (!open) { cur0 = p.first; cur1 = p.second; open = true; }
+                else if (p.first <= cur1) { if (p.second > cur1) cur1 = p.second; }
+                else { busy_ms[st] += cur1 - cur0; cur0 = p.first; cur1 = p.second; }
+            }
+            if (open) busy_ms[st] += cur1 - cur0;
+        }
+    for (auto& r : m->recs) { m->pool.push_back(r.e0); m->pool.push_back(r.e1); }
     m->recs.clear();
     return 0;
 }
 
 struct StageTimer {
-    SttodeModel* m; int stage; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    SttodeModel* m; int stage; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
     StageTimer(SttodeModel* m_, int st, hipStream_t s_) : m(m_), stage(st), s(s_) {
-        if (m->timing) { e0 = get_event(m); e1 = get_event(m); (void)hipEventRecord(e0, s); }
+        // the per-trajectory stages (two events per call) are bracketed on EVERY call while timing is enabled, so that overlapping launches
+        // of consecutive calls are seen; the many short per-agent stages only on the sampled calls
+        on = m->timing || (m->timing_every > 0 && stage >= STT_STAGE_MLP0);
+        if (on) { e0 = get_event(m); e1 = get_event(m); (void)hipEventRecord(e0, s); }
     }
     ~StageTimer() {
-        if (m->timing) { (void)hipEventRecord(e1, s); m->recs.push_back({stage, e0, e1}); }
+        if (on) { (void)hipEventRecord(e1, s); m->recs.push_back({stage, e0, e1}); }
     }
 };
 

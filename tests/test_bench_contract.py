@@ -30,6 +30,35 @@ def test_committed_bench_line_honours_the_contract():
     assert d['parity']['max_err_over_1_plus_abs_ref'] < 1e-4 and d['parity']['ade_abs_diff'] < 1e-4
 
 
+def test_committed_round2_line_honours_the_contract():
+    """profiles/r02/final_bench.json = the default `python bench.py` line of the round-2 collection run: contract keys, every BASELINE config
+    as a leg with parity + roofline + CPU sample, the train object, and a self-consistent busy-time roofline."""
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'final_bench.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'rccl_ranks', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'configs', 'train', 'value_incl_d2h'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 0 and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert 'BASELINE configs[1]' in d['config']['workload'] and d['config']['scenes_per_gpu'] == 512 and d['config']['h2d_bytes_per_step'] > 0
+    traj = d['config']['trajectories_rank0']
+    assert abs(d['value'] - traj / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'flop_per_launch', 'launches', 'busy_time_s', 'mean_launch_s', 'launches_in_flight'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.3 < r['frac'] < 1.0
+    assert abs(r['achieved'] * 1e12 - r['flop_per_launch'] * r['launches'] / r['busy_time_s']) / (r['achieved'] * 1e12) < 1e-6
+    assert abs(r['launches_in_flight'] - r['mean_launch_s'] * r['launches'] / r['busy_time_s']) < 1e-6 and r['launches_in_flight'] >= 0.99
+    # the kernel's rate cannot exceed what the step time allows for its share of the work
+    assert r['flop_per_launch'] / (d['ms_per_step'] * 1e-3) <= r['achieved'] * 1e12 * 1.05
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == d['unit'] and c['cores'] >= 1 and c['value_1_thread'] > 0
+    assert d['parity']['max_err_over_1_plus_abs_ref'] < 1e-4 and d['parity']['ade_abs_diff'] < 1e-4
+    assert set(d['configs']) == {'ucy_2048', 'sdd_1024', 'nba_128', 'nba_long_4096'}
+    for name, leg in d['configs'].items():
+        assert leg['value'] > 0 and leg['roofline'] and leg['parity']['max_err_over_1_plus_abs_ref'] < 1e-4, name
+        assert leg['cpu_baseline']['value'] > 0 and leg['config']['trajectories_rank0'] > 0
+    assert d['train']['steps_per_s'] > 0 and d['train']['cpu_baseline']['value'] > 0
+
+
 def _run_bench(*argv, env=None):
     import subprocess
     import sys
