@@ -272,7 +272,8 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     // STTODE_GRU0_STREAM=1 (default off): same-box A/Bs showed no gain over the resident-weights kernel once the chain keeps one
     // workgroup per CU (63.7 vs 65.7 / 64.3 M trajectories/s), so the streaming form stays an option, not the default
     static const bool gru0_stream = getenv("STTODE_GRU0_STREAM") && atoi(getenv("STTODE_GRU0_STREAM")) != 0;
-    if (!use_side && gru0_stream && (long)n * m->K >= 16384) {
+    // Tp > 8 (two 16-wide input tiles): always the streaming form -- the resident-weights instantiation for that shape spills 44 B per lane
+    if ((!use_side && gru0_stream && (long)n * m->K >= 16384) || TPX == 2) {
         // streaming GRU (24 KiB of LDS): co-resides with the previous calls' chain workgroups
         RUN(STT_STAGE_GRU0, gs,
             sttode_gru_cols32(xpad, 16 * TPX, W[STT_W_G0_POOL], (const int*)W[STT_W_G0_PROG], 13 * Tp, W[STT_W_G0_CONSTS], state0, n, Tp, gs));

@@ -967,6 +967,33 @@ def test_train_mode_rotation_vs_oracle(golden):
     assert abs(ref[0] - float(g['eth_losses'][0])) > 1e-3 * abs(ref[0])        # the rotation changed the objective
 
 
+def test_train_mode_agent_subsampling_follows_numpy_generator():
+    """set_data in train() mode with more agents than max_train_agent (model/STTODE.py:405-413): the scene is sub-sampled with
+    np.random.choice(N, max_train_agent) -- with replacement, from NumPy's global generator.  With the generator seeded, the HIP
+    path must pick the same agents: its objective equals the oracle's on the explicitly sub-sampled (and rotated) scene."""
+    from sttode_amd import scenes
+    _gpu()
+    m, ora = hip_model('eth', 8, 12), oracle_model('eth', 8, 12)
+    obs, pred = scenes.eth_scene(4242, n_min=40, n_max=40)                    # 40 > max_train_agent = 32
+    rng = np.random.default_rng(3)
+    eq, ep1, ep20 = (torch.from_numpy(rng.standard_normal(sh).astype(np.float32)) for sh in ((32, 32), (32, 32), (640, 32)))
+    np.random.seed(1234)
+    ind = np.random.choice(40, 32)                                             # what the reference would draw
+    assert len(set(ind.tolist())) < 32                                         # (with replacement: duplicates occur)
+    m.train()
+    try:
+        np.random.seed(1234)
+        m.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred), torch.ones(40, 8), torch.ones(40, 12), theta=-1.1)
+        assert m.agent_num == 32
+        with torch.no_grad():
+            vals = m.forward(eq, ep1, ep20)
+    finally:
+        m.eval()
+    ora.set_data(None, torch.from_numpy(obs[ind]), torch.from_numpy(pred[ind]), theta=-1.1)
+    ref = ora.forward_losses(eq, ep1, ep20)
+    np.testing.assert_allclose([float(vals[0])] + list(vals[1:]), ref, rtol=1e-4)
+
+
 def test_train_epoch_loop_on_csv_dataset(tmp_path):
     """train.py:72-95 loop over TrajectoryDataset + DataLoader(batch_size=1): augmentation on, losses finite and decreasing
     over repeated epochs on a tiny synthetic file; checkpoint round-trips through the inference path."""
