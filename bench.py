@@ -199,8 +199,8 @@ class Leg:
 
     def _finish(self, h):
         import torch
-        pred = self.model.wait(h)                               # [K, n, Tf, 2]
-        self.last_pred = pred
+        pred = self.model.wait(h)                               # [K, n, Tf, 2] (a permuted view of the contiguous [n, K, Tf, 2] buffer)
+        self.last_pred = h['pred']
         ade, fde = self.model.best_of_k(pred.permute(1, 0, 2, 3), gt=h['gt'])
         return torch.stack((ade.sum(), fde.sum(), self.n_dev))   # local sums; ONE all-reduce after the last step
 
@@ -209,7 +209,7 @@ class Leg:
         self._load()
         if serial:
             pred = self.model.inference(None)
-            self.last_pred = pred
+            self.last_pred = self.model.diverse_pred            # contiguous [n, K, Tf, 2]
             ade, fde = self.model.best_of_k(pred.permute(1, 0, 2, 3))
             return torch.stack((ade.sum(), fde.sum(), self.n_dev))
         h = self.model.inference_async()                        # z is drawn on device exactly like Normal.rsample in the reference
@@ -228,7 +228,7 @@ class Leg:
         d2h: additionally copy every step's futures to pinned host memory inside the timed region."""
         import torch
         dev = self.dev
-        hostbuf = torch.empty((K, self.n, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None
+        hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H target
         acc = None
         for _ in range(warmup):
             self.step(serial)
