@@ -575,7 +575,7 @@ template <int NY> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hi
     if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
-    STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+    if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
     // of LDS stay free for kernels of OTHER streams: the per-agent stage of the next call and the next call's chain run beside this
