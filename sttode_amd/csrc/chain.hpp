@@ -83,3 +83,18 @@ __device__ __forceinline__ void layernorm64(f32x4 (&x)[4], const float* __restri
         for (int r = 0; r < 4; ++r) x[T][r] = (x[T][r] - mean) * rstd * g[r] + b[r];
     }
 }
+
+// LDS byte address of a pointer into shared memory (generic -> address space 3)
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// LDS-DMA issued from inline asm, so hipcc does NOT track it: with the builtin form it inserts s_waitcnt vmcnt(0) in front of
+// later LDS reads it cannot prove disjoint from the DMA's destination (here: every tile read of the other ring buffer), which
+// serialises DMA and MFMA -- measured 3.4x the MFMA time per chunk.  The completion is counted by hand: ChainStream::end() waits
+// vmcnt(0) before the workgroup barrier (the guide's recipe: cdna_hip_programming.md §5.7, glds16_asm).  `lds_dst` is the
+// wave-uniform destination byte address; the hardware adds lane * 16.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}

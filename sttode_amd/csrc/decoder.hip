@@ -567,6 +567,166 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Latency form of the decoder MLPs for FEW columns (a single scene).  The throughput kernels give every wave a 16-column tile and
+// run its 72-96 MFMAs per chunk serially: ~35 chunks x ~1.2 us however few tiles exist.  Here the FOUR waves of a workgroup share ONE
+// 16-column tile: each recomputes the small layer 1 of the chunk and owns 4 of the 16 layer-2 row tiles (24-48 MFMAs per chunk);
+// the layer-2 activation is exchanged through LDS and wave o mod 4 runs output tile o of layer 3.  The same chunk stream as the throughput kernels,
+// in a ring of 4 buffers filled three chunks ahead by asm LDS-DMA (chunks are too short for a one-chunk prefetch distance; counted
+// s_waitcnt vmcnt); the tile's per-agent layer-1 rows (16 columns x 512) are gathered into LDS once.
+// MODE 0: block-0 decoder_x (dbuf = x_true - x_hat0) | 1: block-0 decoder_y (ybuf) | 2: block-1 decoder_y + epilogue (pred)
+// ---------------------------------------------------------------------------------------------------
+struct MlpLatArgs {
+    const float* A0; const f32x4* blob; const float* z; const float* state; const float* xpad; const float* ybuf; const float* cur;
+    const float* orig; float* out; int ncols, K, Tf2;
+};
+#define MLAT_RD 4
+template <int KTV, int NO, int MODE>
+__device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* ring, f32x4* sA0, f32x4* sH2, int tile) {
+    constexpr int CHW = (KTV + 16) * 64;            // f32x4 per chunk
+    constexpr int N16 = KTV + 16;                    // 1 KiB pieces per chunk
+    constexpr int PW = (N16 + 3) / 4;                // pieces per wave and chunk (surplus pieces repeat the last one: uniform counts)
+    constexpr int TOTAL = 32 + NO;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = tile * 16 + c;
+    const int colc = col < a.ncols ? col : a.ncols - 1;
+    const int agent = colc / a.K;
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+    auto dma = [&](int chunk) {
+        const f32x4* src = a.blob + (size_t)chunk * CHW + lane;
+        const unsigned dst = ring_addr + (unsigned)(chunk % MLAT_RD) * (CHW * 16);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int idx = i * 4 + wave;
+            idx = idx < N16 ? idx : N16 - 1;
+            glds16_asm(src + idx * 64, dst + idx * 1024);
+        }
+    };
+    // B operand first (compiler-visible loads, before any asm DMA is in flight)
+    f32x4 B[KTV];
+    B[0] = ld4(a.z + (size_t)colc * 32 + 4 * q);
+    B[1] = ld4(a.z + (size_t)colc * 32 + 16 + 4 * q);
+    if (KTV == 8) {
+#pragma unroll
+        for (int T = 0; T < 6; ++T) B[2 + (T < KTV - 2 ? T : 0)] = ld4(a.state + (size_t)colc * 96 + 16 * T + 4 * q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // the tile's A0 rows: sA0[ch][lane] = A0[agent][16 ch + 4 q ..], 32 pieces dealt to the 4 waves
+        const float* arow = a.A0 + (size_t)agent * 512 + 4 * q;
+        const unsigned a0_addr = __builtin_amdgcn_readfirstlane(lds_addr(sA0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i * 4 + wave;
+            glds16_asm(arow + 16 * ch, a0_addr + ch * 1024);
+        }
+    }
+    dma(0); dma(1); dma(2);
+    constexpr int NR = (NO + 3) / 4;              // output tiles this wave finishes: o = wave, wave + 4
+    f32x4 acc2[4], res[NR];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc2[i] = splat4(0.f);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) res[i] = splat4(0.f);
+#pragma unroll 1
+    for (int p = 0; p < TOTAL; ++p) {
+        // chunk p (and, at p == 0, the A0 gather issued before the chunks) has landed: at most the pieces of chunks p+1, p+2 remain
+        const int ahead = TOTAL - 1 - p;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                             // everybody's pieces of chunk p; everybody done with chunk p-1's buffer
+        if (p + 3 < TOTAL) dma(p + 3);               // into the buffer chunk p-1 used
+        const f32x4* buf = ring + (p % MLAT_RD) * CHW;
+        if (p < 32) {
+            f32x4 h1 = sA0[p * 64 + lane];
+#pragma unroll
+            for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, buf[T * 64 + lane], B[T]);
+            h1 = relu4(h1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[i] = mfma_k16(acc2[i], buf[(KTV + 4 * wave + i) * 64 + lane], h1);
+        } else {
+            const int o = p - 32;
+            const float* b3 = reinterpret_cast<const float*>(buf + 16 * 64);
+            if (p == 32) {                           // b2 sits behind the first layer-3 chunk's tiles and its b3
+                const float* b2 = b3 + 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sH2[(4 * wave + i) * 64 + lane] = relu4(acc2[i] + ld4(b2 + 16 * (4 * wave + i) + 4 * q));
+                __syncthreads();                     // the whole 256-wide layer-2 activation as B-operand fragments
+            }
+            // layer 3 keeps the throughput kernels' summation order (one 16-MFMA chain per output tile from b3), so a scene gives
+            // the same bits alone and inside a batch; output tile o is finished by wave o mod 4
+            if ((o & 3) == wave) {
+                f32x4 v = ld4(b3 + 4 * q);
+#pragma unroll
+                for (int T = 0; T < 16; ++T) v = mfma_k16(v, buf[T * 64 + lane], sH2[T * 64 + lane]);
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if (i == (o >> 2)) res[i] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int o = wave + 4 * i;
+        if (o >= NO) continue;
+        const f32x4 v = res[i];
+        if (col >= a.ncols) continue;
+        if (MODE == 0) {
+            const f32x4 xt = ld4(a.xpad + (size_t)agent * (16 * NO) + 16 * o + 4 * q);
+            st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, xt - v);
+        } else if (MODE == 1) {
+            st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, v);
+        } else {
+            const int row0 = 16 * o + 4 * q;
+            if (row0 < a.Tf2) {
+                const float cx = a.cur[2 * agent], cy = a.cur[2 * agent + 1];
+                const float ox = a.orig[2 * agent], oy = a.orig[2 * agent + 1];
+                const f32x4 y0 = ld4(a.ybuf + (size_t)col * (16 * NO) + row0);
+                f32x4 r;
+                r[0] = ((y0[0] + v[0]) + cx) + ox;
+                r[1] = ((y0[1] + v[1]) + cy) + oy;
+                r[2] = ((y0[2] + v[2]) + cx) + ox;
+                r[3] = ((y0[3] + v[3]) + cy) + oy;
+                float* pp = a.out + (size_t)col * a.Tf2 + row0;
+                if (row0 + 3 < a.Tf2 && (a.Tf2 & 3) == 0) {
+                    st4(pp, r);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row0 + e < a.Tf2) pp[e] = r[e];
+                }
+            }
+        }
+    }
+}
+
+// block 0: blockIdx.y = role (0: decoder_x, 1: decoder_y); block 1: one role
+template <int TPX, int NOY>
+__global__ __launch_bounds__(256) void mlp0_lat_kernel(MlpLatArgs ax, MlpLatArgs ay) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* ring = reinterpret_cast<f32x4*>(smem);
+    f32x4* sA0 = ring + MLAT_RD * (2 + 16) * 64;
+    f32x4* sH2 = sA0 + 32 * 64;
+    if (blockIdx.y == 0) mlp_lat_run<2, TPX, 0>(ax, ring, sA0, sH2, blockIdx.x);
+    else mlp_lat_run<2, NOY, 1>(ay, ring, sA0, sH2, blockIdx.x);
+}
+template <int NOY>
+__global__ __launch_bounds__(256) void mlp1_lat_kernel(MlpLatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* ring = reinterpret_cast<f32x4*>(smem);
+    f32x4* sA0 = ring + MLAT_RD * (8 + 16) * 64;
+    f32x4* sH2 = sA0 + 32 * 64;
+    mlp_lat_run<8, NOY, 2>(a, ring, sA0, sH2, blockIdx.x);
+}
+#define MLAT_LDS(KTV, NOMAX) ((MLAT_RD * ((KTV) + 16) * 64 + 32 * 64 + 16 * 64) * 16)
+// STTODE_MLP_LAT_TILES: largest 16-column tile count served by the latency form of the MLP kernels
+static int g_mlp_lat_tiles = -1, g_gru_lat_tiles = -1;
+static int mlp_lat_tiles() {
+    if (g_mlp_lat_tiles < 0) { const char* e = getenv("STTODE_MLP_LAT_TILES"); g_mlp_lat_tiles = e ? atoi(e) : 128; }
+    return g_mlp_lat_tiles;
+}
+
 // generic single MLP over columns (training-forward needs decoder_x of the LAST block too: recover_traj sums the x_hat of
 // every block, model/STTODE.py:339-341).  KTV = 8: B = [z | state];  output raw tiles [ncols][16*NO].
 template <int NO>
@@ -638,9 +798,13 @@ static int num_cus() {
 
 // STTODE_GRU_LAT_TILES: largest tile count served by the latency form (default: measured crossover)
 static int gru_lat_tiles() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("STTODE_GRU_LAT_TILES"); v = e ? atoi(e) : 512; }
-    return v;
+    if (g_gru_lat_tiles < 0) { const char* e = getenv("STTODE_GRU_LAT_TILES"); g_gru_lat_tiles = e ? atoi(e) : 512; }
+    return g_gru_lat_tiles;
+}
+extern "C" int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles) {
+    if (gru_tiles >= 0) g_gru_lat_tiles = gru_tiles;
+    if (mlp_tiles >= 0) g_mlp_lat_tiles = mlp_tiles;
+    return 0;
 }
 
 extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
@@ -741,6 +905,30 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     STT_REQUIRE(A0x && A0y && stream && z && xpad && dbuf && ybuf, "sttode_mlp_block0: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0, "sttode_mlp_block0: ncols and K must be positive");
     STT_REQUIRE(total_chunks == 64 + TPX + NOY, "sttode_mlp_block0: weight stream must hold (32+TPX) + (32+NOY) chunks");
+    if ((ncols + 15) / 16 <= mlp_lat_tiles()) {   // few columns: latency form (four waves share one 16-column tile)
+        MlpLatArgs ax, ay;
+        ax.A0 = A0x; ax.blob = (const f32x4*)stream; ax.z = z; ax.state = nullptr; ax.xpad = xpad; ax.ybuf = nullptr; ax.cur = nullptr;
+        ax.orig = nullptr; ax.out = dbuf; ax.ncols = ncols; ax.K = K; ax.Tf2 = 0;
+        ay = ax;
+        ay.A0 = A0y; ay.blob = (const f32x4*)stream + (size_t)(32 + TPX) * MLP0_CHW; ay.out = ybuf;
+        const dim3 g((ncols + 15) / 16, 2);
+        hipStream_t sl = (hipStream_t)stream_;
+#define L0L(TX, NY)                                                                                      \
+    do {                                                                                                 \
+        STT_SET_LDS_ONCE((mlp0_lat_kernel<TX, NY>), MLAT_LDS(2, (TX) > (NY) ? (TX) : (NY)));             \
+        hipLaunchKernelGGL((mlp0_lat_kernel<TX, NY>), g, dim3(256), MLAT_LDS(2, (TX) > (NY) ? (TX) : (NY)), sl, ax, ay); \
+    } while (0)
+        if (TPX == 1 && NOY == 2) L0L(1, 2);
+        else if (TPX == 2 && NOY == 5) L0L(2, 5);
+        else if (TPX == 1 && NOY == 1) L0L(1, 1);
+        else if (TPX == 1 && NOY == 3) L0L(1, 3);
+        else if (TPX == 2 && NOY == 2) L0L(2, 2);
+        else if (TPX == 2 && NOY == 3) L0L(2, 3);
+        else STT_REQUIRE(false, "sttode_mlp_block0: unsupported (TPX, NOY); built: (1,1) (1,2) (1,3) (2,2) (2,3) (2,5)");
+#undef L0L
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     const int ngroups = (ncols + 63) / 64;
     int grid = MLP0_WGS * num_cus();   // workgroups per CU; even blockIdx = x role, odd = y role
     if (grid > 2 * ngroups || nonpersistent()) grid = 2 * ngroups;
@@ -771,6 +959,28 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
     STT_REQUIRE(A1y && stream && z && state1 && ybuf && cur && orig && pred, "sttode_mlp_block1: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && Tf > 0 && 2 * Tf <= 16 * NOY, "sttode_mlp_block1: bad ncols/K/Tf/NOY");
     STT_REQUIRE(total_chunks == 32 + NOY, "sttode_mlp_block1: weight stream must hold 32+NOY chunks");
+    if ((ncols + 15) / 16 <= mlp_lat_tiles()) {   // few columns: latency form
+        MlpLatArgs a;
+        a.A0 = A1y; a.blob = (const f32x4*)stream; a.z = z; a.state = state1; a.xpad = nullptr; a.ybuf = ybuf; a.cur = cur; a.orig = orig;
+        a.out = pred; a.ncols = ncols; a.K = K; a.Tf2 = 2 * Tf;
+        const dim3 g((ncols + 15) / 16);
+        hipStream_t sl = (hipStream_t)stream_;
+#define L1L(NY)                                                                                   \
+    do {                                                                                          \
+        STT_SET_LDS_ONCE(mlp1_lat_kernel<NY>, MLAT_LDS(8, NY));                                   \
+        hipLaunchKernelGGL(mlp1_lat_kernel<NY>, g, dim3(256), MLAT_LDS(8, NY), sl, a);            \
+    } while (0)
+        switch (NOY) {
+            case 1: L1L(1); break;
+            case 2: L1L(2); break;
+            case 3: L1L(3); break;
+            case 5: L1L(5); break;
+            default: STT_REQUIRE(false, "sttode_mlp_block1: unsupported NOY; built: 1 2 3 5");
+        }
+#undef L1L
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     const int ngroups = (ncols + 63) / 64;
     int grid = 3 * num_cus();
     if (grid > ngroups || nonpersistent()) grid = ngroups;

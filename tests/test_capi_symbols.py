@@ -75,7 +75,8 @@ def test_every_entry_point_rejects_null_arguments():
     must return a non-zero status with a message naming itself (no crash, no launch) -- runs without a GPU."""
     from sttode_amd import capi
     L = capi.lib()
-    skip = {'sttode_abi_version', 'sttode_last_error', 'sttode_model_destroy', 'sttode_timing_enable', 'sttode_chain_prog_len'}
+    skip = {'sttode_abi_version', 'sttode_last_error', 'sttode_model_destroy', 'sttode_timing_enable', 'sttode_chain_prog_len',
+            'sttode_set_latency_tiles'}
     checked = 0
     for name, argtypes in capi.SIGNATURES.items():
         if name in skip:

@@ -301,6 +301,54 @@ def test_fused_trajectory_chain_vs_three_kernel_form_and_oracle(case):
         assert_close(outs[1], ref, what=f'{case} vs oracle')
 
 
+@pytest.mark.parametrize('case', ['eth_1', 'eth_7', 'eth_32', 'eth_3scenes', 'nba', 'nba_long'])
+def test_latency_forms_are_bitwise_the_throughput_forms_and_match_oracle(case):
+    """The few-column (single scene, test.py:171-188) forms of gru_cols / mlp_block0 / mlp_block1 -- one 16-column tile per WORKGROUP,
+    rows split over its waves -- sum in the order of the throughput forms (a tile per wave): identical bits with the crossover
+    forced either way (sttode_set_latency_tiles), and both match the CPU oracle."""
+    from sttode_amd import capi, scenes
+    if case.startswith('eth'):
+        m, ora = hip_model('eth', 8, 12), oracle_model('eth', 8, 12)
+        if case == 'eth_3scenes':
+            sb = scenes.make_scene_batch(range(700, 703), 'eth')
+        else:
+            n = int(case.split('_')[1])
+            o, p_ = scenes.eth_scene(5100 + n, n_min=n, n_max=n)
+            sb = scenes.SceneBatch(np.ascontiguousarray(o.transpose(0, 2, 1)), np.ascontiguousarray(p_.transpose(0, 2, 1)),
+                                   np.asarray([0, n], np.int32))
+        z = scenes.latents(77, sb.n_agents)
+        feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    else:
+        Tp, Tf, B, N = (5, 10, 2, 11) if case == 'nba' else (10, 40, 3, 10)
+        m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+        d = scenes.nba_batch(43, B, N=N, obs_len=Tp, pred_len=Tf)
+        z = scenes.latents(33, B * N)
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        feed = lambda: m.set_data_nba(data)
+    outs = {}
+    try:
+        m.native().set_chain(0)
+        for tiles in (0, 1 << 30):
+            capi.call('sttode_set_latency_tiles', tiles, tiles)
+            feed()
+            outs[tiles] = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+    finally:
+        capi.call('sttode_set_latency_tiles', 512, 128)
+        m.native().set_chain(-1)
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1 << 30]), f'{case}: max diff {np.abs(outs[0] - outs[1 << 30]).max():.3e}'
+    if case.startswith('eth'):
+        for s in range(sb.n_scenes):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            assert_close(outs[0][:, a:b], oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20]), what=f'{case} scene {s} vs oracle')
+    else:
+        with torch.no_grad():
+            ora.set_data_nba(data)
+            ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
+        assert_close(outs[0], ref, what=f'{case} vs oracle')
+
+
 def test_pmath_op_library_vs_reference_golden(golden):
     """Every hyptorch/pmath.py primitive on HIP vs values produced by the reference's own functions."""
     import sttode_amd.pmath as pm
