@@ -83,7 +83,7 @@ int sttode_gru_cols(const float* xin, const float* convP, const float* convB, co
 
 /* Process-wide crossover between the latency forms of sttode_gru_cols / sttode_mlp_block0 / sttode_mlp_block1 (one 16-column tile per
  * WORKGROUP, its waves splitting the rows: a single scene of test.py:171-188) and their throughput forms (a tile per wave): the latency
- * form serves calls of at most this many 16-column tiles.  Negative = leave unchanged; defaults 512 / 128 (env STTODE_GRU_LAT_TILES /
+ * form serves calls of at most this many 16-column tiles.  Negative = leave unchanged; defaults 512 / 1024 (env STTODE_GRU_LAT_TILES /
  * STTODE_MLP_LAT_TILES).  Both forms sum in the same order: results are bitwise independent of the setting. */
 int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles);
 

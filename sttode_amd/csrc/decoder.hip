@@ -569,41 +569,49 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Latency form of the decoder MLPs for FEW columns (a single scene).  The throughput kernels give every wave a 16-column tile and
-// run its 72-96 MFMAs per chunk serially: ~35 chunks x ~1.2 us however few tiles exist.  Here the FOUR waves of a workgroup share ONE
-// 16-column tile: each recomputes the small layer 1 of the chunk and owns 4 of the 16 layer-2 row tiles (24-48 MFMAs per chunk);
-// the layer-2 activation is exchanged through LDS and wave o mod 4 runs output tile o of layer 3.  The same chunk stream as the throughput kernels,
-// in a ring of 4 buffers filled three chunks ahead by asm LDS-DMA (chunks are too short for a one-chunk prefetch distance; counted
-// s_waitcnt vmcnt); the tile's per-agent layer-1 rows (16 columns x 512) are gathered into LDS once.
+// run its 72-96 MFMAs per chunk serially (~35 chunks x ~1.2 us however few tiles exist: an fp32 16x16x4 MFMA holds a SIMD's matrix
+// pipe for 32 cycles).  Here the FOUR waves of a workgroup share ONE 16-column tile and work through the hidden layer in groups of
+// four 16-row chunks:
+//   phase A   wave w computes layer 1 of chunk 4g+w (KTV k-tiles, in the throughput kernels' order) and publishes relu(h1) as a
+//             B-operand fragment in LDS (double buffered: one barrier per group);
+//   phase B   every wave adds the four chunks, in chunk order, into ITS 4 of the 16 layer-2 row tiles (4 independent MFMA chains).
+// 8 + 64 (block 0) / 32 + 64 (block 1) k16 MFMA quads... per group and wave instead of 4 x (KTV + 16) quads.  Every weight fragment is
+// used by exactly one wave, so the weights skip LDS: plain coalesced 1 KiB loads (same fragment-ordered stream as the throughput
+// kernels), fetched one group ahead into registers.  Layer 3: the 256-wide activation is exchanged through LDS and wave o mod 4 runs
+// the 16-quad chain of output tile o.  Same summation order as the throughput kernels everywhere: identical bits.
 // MODE 0: block-0 decoder_x (dbuf = x_true - x_hat0) | 1: block-0 decoder_y (ybuf) | 2: block-1 decoder_y + epilogue (pred)
 // ---------------------------------------------------------------------------------------------------
 struct MlpLatArgs {
     const float* A0; const f32x4* blob; const float* z; const float* state; const float* xpad; const float* ybuf; const float* cur;
     const float* orig; float* out; int ncols, K, Tf2;
 };
-#define MLAT_RD 4
+template <int KTV>
+struct MlpLatFrag {            // one group's operands of one wave
+    f32x4 a0;                  // A0[agent][16 (4g + w) + 4q ..]
+    f32x4 w1[KTV];             // W1v tiles of chunk 4g + w
+    f32x4 w2[4][4];            // [chunk of the group][own row tile]
+};
 template <int KTV, int NO, int MODE>
-__device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* ring, f32x4* sA0, f32x4* sH2, int tile) {
+__device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* sH1, f32x4* sH2, int tile) {
     constexpr int CHW = (KTV + 16) * 64;            // f32x4 per chunk
-    constexpr int N16 = KTV + 16;                    // 1 KiB pieces per chunk
-    constexpr int PW = (N16 + 3) / 4;                // pieces per wave and chunk (surplus pieces repeat the last one: uniform counts)
-    constexpr int TOTAL = 32 + NO;
+    constexpr int NR = (NO + 3) / 4;                 // output tiles this wave finishes: o = wave, wave + 4
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = tile * 16 + c;
     const int colc = col < a.ncols ? col : a.ncols - 1;
     const int agent = colc / a.K;
-    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_addr(ring));
-    auto dma = [&](int chunk) {
-        const f32x4* src = a.blob + (size_t)chunk * CHW + lane;
-        const unsigned dst = ring_addr + (unsigned)(chunk % MLAT_RD) * (CHW * 16);
+    const float* arow = a.A0 + (size_t)agent * 512 + 4 * q;
+    const f32x4* wl = a.blob + lane;
+    auto fetch = [&](MlpLatFrag<KTV>& f, int g) {
+        f.a0 = ld4(arow + 16 * (4 * g + wave));
+        const f32x4* own = wl + (size_t)(4 * g + wave) * CHW;
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            int idx = i * 4 + wave;
-            idx = idx < N16 ? idx : N16 - 1;
-            glds16_asm(src + idx * 64, dst + idx * 1024);
-        }
+        for (int T = 0; T < KTV; ++T) f.w1[T] = own[T * 64];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f.w2[cc][i] = wl[(size_t)(4 * g + cc) * CHW + (KTV + 4 * wave + i) * 64];
     };
-    // B operand first (compiler-visible loads, before any asm DMA is in flight)
     f32x4 B[KTV];
     B[0] = ld4(a.z + (size_t)colc * 32 + 4 * q);
     B[1] = ld4(a.z + (size_t)colc * 32 + 16 + 4 * q);
@@ -611,66 +619,57 @@ __device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* ring, f3
 #pragma unroll
         for (int T = 0; T < 6; ++T) B[2 + (T < KTV - 2 ? T : 0)] = ld4(a.state + (size_t)colc * 96 + 16 * T + 4 * q);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {   // the tile's A0 rows: sA0[ch][lane] = A0[agent][16 ch + 4 q ..], 32 pieces dealt to the 4 waves
-        const float* arow = a.A0 + (size_t)agent * 512 + 4 * q;
-        const unsigned a0_addr = __builtin_amdgcn_readfirstlane(lds_addr(sA0));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ch = i * 4 + wave;
-            glds16_asm(arow + 16 * ch, a0_addr + ch * 1024);
-        }
-    }
-    dma(0); dma(1); dma(2);
-    constexpr int NR = (NO + 3) / 4;              // output tiles this wave finishes: o = wave, wave + 4
-    f32x4 acc2[4], res[NR];
+    f32x4 acc2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc2[i] = splat4(0.f);
+    auto group = [&](const MlpLatFrag<KTV>& f, int g) {
+        f32x4 h1 = f.a0;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) res[i] = splat4(0.f);
-#pragma unroll 1
-    for (int p = 0; p < TOTAL; ++p) {
-        // chunk p (and, at p == 0, the A0 gather issued before the chunks) has landed: at most the pieces of chunks p+1, p+2 remain
-        const int ahead = TOTAL - 1 - p;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                             // everybody's pieces of chunk p; everybody done with chunk p-1's buffer
-        if (p + 3 < TOTAL) dma(p + 3);               // into the buffer chunk p-1 used
-        const f32x4* buf = ring + (p % MLAT_RD) * CHW;
-        if (p < 32) {
-            f32x4 h1 = sA0[p * 64 + lane];
+        for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, f.w1[T], B[T]);
+        f32x4* hb = sH1 + (g & 1) * 256;
+        hb[wave * 64 + lane] = relu4(h1);
+        __syncthreads();
 #pragma unroll
-            for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, buf[T * 64 + lane], B[T]);
-            h1 = relu4(h1);
+        for (int cc = 0; cc < 4; ++cc) {
+            const f32x4 hv = hb[cc * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc2[i] = mfma_k16(acc2[i], buf[(KTV + 4 * wave + i) * 64 + lane], h1);
-        } else {
-            const int o = p - 32;
-            const float* b3 = reinterpret_cast<const float*>(buf + 16 * 64);
-            if (p == 32) {                           // b2 sits behind the first layer-3 chunk's tiles and its b3
-                const float* b2 = b3 + 16;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sH2[(4 * wave + i) * 64 + lane] = relu4(acc2[i] + ld4(b2 + 16 * (4 * wave + i) + 4 * q));
-                __syncthreads();                     // the whole 256-wide layer-2 activation as B-operand fragments
-            }
-            // layer 3 keeps the throughput kernels' summation order (one 16-MFMA chain per output tile from b3), so a scene gives
-            // the same bits alone and inside a batch; output tile o is finished by wave o mod 4
-            if ((o & 3) == wave) {
-                f32x4 v = ld4(b3 + 4 * q);
-#pragma unroll
-                for (int T = 0; T < 16; ++T) v = mfma_k16(v, buf[T * 64 + lane], sH2[T * 64 + lane]);
-#pragma unroll
-                for (int i = 0; i < NR; ++i)
-                    if (i == (o >> 2)) res[i] = v;
-            }
+            for (int i = 0; i < 4; ++i) acc2[i] = mfma_k16(acc2[i], f.w2[cc][i], hv);
         }
+    };
+    MlpLatFrag<KTV> fa, fb;
+    fetch(fa, 0);
+#pragma unroll 1
+    for (int g = 0; g < 6; g += 2) {
+        fetch(fb, g + 1);
+        group(fa, g);
+        fetch(fa, g + 2);
+        group(fb, g + 1);
     }
+    fetch(fb, 7);
+    group(fa, 6);
+    // layer 3 operands travel during the last group: b2 sits behind the first layer-3 chunk's 16 tiles and its b3 (packing.mlp_stream)
+    const f32x4* l3 = a.blob + (size_t)32 * CHW;
+    f32x4 w3[NR][16], b3v[NR], b2v[4];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int o = wave + 4 * i < NO ? wave + 4 * i : NO - 1;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) w3[i][T] = l3[(size_t)o * CHW + T * 64 + lane];
+        b3v[i] = ld4(reinterpret_cast<const float*>(l3 + (size_t)o * CHW + 16 * 64) + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b2v[i] = ld4(reinterpret_cast<const float*>(l3 + 16 * 64) + 16 + 16 * (4 * wave + i) + 4 * q);
+    group(fb, 7);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sH2[(4 * wave + i) * 64 + lane] = relu4(acc2[i] + b2v[i]);
+    __syncthreads();                                 // the whole 256-wide layer-2 activation as B-operand fragments
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int o = wave + 4 * i;
         if (o >= NO) continue;
-        const f32x4 v = res[i];
+        f32x4 v = b3v[i];
+#pragma unroll
+        for (int T = 0; T < 16; ++T) v = mfma_k16(v, w3[i][T], sH2[T * 64 + lane]);
         if (col >= a.ncols) continue;
         if (MODE == 0) {
             const f32x4 xt = ld4(a.xpad + (size_t)agent * (16 * NO) + 16 * o + 4 * q);
@@ -704,26 +703,19 @@ __device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* ring, f3
 // block 0: blockIdx.y = role (0: decoder_x, 1: decoder_y); block 1: one role
 template <int TPX, int NOY>
 __global__ __launch_bounds__(256) void mlp0_lat_kernel(MlpLatArgs ax, MlpLatArgs ay) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* ring = reinterpret_cast<f32x4*>(smem);
-    f32x4* sA0 = ring + MLAT_RD * (2 + 16) * 64;
-    f32x4* sH2 = sA0 + 32 * 64;
-    if (blockIdx.y == 0) mlp_lat_run<2, TPX, 0>(ax, ring, sA0, sH2, blockIdx.x);
-    else mlp_lat_run<2, NOY, 1>(ay, ring, sA0, sH2, blockIdx.x);
+    __shared__ f32x4 sH1[2 * 4 * 64], sH2[16 * 64];
+    if (blockIdx.y == 0) mlp_lat_run<2, TPX, 0>(ax, sH1, sH2, blockIdx.x);
+    else mlp_lat_run<2, NOY, 1>(ay, sH1, sH2, blockIdx.x);
 }
 template <int NOY>
 __global__ __launch_bounds__(256) void mlp1_lat_kernel(MlpLatArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* ring = reinterpret_cast<f32x4*>(smem);
-    f32x4* sA0 = ring + MLAT_RD * (8 + 16) * 64;
-    f32x4* sH2 = sA0 + 32 * 64;
-    mlp_lat_run<8, NOY, 2>(a, ring, sA0, sH2, blockIdx.x);
+    __shared__ f32x4 sH1[2 * 4 * 64], sH2[16 * 64];
+    mlp_lat_run<8, NOY, 2>(a, sH1, sH2, blockIdx.x);
 }
-#define MLAT_LDS(KTV, NOMAX) ((MLAT_RD * ((KTV) + 16) * 64 + 32 * 64 + 16 * 64) * 16)
 // STTODE_MLP_LAT_TILES: largest 16-column tile count served by the latency form of the MLP kernels
 static int g_mlp_lat_tiles = -1, g_gru_lat_tiles = -1;
 static int mlp_lat_tiles() {
-    if (g_mlp_lat_tiles < 0) { const char* e = getenv("STTODE_MLP_LAT_TILES"); g_mlp_lat_tiles = e ? atoi(e) : 128; }
+    if (g_mlp_lat_tiles < 0) { const char* e = getenv("STTODE_MLP_LAT_TILES"); g_mlp_lat_tiles = e ? atoi(e) : 1024; }
     return g_mlp_lat_tiles;
 }
 
@@ -915,8 +907,7 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
         hipStream_t sl = (hipStream_t)stream_;
 #define L0L(TX, NY)                                                                                      \
     do {                                                                                                 \
-        STT_SET_LDS_ONCE((mlp0_lat_kernel<TX, NY>), MLAT_LDS(2, (TX) > (NY) ? (TX) : (NY)));             \
-        hipLaunchKernelGGL((mlp0_lat_kernel<TX, NY>), g, dim3(256), MLAT_LDS(2, (TX) > (NY) ? (TX) : (NY)), sl, ax, ay); \
+        hipLaunchKernelGGL((mlp0_lat_kernel<TX, NY>), g, dim3(256), 0, sl, ax, ay);                      \
     } while (0)
         if (TPX == 1 && NOY == 2) L0L(1, 2);
         else if (TPX == 2 && NOY == 5) L0L(2, 5);
@@ -967,8 +958,7 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
         hipStream_t sl = (hipStream_t)stream_;
 #define L1L(NY)                                                                                   \
     do {                                                                                          \
-        STT_SET_LDS_ONCE(mlp1_lat_kernel<NY>, MLAT_LDS(8, NY));                                   \
-        hipLaunchKernelGGL(mlp1_lat_kernel<NY>, g, dim3(256), MLAT_LDS(8, NY), sl, a);            \
+        hipLaunchKernelGGL(mlp1_lat_kernel<NY>, g, dim3(256), 0, sl, a);                              \
     } while (0)
         switch (NOY) {
             case 1: L1L(1); break;

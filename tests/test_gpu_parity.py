@@ -333,7 +333,7 @@ def test_latency_forms_are_bitwise_the_throughput_forms_and_match_oracle(case):
             feed()
             outs[tiles] = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
     finally:
-        capi.call('sttode_set_latency_tiles', 512, 128)
+        capi.call('sttode_set_latency_tiles', 512, 1024)
         m.native().set_chain(-1)
     assert np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0], outs[1 << 30]), f'{case}: max diff {np.abs(outs[0] - outs[1 << 30]).max():.3e}'
