@@ -81,11 +81,12 @@ int sttode_post_attn_ode(const float* outP, const float* outb, const float* info
 int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
                     const float* gbias, float* state, int ncols, int Tp, int TPX, void* stream);
 
-/* Process-wide crossover between the latency forms of sttode_gru_cols / sttode_mlp_block0 / sttode_mlp_block1 (one 16-column tile per
- * WORKGROUP, its waves splitting the rows: a single scene of test.py:171-188) and their throughput forms (a tile per wave): the latency
- * form serves calls of at most this many 16-column tiles.  Negative = leave unchanged; defaults 512 / 1024 (env STTODE_GRU_LAT_TILES /
- * STTODE_MLP_LAT_TILES).  Both forms sum in the same order: results are bitwise independent of the setting. */
-int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles);
+/* Process-wide crossover between the latency forms of sttode_gru_cols / sttode_mlp_block0 / sttode_mlp_block1 / sttode_embed_qkv (one
+ * 16-column tile per WORKGROUP, its waves splitting the rows: a single scene of test.py:171-188) and their throughput forms (a tile per
+ * wave): the latency form serves calls of at most this many 16-column tiles.  Negative = leave unchanged; defaults 512 / 1024 / 1024
+ * (env STTODE_GRU_LAT_TILES / STTODE_MLP_LAT_TILES / STTODE_ENC_LAT_TILES).  Both forms sum in the same order: results are bitwise
+ * independent of the setting. */
+int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles, int enc_tiles);
 
 /* Generic per-column linear out[col, 0:N] = act(W [X1 | X2] + b) (nn.Linear; used for the per-agent part of
  * decoder_x/decoder_y layer 0, model/utils.py:86-95, and for the stage-2 Q-net, sampler.py:39,48-52 / utils/mlp.py:26-29).

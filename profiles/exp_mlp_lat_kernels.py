@@ -29,7 +29,7 @@ for n in [int(x) for x in os.environ.get("NAGENTS", "1,8,32,64").split(",")]:
     st1, cur, orig = torch.randn(ncols, 96, device=dev), torch.randn(n, 2, device=dev), torch.randn(n, 2, device=dev)
     pred = torch.zeros(ncols, 24, device=dev)
     for tiles in (1 << 30, 0):
-        capi.call('sttode_set_latency_tiles', -1, tiles)
+        capi.call('sttode_set_latency_tiles', -1, tiles, -1)
         u0 = timeit(lambda: capi.call('sttode_mlp_block0', A0x, A0y, s0, int(P0['n_chunks']), z, xpad, dbuf, ybuf, ncols, K, 1, 2, capi.stream_ptr()))
         u1 = timeit(lambda: capi.call('sttode_mlp_block1', A1y, s1, int(P1['n_chunks']), z, st1, ybuf, cur, orig, pred, ncols, K, 12, 2, capi.stream_ptr()))
         print(f'ncols {ncols:5d} {"latency   " if tiles else "throughput"} form: mlp_block0 {u0:6.1f} us  mlp_block1 {u1:6.1f} us   checksum {float(pred.sum()) + float(dbuf.sum()):.4f}', flush=True)

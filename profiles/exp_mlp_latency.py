@@ -9,11 +9,11 @@ from sttode_amd.weights import make_weights, to_torch_state_dict
 dev = torch.device('cuda')
 m = STTODENet(make_args('eth', 8, 12), dev).eval()
 m.load_state_dict(to_torch_state_dict(make_weights(1234)))
-for n in (2, 8, 32, 64, 128):
+for n in [int(x) for x in os.environ.get("NAGENTS", "2,8,32,64,128").split(",")]:
     o, p = scenes.eth_scene(777 + n, n_min=n, n_max=n)
     o, p = torch.from_numpy(o), torch.from_numpy(p)
-    for gt, mt in ((0, 0), (1 << 30, 0), (1 << 30, 1 << 30)):
-        capi.call('sttode_set_latency_tiles', gt, mt)
+    for gt, mt in (((0, 0), (1 << 30, 0), (1 << 30, 1 << 30)) if not os.environ.get("LAT_ONLY") else ((1 << 30, 1 << 30),)):
+        capi.call('sttode_set_latency_tiles', gt, mt, mt)
         m.set_data(None, o, p, None, None)
         z = torch.randn(n * 20, 32, device=dev)
         for _ in range(5):

@@ -23,7 +23,7 @@ SIGNATURES = {
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_post_attn_ode': [_P] * 16 + [_P, _P, _I, _F, _I, _I, _P],
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'sttode_set_latency_tiles': [_I, _I],
+    'sttode_set_latency_tiles': [_I, _I, _I],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     'sttode_agent_preact': [_P] * 11 + [_I, _P],
     'sttode_mlp_block0': [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -5,6 +5,7 @@
 #include <cstdio>
 
 void stt_set_error(const char* msg);
+int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.hip: sttode_set_latency_tiles)
 
 #define STT_REQUIRE(cond, msg)      \
     do {                            \

@@ -793,9 +793,15 @@ static int gru_lat_tiles() {
     if (g_gru_lat_tiles < 0) { const char* e = getenv("STTODE_GRU_LAT_TILES"); g_gru_lat_tiles = e ? atoi(e) : 512; }
     return g_gru_lat_tiles;
 }
-extern "C" int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles) {
+static int g_enc_lat_tiles = -1;
+int stt_enc_lat_tiles() {
+    if (g_enc_lat_tiles < 0) { const char* e = getenv("STTODE_ENC_LAT_TILES"); g_enc_lat_tiles = e ? atoi(e) : 1024; }
+    return g_enc_lat_tiles;
+}
+extern "C" int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles, int enc_tiles) {
     if (gru_tiles >= 0) g_gru_lat_tiles = gru_tiles;
     if (mlp_tiles >= 0) g_mlp_lat_tiles = mlp_tiles;
+    if (enc_tiles >= 0) g_enc_lat_tiles = enc_tiles;
     return 0;
 }
 

@@ -102,6 +102,90 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
     }
 }
 
+// Latency form of embed_qkv: ONE workgroup (4 waves) per 16-agent tile, the waves split every layer by output row tile instead of
+// each owning a tile (whose serial chain is ~1300 fp32 MFMAs = ~20 us however few tiles exist):
+//   1  wave w: pos-enc fc row tile w of EVERY frame (input_fc recomputed: 4 MFMAs per frame) -> LDS;         one barrier
+//   2  wave w: input_fc2 row tile w accumulated over frames and k-tiles in the throughput kernel's order -> LDS; one barrier
+//   3  wave w: input_fc3 row tile w (+ category column) -> g, LDS;                                              one barrier
+//   4  wave w: in-projection row tiles w, w+4, w+8 -> qkv.
+// ~350 MFMAs per wave.  Every output element is summed in the order of embed_qkv_kernel: identical bits.
+__global__ __launch_bounds__(256) void embed_qkv_lat_kernel(EmbedW w, const float* __restrict__ enc_in, const int* __restrict__ last_flag,
+                                                            float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen) {
+    extern __shared__ __attribute__((aligned(16))) char smem_e[];
+    f32x4* sPt = reinterpret_cast<f32x4*>(smem_e);   // [Tlen][4][64]
+    f32x4* sF = sPt + (size_t)Tlen * 256;            // [4][64]
+    f32x4* sG = sF + 256;                            // [4][64]
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.x * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 pw[4], b1[4];
+    float f1[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        pw[T] = w.posP[(wv * 4 + T) * 64 + lane];
+        f1[T] = w.fc1P[T * 64 + lane];
+        b1[T] = ld4(w.fc1b + 16 * T + 4 * q);
+    }
+    // first fc2 fragments of this wave's row tile travel during phase 1
+    f32x4 w2n[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) w2n[T] = w.fc2P[((size_t)wv * 4 * Tlen + T) * 64 + lane];
+    float xn = enc_in[((size_t)colc * Tlen) * 4 + q];
+    for (int t = 0; t < Tlen; ++t) {
+        const float xin = xn;
+        if (t + 1 < Tlen) xn = enc_in[((size_t)colc * Tlen + t + 1) * 4 + q];
+        f32x4 a = ld4(w.peb + (size_t)t * 64 + 16 * wv + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const f32x4 xt = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[T], xin, b1[T], 0, 0, 0);
+            a = mfma_k16(a, pw[T], xt);
+        }
+        sPt[(t * 4 + wv) * 64 + lane] = a;
+    }
+    __syncthreads();
+    f32x4 f = ld4(w.fc2b + 16 * wv + 4 * q);
+    for (int t = 0; t < Tlen; ++t) {
+        f32x4 w2c[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) w2c[T] = w2n[T];
+        const int tn = t + 1 < Tlen ? t + 1 : t;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) w2n[T] = w.fc2P[((size_t)wv * 4 * Tlen + 4 * tn + T) * 64 + lane];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) f = mfma_k16(f, w2c[T], sPt[(t * 4 + T) * 64 + lane]);
+    }
+    f32x4 w3[4], wi[3][4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) w3[T] = w.fc3P[(wv * 4 + T) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) wi[i][T] = w.inP[((wv + 4 * i) * 4 + T) * 64 + lane];
+    sF[wv * 64 + lane] = f;
+    __syncthreads();
+    const float lastf = last_flag[colc] ? 1.0f : 0.0f;
+    f32x4 gg;
+    {
+        f32x4 a = ld4(w.fc3b + 16 * wv + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a = mfma_k16(a, w3[T], sF[T * 64 + lane]);
+        const f32x4 wl = ld4(w.fc3last + 16 * wv + 4 * q);
+        gg = a + wl * lastf;
+    }
+    if (col < n) st4(g + (size_t)col * 64 + 16 * wv + 4 * q, gg);
+    sG[wv * 64 + lane] = gg;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int it = wv + 4 * i;
+        f32x4 a = ld4(w.inb + 16 * it + 4 * q);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a = mfma_k16(a, wi[i][T], sG[T * 64 + lane]);
+        if (col < n) st4(qkv + (size_t)col * 192 + 16 * it + 4 * q, a);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // geodesic attention:  out_i = sum_j softmax_j( -acos(clamp(<rhat_i, chat_j>)) ) v_j      (hd = 8)
 // element (seq s, batch b, feature f) of R/C/V/out lives at  base + s*seq_stride + b*batch_stride + f
@@ -409,7 +493,12 @@ extern "C" int sttode_embed_qkv(const float* fc1P, const float* fc1b, const floa
     EmbedW w;
     w.fc1P = fc1P; w.fc1b = fc1b; w.posP = (const f32x4*)posP; w.peb = peb; w.fc2P = (const f32x4*)fc2P; w.fc2b = fc2b;
     w.fc3P = (const f32x4*)fc3P; w.fc3b = fc3b; w.fc3last = fc3last; w.inP = (const f32x4*)inP; w.inb = inb;
-    hipLaunchKernelGGL(embed_qkv_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, enc_in, last_flag, g, qkv, n, Tlen);
+    const int ntiles = (n + 15) / 16;
+    const size_t lat_lds = ((size_t)Tlen * 256 + 512) * 16;
+    if (ntiles <= stt_enc_lat_tiles() && lat_lds <= 64 * 1024)   // few agents: one tile per workgroup, rows split over its waves
+        hipLaunchKernelGGL(embed_qkv_lat_kernel, dim3(ntiles), dim3(256), lat_lds, (hipStream_t)stream, w, enc_in, last_flag, g, qkv, n, Tlen);
+    else
+        hipLaunchKernelGGL(embed_qkv_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, enc_in, last_flag, g, qkv, n, Tlen);
     STT_HIP(hipGetLastError());
     return 0;
 }

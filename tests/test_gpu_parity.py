@@ -303,7 +303,7 @@ def test_fused_trajectory_chain_vs_three_kernel_form_and_oracle(case):
 
 @pytest.mark.parametrize('case', ['eth_1', 'eth_7', 'eth_32', 'eth_3scenes', 'nba', 'nba_long'])
 def test_latency_forms_are_bitwise_the_throughput_forms_and_match_oracle(case):
-    """The few-column (single scene, test.py:171-188) forms of gru_cols / mlp_block0 / mlp_block1 -- one 16-column tile per WORKGROUP,
+    """The few-column (single scene, test.py:171-188) forms of embed_qkv / gru_cols / mlp_block0 / mlp_block1 -- one 16-column tile per WORKGROUP,
     rows split over its waves -- sum in the order of the throughput forms (a tile per wave): identical bits with the crossover
     forced either way (sttode_set_latency_tiles), and both match the CPU oracle."""
     from sttode_amd import capi, scenes
@@ -329,11 +329,11 @@ def test_latency_forms_are_bitwise_the_throughput_forms_and_match_oracle(case):
     try:
         m.native().set_chain(0)
         for tiles in (0, 1 << 30):
-            capi.call('sttode_set_latency_tiles', tiles, tiles)
+            capi.call('sttode_set_latency_tiles', tiles, tiles, tiles)
             feed()
             outs[tiles] = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
     finally:
-        capi.call('sttode_set_latency_tiles', 512, 1024)
+        capi.call('sttode_set_latency_tiles', 512, 1024, 1024)
         m.native().set_chain(-1)
     assert np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0], outs[1 << 30]), f'{case}: max diff {np.abs(outs[0] - outs[1 << 30]).max():.3e}'
