@@ -390,7 +390,9 @@ def train_bench(args, rank, world, dev, dist):
     model = STTODENet(make_args('eth', TP, TF), dev)
     model.load_state_dict(sd, strict=True)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    # torch.optim.Adam as in train.py; fused=True is torch's one-kernel-per-step implementation of the same update (the default
+    # 'foreach' form costs ~0.6 ms of host time per step on 88 small parameters); --train-adam foreach restores the default
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=(args.train_adam == 'fused'))
     nsc = args.train_scenes
     data = [scenes.eth_scene(100000 + rank * nsc + i) for i in range(nsc)]
     data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]
@@ -442,7 +444,7 @@ def train_bench(args, rank, world, dev, dist):
            'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
            'data': 'synthetic', 'config': {'workload': f'train.py:72-95 loop over {nsc} synthetic ETH-shaped scenes per GPU (2..32 '
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
-                                                       '(rotation + positional dropout), Adam lr 1e-4',
+                                                       '(rotation + positional dropout), torch.optim.Adam lr 1e-4 (' + args.train_adam + ')',
                                            'parallelism': f'scenes x{world}' + (' + flat gradient all-reduce' if world > 1 else '')}}
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle.sttode_ref import STTODENetRef                 # cpu_baseline leg only
@@ -487,6 +489,7 @@ def main():
     ap.add_argument('--train', action='store_true', help='print ONLY the training line (secondary metric: train.py:72-95 loop)')
     ap.add_argument('--no-train', action='store_true', help='skip the "train" object of the default line')
     ap.add_argument('--train-batch', type=int, default=1, help='scenes per optimizer step (1 = the reference loop)')
+    ap.add_argument('--train-adam', choices=('fused', 'foreach'), default='fused')
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)

@@ -229,6 +229,15 @@ int sttode_loss_kl(const float* params, const int* scene_ptr, int S, int rows, i
  * with scene_ptr / agent_scene: sum over scenes of the per-scene means.  scratch >= n floats. */
 int sttode_loss_diverse(const float* pred, const float* target, const int* scene_ptr, const int* agent_scene, int n, int K, int D,
                         float* out, float* dpred, float* scratch, void* stream);
+/* The four terms of forward()'s objective (:372-395,553-568) and all their gradients for ONE decoder pass over K1 = 1 + K samples per
+ * agent (sample 0: decoded from the posterior draw, enters the prediction / recover terms; samples 1..K: the prior draws, best-of-K):
+ * pred [n,K1,D], rec [n,K1,Dp], fut [n,D], past [n,Dp], qzp [n,2*zd] -> out[0..4] = (mse, recover, kl, diverse as the three entry
+ * points above compute them, then their sum = total_loss), dpred [n,K1,D], drec [n,K1,Dp] (zero rows for samples 1..K), dqzp [n,2*zd].  Two launches.
+ * scratch >= 3 n + max(S, 1) floats. */
+int sttode_loss_objective(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                          const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd, float scale_mse,
+                          float scale_rec, float kl_denom, float min_clip, float* out, float* dpred, float* drec, float* dqzp,
+                          float* scratch, long scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).

@@ -56,6 +56,7 @@ SIGNATURES = {
     'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
     'sttode_loss_kl': [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     'sttode_loss_diverse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    'sttode_loss_objective': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _L, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
     'sttode_pmath_scalar': [_I, _P, _P, _L, _P],

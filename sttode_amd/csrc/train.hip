@@ -285,7 +285,7 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.cols = cols; a.N = N; a.K = K; a.xdiv = xdiv;
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
-    int S = (chunks + 31) / 32;                       // >= 512 columns per split
+    int S = chunks <= 64 ? 1 : (chunks + 31) / 32;    // >= 512 columns per split; up to 1024 columns one workgroup per tile (no reduce launch)
     if (S > 64) S = 64;
     if (!scratch || per * S > scratch_floats) S = scratch && scratch_floats >= 2 * per ? (int)(scratch_floats / per) : 1;
     if (S < 1) S = 1;
@@ -323,7 +323,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     w.ldy = ldy; w.ldx = ldx; w.ldw = ldgw; w.cols = cols; w.N = N; w.K = K; w.xdiv = 1;
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
-    int S = (chunks + 31) / 32;
+    int S = chunks <= 64 ? 1 : (chunks + 31) / 32;
     if (!scratch || per * S > scratch_floats) S = scratch && scratch_floats >= 2 * per ? (int)(scratch_floats / per) : 1;
     if (S < 1) S = 1;
     w.S = S;
@@ -1016,6 +1016,116 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* v, int n, float* 
     for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
     const float s = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = s;
+}
+// The whole objective of forward() (model/STTODE.py:372-395,553-568) for ONE decoder pass over K1 = 1 + K samples per agent (sample 0
+// decoded from the posterior draw, samples 1..K from the prior draws), in two launches:
+//   objective_kernel   blocks [0, n): agent a -- squared errors of sample 0 (prediction and recovered past), best-of-K over samples
+//                      1..K, and every gradient row of the agent (dpred [K1,D], drec [K1,Dp]: zero rows where a sample does not enter);
+//                      blocks [n, n + nb): the KL blocks of kl_kernel;   partial sums -> scratch
+//   objective_sum      fixed-order sums of the partials -> out[0..4] = (mse, recover, kl, diverse, their sum)
+struct ObjArgs {
+    const float* pred; const float* rec; const float* fut; const float* past; const float* qzp; const int* scene_ptr; const int* agent_scene;
+    float* dpred; float* drec; float* dqzp; float* part;   // part: [3][n] agent partials, then [nb] KL values
+    int n, K1, D, Dp, zd, nb;
+    float scale_mse, scale_rec, kl_denom, min_clip;
+};
+__global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
+    __shared__ float red[256];
+    if ((int)blockIdx.x >= o.n) {     // KL block (same arithmetic as kl_kernel)
+        const int b = blockIdx.x - o.n;
+        const float ps = 1.0f + 1e-8f;
+        const long r0 = o.scene_ptr ? o.scene_ptr[b] : 0, r1 = o.scene_ptr ? o.scene_ptr[b + 1] : o.n;
+        const float denom = o.scene_ptr ? (float)(r1 - r0) : o.kl_denom;
+        const int zd = o.zd;
+        float acc = 0.f;
+        for (long i = r0 * zd + threadIdx.x; i < r1 * zd; i += 256) {
+            const long r = i / zd;
+            const int d = (int)(i % zd);
+            const float mu = o.qzp[r * 2 * zd + d], lv = o.qzp[r * 2 * zd + zd + d];
+            const float t1 = mu / ps, t2 = expf(0.5f * lv) / ps;
+            acc += 0.5f * (t1 * t1 + t2 * t2) - 0.5f - logf(t2);
+        }
+        const float sm = block_sum(acc, red) / denom;
+        const bool live = sm >= o.min_clip;
+        if (threadIdx.x == 0) o.part[3 * (long)o.n + b] = live ? sm : o.min_clip;
+        for (long i = r0 * zd + threadIdx.x; i < r1 * zd; i += 256) {
+            const long r = i / zd;
+            const int d = (int)(i % zd);
+            const float mu = o.qzp[r * 2 * zd + d], lv = o.qzp[r * 2 * zd + zd + d];
+            const float t2 = expf(0.5f * lv) / ps;
+            o.dqzp[r * 2 * zd + d] = live ? (mu / (ps * ps)) / denom : 0.f;
+            o.dqzp[r * 2 * zd + zd + d] = live ? (0.5f * t2 * t2 - 0.5f) / denom : 0.f;
+        }
+        return;
+    }
+    const int a = blockIdx.x, t = threadIdx.x, K1 = o.K1, D = o.D, Dp = o.Dp;
+    const float* pa = o.pred + (long)a * K1 * D;
+    const float* ra = o.rec + (long)a * K1 * Dp;
+    // sample 0: squared errors + gradients
+    float e0 = 0.f, e1 = 0.f;
+    for (int d = t; d < D; d += 256) { const float df = pa[d] - o.fut[(long)a * D + d]; e0 += df * df; o.dpred[(long)a * K1 * D + d] = 2.0f * o.scale_mse * df; }
+    for (int d = t; d < Dp; d += 256) { const float df = ra[d] - o.past[(long)a * Dp + d]; e1 += df * df; o.drec[(long)a * K1 * Dp + d] = 2.0f * o.scale_rec * df; }
+    for (int i = Dp + t; i < K1 * Dp; i += 256) o.drec[(long)a * K1 * Dp + i] = 0.f;
+    const float s0 = block_sum(e0, red), s1 = block_sum(e1, red);
+    // samples 1..K: first minimum of the summed squared error (torch.min), weight 1 / (agents of the scene)
+    float wgt = 1.0f / (float)o.n;
+    if (o.scene_ptr) { const int sc = o.agent_scene[a]; wgt = 1.0f / (float)(o.scene_ptr[sc + 1] - o.scene_ptr[sc]); }
+    __shared__ float sv[64];
+    __shared__ int sk;
+    if (t < 64) {
+        float sq = 3.4e38f;
+        if (t + 1 < K1) {
+            sq = 0.f;
+            for (int d = 0; d < D; ++d) { const float df = o.fut[(long)a * D + d] - pa[(long)(t + 1) * D + d]; sq += df * df; }
+        }
+        float bs = sq;
+        int bk = t;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            const float os = __shfl_xor(bs, sh, 64);
+            const int ok = __shfl_xor(bk, sh, 64);
+            if (os < bs || (os == bs && ok < bk)) { bs = os; bk = ok; }
+        }
+        if (t == 0) { sv[0] = bs; sk = bk; }
+    }
+    __syncthreads();
+    const int bk = sk + 1;
+    for (int i = D + t; i < K1 * D; i += 256) {
+        const int k = i / D, d = i % D;
+        o.dpred[(long)a * K1 * D + i] = k == bk ? 2.0f * (pa[i] - o.fut[(long)a * D + d]) * wgt : 0.f;
+    }
+    if (t == 0) { o.part[a] = s0; o.part[o.n + a] = s1; o.part[2 * (long)o.n + a] = sv[0] * wgt; }
+}
+__global__ __launch_bounds__(256) void objective_sum_kernel(const float* part, int n, int nb, float scale_mse, float scale_rec, float* out) {
+    __shared__ float red[256];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { a0 += part[i]; a1 += part[n + i]; a2 += part[2 * (long)n + i]; }
+    for (int i = threadIdx.x; i < nb; i += 256) a3 += part[3 * (long)n + i];
+    const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red), s3 = block_sum(a3, red);
+    if (threadIdx.x == 0) {
+        const float l0 = s0 * scale_mse, l1 = s1 * scale_rec;
+        out[0] = l0; out[1] = l1; out[2] = s3; out[3] = s2;
+        out[4] = ((l0 + l1) + s3) + s2;   // total_loss (model/STTODE.py:568)
+    }
+}
+extern "C" int sttode_loss_objective(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                                     const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd,
+                                     float scale_mse, float scale_rec, float kl_denom, float min_clip, float* out, float* dpred,
+                                     float* drec, float* dqzp, float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(pred && rec && fut && past && qzp && out && dpred && drec && dqzp && scratch, "sttode_loss_objective: null pointer");
+    STT_REQUIRE(n > 0 && K1 >= 2 && K1 <= 65 && D > 0 && Dp > 0 && zd > 0, "sttode_loss_objective: bad sizes (2 <= K1 <= 65)");
+    STT_REQUIRE(scene_ptr ? (S > 0 && agent_scene) : kl_denom > 0.f, "sttode_loss_objective: scene_ptr needs S > 0 and agent_scene, otherwise kl_denom > 0");
+    const int nb = scene_ptr ? S : 1;
+    STT_REQUIRE(3L * n + nb <= scratch_floats, "sttode_loss_objective: scratch too small (3 n + S floats)");
+    ObjArgs o;
+    o.pred = pred; o.rec = rec; o.fut = fut; o.past = past; o.qzp = qzp; o.scene_ptr = scene_ptr; o.agent_scene = agent_scene;
+    o.dpred = dpred; o.drec = drec; o.dqzp = dqzp; o.part = scratch;
+    o.n = n; o.K1 = K1; o.D = D; o.Dp = Dp; o.zd = zd; o.nb = nb;
+    o.scale_mse = scale_mse; o.scale_rec = scale_rec; o.kl_denom = kl_denom; o.min_clip = min_clip;
+    hipLaunchKernelGGL(objective_kernel, dim3(n + nb), dim3(256), 0, (hipStream_t)stream, o);
+    hipLaunchKernelGGL(objective_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, nb, scale_mse, scale_rec, out);
+    STT_HIP(hipGetLastError());
+    return 0;
 }
 extern "C" int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream) {
     STT_REQUIRE(pred && target && out && count > 0, "sttode_loss_sqerr: bad argument");

@@ -110,7 +110,8 @@ class _SamplerFn(torch.autograd.Function):
         eng = getattr(net, '_engine', None)
         if eng is None or eng.dev != net.device:
             eng = net._engine = Engine(net)
-        eng.st = capi.stream_ptr()
+        eng.multi, eng._hold = False, []                            # single chain: no side streams
+        eng._enter(-1)
         eng.P = {k: v for k, v in net.named_parameters()}
         K, nz, a = smp.nk, smp.nz, net.args
         pf = net.past_feature
@@ -141,6 +142,8 @@ class _SamplerFn(torch.autograd.Function):
         eng, smp, d, hs, A = ctx.eng, ctx.smp, ctx.d, ctx.hs, ctx.A
         n, K, nz = hs[0].shape[0], smp.nk, smp.nz
         m = n * K
+        eng.multi = False
+        eng._enter(-1)
         eng._grad_views()
         eng.param_grads = False                                     # the STTODENet is frozen in stage 2
         try:

@@ -33,15 +33,70 @@ class Engine:
     def __init__(self, net):
         self.net = net
         self.dev = net.device
-        self.scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
+        self.scratch = self.main_scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
         self.param_grads = True     # False: skip the weight-gradient GEMMs (stage-2 sampler training keeps this net frozen)
+        # The two encoder trunks (disjoint parameters) run on two streams, forward and backward (see forward_segments /
+        # backward_segments); the side stream has its own split-k scratch.
+        self.side = None            # [stream, stream], created on first use
+        self.main_cap = None        # capture stream of the caller's-stream segments
+        self.side_scratch = None
+        self.multi = False
+        self._hold = []
+
+    # ---------------------------------------------------------------- streams
+    def _use_streams(self, n):
+        """Launch-latency-bound regime only (every kernel is a few workgroups): at larger batches the kernels fill the device and
+        the serial order is as fast (and keeps fewer temporaries alive)."""
+        env = os.environ.get('STTODE_TRAIN_STREAMS')
+        on = (n * 20 <= 32768) if env is None else env != '0'
+        if on and self.side is None:
+            self.side = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+            self.side_scratch = [torch.empty(4 << 20, dtype=torch.float32, device=self.dev) for _ in self.side]
+        return on
+
+    def _enter(self, idx):
+        """Bind the launch state to the stream a segment runs on (idx -1: the caller's stream, 0 / 1: side streams)."""
+        self.st = capi.stream_ptr()
+        self.scratch = self.main_scratch if idx < 0 else self.side_scratch[idx]
+
+    def run_segments(self, segs, launch=None):
+        """A step is a list of segments (stream, waits, fn): fn enqueues a chain of kernels on its stream; a side-stream segment starts
+        after everything enqueued so far on the caller's stream, a caller's-stream segment after the side streams named in ``waits``.
+        ``launch(i)`` replaces fn (replay of the segment's captured hipGraph).  With streams off everything runs in list order."""
+        main = torch.cuda.current_stream()
+        used = set()
+        for i, (stream, waits, fn) in enumerate(segs):
+            if not self.multi or stream < 0:
+                if self.multi:
+                    for w in waits:
+                        main.wait_stream(self.side[w])
+                        used.discard(w)
+                self._enter(-1)
+                fn() if launch is None else launch(i)
+            else:
+                sd = self.side[stream]
+                sd.wait_stream(main)
+                used.add(stream)
+                with torch.cuda.stream(sd):
+                    self._enter(stream)
+                    fn() if launch is None else launch(i)
+        for w in used:                       # the caller's stream ends behind every side stream
+            main.wait_stream(self.side[w])
+        self._enter(-1)
+
+    def hold(self, t):
+        """Keeps a tensor that crosses streams alive until the step's last kernel is enqueued AND the next step begins: the caching
+        allocator would otherwise hand its block to a later allocation of the allocating stream while another stream still uses it."""
+        if self.multi:
+            self._hold.append(t)
+        return t
 
     # ---------------------------------------------------------------- primitives
     def new(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+        return self.hold(torch.empty(*shape, dtype=torch.float32, device=self.dev))
 
     def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        return self.hold(torch.zeros(*shape, dtype=torch.float32, device=self.dev))
 
     def lin(self, X, W, b, act=None, xdiv=1, out=None, cols=None):
         """out[c] = act(W X[c / xdiv] + b); X [rows, J] (row stride free), W [I, J] row-major view."""
@@ -118,7 +173,7 @@ class Engine:
             self.ew(EW_MUL, tp, tp, drop_mask)
         h3in = self.zeros(n, 68)
         self.lin(tp.view(n, T * 64), P[pre + 'input_fc2.weight'], P[pre + 'input_fc2.bias'], out=h3in[:, :64])
-        h3in[:, 66] = last.to(torch.float32)            # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
+        h3in[:, 66] = self.hold(last.to(torch.float32))  # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
         x = feat[:, :64]
         self.lin(h3in[:, :67], P[pre + 'input_fc3.weight'], P[pre + 'input_fc3.bias'], out=x)
         a = pre + _ATT
@@ -277,92 +332,141 @@ class Engine:
             dz.copy_(din0[:, 128:160])
 
     # ---------------------------------------------------------------- the objective (model/STTODE.py:553-568)
-    def run_forward(self, eps_q, eps20, drop_past=None, drop_future=None):
+    def forward_segments(self, eps_q, eps20, drop_past=None, drop_future=None):
+        """The forward pass as segments (see run_segments): future trunk on side 1 beside the past trunk; then the q-net and ONE decoder
+        pass over 1 + 20 samples per agent -- sample 0 decoded from the posterior draw (pred_traj / recover_traj, model/STTODE.py:
+        553-560), samples 1..20 from the prior draws (diverse_pred_traj, :562-566): the two passes of the reference share every
+        weight, so one pass over 21 columns per agent halves the launches of the decoder's forward and backward."""
         net, a = self.net, self.net.args
-        self.st = capi.stream_ptr()
         self.P = {k: v for k, v in net.named_parameters()}
+        P = self.P
+        self._hold = []
+        self.multi = self._use_streams(net._past.shape[0])
+        for t_in in (eps_q, eps20, drop_past, drop_future):       # the caller may drop them while a side stream still reads them
+            if t_in is not None:
+                self.hold(t_in)
         B = net.batch_size if net._mode == 'nba' else 1
         N = net.agent_num
-        ws = net._frontend(vel_from_norm=0)
         n, Tp, Tf, zd = net._past.shape[0], a.past_length, a.future_length, a.zdim
-        past = ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2).contiguous()
-        cur = ws['cur']
-        enc_f = self.new(n, Tf, 4)
         mode = 0 if net._mode == 'scenes' else 1
-        capi.call('sttode_frontend_future', net._future, net._past[:, -1].contiguous(), n, Tf, mode, net._N or 1, ws.get('scene_orig'),
-                  ws.get('agent_scene'), net._scene_ptr if mode == 0 else None, enc_f, self.st)
-        fut = (net._future - ws['orig'][:, None, :]).contiguous()
-        hcat = self.new(n, 256)
-        tp_ = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
-        tf_ = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
-        P = self.P
-        hq = self.lin(hcat, P['future_encoder.out_mlp.affine_layers.0.weight'], P['future_encoder.out_mlp.affine_layers.0.bias'], act='relu')
-        qzp = self.lin(hq, P['future_encoder.qz_layer.weight'], P['future_encoder.qz_layer.bias'])
-        qz = self.new(n, zd)
-        self.ew(EW_RSAMPLE, qz, qzp, eps_q, i0=zd)
-        pf = hcat[:, :128]
-        d1 = self.decoder_fwd(pf, qz, 1, past, cur, True)
-        d20 = self.decoder_fwd(pf, eps20, 20, past, cur, False)
-        losses = self.new(4)
-        dpred1, drec1, dqzp, dpred20 = self.new(n, 2 * Tf), self.new(n, 2 * Tp), self.new(n, 2 * zd), self.new(n * 20, 2 * Tf)
-        capi.call('sttode_loss_sqerr', d1['pred'], fut, n * 2 * Tf, 1.0 / (B * Tf), losses[0:], dpred1, self.st)
-        capi.call('sttode_loss_sqerr', d1['rec'], past, n * 2 * Tp, 1.0 / (B * Tp), losses[1:], drec1, self.st)
-        # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
-        # gradient equals what S reference steps would accumulate (per-scene KL clamp and per-scene mean of the best-of-20 term)
-        seg = net._mode == 'scenes' and net._S > 1
-        sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
-        capi.call('sttode_loss_kl', qzp, sp, S, n, zd, float(B * N), float(a.min_clip), losses[2:], dqzp, self.scratch, self.st)
-        capi.call('sttode_loss_diverse', d20['pred'], fut, sp, ags, n, 20, 2 * Tf, losses[3:], dpred20, self.scratch, self.st)
-        self.step_id = getattr(self, 'step_id', 0) + 1
-        self.tape = dict(step_id=self.step_id, tp=tp_, tf=tf_, hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d1=d1, d20=d20, dpred1=dpred1, drec1=drec1, dqzp=dqzp,
-                         dpred20=dpred20, n=n, zd=zd)
-        # attributes the reference sets (read by callers)
-        net.past_feature = pf
-        net.qz_param = qzp
-        net.qz_sampled = qz
-        net.pred_traj = d1['pred'].view(n, Tf, 2)
-        net.recover_traj = d1['rec'].view(n, Tp, 2)
-        net.diverse_pred_traj = d20['pred'].view(n, 20, Tf, 2)
-        net.past_traj, net.future_traj, net.cur_location = past, fut, past[:, -1:]
-        return losses
+        K1 = 21
+        V = self.V = {}
 
-    def run_backward(self, gout=None, step_id=None):
+        def f_front():
+            V['ws'] = ws = net._frontend(vel_from_norm=0)
+            V['past'] = ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2).contiguous()
+            V['fut'] = (net._future - ws['orig'][:, None, :]).contiguous()
+            V['hcat'] = self.new(n, 256)
+            V['lastpos'] = self.hold(net._past[:, -1].contiguous())
+
+        def f_future():
+            ws, hcat = V['ws'], V['hcat']
+            enc_f = self.new(n, Tf, 4)
+            capi.call('sttode_frontend_future', net._future, V['lastpos'], n, Tf, mode, net._N or 1, ws.get('scene_orig'),
+                      ws.get('agent_scene'), net._scene_ptr if mode == 0 else None, enc_f, self.st)
+            V['tf'] = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
+
+        def f_past():
+            ws, hcat = V['ws'], V['hcat']
+            V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+
+        def f_dec():
+            ws, hcat, fut, past = V['ws'], V['hcat'], V['fut'], V['past']
+            hq = self.lin(hcat, P['future_encoder.out_mlp.affine_layers.0.weight'], P['future_encoder.out_mlp.affine_layers.0.bias'], act='relu')
+            qzp = self.lin(hq, P['future_encoder.qz_layer.weight'], P['future_encoder.qz_layer.bias'])
+            qz = self.new(n, zd)
+            self.ew(EW_RSAMPLE, qz, qzp, eps_q, i0=zd)
+            z21 = self.new(n * K1, zd)                              # [agent][sample 0 = q draw | samples 1..20 = prior draws]
+            zrow = z21.view(n, K1 * zd)
+            capi.call('sttode_rows_copy', zrow, K1 * zd, qz, zd, n, zd, 1, n, self.st)
+            capi.call('sttode_rows_copy', zrow[:, zd:], K1 * zd, eps20, 20 * zd, n, 20 * zd, 1, n, self.st)
+            d = self.decoder_fwd(hcat[:, :128], z21, K1, past, ws['cur'], True)
+            losses = self.new(5)                                    # the four terms and their sum
+            dpred, drec, dqzp = self.new(n * K1, 2 * Tf), self.new(n * K1, 2 * Tp), self.new(n, 2 * zd)
+            # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
+            # gradient equals what S reference steps would accumulate (per-scene KL clamp and per-scene mean of the best-of-20 term)
+            seg = net._mode == 'scenes' and net._S > 1
+            sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
+            capi.call('sttode_loss_objective', d['pred'], d['rec'], fut, past, qzp, sp, ags, S, n, K1, 2 * Tf, 2 * Tp, zd, 1.0 / (B * Tf),
+                      1.0 / (B * Tp), float(B * N), float(a.min_clip), losses, dpred, drec, dqzp, self.scratch, self.scratch.numel(), self.st)
+            self.step_id = getattr(self, 'step_id', 0) + 1
+            self.tape = dict(step_id=self.step_id, tp=V['tp'], tf=V['tf'], hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d=d, dpred=dpred,
+                             drec=drec, dqzp=dqzp, n=n, zd=zd, K1=K1)
+            V['losses'] = losses
+            # attributes the reference sets (read by callers)
+            pr = d['pred'].view(n, K1, Tf, 2)
+            net.past_feature = hcat[:, :128]
+            net.qz_param = qzp
+            net.qz_sampled = qz
+            net.pred_traj = pr[:, 0]
+            net.recover_traj = d['rec'].view(n, K1, Tp, 2)[:, 0]
+            net.diverse_pred_traj = pr[:, 1:]
+            net.past_traj, net.future_traj, net.cur_location = past, fut, past[:, -1:]
+
+        return [(-1, (), f_front), (1, (), f_future), (-1, (), f_past), (-1, (1,), f_dec)]
+
+    def run_forward(self, eps_q, eps20, drop_past=None, drop_future=None):
+        self.run_segments(self.forward_segments(eps_q, eps20, drop_past, drop_future))
+        return self.V['losses']
+
+    def backward_segments(self):
+        """The backward pass as segments: decoder pass + q-net on the caller's stream, then the future trunk on side 1 beside the past
+        trunk (disjoint parameters)."""
         T = self.tape
         # The tape (and the flat gradient buffer it fills) belongs to the MOST RECENT eager forward().  backward() of an older loss, or
         # a second backward() of the same loss, would silently differentiate the wrong step: refuse instead.
         if T is None:
             raise SttodeError('training backward: the tape of this forward() was already consumed (backward() called twice, or '
                               'retain_graph reuse); run forward() again')
-        if step_id is not None and T.get('step_id') != step_id:
+        n, zd, K1 = T['n'], T['zd'], T['K1']
+        P, g = self.P, self.grad
+        W = {}
+
+        def b_dec():
+            self._grad_views()
+            W['dpf'] = dpf = self.zeros(n, 128)
+            dz = self.new(n * K1, zd)
+            self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, dz)
+            dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent
+            capi.call('sttode_rows_copy', dqz, zd, dz, K1 * zd, n, zd, 1, n, self.st)
+            dqzp = T['dqzp']                                            # starts as the KL gradient
+            self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
+            dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
+                               g('future_encoder.qz_layer.bias'), mask=T['hq'])
+            W['dhcat'] = self.hold(self.lin_bwd(dhq, P['future_encoder.out_mlp.affine_layers.0.weight'], T['hcat'],
+                                                g('future_encoder.out_mlp.affine_layers.0.weight'),
+                                                g('future_encoder.out_mlp.affine_layers.0.bias')))
+
+        def b_future():
+            self.trunk_bwd(T['tf'], W['dhcat'][:, 128:])
+
+        def b_past():
+            dpf = W['dpf']
+            self.ew(EW_AXPY, dpf, self.hold(W['dhcat'][:, :128].contiguous()), f0=1.0)
+            self.trunk_bwd(T['tp'], dpf)
+
+            self.tape = None
+
+        return [(-1, (), b_dec), (1, (), b_future), (-1, (), b_past)]
+
+    def run_backward(self, gout=None, step_id=None):
+        T = self.tape
+        if T is not None and step_id is not None and T.get('step_id') != step_id:
             raise SttodeError('training backward: this loss belongs to an earlier forward(); only the most recent forward() of a model '
                               'can be differentiated (its tape was overwritten by the newer forward())')
-        self._grad_views()
-        n, zd = T['n'], T['zd']
-        P, g = self.P, self.grad
-        dpf = self.zeros(n, 128)
-        self.decoder_bwd(T['d20'], T['dpred20'], None, dpf, None)
-        dqz = self.new(n, zd)
-        self.decoder_bwd(T['d1'], T['dpred1'], T['drec1'], dpf, dqz)
-        dqzp = T['dqzp']                                            # starts as the KL gradient
-        self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
-        dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
-                           g('future_encoder.qz_layer.bias'), mask=T['hq'])
-        dhcat = self.lin_bwd(dhq, P['future_encoder.out_mlp.affine_layers.0.weight'], T['hcat'],
-                             g('future_encoder.out_mlp.affine_layers.0.weight'), g('future_encoder.out_mlp.affine_layers.0.bias'))
-        self.ew(EW_AXPY, dpf, dhcat[:, :128].contiguous(), f0=1.0)
-        self.trunk_bwd(T['tf'], dhcat[:, 128:])
-        self.trunk_bwd(T['tp'], dpf)
-        self.tape = None
+        self.run_segments(self.backward_segments())
         if gout is not None:
             self.Gflat.mul_(gout)
         return {k: self.G[k] for k in self.touched}
 
 
 class _LossFn(torch.autograd.Function):
-    """Hands the HIP-computed parameter gradients to autograd: ``total_loss.backward()`` fills ``.grad`` (train.py:83-87)."""
+    """Hands the HIP-computed parameter gradients to autograd: ``total_loss.backward()`` fills ``.grad`` (train.py:83-87).
+    The only autograd input is a private scalar anchor (one graph edge instead of one per parameter: the step is host-bound); the
+    gradients are written to the parameters' ``.grad`` directly, so ``torch.autograd.grad(total, params)`` is not supported."""
 
     @staticmethod
-    def forward(ctx, total, engine, names, ready, *params):
+    def forward(ctx, total, engine, names, ready, params, anchor):
         ctx.engine, ctx.names, ctx.ready, ctx.params = engine, names, ready, params
         ctx.step_id = engine.tape['step_id'] if (ready is None and engine.tape is not None) else None
         return total.clone()
@@ -386,12 +490,12 @@ class _LossFn(torch.autograd.Function):
                 p.grad = g
             else:
                 p.grad.add_(g)
-        return (None, None, None, None) + (None,) * len(ctx.names)
+        return None, None, None, None, None, None
 
 
 class _GraphedStep:
-    """One hipGraph per step shape: the ~330 launches of forward-with-tape + backward replayed as a single graph launch
-    (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
+    """hipGraphs per step shape: the ~270 launches of forward-with-tape + backward replayed as a dozen graph launches on three
+    streams (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
     the loss values and the flat gradient buffer are static outputs."""
 
     def __init__(self, eng, net, inputs):
@@ -405,11 +509,33 @@ class _GraphedStep:
         if st['scene_ptr'] is not None:
             net._scene_ptr = st['scene_ptr']
 
-    def _body(self):
-        st = self.static
-        losses = self.eng.run_forward(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'])
-        G = self.eng.run_backward(None)
-        return losses, self.eng.Gflat, G
+    def _capture(self):
+        """One hipGraph per segment, captured on the stream kind it replays on (the private pool keeps blocks per capture stream, so a
+        temporary freed inside a side-stream segment is only ever reused by the same side stream) and replayed in capture order.
+        A single graph with forked branches is NOT used: hipGraph's executor runs such branches largely one after the other."""
+        eng, st = self.eng, self.static
+        segs = eng.forward_segments(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'])
+        if eng.main_cap is None:
+            eng.main_cap = torch.cuda.Stream(device=eng.dev)
+        pool = torch.cuda.graph_pool_handle()
+        self.graphs, self.segs = [], []
+        torch.cuda.synchronize()
+
+        def cap(part):
+            for stream, waits, fn in part:
+                g = torch.cuda.CUDAGraph()
+                cs = eng.main_cap if (not eng.multi or stream < 0) else eng.side[stream]
+                with torch.cuda.graph(g, pool=pool, stream=cs):
+                    eng._enter(-1 if (not eng.multi or stream < 0) else stream)
+                    fn()
+                self.graphs.append(g)
+                self.segs.append((stream, waits, None))
+        cap(segs)
+        cap(eng.backward_segments())
+        self.multi = eng.multi
+        self.keep = (eng._hold, eng.V, eng.G)                          # static buffers of the graphs
+        eng._hold = []
+        self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
 
     def run(self, inputs):
         for k, v in inputs.items():
@@ -417,13 +543,12 @@ class _GraphedStep:
                 self.static[k].copy_(v)
         self._bind()
         if self.graph is None:
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._body()
+            self._capture()
+            self.graph = True
             self.attrs = {k: getattr(self.net, k) for k in ('past_feature', 'qz_param', 'qz_sampled', 'pred_traj', 'recover_traj',
                                                             'diverse_pred_traj', 'past_traj', 'future_traj', 'cur_location')}
-        self.graph.replay()
+        self.eng.multi = self.multi
+        self.eng.run_segments(self.segs, launch=lambda i: self.graphs[i].replay())
         for k, v in self.attrs.items():
             setattr(self.net, k, v)
         losses, flat, G = self.out
@@ -455,8 +580,10 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     if eng is None or eng.dev != dev:
         eng = net._engine = Engine(net)
         net._graphs, net._graph_seen = {}, set()
-    names = [k for k, _ in net.named_parameters()]
-    params = [p for _, p in net.named_parameters()]
+    cache = getattr(eng, '_names_params', None)
+    if cache is None or cache[1][0] is not next(net.parameters()):
+        cache = eng._names_params = ([k for k, _ in net.named_parameters()], [p for _, p in net.named_parameters()])
+    names, params = cache
     ready = None
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
            params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
@@ -475,7 +602,8 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
             net._graph_seen.add(key)                                # first time: eager (also warms one-time kernel attributes)
     if ready is None:
         losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)
-    total_v = losses.sum()
-    total = _LossFn.apply(total_v, eng, names, ready, *params)
+    if getattr(eng, 'anchor', None) is None:
+        eng.anchor = torch.zeros((), device=dev, requires_grad=True)
+    total = _LossFn.apply(losses[4], eng, names, ready, params, eng.anchor)
     lv = losses.tolist()
     return total, lv[0], lv[1], lv[2], lv[3]
