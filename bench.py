@@ -238,6 +238,9 @@ class Leg:
             dist.barrier()
         torch.cuda.synchronize()
         self.model.native().timing(time_every)
+        import gc
+        gc.collect()
+        gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
         t0 = time.perf_counter()
         for _ in range(steps):
             r = self.step(serial)
@@ -245,6 +248,7 @@ class Leg:
                 acc = r
                 if d2h:
                     hostbuf.copy_(self.last_pred, non_blocking=True)
+        t_host = time.perf_counter() - t0                         # the host's share: enqueueing `steps` steps (no device sync inside)
         r = self.drain()                                          # every one of the K steps completes inside the timed region
         if r is not None:
             acc = r
@@ -257,6 +261,7 @@ class Leg:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         stage_ms = self.model.native().read_timing()
         self.busy_ms = dict(getattr(self.model.native(), 'busy_ms', {}))
         self.model.native().timing(0)
@@ -268,7 +273,7 @@ class Leg:
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             dt, total = float(tmax[0]), float(tt[1])
         return {'dt': dt, 'total_traj': total, 'value': total * steps / dt, 'ms_per_step': 1e3 * dt / steps, 'stage_ms': stage_ms,
-                'metrics': acc}
+                'metrics': acc, 'host_ms_per_step': 1e3 * t_host / steps}
 
     def roofline(self, stage_ms, value_per_gpu, time_every):
         """Dominant kernel's rate.  Launches of consecutive pipelined steps run CONCURRENTLY (two streams, one workgroup per CU each), so
@@ -485,7 +490,7 @@ def main():
     ap.add_argument('--depth', type=int, default=3, help='calls in flight of the software pipeline (2..4)')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
     ap.add_argument('--legs', default='all', help="secondary legs: 'all', 'none' or a comma list of " + ','.join(k for k in LEGS if k != 'eth_512'))
-    ap.add_argument('--leg-steps', type=int, default=10)
+    ap.add_argument('--leg-steps', type=int, default=40)
     ap.add_argument('--train', action='store_true', help='print ONLY the training line (secondary metric: train.py:72-95 loop)')
     ap.add_argument('--no-train', action='store_true', help='skip the "train" object of the default line')
     ap.add_argument('--train-batch', type=int, default=1, help='scenes per optimizer step (1 = the reference loop)')
@@ -528,7 +533,8 @@ def main():
     acc = r['metrics']
     out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'steps': args.steps, 'warmup': args.warmup,
-           'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'ms_per_step': r['ms_per_step'], 'host_enqueue_ms_per_step': r['host_ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': head.config(world), 'roofline': roof, 'kernels': kern,
            'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
                            'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
@@ -562,9 +568,10 @@ def main():
             sys.stderr.write(f'bench.py: unknown leg {name!r}\n')
             return 2
         leg = Leg(name, rank, dev)
-        lr = leg.timed(args.leg_steps, 2, dist, 2)
+        lr = leg.timed(args.leg_steps, 5, dist, 2)
         lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2)
-        e = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'], 'steps': args.leg_steps, 'config': leg.config(world),
+        e = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'], 'host_enqueue_ms_per_step': lr['host_ms_per_step'],
+             'steps': args.leg_steps, 'config': leg.config(world),
              'roofline': lroof, 'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}
         if do_cpu:
             e['cpu_baseline'], e['parity'] = leg.cpu_sample(args.leg_cpu_seconds, nthr)
