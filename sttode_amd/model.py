@@ -273,8 +273,13 @@ class STTODENet(nn.Module):
         def to_dev(x):      # [N, 2, T] loader layout -> [N, T, 2]; a host tensor is transposed on the host (one H2D copy, no kernel)
             x = torch.as_tensor(x, dtype=torch.float32)
             return x.permute(0, 2, 1).contiguous().to(dev)
-        past = to_dev(pre_motion)
-        fut = to_dev(fut_motion) if fut_motion is not None else None
+        pre_motion = torch.as_tensor(pre_motion, dtype=torch.float32)
+        fut_motion = torch.as_tensor(fut_motion, dtype=torch.float32) if fut_motion is not None else None
+        if torch.device(dev).type == 'cuda' and not pre_motion.is_cuda and (fut_motion is None or not fut_motion.is_cuda):
+            past, fut = self._stage_scene(pre_motion, fut_motion)
+        else:
+            past = to_dev(pre_motion)
+            fut = to_dev(fut_motion) if fut_motion is not None else None
         if self.training and past.shape[0] > self.max_train_agent:
             ind = torch.tensor(np.random.choice(past.shape[0], self.max_train_agent).tolist(), device=dev)
             past = past.index_select(0, ind).contiguous()
@@ -300,6 +305,30 @@ class STTODENet(nn.Module):
         self.set_scene_batch(past, fut, ptr)
         self.batch_size = 1
         self.pre_motion_mask, self.fut_motion_mask = pre_motion_mask, fut_motion_mask
+
+    def _stage_scene(self, pre, fut):
+        """Host tensors of one scene (loader layout [N,2,T]) -> device [N,T,2] tensors through ONE asynchronous H2D copy: both tracks
+        are transposed into a pinned staging buffer (a ring of four, each guarded by an event) and travel together.  ``.to(device)`` of
+        a pageable tensor is a synchronous copy that also waits for the stream's earlier kernels -- two of them per scene were a third
+        of the per-scene loop of test.py:171-188."""
+        N, Tp = pre.shape[0], pre.shape[2]
+        Tf = fut.shape[2] if fut is not None else 0
+        need = N * (Tp + Tf) * 2
+        ring = self.__dict__.setdefault('_stage_ring', {'bufs': [None] * 4, 'events': [None] * 4, 'k': 0})
+        k = ring['k'] = (ring['k'] + 1) % 4
+        if ring['bufs'][k] is None or ring['bufs'][k].numel() < need:
+            ring['bufs'][k] = torch.empty(max(need, 4096), dtype=torch.float32).pin_memory()
+            ring['events'][k] = torch.cuda.Event()
+        else:
+            ring['events'][k].synchronize()                      # the copy that last read this buffer has completed (long ago, normally)
+        host = ring['bufs'][k][:need]
+        host[:N * Tp * 2].view(N, Tp, 2).copy_(pre.permute(0, 2, 1))
+        if fut is not None:
+            host[N * Tp * 2:].view(N, Tf, 2).copy_(fut.permute(0, 2, 1))
+        dev = torch.empty(need, dtype=torch.float32, device=self.device)
+        dev.copy_(host, non_blocking=True)
+        ring['events'][k].record()
+        return dev[:N * Tp * 2].view(N, Tp, 2), (dev[N * Tp * 2:].view(N, Tf, 2) if fut is not None else None)
 
     def set_scene_batch(self, past, future, scene_ptr):
         """Many independent scenes: past [n,Tp,2] / future [n,Tf,2] world coordinates, agent-major;
