@@ -397,7 +397,7 @@ def train_bench(args, rank, world, dev, dist):
     model.train()
     # torch.optim.Adam as in train.py; fused=True is torch's one-kernel-per-step implementation of the same update (the default
     # 'foreach' form costs ~0.6 ms of host time per step on 88 small parameters); --train-adam foreach restores the default
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=(args.train_adam == 'fused'))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, **({'fused': True} if args.train_adam == 'fused' else {}))   # (fused=False would select the single-tensor loop)
     nsc = args.train_scenes
     data = [scenes.eth_scene(100000 + rank * nsc + i) for i in range(nsc)]
     data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]

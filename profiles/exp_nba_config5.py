@@ -5,7 +5,10 @@ from helpers import make_args
 from sttode_amd import STTODENet, scenes
 from sttode_amd.weights import make_weights, to_torch_state_dict
 dev = torch.device('cuda')
-for (B, N, Tp, Tf) in ((128, 11, 5, 10), (1024, 10, 10, 40), (4096, 10, 10, 40)):
+CASES = ((128, 11, 5, 10), (1024, 10, 10, 40), (4096, 10, 10, 40))
+if os.environ.get('ONLY_CONFIG5'):
+    CASES = CASES[2:]
+for (B, N, Tp, Tf) in CASES:
     m = STTODENet(make_args('nba', Tp, Tf), dev).eval()
     m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=Tp, future_length=Tf)))
     d = scenes.nba_batch(1, B, N=N, obs_len=Tp, pred_len=Tf)
