@@ -231,6 +231,14 @@ class STTODENet(nn.Module):
             self._async_bufs = {}
         return self._packed
 
+    def release_native(self):
+        """Drop the native pipeline (its HIP streams and events: every stream takes a share of the few hardware queues), the packed
+        weights and the cached workspaces; all are rebuilt on the next call."""
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+        self._native, self._packed, self._packed_key = None, None, None
+        self._wscache, self._async_bufs = {}, {}
+
     def native(self):
         self.packed()
         ode = (self.ODE_METHODS[self.ode_method], int(self.ode_steps))
