@@ -802,7 +802,7 @@ extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, 
         hipLaunchKernelGGL(conv_bwd_x_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, de, w, dx, m, T);
     }
     const long rows = (long)m * T;
-    int G = (int)((rows + 511) / 512);
+    int G = (int)((rows + 63) / 64);     // 8 rows per thread at scene sizes (512 per workgroup made an 11-workgroup launch of 43 us)
     if (G > 256) G = 256;
     STT_REQUIRE(scratch_floats >= (long)G * 224, "sttode_conv_bwd: scratch too small");
     const int rpw = (int)((rows + G - 1) / G);

@@ -38,7 +38,6 @@ class Engine:
         # The two encoder trunks (disjoint parameters) run on two streams, forward and backward (see forward_segments /
         # backward_segments); the side stream has its own split-k scratch.
         self.side = None            # [stream, stream], created on first use
-        self.main_cap = None        # capture stream of the caller's-stream segments
         self.side_scratch = None
         self.multi = False
         self._hold = []
@@ -332,7 +331,7 @@ class Engine:
             dz.copy_(din0[:, 128:160])
 
     # ---------------------------------------------------------------- the objective (model/STTODE.py:553-568)
-    def forward_segments(self, eps_q, eps20, drop_past=None, drop_future=None):
+    def forward_segments(self, eps_q, eps20, drop_past=None, drop_future=None, streams=None):
         """The forward pass as segments (see run_segments): future trunk on side 1 beside the past trunk; then the q-net and ONE decoder
         pass over 1 + 20 samples per agent -- sample 0 decoded from the posterior draw (pred_traj / recover_traj, model/STTODE.py:
         553-560), samples 1..20 from the prior draws (diverse_pred_traj, :562-566): the two passes of the reference share every
@@ -341,7 +340,7 @@ class Engine:
         self.P = {k: v for k, v in net.named_parameters()}
         P = self.P
         self._hold = []
-        self.multi = self._use_streams(net._past.shape[0])
+        self.multi = self._use_streams(net._past.shape[0]) if streams is None else bool(streams)
         for t_in in (eps_q, eps20, drop_past, drop_future):       # the caller may drop them while a side stream still reads them
             if t_in is not None:
                 self.hold(t_in)
@@ -494,8 +493,8 @@ class _LossFn(torch.autograd.Function):
 
 
 class _GraphedStep:
-    """hipGraphs per step shape: the ~270 launches of forward-with-tape + backward replayed as a dozen graph launches on three
-    streams (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
+    """One hipGraph per step shape: the ~165 launches of forward-with-tape + backward replayed as a single graph launch
+    (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
     the loss values and the flat gradient buffer are static outputs."""
 
     def __init__(self, eng, net, inputs):
@@ -510,30 +509,18 @@ class _GraphedStep:
             net._scene_ptr = st['scene_ptr']
 
     def _capture(self):
-        """One hipGraph per segment, captured on the stream kind it replays on (the private pool keeps blocks per capture stream, so a
-        temporary freed inside a side-stream segment is only ever reused by the same side stream) and replayed in capture order.
-        A single graph with forked branches is NOT used: hipGraph's executor runs such branches largely one after the other."""
+        """The whole step (forward with tape + backward) as ONE hipGraph on one stream.  Measured alternatives: the future trunk's
+        segments as branches of the same graph, or every segment as its own graph replayed on two streams -- hipGraphLaunch feeds a
+        graph's kernels at about the rate a queue executes small dependent kernels (~5 us each), so neither ran the trunks
+        concurrently, and every graph boundary cost 20-60 us of idle queue (7 graphs: ~0.15 ms per step)."""
         eng, st = self.eng, self.static
-        segs = eng.forward_segments(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'])
-        if eng.main_cap is None:
-            eng.main_cap = torch.cuda.Stream(device=eng.dev)
-        pool = torch.cuda.graph_pool_handle()
-        self.graphs, self.segs = [], []
+        segs = eng.forward_segments(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'], streams=False)
         torch.cuda.synchronize()
-
-        def cap(part):
-            for stream, waits, fn in part:
-                g = torch.cuda.CUDAGraph()
-                cs = eng.main_cap if (not eng.multi or stream < 0) else eng.side[stream]
-                with torch.cuda.graph(g, pool=pool, stream=cs):
-                    eng._enter(-1 if (not eng.multi or stream < 0) else stream)
-                    fn()
-                self.graphs.append(g)
-                self.segs.append((stream, waits, None))
-        cap(segs)
-        cap(eng.backward_segments())
-        self.multi = eng.multi
-        self.keep = (eng._hold, eng.V, eng.G)                          # static buffers of the graphs
+        self.graph_obj = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_obj):
+            eng.run_segments(segs)
+            eng.run_segments(eng.backward_segments())
+        self.keep = (eng._hold, eng.V, eng.G)                          # static buffers of the graph
         eng._hold = []
         self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
 
@@ -547,8 +534,7 @@ class _GraphedStep:
             self.graph = True
             self.attrs = {k: getattr(self.net, k) for k in ('past_feature', 'qz_param', 'qz_sampled', 'pred_traj', 'recover_traj',
                                                             'diverse_pred_traj', 'past_traj', 'future_traj', 'cur_location')}
-        self.eng.multi = self.multi
-        self.eng.run_segments(self.segs, launch=lambda i: self.graphs[i].replay())
+        self.graph_obj.replay()
         for k, v in self.attrs.items():
             setattr(self.net, k, v)
         losses, flat, G = self.out
