@@ -5,6 +5,8 @@
 #include <cstdio>
 
 void stt_set_error(const char* msg);
+int stt_gru_cols_form(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP, const float* gbias,
+                      float* state, int ncols, int Tp, int TPX, int lat_max_tiles, void* stream);   // decoder.hip
 int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.hip: sttode_set_latency_tiles)
 
 #define STT_REQUIRE(cond, msg)      \

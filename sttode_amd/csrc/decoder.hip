@@ -807,11 +807,17 @@ extern "C" int sttode_set_latency_tiles(int gru_tiles, int mlp_tiles, int enc_ti
 
 extern "C" int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
                                const float* gbias, float* state, int ncols, int Tp, int TPX, void* stream) {
+    return stt_gru_cols_form(xin, convP, convB, wihP, whhP, gbias, state, ncols, Tp, TPX, 0, stream);
+}
+// lat_max_tiles > 0: the caller's own crossover (the pipelined per-agent stage: the latency form has no LDS-resident weights, so its
+// workgroups run BESIDE a chain workgroup of another stream instead of waiting for a chain-free CU); 0: sttode_set_latency_tiles
+int stt_gru_cols_form(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP, const float* gbias,
+                      float* state, int ncols, int Tp, int TPX, int lat_max_tiles, void* stream) {
     STT_REQUIRE(xin && convP && convB && wihP && whhP && gbias && state, "sttode_gru_cols: null pointer");
     STT_REQUIRE(ncols > 0 && Tp > 0 && (TPX == 1 || TPX == 2) && 2 * Tp <= 16 * TPX, "sttode_gru_cols: bad ncols/Tp/TPX");
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (ncols + 15) / 16;
-    if (ntiles <= gru_lat_tiles()) {   // few columns: one tile per workgroup, hidden units split over six waves (latency form)
+    if (ntiles <= (lat_max_tiles > 0 ? lat_max_tiles : gru_lat_tiles())) {   // few columns: one tile per workgroup, hidden units split over six waves (latency form)
         if (TPX == 1)
             hipLaunchKernelGGL(gru_cols_lat_kernel<1>, dim3(ntiles), dim3(384), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
                                (const f32x4*)whhP, gbias, state, ncols, Tp);

@@ -278,9 +278,15 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         RUN(STT_STAGE_GRU0, gs,
             sttode_gru_cols32(xpad, 16 * TPX, W[STT_W_G0_POOL], (const int*)W[STT_W_G0_PROG], 13 * Tp, W[STT_W_G0_CONSTS], state0, n, Tp, gs));
     } else
+    {
+    // pipelined form: the latency form up to 4096 tiles -- its workgroups (no LDS-resident weights) co-reside with the previous calls' chain
+    // workgroups, the resident-weights form (144 KiB of LDS) only gets chain-free CUs: 65 -> 68 M trajectories/s at 512 scenes (same box),
+    // neutral at 128 / 256 / 1024 / 2048 scenes (STTODE_GRU0_LAT_TILES overrides)
+    static const int gru0_lat = getenv("STTODE_GRU0_LAT_TILES") ? atoi(getenv("STTODE_GRU0_LAT_TILES")) : 4096;
     RUN(STT_STAGE_GRU0, gs,
-        sttode_gru_cols(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
-                        Tp, TPX, gs));
+        stt_gru_cols_form(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
+                          Tp, TPX, use_side ? 0 : gru0_lat, gs));
+    }
     if (use_side) STT_HIP(hipEventRecord(m->ev_join, m->side));
 
     RUN(STT_STAGE_EMBED, s,
