@@ -1430,3 +1430,49 @@ def test_batched_scene_training_step_equals_sum_of_per_scene_steps():
     with torch.no_grad():                                       # the value path agrees on the batched objective
         v = m.forward(*cat)
     np.testing.assert_allclose([float(v[0])] + list(v[1:]), [tot_sum] + list(parts_sum), rtol=1e-4)
+
+
+@pytest.mark.parametrize('scenes_csr', [False, True])
+def test_fused_objective_kernel_vs_the_three_loss_entry_points(scenes_csr):
+    """sttode_loss_objective (all four terms of model/STTODE.py:372-395 + every gradient for ONE decoder pass over 1 + K samples per
+    agent) against sttode_loss_sqerr / _kl / _diverse on the corresponding slices, with and without a scene CSR, and against a
+    float64 numpy evaluation of the same formulas."""
+    from sttode_amd import capi
+    dev = _gpu()
+    rng = np.random.default_rng(11)
+    n, K, D, Dp, zd = 37, 20, 24, 16, 32
+    K1 = K + 1
+    pred = rng.standard_normal((n, K1, D)).astype(np.float32)
+    rec = rng.standard_normal((n, K1, Dp)).astype(np.float32)
+    fut = rng.standard_normal((n, D)).astype(np.float32)
+    past = rng.standard_normal((n, Dp)).astype(np.float32)
+    qzp = (0.3 * rng.standard_normal((n, 2 * zd))).astype(np.float32)
+    ptr = np.array([0, 5, 6, 20, 37], np.int32)
+    ags = np.repeat(np.arange(4), np.diff(ptr)).astype(np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P, R, F, PA, Q = t(pred), t(rec), t(fut), t(past), t(qzp)
+    sp, ag, S = (t(ptr), t(ags), 4) if scenes_csr else (None, None, 0)
+    out = torch.zeros(5, device=dev)
+    dpred, drec, dq = torch.empty_like(P), torch.empty_like(R), torch.empty_like(Q)
+    scratch = torch.empty(1 << 16, device=dev)
+    sm, sr, min_clip = 1.0 / 12, 1.0 / 8, 2.0
+    capi.call('sttode_loss_objective', P, R, F, PA, Q, sp, ag, S, n, K1, D, Dp, zd, sm, sr, float(n), min_clip, out, dpred, drec, dq,
+              scratch, scratch.numel(), capi.stream_ptr())
+    # the three stand-alone entry points on the slices
+    ref = torch.zeros(4, device=dev)
+    p0, r0, pk = P[:, 0].contiguous(), R[:, 0].contiguous(), P[:, 1:].contiguous()
+    g0, g1, gq, gk = torch.empty_like(p0), torch.empty_like(r0), torch.empty_like(Q), torch.empty_like(pk)
+    capi.call('sttode_loss_sqerr', p0, F, n * D, sm, ref[0:], g0, capi.stream_ptr())
+    capi.call('sttode_loss_sqerr', r0, PA, n * Dp, sr, ref[1:], g1, capi.stream_ptr())
+    capi.call('sttode_loss_kl', Q, sp, S, n, zd, float(n), min_clip, ref[2:], gq, scratch, capi.stream_ptr())
+    capi.call('sttode_loss_diverse', pk, F, sp, ag, n, K, D, ref[3:], gk, scratch, capi.stream_ptr())
+    o, r = out.cpu().numpy(), ref.cpu().numpy()
+    np.testing.assert_allclose(o[:4], r, rtol=2e-6)
+    np.testing.assert_allclose(o[4], r.sum(), rtol=2e-6)
+    assert torch.equal(dpred[:, 0], g0) and torch.equal(drec[:, 0], g1) and torch.equal(dq, gq) and torch.equal(dpred[:, 1:], gk)
+    assert float(drec[:, 1:].abs().max()) == 0.0
+    # float64 yardstick of the best-of-K term
+    d2 = ((fut[:, None, :].astype(np.float64) - pred[:, 1:].astype(np.float64)) ** 2).sum(-1).min(1)
+    w = 1.0 / np.diff(ptr)[ags] if scenes_csr else np.full(n, 1.0 / n)
+    np.testing.assert_allclose(o[3], (d2 * w).sum(), rtol=1e-5)
+    np.testing.assert_allclose(o[0], ((pred[:, 0].astype(np.float64) - fut) ** 2).sum() * sm, rtol=1e-5)
