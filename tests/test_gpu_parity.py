@@ -1476,3 +1476,19 @@ def test_fused_objective_kernel_vs_the_three_loss_entry_points(scenes_csr):
     w = 1.0 / np.diff(ptr)[ags] if scenes_csr else np.full(n, 1.0 / n)
     np.testing.assert_allclose(o[3], (d2 * w).sum(), rtol=1e-5)
     np.testing.assert_allclose(o[0], ((pred[:, 0].astype(np.float64) - fut) ** 2).sum() * sm, rtol=1e-5)
+
+
+def test_release_native_rebuilds_the_pipeline_with_identical_results():
+    """STTODENet.release_native() drops the native pipeline (streams, packed weights, workspaces); the next call rebuilds it and gives
+    the same bits (bench.py releases a finished leg's pipeline so that its streams do not share hardware queues with the next leg's)."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(40, 52), 'eth')
+    z = torch.from_numpy(scenes.latents(5, sb.n_agents))
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    a = m.inference(None, z=z).cpu().numpy()
+    m.release_native()
+    assert m._native is None
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    b = m.inference(None, z=z).cpu().numpy()
+    assert np.array_equal(a, b)
