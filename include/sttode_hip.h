@@ -291,7 +291,7 @@ enum SttodeBuffer {
 /* pipeline stages reported by sttode_timing_read */
 enum SttodeStage {
     STT_STAGE_FRONTEND, STT_STAGE_EMBED, STT_STAGE_ATTN, STT_STAGE_POST, STT_STAGE_GRU0, STT_STAGE_LINEAR, STT_STAGE_MLP0,
-    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_COUNT
+    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_AGENTS /* encoder + block-0 GRU in one launch (scene batches) */, STT_STAGE_COUNT
 };
 
 /* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366). */

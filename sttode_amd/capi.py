@@ -91,7 +91,7 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
            'A1y', 'dbuf', 'ybuf', 'state1', 'queue')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',
-          'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain')
+          'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain', 'agents_fused[encoder+block0 GRU]')
 
 
 class NativeModel:

@@ -7,6 +7,9 @@
 void stt_set_error(const char* msg);
 int stt_gru_cols_form(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP, const float* gbias,
                       float* state, int ncols, int Tp, int TPX, int lat_max_tiles, void* stream);   // decoder.hip
+int stt_agents_fused(const float* const* W, const float* enc_in, const int* last, float* g, float* qkv, float* pf, const float* xpad,
+                     float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip; -1 = shape not covered
+int stt_gru_lat_tiles();
 int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.hip: sttode_set_latency_tiles)
 
 #define STT_REQUIRE(cond, msg)      \

@@ -13,7 +13,9 @@
 //               hidden tile, never materialised) -> +res, LN2 -> one explicit Euler step  x + T*f(x)  -> relu,
 //               writes past_feature = cat(ftraj_input, ode_out).
 #include "chain.hpp"
+#include "latency_bodies.hpp"
 #include "api_util.hpp"
+#include "../../include/sttode_hip.h"
 
 struct EmbedW {
     const float* fc1P;    // [4 row tiles][64 lanes]  lane(i,q) -> W_fc[16it+i][q]
@@ -109,15 +111,15 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
 //   3  wave w: input_fc3 row tile w (+ category column) -> g, LDS;                                              one barrier
 //   4  wave w: in-projection row tiles w, w+4, w+8 -> qkv.
 // ~350 MFMAs per wave.  Every output element is summed in the order of embed_qkv_kernel: identical bits.
-__global__ __launch_bounds__(256) void embed_qkv_lat_kernel(EmbedW w, const float* __restrict__ enc_in, const int* __restrict__ last_flag,
-                                                            float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen) {
-    extern __shared__ __attribute__((aligned(16))) char smem_e[];
-    f32x4* sPt = reinterpret_cast<f32x4*>(smem_e);   // [Tlen][4][64]
+// smem: (Tlen * 256 + 512) f32x4 of LDS; `tile` = the workgroup's 16-agent tile; waves 0..3 of the workgroup.
+__device__ __forceinline__ void embed_lat_body(const EmbedW& w, const float* __restrict__ enc_in, const int* __restrict__ last_flag,
+                                               float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen, int tile, f32x4* smem) {
+    f32x4* sPt = smem;                               // [Tlen][4][64]
     f32x4* sF = sPt + (size_t)Tlen * 256;            // [4][64]
     f32x4* sG = sF + 256;                            // [4][64]
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = blockIdx.x * 16 + c;
+    const int col = tile * 16 + c;
     const int colc = col < n ? col : n - 1;
     f32x4 pw[4], b1[4];
     float f1[4];
@@ -184,6 +186,12 @@ __global__ __launch_bounds__(256) void embed_qkv_lat_kernel(EmbedW w, const floa
         for (int T = 0; T < 4; ++T) a = mfma_k16(a, wi[i][T], sG[T * 64 + lane]);
         if (col < n) st4(qkv + (size_t)col * 192 + 16 * it + 4 * q, a);
     }
+}
+
+__global__ __launch_bounds__(256) void embed_qkv_lat_kernel(EmbedW w, const float* __restrict__ enc_in, const int* __restrict__ last_flag,
+                                                            float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen) {
+    extern __shared__ __attribute__((aligned(16))) char smem_e[];
+    embed_lat_body(w, enc_in, last_flag, g, qkv, n, Tlen, blockIdx.x, reinterpret_cast<f32x4*>(smem_e));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -398,16 +406,16 @@ __device__ __forceinline__ void ode_rhs(const PostW& w, f32x4 (*sX)[4][64], cons
 // 2 classical RK4) over [0, ode_time]; every stage needs the attention output of ITS state, which for attention length 1 (the
 // ETH/UCY/SDD path: softmax over one element) is just v(y) = W_v y + b_v and is computed here (vP, vb = value rows of the packed
 // in-projection).  With attention length > 1 a stage needs a pass over the whole group: op level (hypertransformer.ODEG_Encoder).
+// sX: [4][4][64] f32x4 exchange buffer (16 KiB of LDS); `tile` = the workgroup's 16-agent tile; waves 0..3 of the workgroup.
 template <bool ODE>
-__global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g,  // [n][64]
-                                                        const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
-                                                        float* __restrict__ pf,                       // [n][128]
-                                                        int n, float ode_time, int method, int steps, const f32x4* __restrict__ vP,
-                                                        const float* __restrict__ vb) {
-    __shared__ f32x4 sX[4][4][64];  // [slot][tile][lane] exchange buffer (16 KiB)
+__device__ __forceinline__ void post_attn_body(const PostW& w, const float* __restrict__ g,  // [n][64]
+                                               const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
+                                               float* __restrict__ pf,                       // [n][128]
+                                               int n, float ode_time, int method, int steps, const f32x4* __restrict__ vP,
+                                               const float* __restrict__ vb, int tile, f32x4 (*sX)[4][64]) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wv = threadIdx.x >> 6;
-    const int col = blockIdx.x * 16 + c;
+    const int col = tile * 16 + c;
     const int colc = col < n ? col : n - 1;
     f32x4 a[4], gg[4], x[4];
 #pragma unroll
@@ -478,6 +486,39 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
         st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
         st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
     }
+}
+
+template <bool ODE>
+__global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g, const float* __restrict__ attn, int ld_attn,
+                                                        float* __restrict__ pf, int n, float ode_time, int method, int steps,
+                                                        const f32x4* __restrict__ vP, const float* __restrict__ vb) {
+    __shared__ f32x4 sX[4][4][64];  // [slot][tile][lane] exchange buffer (16 KiB)
+    post_attn_body<ODE>(w, g, attn, ld_attn, pf, n, ode_time, method, steps, vP, vb, blockIdx.x, sX);
+}
+
+// The per-agent stage of a scene batch (attention length 1, the reference's one Euler step) in ONE launch: workgroup role 0 runs the
+// encoder of its 16-agent tile (embed_lat_body, then post_attn_body on what it just wrote: softmax over one key == 1, so the attention
+// output is the value projection), role 1 the block-0 conv + GRU of the same tile (gru_lat_body, six waves).  Replaces three launches and
+// the side-stream fork / join of the serial pipeline (one scene: ~62 us from the front-end's end to agent_preact's start -> ~30 us).
+// The bodies are the stand-alone kernels' code: identical bits.
+struct AgentsFusedArgs {
+    EmbedW ew; PostW pw;
+    const float* enc_in; const int* last; float* g; float* qkv; float* pf;
+    const float* xpad; const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
+    int n, Tp, ntiles; float ode_time;
+};
+__global__ __launch_bounds__(384) void agents_fused_kernel(AgentsFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_a[];
+    const int tile = blockIdx.x >= a.ntiles ? blockIdx.x - a.ntiles : blockIdx.x;
+    if ((int)blockIdx.x >= a.ntiles) {
+        gru_lat_body<1>(a.xpad, a.convP, a.convB, a.wihP, a.whhP, a.gbias, a.state0, a.n, a.Tp, tile, reinterpret_cast<f32x4(*)[6][64]>(smem_a));
+        return;
+    }
+    if (threadIdx.x >= 256) return;                 // the encoder bodies are four-wave code; ended waves take no part in their barriers
+    embed_lat_body(a.ew, a.enc_in, a.last, a.g, a.qkv, a.n, a.Tp, tile, reinterpret_cast<f32x4*>(smem_a));
+    __syncthreads();                                 // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
+    post_attn_body<false>(a.pw, a.g, a.qkv + 128, 192, a.pf, a.n, a.ode_time, 0, 1, nullptr, nullptr, tile,
+                          reinterpret_cast<f32x4(*)[4][64]>(smem_a));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -556,6 +597,29 @@ extern "C" int sttode_post_attn_ode(const float* outP, const float* outb, const 
     w.ln2w = ln2w; w.ln2b = ln2b;
     hipLaunchKernelGGL(post_attn_kernel<true>, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, g, (const float*)nullptr, 64, pf, n,
                        ode_time, method, steps, (const f32x4*)inP + 8 * 4 * 64, inb + 128);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Internal (csrc/pipeline.hip): the fused per-agent stage above.  W = the model's weight table (enum SttodeWeight).  Returns -1 (nothing
+// launched) when the shape is outside the fused kernel's instantiation: the caller then takes the kernel-by-kernel path.
+int stt_agents_fused(const float* const* W, const float* enc_in, const int* last, float* g, float* qkv, float* pf, const float* xpad,
+                     float* state0, int n, int Tp, int TPX, float ode_time, void* stream) {
+    const size_t lds = ((size_t)Tp * 256 + 512) * 16;          // embed's need (>= post_attn's 16 KiB and the GRU's 12 KiB for Tp >= 2)
+    if (TPX != 1 || lds > 64 * 1024 || lds < 16 * 1024) return -1;
+    AgentsFusedArgs a;
+    a.ew.fc1P = W[STT_W_FC1P]; a.ew.fc1b = W[STT_W_FC1B]; a.ew.posP = (const f32x4*)W[STT_W_POSP]; a.ew.peb = W[STT_W_PEB];
+    a.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; a.ew.fc2b = W[STT_W_FC2B]; a.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; a.ew.fc3b = W[STT_W_FC3B];
+    a.ew.fc3last = W[STT_W_FC3LAST]; a.ew.inP = (const f32x4*)W[STT_W_INP]; a.ew.inb = W[STT_W_INB];
+    a.pw.outP = (const f32x4*)W[STT_W_OUTP]; a.pw.outb = W[STT_W_OUTB]; a.pw.infoP = (const f32x4*)W[STT_W_INFOP]; a.pw.infob = W[STT_W_INFOB];
+    a.pw.gateP = (const f32x4*)W[STT_W_GATEP]; a.pw.gateb = W[STT_W_GATEB]; a.pw.ln1w = W[STT_W_LN1W]; a.pw.ln1b = W[STT_W_LN1B];
+    a.pw.l1P = (const f32x4*)W[STT_W_L1P]; a.pw.l1b = W[STT_W_L1B]; a.pw.l2P = (const f32x4*)W[STT_W_L2P]; a.pw.l2b = W[STT_W_L2B];
+    a.pw.ln2w = W[STT_W_LN2W]; a.pw.ln2b = W[STT_W_LN2B];
+    a.enc_in = enc_in; a.last = last; a.g = g; a.qkv = qkv; a.pf = pf;
+    a.xpad = xpad; a.convP = (const f32x4*)W[STT_W_B0_CONVP]; a.convB = W[STT_W_B0_CONVB]; a.wihP = (const f32x4*)W[STT_W_B0_WIHP];
+    a.whhP = (const f32x4*)W[STT_W_B0_WHHP]; a.gbias = W[STT_W_B0_GBIAS]; a.state0 = state0;
+    a.n = n; a.Tp = Tp; a.ntiles = (n + 15) / 16; a.ode_time = ode_time;
+    hipLaunchKernelGGL(agents_fused_kernel, dim3(2 * a.ntiles), dim3(384), lds, (hipStream_t)stream, a);
     STT_HIP(hipGetLastError());
     return 0;
 }

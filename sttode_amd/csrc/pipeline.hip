@@ -233,7 +233,7 @@ struct StageTimer {
     StageTimer(SttodeModel* m_, int st, hipStream_t s_) : m(m_), stage(st), s(s_) {
         // the per-trajectory stages (two events per call) are bracketed on EVERY call while timing is enabled, so that overlapping launches
         // of consecutive calls are seen; the many short per-agent stages only on the sampled calls
-        on = m->timing || (m->timing_every > 0 && stage >= STT_STAGE_MLP0);
+        on = m->timing || (m->timing_every > 0 && stage >= STT_STAGE_MLP0 && stage <= STT_STAGE_CHAIN);
         if (on) { e0 = get_event(m); e1 = get_event(m); (void)hipEventRecord(e0, s); }
     }
     ~StageTimer() {
@@ -260,6 +260,21 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     float* state0 = ws + off[STT_B_STATE0];
     float *A0x = ws + off[STT_B_A0X], *A0y = ws + off[STT_B_A0Y], *A1y = ws + off[STT_B_A1Y];
 
+    // Scene batches (attention length 1) with the reference's integrator: encoder and block-0 GRU of every 16-agent tile as two workgroup
+    // roles of ONE launch (csrc/encoder.hip agents_fused_kernel) -- no side stream, no event fork / join, three launches fewer.  Used
+    // wherever the latency forms of both halves would be chosen anyway (same code, same bits); STTODE_AGENTS_FUSED=0 disables it.
+    static const bool fuse_on = !(getenv("STTODE_AGENTS_FUSED") && atoi(getenv("STTODE_AGENTS_FUSED")) == 0);
+    static const int gru0_lat_p = getenv("STTODE_GRU0_LAT_TILES") ? atoi(getenv("STTODE_GRU0_LAT_TILES")) : 4096;
+    const int ntiles = (n + 15) / 16;
+    if (fuse_on && attn_len == 1 && m->ode_method == 0 && m->ode_steps == 1 && TPX == 1 && Tp >= 2 &&
+        ntiles <= (use_side ? stt_gru_lat_tiles() : gru0_lat_p) && ntiles <= stt_enc_lat_tiles()) {
+        RUN(STT_STAGE_AGENTS, s,
+            stt_agents_fused(W, ws + off[STT_B_ENC_IN], (const int*)(ws + off[STT_B_LAST]), g, qkv, pf, xpad, state0, n, Tp, TPX, 12.0f, s));
+        RUN(STT_STAGE_LINEAR, s,
+            sttode_agent_preact(pf, state0, W[STT_W_B0_XWA], W[STT_W_B0_XB1], W[STT_W_B0_YWA], W[STT_W_B0_YB1], W[STT_W_B1_YWA], W[STT_W_B1_YB1],
+                                A0x, A0y, A1y, n, s));
+        return 0;
+    }
     // fork: block-0 conv+GRU (per agent) only needs the front-end output; it runs beside the encoder
     // (pipelined form: no side stream -- the stage already runs beside the previous calls' per-trajectory kernels, and every
     // extra stream shares one of the 4 hardware queues with the streams that must overlap)
@@ -282,7 +297,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     // pipelined form: the latency form up to 4096 tiles -- its workgroups (no LDS-resident weights) co-reside with the previous calls' chain
     // workgroups, the resident-weights form (144 KiB of LDS) only gets chain-free CUs: 65 -> 68 M trajectories/s at 512 scenes (same box),
     // neutral at 128 / 256 / 1024 / 2048 scenes (STTODE_GRU0_LAT_TILES overrides)
-    static const int gru0_lat = getenv("STTODE_GRU0_LAT_TILES") ? atoi(getenv("STTODE_GRU0_LAT_TILES")) : 4096;
+    const int gru0_lat = gru0_lat_p;
     RUN(STT_STAGE_GRU0, gs,
         stt_gru_cols_form(xpad, W[STT_W_B0_CONVP], W[STT_W_B0_CONVB], W[STT_W_B0_WIHP], W[STT_W_B0_WHHP], W[STT_W_B0_GBIAS], state0, n,
                           Tp, TPX, use_side ? 0 : gru0_lat, gs));
