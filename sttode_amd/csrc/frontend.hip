@@ -29,14 +29,12 @@ __global__ void scene_orig_kernel(const float* __restrict__ past, const int* __r
 
 // mode 0: ETH/UCY/SDD (normalise by scene_orig, flag last agent of each scene)
 // mode 1: NBA (no normalisation, flag slot N-1)
-__global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T, int TPX, int mode, int vel_from_norm,
-                                    const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq (future encoder), world coords
-                                    const float* __restrict__ scene_orig, const int* __restrict__ agent_scene,
-                                    const int* __restrict__ scene_ptr, int nba_N, float* __restrict__ xpad,
-                                    float* __restrict__ enc_in, float* __restrict__ cur, float* __restrict__ orig,
-                                    int* __restrict__ last_flag) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
+__device__ __forceinline__ void agent_inputs_one(int a, const float* __restrict__ seq, int n, int T, int TPX, int mode, int vel_from_norm,
+                                                 const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq (future encoder), world coords
+                                                 const float* __restrict__ scene_orig, const int* __restrict__ agent_scene,
+                                                 const int* __restrict__ scene_ptr, int nba_N, float* __restrict__ xpad,
+                                                 float* __restrict__ enc_in, float* __restrict__ cur, float* __restrict__ orig,
+                                                 int* __restrict__ last_flag) {
     float ox = 0.f, oy = 0.f;
     int last;
     if (mode == 0) {
@@ -81,6 +79,38 @@ __global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T,
     if (cur) { cur[2 * a] = pnx; cur[2 * a + 1] = pny; }
     if (orig) { orig[2 * a] = ox; orig[2 * a + 1] = oy; }
     if (last_flag) last_flag[a] = last;
+}
+__global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T, int TPX, int mode, int vel_from_norm,
+                                    const float* __restrict__ prev_last, const float* __restrict__ scene_orig,
+                                    const int* __restrict__ agent_scene, const int* __restrict__ scene_ptr, int nba_N,
+                                    float* __restrict__ xpad, float* __restrict__ enc_in, float* __restrict__ cur,
+                                    float* __restrict__ orig, int* __restrict__ last_flag) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    agent_inputs_one(a, seq, n, T, TPX, mode, vel_from_norm, prev_last, scene_orig, agent_scene, scene_ptr, nba_N, xpad, enc_in, cur, orig, last_flag);
+}
+// Few scenes (the per-scene loop of test.py:171-188): both steps in ONE single-workgroup launch -- thread s sums scene s in agent order
+// exactly as scene_orig_kernel does, a barrier, then the threads stride the agents.
+__global__ __launch_bounds__(256) void frontend_small_kernel(const float* __restrict__ past, const int* __restrict__ scene_ptr, int n, int S,
+                                                             int Tp, int TPX, int vel_from_norm, float* __restrict__ scene_orig,
+                                                             int* __restrict__ agent_scene, float* __restrict__ xpad,
+                                                             float* __restrict__ enc_in, float* __restrict__ cur, float* __restrict__ orig,
+                                                             int* __restrict__ last_flag) {
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int a0 = scene_ptr[s], a1 = scene_ptr[s + 1];
+        float sx = 0.f, sy = 0.f;
+        for (int a = a0; a < a1; ++a) {
+            sx += past[((size_t)a * Tp + (Tp - 1)) * 2 + 0];
+            sy += past[((size_t)a * Tp + (Tp - 1)) * 2 + 1];
+            agent_scene[a] = s;
+        }
+        const float inv = (float)(a1 - a0);
+        scene_orig[2 * s] = sx / inv;
+        scene_orig[2 * s + 1] = sy / inv;
+    }
+    __syncthreads();   // scene_orig / agent_scene written above are visible to the workgroup
+    for (int a = threadIdx.x; a < n; a += 256)
+        agent_inputs_one(a, past, n, Tp, TPX, 0, vel_from_norm, nullptr, scene_orig, agent_scene, scene_ptr, 1, xpad, enc_in, cur, orig, last_flag);
 }
 
 // one wave per agent: lanes stride the K*Tf displacement norms (coalesced 8-byte reads), per-sample sums by a
@@ -137,6 +167,12 @@ extern "C" int sttode_frontend_scenes(const float* past, const int* scene_ptr, i
     STT_REQUIRE(past && scene_ptr && scene_orig && agent_scene && xpad && enc_in && cur && orig && last_flag, "sttode_frontend_scenes: null pointer");
     STT_REQUIRE(n > 0 && S > 0 && Tp >= 2 && 2 * Tp <= 16 * TPX, "sttode_frontend_scenes: need n,S > 0, Tp >= 2, 2*Tp <= 16*TPX");
     hipStream_t s = (hipStream_t)stream;
+    if (S <= 16 && n <= 1024) {   // a scene or a handful: one single-workgroup launch
+        hipLaunchKernelGGL(frontend_small_kernel, dim3(1), dim3(256), 0, s, past, scene_ptr, n, S, Tp, TPX, vel_from_norm, scene_orig,
+                           agent_scene, xpad, enc_in, cur, orig, last_flag);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(scene_orig_kernel, dim3((S + 127) / 128), dim3(128), 0, s, past, scene_ptr, S, Tp, scene_orig, agent_scene);
     hipLaunchKernelGGL(agent_inputs_kernel, dim3((n + 127) / 128), dim3(128), 0, s, past, n, Tp, TPX, 0, vel_from_norm,
                        (const float*)nullptr, scene_orig, agent_scene, scene_ptr, 1, xpad, enc_in, cur, orig, last_flag);
