@@ -10,7 +10,7 @@ mkdir -p $O
 if [ "$1" = b ]; then
 # single-scene call: GPU latency with the latency forms off / on, kernel timeline of one call
 timeout -k 10 200 python profiles/exp_mlp_latency.py 2>&1 | grep -v amdgpu.ids > $O/single_scene_call_latency.txt
-(cd /tmp && NAGENTS=32 LAT_ONLY=1 timeout -k 10 200 rocprofv3 --kernel-trace -d $O/prof_scene -o scene -- python3 $R/profiles/exp_mlp_latency.py > $O/prof_scene.log 2>&1) && python profiles/summarize_timeline.py $O/prof_scene/scene_results.db scene_orig 10 > $O/single_scene_timeline.txt
+(cd /tmp && NAGENTS=32 LAT_ONLY=1 timeout -k 10 200 rocprofv3 --kernel-trace -d $O/prof_scene -o scene -- python3 $R/profiles/exp_mlp_latency.py > $O/prof_scene.log 2>&1) && python profiles/summarize_timeline.py $O/prof_scene/scene_results.db scene_orig,frontend_small 8 > $O/single_scene_timeline.txt
 # training step: host split, kernel timeline of one step, bench lines with torch's fused / foreach Adam
 timeout -k 10 200 python profiles/exp_train_timeline.py 2>&1 | grep "ms/step" > $O/train_step_split.txt
 (cd /tmp && REPS=20 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/prof_train -o tr -- python3 $R/profiles/exp_train_timeline.py > $O/prof_train.log 2>&1) && python profiles/summarize_train_timeline.py $O/prof_train/tr_results.db >> $O/train_step_split.txt
@@ -36,7 +36,7 @@ cd $R
 STTODE_CHAIN=0 STTODE_B_STREAMS=1 timeout -k 10 200 python bench.py --legs none --no-cpu --depth 2 > $O/bench_three_kernel_form.json 2>/dev/null
 # batch-size sweep (pipelined, as the headline)
 for S in 128 256 512 1024 2048 4096; do
-  timeout -k 10 200 python bench.py --legs none --no-cpu --scenes $S --steps 12 > $O/sweep_s$S.json 2>/dev/null || echo "sweep $S failed"
+  timeout -k 10 200 python bench.py --legs none --no-cpu --scenes $S --steps 40 > $O/sweep_s$S.json 2>/dev/null || echo "sweep $S failed"
 done
 timeout -k 10 300 python profiles/exp_nba_config5.py > $O/nba_config5.txt 2>&1
 timeout -k 10 300 python profiles/exp_per_scene_latency.py > $O/per_scene_latency.txt 2>&1

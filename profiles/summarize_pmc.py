@@ -17,7 +17,7 @@ import os
 import sys
 
 STAGE_OF = {'traj_chain_kernel': 'trajectory_chain', 'mlp_block0_kernel': 'mlp_block0', 'mlp_block1_kernel': 'mlp_block1', 'post_attn_kernel': 'post_attn',
-            'embed_qkv_kernel': 'embed_qkv', 'embed_qkv_lat_kernel': 'embed_qkv', 'mhgsa_attn_kernel': 'mhgsa_attn', 'linear_cols_kernel': 'agent_preact', 'gru_cols_kernel': 'gru_cols'}
+            'embed_qkv_kernel': 'embed_qkv', 'embed_qkv_lat_kernel': 'embed_qkv', 'agents_fused_kernel': 'agents_fused', 'mhgsa_attn_kernel': 'mhgsa_attn', 'linear_cols_kernel': 'agent_preact', 'gru_cols_kernel': 'gru_cols'}
 
 
 def main(src, dst):

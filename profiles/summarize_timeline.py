@@ -3,7 +3,7 @@
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,start,end,queue_id from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if r[0].startswith(sys.argv[2])]
+marks = [i for i, r in enumerate(rows) if r[0].startswith(tuple(sys.argv[2].split(',')))]
 i0 = marks[len(marks) // 2]
 t0 = rows[i0][1]
 print('# start_us  duration_us  queue  kernel')

@@ -1,9 +1,9 @@
 """Summary of a rocprofv3 --kernel-trace database of profiles/exp_train_timeline.py: per training step (delimited by the front-end's
-scene_orig kernel) the number of kernels, the sum of their durations, the busy time (union of intervals) and the step period."""
+first kernel) the number of kernels, the sum of their durations, the busy time (union of intervals) and the step period."""
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,start,end,queue_id from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if r[0].startswith('scene_orig')]
+marks = [i for i, r in enumerate(rows) if r[0].startswith(('scene_orig', 'frontend_small'))]
 marks = marks[len(marks) // 2: len(marks) // 2 + 11]
 out = []
 for a, b in zip(marks[:-1], marks[1:]):
