@@ -584,7 +584,7 @@ def main():
                       'host_enqueue_ms_per_step': lr['host_ms_per_step'], 'ms_per_step_runs': [r['ms_per_step'] for r in runs],
                       'steps': args.leg_steps, 'config': leg.config(world), 'roofline': lroof,
                       'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}
-        leg.model.release_native()                                # its streams would share the hardware queues with the next leg's
+        leg.model.release_native()                                # packed weights / workspaces back to the allocator
         leg_objs[name] = leg
         torch.cuda.empty_cache()
     train = None

@@ -94,10 +94,19 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
         ok = hipEventCreateWithFlags(&m->ev_part[p], hipEventDisableTiming) == hipSuccess &&
              true;   // part streams are created on first use (every stream takes a share of the 4 hardware queues)
     }
-    ok = ok && mk_stream(&m->sA, a_prio) &&
-         hipStreamCreateWithFlags(&m->sB, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&m->sB2, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
+    // The pipeline's streams are PROCESS-WIDE (created with the first model, shared by every later one, never destroyed).  The runtime
+    // deals its few hardware queues (4) to streams round-robin at creation: the first model's three streams get the three queues the
+    // default stream does not use, but the streams of a second model -- or of one created after an earlier model was destroyed -- start
+    // wherever the counter stands, and a per-agent or chain stream that shares the caller's queue serialises the pipeline (measured: the
+    // same leg of the bench at 51 or 63 M trajectories/s depending on how many models had been created before it).
+    static hipStream_t g_sA = nullptr, g_sB = nullptr, g_sB2 = nullptr;
+    if (ok && !g_sA) {
+        ok = mk_stream(&g_sA, a_prio) && hipStreamCreateWithFlags(&g_sB, hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithFlags(&g_sB2, hipStreamNonBlocking) == hipSuccess;
+        if (!ok) g_sA = nullptr;
+    }
+    m->sA = g_sA; m->sB = g_sB; m->sB2 = g_sB2;
+    ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evB_done[p], hipEventDisableTiming) == hipSuccess;
@@ -116,8 +125,7 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     for (auto e : m->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); (void)hipEventDestroy(m->ev_agents);
     for (int p = 0; p < STT_MAX_PARTS; ++p) { (void)hipEventDestroy(m->ev_part[p]); if (p && m->part_stream[p]) (void)hipStreamDestroy(m->part_stream[p]); }
-    if (m->side) (void)hipStreamDestroy(m->side);
-    (void)hipStreamDestroy(m->sA); (void)hipStreamDestroy(m->sB); (void)hipStreamDestroy(m->sB2);
+    // sA / sB / sB2 are process-wide (sttode_model_create)
     (void)hipEventDestroy(m->ev_call);
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
     delete m;
@@ -278,7 +286,11 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     // fork: block-0 conv+GRU (per agent) only needs the front-end output; it runs beside the encoder
     // (pipelined form: no side stream -- the stage already runs beside the previous calls' per-trajectory kernels, and every
     // extra stream shares one of the 4 hardware queues with the streams that must overlap)
-    if (use_side && !m->side) STT_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    if (use_side && !m->side) {
+        static hipStream_t g_side = nullptr;     // process-wide, like sA / sB / sB2
+        if (!g_side) STT_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+        m->side = g_side;
+    }
     hipStream_t gs = use_side ? m->side : s;
     if (use_side) {
         STT_HIP(hipEventRecord(m->ev_fork, s));

@@ -232,8 +232,8 @@ class STTODENet(nn.Module):
         return self._packed
 
     def release_native(self):
-        """Drop the native pipeline (its HIP streams and events: every stream takes a share of the few hardware queues), the packed
-        weights and the cached workspaces; all are rebuilt on the next call."""
+        """Drop the native pipeline handle (its events; the pipeline's streams are process-wide), the packed weights and the cached
+        workspaces; all are rebuilt on the next call."""
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
         self._native, self._packed, self._packed_key = None, None, None

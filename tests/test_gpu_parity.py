@@ -1479,8 +1479,8 @@ def test_fused_objective_kernel_vs_the_three_loss_entry_points(scenes_csr):
 
 
 def test_release_native_rebuilds_the_pipeline_with_identical_results():
-    """STTODENet.release_native() drops the native pipeline (streams, packed weights, workspaces); the next call rebuilds it and gives
-    the same bits (bench.py releases a finished leg's pipeline so that its streams do not share hardware queues with the next leg's)."""
+    """STTODENet.release_native() drops the native pipeline handle, packed weights and workspaces; the next call rebuilds them and gives
+    the same bits (bench.py releases a finished leg's buffers before the next leg)."""
     from sttode_amd import scenes
     m = hip_model('eth', 8, 12)
     sb = scenes.make_scene_batch(range(40, 52), 'eth')
