@@ -35,8 +35,8 @@ class Engine:
         self.dev = net.device
         self.scratch = self.main_scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
         self.param_grads = True     # False: skip the weight-gradient GEMMs (stage-2 sampler training keeps this net frozen)
-        # The two encoder trunks (disjoint parameters) run on two streams, forward and backward (see forward_segments /
-        # backward_segments); the side stream has its own split-k scratch.
+        # The step is written as segments (forward_segments / backward_segments); optionally the future trunk's segments run on a side
+        # stream with its own split-k scratch (_use_streams: off by default).
         self.side = None            # [stream, stream], created on first use
         self.side_scratch = None
         self.multi = False
@@ -44,10 +44,10 @@ class Engine:
 
     # ---------------------------------------------------------------- streams
     def _use_streams(self, n):
-        """Launch-latency-bound regime only (every kernel is a few workgroups): at larger batches the kernels fill the device and
-        the serial order is as fast (and keeps fewer temporaries alive)."""
-        env = os.environ.get('STTODE_TRAIN_STREAMS')
-        on = (n * 20 <= 32768) if env is None else env != '0'
+        """The future trunk's segments on a side stream (STTODE_TRAIN_STREAMS=1; default off).  Measured on one-scene steps: in the eager form
+        the host enqueues too slowly for two streams to overlap (and holding every temporary alive costs more than it buys: 6.5 vs 4.0 ms),
+        in the captured form hipGraphLaunch feeds kernels at the rate one queue executes them (see _GraphedStep._capture)."""
+        on = os.environ.get('STTODE_TRAIN_STREAMS', '0') not in ('', '0') and n * 20 <= 32768
         if on and self.side is None:
             self.side = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
             self.side_scratch = [torch.empty(4 << 20, dtype=torch.float32, device=self.dev) for _ in self.side]
