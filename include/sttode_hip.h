@@ -229,6 +229,22 @@ int sttode_loss_kl(const float* params, const int* scene_ptr, int S, int rows, i
  * with scene_ptr / agent_scene: sum over scenes of the per-scene means.  scratch >= n floats. */
 int sttode_loss_diverse(const float* pred, const float* target, const int* scene_ptr, const int* agent_scene, int n, int K, int D,
                         float* out, float* dpred, float* scratch, void* stream);
+/* Training step, forward of ONE encoder trunk with its tape in one launch (PastEncoder / FutureEncoder trunk, model/STTODE.py:214-236 /
+ * :276-300, hypertransformer.py:134-153, ode_demo.py:188,228) for attention length 1 (scene batches: softmax over one key == 1).
+ * `ptrs`: table of STT_TT_COUNT device pointers -- the trunk's parameters in their row-major nn.Parameter storage, the inputs, and every
+ * tensor sttode_amd/training.py's trunk_bwd reads.  feat: row stride ld_feat, [0,64) = ftraj_input, [64,128) = ODE encoder output.
+ * T <= 12 (LDS); otherwise, and for attention groups > 1, the caller runs the layer-by-layer entry points. */
+enum SttodeTrunkPtr {
+    STT_TT_FC1_W, STT_TT_FC1_B, STT_TT_POS_W, STT_TT_POS_B, STT_TT_FC2_W, STT_TT_FC2_B, STT_TT_FC3_W, STT_TT_FC3_B, STT_TT_INPROJ_W,
+    STT_TT_INPROJ_B, STT_TT_OUT_W, STT_TT_OUT_B, STT_TT_INFO_W, STT_TT_INFO_B, STT_TT_GATE_W, STT_TT_GATE_B, STT_TT_LN1_W, STT_TT_LN1_B,
+    STT_TT_L1_W, STT_TT_L1_B, STT_TT_L2_W, STT_TT_L2_B, STT_TT_LN2_W, STT_TT_LN2_B,
+    STT_TT_ENC_IN /* [n,T,4] */, STT_TT_LAST /* int32 [n] */, STT_TT_PE /* [>=T,64] */, STT_TT_DROP /* [n*T,64] keep mask / keep, or NULL */,
+    STT_TT_POSIN /* [n*T,128] */, STT_TT_TP /* [n*T,64] */, STT_TT_H3IN /* [n,68] */, STT_TT_FEAT, STT_TT_XC /* [n,64] */,
+    STT_TT_QKV /* [n,192] */, STT_TT_AO, STT_TT_TT, STT_TT_SS, STT_TT_H, STT_TT_XH1 /* [n,64] each */, STT_TT_RS1 /* [n] */,
+    STT_TT_F1 /* [n,1024] */, STT_TT_XH2, STT_TT_RS2, STT_TT_ODE, STT_TT_COUNT
+};
+int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, void* stream);
+
 /* The four terms of forward()'s objective (:372-395,553-568) and all their gradients for ONE decoder pass over K1 = 1 + K samples per
  * agent (sample 0: decoded from the posterior draw, enters the prediction / recover terms; samples 1..K: the prior draws, best-of-K):
  * pred [n,K1,D], rec [n,K1,Dp], fut [n,D], past [n,Dp], qzp [n,2*zd] -> out[0..4] = (mse, recover, kl, diverse as the three entry

@@ -41,6 +41,7 @@ class Engine:
         self.side_scratch = None
         self.multi = False
         self._hold = []
+        self.fused_trunk = os.environ.get('STTODE_TRUNK_FUSED', '1') != '0'   # scene batches: a trunk's forward + tape in one launch
 
     # ---------------------------------------------------------------- streams
     def _use_streams(self, n):
@@ -163,6 +164,8 @@ class Engine:
         n, T = enc_in.shape[0], enc_in.shape[1]
         t = {'n': n, 'T': T, 'pre': pre, 'feat': feat}
         X0 = enc_in.reshape(n * T, 4)
+        if net._mode != 'nba' and T <= 12 and self.fused_trunk:
+            return self._trunk_fwd_fused(t, X0, last, feat, drop_mask)
         posin = self.new(n * T, 128)
         self.lin(X0, P[pre + 'input_fc.weight'], P[pre + 'input_fc.bias'], out=posin[:, :64])
         pe = getattr(net, pre[:-1]).pos_encoder.pe
@@ -204,6 +207,33 @@ class Engine:
         feat[:, 64:128] = ode
         t.update(X0=X0, posin=posin, tp=tp, drop=drop_mask, h3in=h3in, xc=xc, qkv=qkv, attn=attn, ao=ao, tt=tt, ss=ss, h=h, xh1=xh1,
                  rs1=rs1, f1=f1, xh2=xh2, rs2=rs2, ode=ode, L=L, Nb=Nb)
+        return t
+
+    def _trunk_fwd_fused(self, t, X0, last, feat, drop_mask):
+        """The same forward and the same tape in ONE launch (csrc/train_trunk.hip, attention length 1): the step is bound by the number of
+        launches, and a trunk is 21 of them layer by layer."""
+        import ctypes
+        P, net = self.P, self.net
+        pre, n, T = t['pre'], t['n'], t['T']
+        a = pre + _ATT
+        sa = a + 'self_attn.temporal_attention_before.'
+        out = dict(posin=self.new(n * T, 128), tp=self.new(n * T, 64), h3in=self.new(n, 68), xc=self.new(n, 64), qkv=self.new(n, 192),
+                   ao=self.new(n, 64), tt=self.new(n, 64), ss=self.new(n, 64), h=self.new(n, 64), xh1=self.new(n, 64), rs1=self.new(n),
+                   f1=self.new(n, 1024), xh2=self.new(n, 64), rs2=self.new(n), ode=self.new(n, 64))
+        src = dict(fc1_w=P[pre + 'input_fc.weight'], fc1_b=P[pre + 'input_fc.bias'], pos_w=P[pre + 'pos_encoder.fc.weight'],
+                   pos_b=P[pre + 'pos_encoder.fc.bias'], fc2_w=P[pre + 'input_fc2.weight'], fc2_b=P[pre + 'input_fc2.bias'],
+                   fc3_w=P[pre + 'input_fc3.weight'], fc3_b=P[pre + 'input_fc3.bias'], inproj_w=P[sa + 'in_proj_weight'],
+                   inproj_b=P[sa + 'in_proj_bias'], out_w=P[sa + 'out_proj.weight'], out_b=P[sa + 'out_proj.bias'],
+                   info_w=P[a + 'self_attn.temporal_info.weight'], info_b=P[a + 'self_attn.temporal_info.bias'],
+                   gate_w=P[a + 'self_attn.temporal_gate.weight'], gate_b=P[a + 'self_attn.temporal_gate.bias'],
+                   ln1_w=P[a + 'norm1.weight'], ln1_b=P[a + 'norm1.bias'], l1_w=P[a + 'linear1.weight'], l1_b=P[a + 'linear1.bias'],
+                   l2_w=P[a + 'linear2.weight'], l2_b=P[a + 'linear2.bias'], ln2_w=P[a + 'norm2.weight'], ln2_b=P[a + 'norm2.bias'],
+                   enc_in=X0, last=last, pe=getattr(net, pre[:-1]).pos_encoder.pe, drop=drop_mask, feat=feat, **out)
+        for k, v in src.items():
+            assert v is None or v.is_contiguous() or k == 'feat', k
+        tbl = (ctypes.c_void_p * len(capi.TRUNK_PTRS))(*[(src[k].data_ptr() if src[k] is not None else None) for k in capi.TRUNK_PTRS])
+        capi.call('sttode_ttrunk_fwd', tbl, len(capi.TRUNK_PTRS), n, T, feat.stride(0), float(net.ODE_TIME), self.st)
+        t.update(X0=X0, drop=drop_mask, attn=out['qkv'][:, 128:], L=1, Nb=n, **out)
         return t
 
     def trunk_bwd(self, t, dfeat):

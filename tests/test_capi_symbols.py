@@ -56,10 +56,12 @@ def test_enums_match_python_tables():
 
     def enum(name):
         body = re.search(r'enum %s \{(.*?)\};' % name, src, flags=re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)            # comments may contain commas
         return [t.strip() for t in body.replace('\n', ' ').split(',') if t.strip()]
     assert len(enum('SttodeWeight')) - 1 == len(capi.WEIGHT_ORDER)
     assert [e[len('STT_B_'):].lower() for e in enum('SttodeBuffer')[:-1]] == [b.lower() for b in capi.BUFFERS]
     assert len(enum('SttodeStage')) - 1 == len(capi.STAGES)
+    assert [e[len('STT_TT_'):].lower() for e in enum('SttodeTrunkPtr')[:-1]] == list(capi.TRUNK_PTRS)
 
 
 def test_calls_fail_loudly_without_gpu_or_with_bad_arguments():

@@ -938,8 +938,10 @@ def test_training_step_gradients_vs_reference_and_oracle(golden, tag, dataset, T
             continue
         ref = g[f'{tag}_grad::{name}']
         got = grad_digest(gr)
-        assert abs(got[1] - ref[1]) <= 2e-4 * ref[1] + 1e-9, (name, got[1], ref[1])
-        assert np.abs(got[3:] - ref[3:]).max() <= 2e-4 * (ref[2] + 1e-12), (name, np.abs(got[3:] - ref[3:]).max(), ref[2])
+        # two fp32 evaluations of the same gradient: the reference's own autograd sits 0.8e-4 .. 4.6e-4 of max |g| from the float64
+        # evaluation of the graph (below), ours 1.8e-4 .. 2.1e-4 -- the digests are held to the same 5e-4 as the float64 comparison
+        assert abs(got[1] - ref[1]) <= 5e-4 * ref[1] + 1e-9, (name, got[1], ref[1])
+        assert np.abs(got[3:] - ref[3:]).max() <= 5e-4 * (ref[2] + 1e-12), (name, np.abs(got[3:] - ref[3:]).max(), ref[2])
     # entry by entry: against the float64 evaluation of the same graph (torch's own fp32 autograd is 0.8e-4 .. 4.6e-4 of
     # max |g| away from it on these cases, the HIP step 1.8e-4 .. 2.0e-4), and against the fp32 oracle
     g64, l64 = oracle_grads(tag, dataset, Tp, Tf, g, double=True)
