@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
 //   phase A   wave w computes layer 1 of chunk 4g+w (KTV k-tiles, in the throughput kernels' order) and publishes relu(h1) as a
 //             B-operand fragment in LDS (double buffered: one barrier per group);
 //   phase B   every wave adds the four chunks, in chunk order, into ITS 4 of the 16 layer-2 row tiles (4 independent MFMA chains).
-// 8 + 64 (block 0) / 32 + 64 (block 1) k16 MFMA quads... per group and wave instead of 4 x (KTV + 16) quads.  Every weight fragment is
+// 2 + 16 (block 0) / 8 + 16 (block 1) k16 quads (of four MFMAs) per group and wave instead of 4 x (KTV + 16) = 72 / 96.  Every weight fragment is
 // used by exactly one wave, so the weights skip LDS: plain coalesced 1 KiB loads (same fragment-ordered stream as the throughput
 // kernels), fetched one group ahead into registers.  Layer 3: the 256-wide activation is exchanged through LDS and wave o mod 4 runs
 // the 16-quad chain of output tile o.  Same summation order as the throughput kernels everywhere: identical bits.
