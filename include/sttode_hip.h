@@ -20,6 +20,10 @@ extern "C" {
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
+/* Train-mode augmentation of set_data (model/STTODE.py:417-426, rotation_2d_torch :6-14): past [n,Tp,2] and fut [n,Tf,2] (optional) rotated in
+ * place about the mean of the agents' last observed positions by the angle with cosine c and sine s.  One scene per call. */
+int sttode_rotate_scene(float* past, float* fut, int n, int Tp, int Tf, float c, float s, void* stream);
+
 /* STTODENet.set_data (model/STTODE.py:397-461), batched over S independent scenes (CSR scene_ptr ==
  * seq_start_end, utils/dataloader.py:177-181): scene_orig = mean_n(last obs) (:417), normalised past (:429),
  * first-difference velocities with the first duplicated (:432-433 / inference :588-589), cur_location (:461),

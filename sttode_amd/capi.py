@@ -15,6 +15,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
     'sttode_abi_version': [],
+    'sttode_rotate_scene': [_P, _P, _I, _I, _I, _F, _F, _P],
     'sttode_frontend_scenes': [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     'sttode_frontend_nba': [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     'sttode_frontend_future': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -161,6 +161,31 @@ __global__ __launch_bounds__(256) void best_of_k_kernel(const float* __restrict_
     if (lane == 0) { ade[a] = best_a; fde[a] = best_f; }
 }
 
+// Train-mode augmentation of set_data (model/STTODE.py:417-426): the scene's tracks rotated IN PLACE about scene_orig = mean over the agents
+// of the last observed position, x' = R (x - orig) + orig, R = [[c, -s], [s, c]] (rotation_2d_torch, :6-14).  One workgroup: every thread
+// forms the mean itself, in agent order, before any position is overwritten.
+__global__ __launch_bounds__(256) void rotate_scene_kernel(float* __restrict__ past, float* __restrict__ fut, int n, int Tp, int Tf, float c, float s) {
+    float sx = 0.f, sy = 0.f;
+    for (int a = 0; a < n; ++a) {
+        sx += past[((size_t)a * Tp + (Tp - 1)) * 2 + 0];
+        sy += past[((size_t)a * Tp + (Tp - 1)) * 2 + 1];
+    }
+    const float ox = sx / (float)n, oy = sy / (float)n;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * (Tp + Tf); i += 256) {
+        float* p = i < n * Tp ? past + (size_t)i * 2 : fut + (size_t)(i - n * Tp) * 2;
+        const float dx = p[0] - ox, dy = p[1] - oy;
+        p[0] = (dx * c + dy * (-s)) + ox;
+        p[1] = (dx * s + dy * c) + oy;
+    }
+}
+extern "C" int sttode_rotate_scene(float* past, float* fut, int n, int Tp, int Tf, float c, float s, void* stream) {
+    STT_REQUIRE(past && n > 0 && Tp >= 1 && Tf >= 0 && (fut || Tf == 0), "sttode_rotate_scene: bad argument");
+    hipLaunchKernelGGL(rotate_scene_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, past, fut, n, Tp, fut ? Tf : 0, c, s);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_frontend_scenes(const float* past, const int* scene_ptr, int n, int S, int Tp, int TPX, int vel_from_norm,
                                       float* scene_orig, int* agent_scene, float* xpad, float* enc_in, float* cur, float* orig,
                                       int* last_flag, void* stream) {

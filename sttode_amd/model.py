@@ -299,11 +299,17 @@ class STTODENet(nn.Module):
                 theta = (torch.randint(high=24, size=(1,)) * (np.pi / 12)) if self.discrete_rot else torch.rand(1) * np.pi * 2
             th = float(theta)
             c, s_ = float(np.cos(np.float32(th))), float(np.sin(np.float32(th)))
-            R = torch.tensor([[c, -s_], [s_, c]], dtype=torch.float32, device=dev)        # rotation_2d_torch (:6-14)
-            orig = past[:, -1].mean(dim=0)                       # scene_orig (:417); invariant under the rotation about itself
-            rot = lambda x: (((x - orig).unsqueeze(-2) * R).sum(-1) + orig).contiguous()  # x'_i = sum_j R[i][j] (x - orig)_j + orig_i
-            past = rot(past)
-            fut = rot(fut) if fut is not None else None
+            if past.is_cuda:                                     # one small kernel (a dozen torch ops were ~0.1 ms of host time per training step)
+                past = past.contiguous()                         # (fresh [N,T,2] copies of the loader's [N,2,T] tracks: rotated in place)
+                fut = fut.contiguous() if fut is not None else None
+                capi.call('sttode_rotate_scene', past, fut, past.shape[0], past.shape[1], fut.shape[1] if fut is not None else 0, c, s_,
+                          capi.stream_ptr())
+            else:
+                R = torch.tensor([[c, -s_], [s_, c]], dtype=torch.float32, device=dev)        # rotation_2d_torch (:6-14)
+                orig = past[:, -1].mean(dim=0)                       # scene_orig (:417); invariant under the rotation about itself
+                rot = lambda x: (((x - orig).unsqueeze(-2) * R).sum(-1) + orig).contiguous()  # x'_i = sum_j R[i][j] (x - orig)_j + orig_i
+                past = rot(past)
+                fut = rot(fut) if fut is not None else None
         N = past.shape[0]
         if N == 0:
             raise ValueError('empty scene')
