@@ -23,3 +23,12 @@ run(True)
 for sync_each in (True, False):
     t = time.perf_counter(); tot = run(sync_each); dt = time.perf_counter() - t
     print(f'per-scene loop, D2H each call={sync_each}: {dt / len(data) * 1e3:.3f} ms/scene, {tot / dt / 1e6:.2f} M traj/s')
+# host split of the loop with the D2H of every prediction
+T = [0.0, 0.0, 0.0]
+for o, p in data:
+    t0 = time.perf_counter(); m.set_data(None, o, p, None, None)
+    t1 = time.perf_counter(); out = m.inference(None)
+    t2 = time.perf_counter(); out = out.cpu()
+    t3 = time.perf_counter()
+    T[0] += t1 - t0; T[1] += t2 - t1; T[2] += t3 - t2
+print('host split per scene (ms): set_data %.3f, inference (enqueue) %.3f, .cpu() (waits for the GPU + D2H) %.3f' % tuple(1e3 * x / len(data) for x in T))

@@ -120,7 +120,14 @@ class _Decoder(nn.Module):  # model/STTODE.py:303-318
                                        for _ in range(args.num_decompose))
 
 
+def _on(t, device):
+    device = torch.device(device)
+    return t.device.type == device.type and (device.index is None or t.device.index == device.index)
+
+
 def _f32(t, device):
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float32 and _on(t, device) and t.is_contiguous():
+        return t                                     # the per-scene loop passes tensors that are already in place
     return torch.as_tensor(t, dtype=torch.float32).to(device).contiguous()
 
 
@@ -350,7 +357,10 @@ class STTODENet(nn.Module):
         a, dev = self.args, self.device
         self._past = _f32(past, dev)
         self._future = _f32(future, dev) if future is not None else None
-        self._scene_ptr = torch.as_tensor(scene_ptr, dtype=torch.int32).to(dev).contiguous()
+        if isinstance(scene_ptr, torch.Tensor) and scene_ptr.dtype == torch.int32 and _on(scene_ptr, dev) and scene_ptr.is_contiguous():
+            self._scene_ptr = scene_ptr
+        else:
+            self._scene_ptr = torch.as_tensor(scene_ptr, dtype=torch.int32).to(dev).contiguous()
         if self._past.dim() != 3 or self._past.shape[1] != a.past_length or self._past.shape[2] != 2:
             raise ValueError(f'past must be [n, {a.past_length}, 2], got {tuple(self._past.shape)}')
         if self._past.shape[0] == 0 or self._scene_ptr.numel() < 2:
