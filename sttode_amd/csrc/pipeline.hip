@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #define STT_MAX_PARTS 8
+#define STT_MAX_DEVICES 64
 #define STT_MAX_SLOTS 4   // workspace / prediction slots of the cross-call pipeline (sttode_inference_*_async)
 struct TimRec { int stage; hipEvent_t e0, e1; };
 
@@ -99,13 +100,15 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     // default stream does not use, but the streams of a second model -- or of one created after an earlier model was destroyed -- start
     // wherever the counter stands, and a per-agent or chain stream that shares the caller's queue serialises the pipeline (measured: the
     // same leg of the bench at 51 or 63 M trajectories/s depending on how many models had been created before it).
-    static hipStream_t g_sA = nullptr, g_sB = nullptr, g_sB2 = nullptr;
-    if (ok && !g_sA) {
-        ok = mk_stream(&g_sA, a_prio) && hipStreamCreateWithFlags(&g_sB, hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithFlags(&g_sB2, hipStreamNonBlocking) == hipSuccess;
-        if (!ok) g_sA = nullptr;
+    static hipStream_t g_sA[STT_MAX_DEVICES] = {}, g_sB[STT_MAX_DEVICES] = {}, g_sB2[STT_MAX_DEVICES] = {};   // per device of this process
+    int dev = 0;
+    ok = ok && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STT_MAX_DEVICES;
+    if (ok && !g_sA[dev]) {
+        ok = mk_stream(&g_sA[dev], a_prio) && hipStreamCreateWithFlags(&g_sB[dev], hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithFlags(&g_sB2[dev], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) g_sA[dev] = nullptr;
     }
-    m->sA = g_sA; m->sB = g_sB; m->sB2 = g_sB2;
+    if (ok) { m->sA = g_sA[dev]; m->sB = g_sB[dev]; m->sB2 = g_sB2[dev]; }
     ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
@@ -287,9 +290,12 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     // (pipelined form: no side stream -- the stage already runs beside the previous calls' per-trajectory kernels, and every
     // extra stream shares one of the 4 hardware queues with the streams that must overlap)
     if (use_side && !m->side) {
-        static hipStream_t g_side = nullptr;     // process-wide, like sA / sB / sB2
-        if (!g_side) STT_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-        m->side = g_side;
+        static hipStream_t g_side[STT_MAX_DEVICES] = {};     // process-wide per device, like sA / sB / sB2
+        int dev = 0;
+        STT_HIP(hipGetDevice(&dev));
+        STT_REQUIRE(dev >= 0 && dev < STT_MAX_DEVICES, "sttode_inference_*: device index beyond STT_MAX_DEVICES");
+        if (!g_side[dev]) STT_HIP(hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking));
+        m->side = g_side[dev];
     }
     hipStream_t gs = use_side ? m->side : s;
     if (use_side) {
