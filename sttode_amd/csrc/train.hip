@@ -779,12 +779,18 @@ __global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const 
         part[(long)blockIdx.x * 224 + threadIdx.x] = s;
     }
 }
-__global__ void conv_bwd_w_reduce_kernel(const float* part, int G, float* dw, float* db) {
-    const int j = threadIdx.x;  // 224 threads
+// one wave per output j: lane l adds the partials g = l, l + 64, ... in order, then a fixed xor-shuffle tree (deterministic); a single
+// 224-thread block walking up to 256 partials one after the other took 60 us at NBA batch sizes
+__global__ __launch_bounds__(64) void conv_bwd_w_reduce_kernel(const float* part, int G, float* dw, float* db) {
+    const int j = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(long)g * 224 + j];
-    if (j < 192) dw[j] += s;
-    else db[j - 192] += s;
+    for (int g = lane; g < G; g += 64) s += part[(long)g * 224 + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        if (j < 192) dw[j] += s;
+        else db[j - 192] += s;
+    }
 }
 extern "C" int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, const float* b, float* x, float* e, int m,
                                int T, void* stream) {
@@ -807,7 +813,7 @@ extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, 
     STT_REQUIRE(scratch_floats >= (long)G * 224, "sttode_conv_bwd: scratch too small");
     const int rpw = (int)((rows + G - 1) / G);
     hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, de, x, scratch, m, T, rpw);
-    hipLaunchKernelGGL(conv_bwd_w_reduce_kernel, dim3(1), dim3(224), 0, (hipStream_t)stream, scratch, G, dw, db);
+    hipLaunchKernelGGL(conv_bwd_w_reduce_kernel, dim3(224), dim3(64), 0, (hipStream_t)stream, scratch, G, dw, db);
     STT_HIP(hipGetLastError());
     return 0;
 }
