@@ -1494,3 +1494,47 @@ def test_release_native_rebuilds_the_pipeline_with_identical_results():
     m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
     b = m.inference(None, z=z).cpu().numpy()
     assert np.array_equal(a, b)
+
+
+def test_fused_trunk_forward_writes_the_layer_by_layer_tape(golden):
+    """sttode_ttrunk_fwd (a trunk's forward with its tape in one launch, csrc/train_trunk.hip) against the layer-by-layer path
+    (Engine.trunk_fwd: 21 launches): every tensor of both trunks' tapes, with dropout masks, to fp32 rounding."""
+    from sttode_amd import training
+    dev = _gpu()
+    g = golden('forward_grads')
+    m = hip_model('eth', 8, 12)
+    rng = np.random.default_rng(9)
+    n = g['eth_obs'].shape[0]
+    drops = tuple(torch.from_numpy(((rng.random((n * T, 64)) < 0.9) / 0.9).astype(np.float32)).to(dev) for T in (8, 12))
+    tapes = {}
+    was = getattr(m, 'train_graphs', None)
+    m.train_graphs = False
+    try:
+        for fused in (True, False):
+            m.eval()                                              # no random rotation in set_data; the masks are passed explicitly
+            eq, ep1, ep20 = grad_case_setup(g, 'eth', m, dev)
+            eng = getattr(m, '_engine', None)
+            if eng is not None:
+                eng.fused_trunk = fused
+            training.training_forward(m, eq, ep1, ep20, drop_past=drops[0], drop_future=drops[1])
+            m._engine.fused_trunk = fused
+            if eng is None:                                       # the engine is created by the first call: run it again with the flag set
+                eq, ep1, ep20 = grad_case_setup(g, 'eth', m, dev)
+                training.training_forward(m, eq, ep1, ep20, drop_past=drops[0], drop_future=drops[1])
+            T = m._engine.tape
+            tapes[fused] = {f'{tr}.{k}': v.detach().float().cpu().numpy().copy() for tr in ('tp', 'tf') for k, v in T[tr].items()
+                            if isinstance(v, torch.Tensor) and k not in ('feat', 'X0', 'drop')}
+            tapes[fused]['hcat'] = T['hcat'].cpu().numpy().copy()
+    finally:
+        m.eval()
+        m._engine.fused_trunk = True
+        if was is None:
+            del m.train_graphs
+        else:
+            m.train_graphs = was
+    assert set(tapes[True]) == set(tapes[False]) and len(tapes[True]) >= 30
+    for k in sorted(tapes[True]):
+        a, b = tapes[True][k], tapes[False][k]
+        if k.endswith('h3in'):
+            a, b = a[:, :67], b[:, :67]
+        assert_close(a, b, rtol=2e-5, atol=2e-5, what='tape ' + k)
