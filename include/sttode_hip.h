@@ -314,7 +314,10 @@ enum SttodeStage {
     STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_AGENTS /* encoder + block-0 GRU in one launch (scene batches) */, STT_STAGE_COUNT
 };
 
-/* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366). */
+/* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366).  The library keeps the weight pointers
+ * (the caller keeps the tensors alive) and the model's events; the pipeline's HIP streams are created with the first model of a device
+ * and shared by every later model of that device for the life of the process (the runtime deals its few hardware queues to streams
+ * round-robin at creation: a later model's own streams could land on the caller's queue and serialise the pipeline). */
 int sttode_model_create(SttodeModel** out, const void* const* weights, int count, int Tp, int Tf, int K, int n_chunks0,
                         int n_chunks1);
 int sttode_model_destroy(SttodeModel* m);
