@@ -17,6 +17,8 @@
 extern "C" {
 #endif
 
+/* Version of this header: the library returns it from sttode_abi_version(); a binding compares before its first call (round 1-2: 1). */
+#define STTODE_ABI_VERSION 3
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
@@ -305,13 +307,14 @@ enum SttodeWeight {
 /* workspace buffers (offsets in floats from sttode_workspace_layout) */
 enum SttodeBuffer {
     STT_B_SCENE_ORIG, STT_B_AGENT_SCENE, STT_B_XPAD, STT_B_ENC_IN, STT_B_CUR, STT_B_ORIG, STT_B_LAST, STT_B_G, STT_B_QKV,
-    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_QUEUE, STT_B_COUNT
+    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_QUEUE, STT_B_FLAGS /* tile flags of the fused launch */, STT_B_COUNT
 };
 
 /* pipeline stages reported by sttode_timing_read */
 enum SttodeStage {
     STT_STAGE_FRONTEND, STT_STAGE_EMBED, STT_STAGE_ATTN, STT_STAGE_POST, STT_STAGE_GRU0, STT_STAGE_LINEAR, STT_STAGE_MLP0,
-    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_AGENTS /* encoder + block-0 GRU in one launch (scene batches) */, STT_STAGE_COUNT
+    STT_STAGE_GRU1, STT_STAGE_MLP1, STT_STAGE_CHAIN, STT_STAGE_AGENTS /* encoder + block-0 GRU in one launch (scene batches) */,
+    STT_STAGE_FUSED /* per-agent roles + trajectory chain in ONE launch (scene batches, round 3) */, STT_STAGE_COUNT
 };
 
 /* STTODENet.__init__ + load_state_dict equivalent for the packed weights (model/STTODE.py:350-366).  The library keeps the weight pointers
@@ -328,6 +331,11 @@ int sttode_set_col_parts(SttodeModel* m, int parts);
 /* per-trajectory stage: 1 = fused chain kernel (sttode_traj_chain), 0 = the three-kernel form (mlp_block0 -> gru_cols -> mlp_block1),
  * -1 = automatic (fused when the batch has >= 128 trajectories per workgroup slot to fill; default, or env STTODE_CHAIN). */
 int sttode_set_chain(SttodeModel* m, int mode);
+/* Scene batches whose per-trajectory stage takes the fused chain: 1 (default, or env STTODE_FUSED) = the per-agent stage (encoder, block-0
+ * GRU, layer-1 pre-activation tables: PastEncoder.forward model/STTODE.py:214-236, DecomposeBlock.forward :62-75 of block 0) runs as the
+ * leading workgroups of the chain launch, trajectory groups wait on one flag per 16-agent tile; 0 = separate launches on the pipeline's
+ * per-agent stream.  Results are bitwise the same either way. */
+int sttode_set_fused(SttodeModel* m, int mode);
 /* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
  * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */
 int sttode_set_ode(SttodeModel* m, int method, int steps);
@@ -348,10 +356,10 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
 
-/* Pipelined forms: the per-agent stage runs on an internal stream beside the per-trajectory stage of the PREVIOUS call
- * (its kernels fill the grid tails of the big kernels).  Two workspace/pred slots alternate (slot = call index & 1);
- * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream.
- * Results are bitwise identical to the serial forms. */
+/* Pipelined forms: consecutive calls run on the pipeline's internal streams so that the grid tail of one call's big launch is filled by
+ * the next call's (fused launches rotate over three streams; unfused: the per-agent stage on one stream beside the per-trajectory stage
+ * of the PREVIOUS call on two others).  Up to four workspace/pred slots (slot in [0, 4)); workspace, pred and z of a slot must stay
+ * untouched until sttode_wait(slot) has been enqueued on the consuming stream.  Results are bitwise identical to the serial forms. */
 int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
                                   float* workspace, float* pred, int slot, void* stream);
 int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,

@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   cd sttode_amd/csrc
   for name in ${VARIANTS:-base nodma nogather nogates nodma_nobarrier nodma_nogather_nogates all stamps st_nodma st_nogather st_nogates st_nodma_nogather st_all}; do
     case $name in
-      stamps) D="-DC32_DIAG_STAMPS" ;; st_nodma) D="-DC32_DIAG_STAMPS -DC32_DIAG_NODMA" ;; st_nogather) D="-DC32_DIAG_STAMPS -DC32_DIAG_NOGATHER" ;;
+      stamps) D="-DC32_DIAG_STAMPS" ;; trace) D="-DC32_DIAG_TRACE" ;; trace_prio0) D="-DC32_DIAG_TRACE -DROLE_PRIO=0" ;; prio0) D="-DROLE_PRIO=0" ;; st_nodma) D="-DC32_DIAG_STAMPS -DC32_DIAG_NODMA" ;; st_nogather) D="-DC32_DIAG_STAMPS -DC32_DIAG_NOGATHER" ;;
       st_nogates) D="-DC32_DIAG_STAMPS -DC32_DIAG_NOGATES" ;; st_nodma_nogather) D="-DC32_DIAG_STAMPS -DC32_DIAG_NODMA -DC32_DIAG_NOGATHER" ;;
       st_all) D="-DC32_DIAG_STAMPS -DC32_DIAG_NODMA -DC32_DIAG_NOGATHER -DC32_DIAG_NOGATES -DC32_DIAG_NOBARRIER" ;;
       base) D="" ;; nodma) D="-DC32_DIAG_NODMA" ;; nogather) D="-DC32_DIAG_NOGATHER" ;; nogates) D="-DC32_DIAG_NOGATES" ;;

@@ -11,6 +11,7 @@ _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+ABI_VERSION = 3   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
@@ -73,6 +74,7 @@ SIGNATURES = {
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
+    'sttode_set_fused': [_P, _I],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
@@ -94,9 +96,9 @@ TRUNK_PTRS = ('fc1_w', 'fc1_b', 'pos_w', 'pos_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc
               'gate_w', 'gate_b', 'ln1_w', 'ln1_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'ln2_w', 'ln2_b', 'enc_in', 'last', 'pe', 'drop', 'posin', 'tp',
               'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode')   # enum SttodeTrunkPtr
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
-           'A1y', 'dbuf', 'ybuf', 'state1', 'queue')
+           'A1y', 'dbuf', 'ybuf', 'state1', 'queue', 'flags')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',
-          'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain', 'agents_fused[encoder+block0 GRU]')
+          'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain', 'agents_fused[encoder+block0 GRU]', 'agents+trajectory_chain[fused launch]')
 
 
 class NativeModel:
@@ -132,6 +134,11 @@ class NativeModel:
         """1: fused per-trajectory chain kernel, 0: three-kernel form, -1: automatic."""
         if lib().sttode_set_chain(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_chain failed: ' + lib().sttode_last_error().decode())
+
+    def set_fused(self, mode):
+        """1: per-agent roles inside the chain launch (default), 0: separate per-agent launches."""
+        if lib().sttode_set_fused(self.h, int(mode)) != 0:
+            raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())
 
     def set_ode(self, method, steps):
         if lib().sttode_set_ode(self.h, int(method), int(steps)) != 0:
@@ -175,6 +182,12 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.sttode_last_error.restype = ctypes.c_char_p
         L.sttode_last_error.argtypes = []
+        try:
+            got = int(L.sttode_abi_version())
+        except AttributeError:
+            got = None
+        if got != ABI_VERSION:   # a stale or variant build (STTODE_HIP_LIB): its enums / signatures would be indexed with this file's tables
+            raise SttodeError(f'{LIB_PATH}: ABI version {got}, this binding needs {ABI_VERSION}; rebuild with `make -C sttode_amd/csrc`')
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -8,7 +8,10 @@ void stt_set_error(const char* msg);
 int stt_gru_cols_form(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP, const float* gbias,
                       float* state, int ncols, int Tp, int TPX, int lat_max_tiles, void* stream);   // decoder.hip
 int stt_agents_fused(const float* const* W, const float* enc_in, const int* last, float* g, float* qkv, float* pf, const float* xpad,
-                     float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip; -1 = shape not covered
+                     float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip
+bool stt_agents_fused_covers(int Tp, int TPX);                                          // encoder.hip: shapes the fused per-agent kernel is built for
+int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
+                    float ode_time, int wgs_per_cu, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
 int stt_gru_lat_tiles();
 int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.hip: sttode_set_latency_tiles)
 
@@ -29,4 +32,19 @@ int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.h
             stt_set_error(_b);                                                              \
             return 2;                                                                       \
         }                                                                                   \
+    } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call and applies to the function ON THE CURRENT DEVICE: made once per
+// (kernel instantiation, device) -- a process that drives several GPUs (the pipeline keeps per-device stream tables) must not launch
+// a > 64 KiB kernel on its second device without it.
+#define STT_ATTR_DEVICES 64
+#define STT_SET_LDS_ONCE(kernel, bytes)                                                                         \
+    do {                                                                                                        \
+        static bool _done[STT_ATTR_DEVICES] = {};                                                               \
+        int _dev = 0;                                                                                           \
+        STT_HIP(hipGetDevice(&_dev));                                                                           \
+        if (_dev < 0 || _dev >= STT_ATTR_DEVICES || !_done[_dev]) {                                             \
+            STT_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            if (_dev >= 0 && _dev < STT_ATTR_DEVICES) _done[_dev] = true;                                       \
+        }                                                                                                       \
     } while (0)

@@ -23,7 +23,9 @@
 //     handed out by an atomic work counter (one tail for the whole chain instead of three, and a later launch on
 //     another stream fills it: the kernel holds no chip-wide resource).
 #include "chain.hpp"
+#include "latency_bodies.hpp"
 #include "api_util.hpp"
+#include "../../include/sttode_hip.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,6 +44,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define C32_RING (2 * C32_CMAX * C32_TILE)  // f32x4 in the double buffer (24 KiB)
 #define C32_SLOT 256                        // f32x4 per wave gather slot (4 KiB)
 
+// Per-agent ROLE of the fused launch (round 3): the first `ntiles` workgroups of the grid run, for one 16-agent tile each, the whole
+// per-agent stage -- encoder (embed_lat_body -> post_attn_body), block-0 conv + GRU (gru_lat4_body) and the three layer-1 pre-activation
+// tables (preact_rows) -- and publish ONE flag per tile; the trajectory groups behind them in the grid wait for the flags of the tiles
+// their agents live in.  Why: as separate launches on their own stream these kernels were starved by the running chain (its queue keeps
+// every freed workgroup slot until its grid is fully dispatched: 1.85 ms for a 0.1 ms stage, profiles/r03/timeline_default.txt), which
+// forced ONE chain workgroup per CU in the pipelined path; inside the launch nothing needs a chain-free CU.
+struct RoleArgs {
+    EmbedW ew; PostW pw;
+    const float* enc_in; const int* last; float* g; float* qkv; float* pf;
+    const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
+    const f32x4* WAx; const float* b1x; const f32x4* WAy; const float* b1y; const f32x4* WA1; const float* b11;
+    float* A0x; float* A0y; float* A1y;
+    unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
+    int ntiles; float ode_time;
+};
+
+#ifndef ROLE_PRIO
+#define ROLE_PRIO 3
+#endif
+
 struct ChainArgs {
     const float* A0x; const float* A0y; const float* A1y;  // [nagents][512] per-agent layer-1 pre-activations (b1 included)
     const f32x4* pool;                                      // PK32 tile pool
@@ -54,7 +76,9 @@ struct ChainArgs {
     int* counter;                                           // work queue (zeroed before the launch)
     int ncols, K, Tp, Tf2;
     int persistent;  // 1: workgroups pull groups from the work queue until it is empty; 0: one group per workgroup (grid = groups)
-    long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS): per-workgroup phase stamps
+    long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS / C32_DIAG_TRACE): per-workgroup stamps
+    int trace_tag;   // diagnostic builds only: launch number
+    RoleArgs R;      // fused launch only (traj_chain_kernel<NY, true>)
 };
 
 // consts layout (floats): b2x[256] b3x[32] | b2y[256] b3y[32*NY] | gbias[4][96] convb[32] | b2m[256] b3m[32*NY]
@@ -320,6 +344,24 @@ __device__ __forceinline__ void gru32_steps(ChainStream& st, const float* gb, co
 // being computed once at the top of the group and kept live (64-bit pointers held across phases were what spilled)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// C32_DIAG_TRACE (diagnostic build, profiles/exp_r03_trace.py): every workgroup appends one record {launch tag, block, kind, start, end (100 MHz
+// s_memrealtime), HW_ID, XCC_ID} to the debug buffer -- who ran where and when, across overlapping launches
+#ifdef C32_DIAG_TRACE
+__shared__ long long g_tr_ph[4];   // role phase stamps (thread 0)
+#define C32_TRACE_BEGIN() long long _tr_t0 = 0, _tr_c0 = 0; if (threadIdx.x == 0 && A.dbg) { _tr_t0 = __builtin_amdgcn_s_memrealtime(); _tr_c0 = __builtin_amdgcn_s_memtime(); }
+#define C32_TRACE_END(kind) do { if (threadIdx.x == 0 && A.dbg) { \
+        const long long _t1 = __builtin_amdgcn_s_memrealtime(); unsigned _hw, _xcc; \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(_hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(_xcc)); \
+        const unsigned long long _r = atomicAdd((unsigned long long*)A.dbg, 1ull); if ((long long)_r >= A.dbg[1]) break; /* dbg[1] = capacity in records */ \
+        long long* _p = A.dbg + 8 + _r * 12; _p[0] = A.trace_tag; _p[1] = blockIdx.x; _p[2] = (kind); _p[3] = _tr_t0; _p[4] = _t1; _p[5] = _hw; _p[6] = _xcc; \
+        _p[8] = g_tr_ph[0]; _p[9] = g_tr_ph[1]; _p[10] = g_tr_ph[2]; _p[7] = __builtin_amdgcn_s_memtime() - _tr_c0; _p[11] = g_tr_ph[3]; } } while (0)
+#define C32_TRACE_PHASE(i) do { if (threadIdx.x == 0) g_tr_ph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C32_TRACE_PHASE(i) do { } while (0)
+#define C32_TRACE_BEGIN() do { } while (0)
+#define C32_TRACE_END(kind) do { } while (0)
+#endif
+
 #ifdef C32_DIAG_STAMPS
 #define C32_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && gi < 4) { A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k)] = __builtin_amdgcn_s_memtime(); \
                                                                     A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -327,7 +369,67 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 #define C32_STAMP(k) do { } while (0)
 #endif
 
-template <int NY>
+// The per-agent stage of ONE 16-agent tile on a chain workgroup's resources (4 waves, <= 256 VGPRs, the chain's dynamic LDS).  The
+// bodies are the stand-alone kernels' code (latency_bodies.hpp), so g / qkv / pf / state0 / A0x / A0y / A1y carry the bits the separate
+// launches produce.  LDS: [0, 40 KiB) embed, then [0, 16 KiB) post-attention exchange, then [0, 12 KiB) h tiles + [12, 60 KiB) GRU image.
+__device__ __forceinline__ void agent_role(const ChainArgs& A, int tile, char* smem) {
+    const RoleArgs& R = A.R;
+    const int nag = (A.ncols + A.K - 1) / A.K;   // == ncols / K: agents
+    // The role is a short chain of DEPENDENT steps (barriers, L2 round trips, 32-cycle MFMAs) sharing each SIMD with a chain wave that has
+    // a 64-cycle MFMA ready every cycle it is asked: at equal priority the older chain wave wins every arbitration and the role ran 2x
+    // slower than alone (283 vs 150 us, profiles/r03/trace_*), holding a workgroup slot all the while.  Raised priority lets its few
+    // instructions issue first; the chain wave loses the same handful of pipe cycles either way.
+    __builtin_amdgcn_s_setprio(ROLE_PRIO);
+    embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, A.Tp, tile, reinterpret_cast<f32x4*>(smem));
+    __syncthreads();                              // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
+    C32_TRACE_PHASE(0);
+    post_attn_body<false>(R.pw, R.g, R.qkv + 128, 192, R.pf, nag, R.ode_time, 0, 1, nullptr, nullptr, tile,
+                          reinterpret_cast<f32x4(*)[4][64]>(smem));
+    __syncthreads();                              // pf of this tile is visible to the workgroup; LDS changes hands again
+    C32_TRACE_PHASE(1);
+    f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
+    const int cur = gru_lat4_body(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH,
+                                  reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64);
+    C32_TRACE_PHASE(2);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = tile * 16 + c;
+    const int colc = col < nag ? col : nag - 1;
+    f32x4 B[14];                                  // [pf | state0] of this lane's agent as B-operand fragments
+#pragma unroll
+    for (int T = 0; T < 8; ++T) B[T] = ld4(R.pf + (size_t)colc * 128 + 16 * T + 4 * q);
+#pragma unroll
+    for (int T = 0; T < 6; ++T) B[8 + T] = sH[cur][T][lane];
+    preact_rows<14, true>(R.WAx, R.b1x, R.A0x, B, col, col < nag, lane, q, wv);
+    preact_rows<14, true>(R.WAy, R.b1y, R.A0y, B, col, col < nag, lane, q, wv);
+    preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < nag, lane, q, wv);
+    // publish (guide §6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(R.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer side: wave 0 polls the flags of tiles [t_lo, t_hi] (relaxed agent-scope loads, one lane per tile, s_sleep between polls), then
+// ONE agent-scope acquire drops this CU's stale L1 lines; the caller's barrier releases the other waves.  The spin is bounded (~1 s): a
+// producer that never arrives -- it cannot, in-order dispatch puts every producer in front of its consumers -- would poison this group's
+// predictions with NaN and set the time-out word instead of hanging the device.
+__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane) {
+    bool ok = true;
+    for (int t = t_lo + lane; t <= t_hi; t += 64) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 20)) { ok = false; break; }
+        }
+    }
+    ok = __all(ok);
+    if (!ok && lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return ok;
+}
+
+template <int NY, bool FUSE>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
@@ -346,11 +448,30 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     const unsigned zslot_addr = __builtin_amdgcn_readfirstlane(lds_addr(zslot));
     const int ngroups = (A.ncols + 127) >> 7;
 
+    C32_TRACE_BEGIN();
+    if (FUSE && (int)blockIdx.x < A.R.ntiles) {   // (uniform) the leading workgroups of a fused launch: per-agent roles
+        agent_role(A, blockIdx.x, smem);
+        C32_TRACE_END(1);
+        return;
+    }
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
     for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
-    if (threadIdx.x == 0) sq[0] = A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
+    if (threadIdx.x == 0) sq[0] = FUSE ? (int)blockIdx.x - A.R.ntiles : A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
+    if (FUSE) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
+        const int g0 = (int)blockIdx.x - A.R.ntiles;
+        const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
+        if (wave == 0 && !wait_tiles(A.R.flags, (c_lo / A.K) >> 4, (c_hi / A.K) >> 4, A.R.flags + A.R.ntiles, lane) && lane == 0) sq[0] = -1;
+    }
     __syncthreads();
+    C32_TRACE_PHASE(3);   // (groups) flags seen
     int g = sq[0];
+    if (FUSE && g < 0) {   // (uniform) time-out: poison the group's predictions, never hang
+        for (int i = threadIdx.x; i < 128 * A.Tf2; i += blockDim.x) {
+            const size_t o = (size_t)((int)blockIdx.x - A.R.ntiles) * 128 * A.Tf2 + i;
+            if (o < (size_t)A.ncols * A.Tf2) A.pred[o] = __builtin_nanf("");
+        }
+        return;
+    }
     if (g >= ngroups) return;  // (uniform) cannot happen with grid <= ngroups; nothing is in flight yet
     ChainStream st;
     st.init(A.pool, lprog, A.prog_len, ring);
@@ -379,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         // the NEXT group is requested now (one ticket of look-ahead: the last MLP prefetches its first gather); every wave reads
         // it after the many barriers of this group
         __syncthreads();  // every wave has read sq[1] of the previous hand-over before it is overwritten
-        if (threadIdx.x == 0) sq[1] = A.persistent ? atomicAdd(A.counter, 1) : ngroups;
+        if (threadIdx.x == 0) sq[1] = (!FUSE && A.persistent) ? atomicAdd(A.counter, 1) : ngroups;
 
         f32x16 acc2[8];
         f32x16 d;
@@ -478,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         g = gnext;
         if (g >= ngroups) break;  // uniform: every wave read the same sq word
     }
+    C32_TRACE_END(0);
 }
 
 // Stand-alone streaming GRU over columns (block 0: one column per AGENT): the same 32-column MFMA tiles and weight stream as the
@@ -547,12 +669,13 @@ static int chain_cus() {
 }
 static int chain_lds(int NY, int prog_len) { return (C32_RING + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
-template <int NY> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
-    static bool attr_set = false;  // once per instantiation (hipFuncSetAttribute is a driver call)
-    if (!attr_set) {
-        STT_HIP(hipFuncSetAttribute((const void*)traj_chain_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
-    }
+static int role_lds(int Tp) {   // agent_role's phases: embed (Tp*256 + 512 f32x4), GRU (h tiles 12 KiB + image of hidden tiles 4, 5: 48 KiB)
+    const int e = (Tp * 256 + 512) * 16, g = (2 * 6 * 64 + 2 * 24 * 64) * 16;
+    return e > g ? e : g;
+}
+
+template <int NY, bool FUSE> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
+    STT_SET_LDS_ONCE((traj_chain_kernel<NY, FUSE>), 96 * 1024);   // once per (instantiation, device)
     const int ngroups = (a.ncols + 127) / 128;
     // STTODE_CHAIN_RESERVE=r leaves r of the chip's 2-per-CU workgroup slots to concurrently running kernels (the per-agent stage
     // of the next call in the pipelined form); the work queue makes the remaining workgroups absorb the groups
@@ -560,18 +683,21 @@ template <int NY> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hi
     if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
-    if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
+    if (FUSE) grid = a.R.ntiles + ngroups;   // roles first (dispatch order = index order), one group per workgroup behind them
+    else if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
-    // of LDS stay free for kernels of OTHER streams: the per-agent stage of the next call and the next call's chain run beside this
-    // one instead of waiting for its tail (pipelined callers: 72.9 vs 62.4 M trajectories/s at 512 scenes on one box).  A single
-    // serial call is ~4 % faster with two resident workgroups.
+    // of LDS stay free for kernels of OTHER streams (the separate per-agent launches of the unfused pipeline).  The fused launch needs
+    // no co-residency and runs two per CU everywhere.
     static int wgs_env = -1;   // STTODE_CHAIN_WGS=1|2 overrides the caller's choice (experiments)
     if (wgs_env < 0) { const char* e = getenv("STTODE_CHAIN_WGS"); wgs_env = e ? atoi(e) : 0; }
     const int wgs = wgs_env > 0 ? wgs_env : wgs_per_cu;
     int lds = chain_lds(NY, a.prog_len);
+    if (FUSE && lds < role_lds(a.Tp)) lds = role_lds(a.Tp);
     if (wgs == 1 && lds < 84 * 1024) lds = 84 * 1024;
-    hipLaunchKernelGGL(traj_chain_kernel<NY>, dim3(grid), dim3(256), lds, s, a);
+    STT_REQUIRE(lds <= 96 * 1024, "sttode_traj_chain: dynamic LDS beyond the 96 KiB the kernel is registered for");
+    if (FUSE) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
+    hipLaunchKernelGGL((traj_chain_kernel<NY, FUSE>), dim3(grid), dim3(256), lds, s, a);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -592,8 +718,9 @@ extern "C" int sttode_gru_cols32(const float* xin, int ldx, const float* pool, c
     return 0;
 }
 
-#ifdef C32_DIAG_STAMPS
+#if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
 static long long* g_chain_dbg = nullptr;
+static int g_trace_tag = 0;
 extern "C" int sttode_chain_debug_buffer(void* p) { g_chain_dbg = (long long*)p; return 0; }  // >= grid * 4 * 16 int64, zeroed
 #endif
 
@@ -617,7 +744,8 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
     a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
     a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
     a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.trace_tag = 0;
+    a.R = RoleArgs();   // unused by the unfused instantiation
     {
         static int pers = -1;   // default 0: one group per workgroup (slots free up continuously, so kernels of other streams -- the next
                                 // call's per-agent stage, the next chain -- interleave at group granularity; measured 1.38 vs 1.87 ms per
@@ -625,16 +753,64 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
         if (pers < 0) { const char* e = getenv("STTODE_CHAIN_PERSISTENT"); pers = e ? (atoi(e) != 0) : 0; }
         a.persistent = pers;
     }
-#ifdef C32_DIAG_STAMPS
+#if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
     a.dbg = g_chain_dbg;
+    a.trace_tag = g_trace_tag++;
 #endif
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {
-        case 1: return chain_launch<1>(a, wgs_per_cu, s);
-        case 2: return chain_launch<2>(a, wgs_per_cu, s);
-        case 3: return chain_launch<3>(a, wgs_per_cu, s);
+        case 1: return chain_launch<1, false>(a, wgs_per_cu, s);
+        case 2: return chain_launch<2, false>(a, wgs_per_cu, s);
+        case 3: return chain_launch<3, false>(a, wgs_per_cu, s);
         default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
+    }
+    return 0;
+}
+
+// Internal (csrc/pipeline.hip): the fused launch -- per-agent roles + trajectory groups in ONE grid (see RoleArgs).  W = the model's
+// weight table (enum SttodeWeight), ws / off = the caller's workspace and its layout; the front-end (xpad, enc_in, cur, orig, last) has
+// run on `stream` before.  Covers what the stand-alone fused per-agent kernel covers (stt_agents_fused_covers: attention length 1, the
+// reference's one Euler step, 2*Tp <= 16).
+int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
+                    float ode_time, int wgs_per_cu, void* stream) {
+    STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
+    STT_REQUIRE(n > 0 && K > 0 && stt_agents_fused_covers(Tp, 1) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
+    STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "stt_chain_fused: chunk program length does not match (Tp, Tf)");
+    STT_REQUIRE((long)n * K <= 0x7fffffffL, "stt_chain_fused: too many trajectories");
+    ChainArgs a;
+    a.A0x = ws + off[STT_B_A0X]; a.A0y = ws + off[STT_B_A0Y]; a.A1y = ws + off[STT_B_A1Y];
+    a.pool = (const f32x4*)W[STT_W_CHAIN_POOL]; a.prog = (const int2*)W[STT_W_CHAIN_PROG]; a.prog_len = prog_len;
+    a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 16; a.cur = ws + off[STT_B_CUR];
+    a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
+    a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0;
+#if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
+    a.dbg = g_chain_dbg;
+    a.trace_tag = g_trace_tag++;
+#endif
+    RoleArgs& r = a.R;
+    r.ew.fc1P = W[STT_W_FC1P]; r.ew.fc1b = W[STT_W_FC1B]; r.ew.posP = (const f32x4*)W[STT_W_POSP]; r.ew.peb = W[STT_W_PEB];
+    r.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; r.ew.fc2b = W[STT_W_FC2B]; r.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; r.ew.fc3b = W[STT_W_FC3B];
+    r.ew.fc3last = W[STT_W_FC3LAST]; r.ew.inP = (const f32x4*)W[STT_W_INP]; r.ew.inb = W[STT_W_INB];
+    r.pw.outP = (const f32x4*)W[STT_W_OUTP]; r.pw.outb = W[STT_W_OUTB]; r.pw.infoP = (const f32x4*)W[STT_W_INFOP]; r.pw.infob = W[STT_W_INFOB];
+    r.pw.gateP = (const f32x4*)W[STT_W_GATEP]; r.pw.gateb = W[STT_W_GATEB]; r.pw.ln1w = W[STT_W_LN1W]; r.pw.ln1b = W[STT_W_LN1B];
+    r.pw.l1P = (const f32x4*)W[STT_W_L1P]; r.pw.l1b = W[STT_W_L1B]; r.pw.l2P = (const f32x4*)W[STT_W_L2P]; r.pw.l2b = W[STT_W_L2B];
+    r.pw.ln2w = W[STT_W_LN2W]; r.pw.ln2b = W[STT_W_LN2B];
+    r.enc_in = ws + off[STT_B_ENC_IN]; r.last = (const int*)(ws + off[STT_B_LAST]); r.g = ws + off[STT_B_G]; r.qkv = ws + off[STT_B_QKV];
+    r.pf = ws + off[STT_B_PF];
+    r.convP = (const f32x4*)W[STT_W_B0_CONVP]; r.convB = W[STT_W_B0_CONVB]; r.wihP = (const f32x4*)W[STT_W_B0_WIHP];
+    r.whhP = (const f32x4*)W[STT_W_B0_WHHP]; r.gbias = W[STT_W_B0_GBIAS]; r.state0 = ws + off[STT_B_STATE0];
+    r.WAx = (const f32x4*)W[STT_W_B0_XWA]; r.b1x = W[STT_W_B0_XB1]; r.WAy = (const f32x4*)W[STT_W_B0_YWA]; r.b1y = W[STT_W_B0_YB1];
+    r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
+    r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
+    r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
+    const int NY = (2 * Tf + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    switch (NY) {
+        case 1: return chain_launch<1, true>(a, wgs_per_cu, s);
+        case 2: return chain_launch<2, true>(a, wgs_per_cu, s);
+        case 3: return chain_launch<3, true>(a, wgs_per_cu, s);
+        default: STT_REQUIRE(false, "stt_chain_fused: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;
 }

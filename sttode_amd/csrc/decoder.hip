@@ -105,25 +105,33 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_cols_kernel(
     const int ntiles = (ncols + 15) >> 4;
     const f32x4 cb0 = ld4(convB + 4 * q), cb1 = ld4(convB + 16 + 4 * q);
     // conv fragments of step t are fetched one step ahead (step 0's are tile independent, so the prefetch wraps)
+    // (TPX == 2, Tp > 8: the four prefetched fragments + the second input tile do not fit the 128-VGPR budget of a 16-wave workgroup --
+    // that instantiation spilled 44 B per lane -- so it reads each conv fragment where it is used: one L2 round trip per step on a
+    // shape whose model path takes the streaming / chain forms anyway)
+    constexpr int CWN = TPX == 1 ? 1 : 0;
     f32x4 cw[2][TPX];
+    if (CWN) {
 #pragma unroll
-    for (int io = 0; io < 2; ++io)
+        for (int io = 0; io < 2; ++io)
 #pragma unroll
-        for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
+            for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
+    }
     auto conv = [&](int t, f32x4 (&e)[2], const f32x4 (&d)[TPX]) {
         e[0] = cb0;
         e[1] = cb1;
 #pragma unroll
         for (int io = 0; io < 2; ++io) {
 #pragma unroll
-            for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
+            for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], CWN ? cw[io][T] : convP[((2 * t + io) * TPX + T) * 64 + lane], d[T]);
             e[io] = relu4(e[io]);
         }
-        const int tn = (t + 1 < Tp) ? t + 1 : 0;
+        if (CWN) {
+            const int tn = (t + 1 < Tp) ? t + 1 : 0;
 #pragma unroll
-        for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < 2; ++io)
 #pragma unroll
-            for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
+                for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
+        }
     };
     // interleaved assignment: consecutive tiles go to different CUs first, then to different waves
     for (int tile = blockIdx.x + gridDim.x * wave; tile < ntiles; tile += gridDim.x * nw) {
@@ -695,15 +703,6 @@ static int nonpersistent() {
     if (v < 0) { const char* e = getenv("STTODE_NONPERSISTENT"); v = (e && e[0] == '1') ? 1 : 0; }
     return v;
 }
-// hipFuncSetAttribute is a driver call: once per kernel instantiation, not once per launch
-#define STT_SET_LDS_ONCE(kernel, bytes)                                                                        \
-    do {                                                                                                       \
-        static bool _done = false;                                                                             \
-        if (!_done) {                                                                                          \
-            STT_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
-            _done = true;                                                                                      \
-        }                                                                                                      \
-    } while (0)
 static int g_num_cu = 0;
 static int num_cus() {
     if (!g_num_cu) {

@@ -17,20 +17,6 @@
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
 
-struct EmbedW {
-    const float* fc1P;    // [4 row tiles][64 lanes]  lane(i,q) -> W_fc[16it+i][q]
-    const float* fc1b;    // [64]
-    const f32x4* posP;    // PK16 of pos fc weight[:, :64]   [4][4][64]
-    const float* peb;     // [Tlen][64]  pos fc weight[:, 64:] @ pe[t] + pos fc bias
-    const f32x4* fc2P;    // PK16 of input_fc2 [64 x 64*Tlen] -> [4][4*Tlen][64]
-    const float* fc2b;    // [64]
-    const f32x4* fc3P;    // PK16 of input_fc3[:, :64]  [4][4][64]
-    const float* fc3b;    // [64]
-    const float* fc3last; // [64] = input_fc3.weight[:, 66]  (category [0,0,1] of the last agent)
-    const f32x4* inP;     // PK16 of in_proj_weight [192 x 64] -> [12][4][64]
-    const float* inb;     // [192]
-};
-
 __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* __restrict__ enc_in,  // [n][Tlen][4]
                                                         const int* __restrict__ last_flag,           // [n]
                                                         float* __restrict__ g,                       // [n][64]
@@ -101,90 +87,6 @@ __global__ __launch_bounds__(256) void embed_qkv_kernel(EmbedW w, const float* _
         for (int T = 0; T < 4; ++T) a = mfma_k16(a, w.inP[(it * 4 + T) * 64 + lane], gg[T]);
         if (col < n) st4(qkv + (size_t)col * 192 + 16 * it + 4 * q, a);
         if ((it & 3) == 3) STT_FENCE();
-    }
-}
-
-// Latency form of embed_qkv: ONE workgroup (4 waves) per 16-agent tile, the waves split every layer by output row tile instead of
-// each owning a tile (whose serial chain is ~1300 fp32 MFMAs = ~20 us however few tiles exist):
-//   1  wave w: pos-enc fc row tile w of EVERY frame (input_fc recomputed: 4 MFMAs per frame) -> LDS;         one barrier
-//   2  wave w: input_fc2 row tile w accumulated over frames and k-tiles in the throughput kernel's order -> LDS; one barrier
-//   3  wave w: input_fc3 row tile w (+ category column) -> g, LDS;                                              one barrier
-//   4  wave w: in-projection row tiles w, w+4, w+8 -> qkv.
-// ~350 MFMAs per wave.  Every output element is summed in the order of embed_qkv_kernel: identical bits.
-// smem: (Tlen * 256 + 512) f32x4 of LDS; `tile` = the workgroup's 16-agent tile; waves 0..3 of the workgroup.
-__device__ __forceinline__ void embed_lat_body(const EmbedW& w, const float* __restrict__ enc_in, const int* __restrict__ last_flag,
-                                               float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen, int tile, f32x4* smem) {
-    f32x4* sPt = smem;                               // [Tlen][4][64]
-    f32x4* sF = sPt + (size_t)Tlen * 256;            // [4][64]
-    f32x4* sG = sF + 256;                            // [4][64]
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = tile * 16 + c;
-    const int colc = col < n ? col : n - 1;
-    f32x4 pw[4], b1[4];
-    float f1[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-        pw[T] = w.posP[(wv * 4 + T) * 64 + lane];
-        f1[T] = w.fc1P[T * 64 + lane];
-        b1[T] = ld4(w.fc1b + 16 * T + 4 * q);
-    }
-    // first fc2 fragments of this wave's row tile travel during phase 1
-    f32x4 w2n[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) w2n[T] = w.fc2P[((size_t)wv * 4 * Tlen + T) * 64 + lane];
-    float xn = enc_in[((size_t)colc * Tlen) * 4 + q];
-    for (int t = 0; t < Tlen; ++t) {
-        const float xin = xn;
-        if (t + 1 < Tlen) xn = enc_in[((size_t)colc * Tlen + t + 1) * 4 + q];
-        f32x4 a = ld4(w.peb + (size_t)t * 64 + 16 * wv + 4 * q);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const f32x4 xt = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[T], xin, b1[T], 0, 0, 0);
-            a = mfma_k16(a, pw[T], xt);
-        }
-        sPt[(t * 4 + wv) * 64 + lane] = a;
-    }
-    __syncthreads();
-    f32x4 f = ld4(w.fc2b + 16 * wv + 4 * q);
-    for (int t = 0; t < Tlen; ++t) {
-        f32x4 w2c[4];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2c[T] = w2n[T];
-        const int tn = t + 1 < Tlen ? t + 1 : t;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2n[T] = w.fc2P[((size_t)wv * 4 * Tlen + 4 * tn + T) * 64 + lane];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) f = mfma_k16(f, w2c[T], sPt[(t * 4 + T) * 64 + lane]);
-    }
-    f32x4 w3[4], wi[3][4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) w3[T] = w.fc3P[(wv * 4 + T) * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int T = 0; T < 4; ++T) wi[i][T] = w.inP[((wv + 4 * i) * 4 + T) * 64 + lane];
-    sF[wv * 64 + lane] = f;
-    __syncthreads();
-    const float lastf = last_flag[colc] ? 1.0f : 0.0f;
-    f32x4 gg;
-    {
-        f32x4 a = ld4(w.fc3b + 16 * wv + 4 * q);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) a = mfma_k16(a, w3[T], sF[T * 64 + lane]);
-        const f32x4 wl = ld4(w.fc3last + 16 * wv + 4 * q);
-        gg = a + wl * lastf;
-    }
-    if (col < n) st4(g + (size_t)col * 64 + 16 * wv + 4 * q, gg);
-    sG[wv * 64 + lane] = gg;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int it = wv + 4 * i;
-        f32x4 a = ld4(w.inb + 16 * it + 4 * q);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) a = mfma_k16(a, wi[i][T], sG[T * 64 + lane]);
-        if (col < n) st4(qkv + (size_t)col * 192 + 16 * it + 4 * q, a);
     }
 }
 
@@ -311,183 +213,6 @@ __global__ __launch_bounds__(256) void mhgsa_weights_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct PostW {
-    const f32x4* outP;  const float* outb;    // out_proj       PK16 [4][4][64], [64]
-    const f32x4* infoP; const float* infob;   // temporal_info
-    const f32x4* gateP; const float* gateb;   // temporal_gate
-    const float* ln1w;  const float* ln1b;
-    const f32x4* l1P;   const float* l1b;     // linear1 [1024 x 64]  PK16 [64][4][64], [1024]
-    const f32x4* l2P;   const float* l2b;     // linear2 [64 x 1024]  PK16 [4][64][64], [64]
-    const float* ln2w;  const float* ln2b;
-};
-
-// One workgroup (4 waves) per 16-agent tile; the waves split every layer instead of each owning a tile:
-//   out_proj / info / gate : wave w computes output row tile w (16 of the 64 features), tiles are exchanged through LDS;
-//   FFN                    : wave w owns hidden tiles w, w+4, ... (16 of 64) and accumulates a PARTIAL 64-wide output,
-//                            the four partials are summed through LDS;
-//   LayerNorms / Euler     : recomputed by every wave on the full 64 features (cheap VALU), wave w stores tile w.
-// The serial MFMA chain per wave drops from ~2200 to ~560 instructions (this kernel is latency-bound: 541 tiles only).
-// Right-hand side of the tensor ODE for 16 columns held by this workgroup: f(y) = LN2(h + FFN(h)), h = LN1(y + gate(out_proj(a)))
-// (hypertransformer.py:134-153, :81-83), `a` = attention output for state y.  Every wave enters with the full a[4], y[4] tiles and
-// leaves with the full result in x[4]; sX is the 16 KiB exchange buffer.  Ends with a barrier-protected sX, so calls can be chained.
-__device__ __forceinline__ void ode_rhs(const PostW& w, f32x4 (*sX)[4][64], const f32x4 (&a)[4], const f32x4 (&y)[4], f32x4 (&x)[4],
-                                        int lane, int q, int wv) {
-    // FFN fragments of this wave's first hidden tile: issue early
-    f32x4 wn1[4], wn2[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) { wn1[T] = w.l1P[(wv * 4 + T) * 64 + lane]; wn2[T] = w.l2P[(T * 64 + wv) * 64 + lane]; }
-    f32x4 hbn = ld4(w.l1b + 16 * wv + 4 * q);
-    // out_proj, row tile wv
-    {
-        f32x4 v = ld4(w.outb + 16 * wv + 4 * q);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) v = mfma_k16(v, w.outP[(wv * 4 + T) * 64 + lane], a[T]);
-        sX[0][wv][lane] = v;
-    }
-    __syncthreads();
-    f32x4 o[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) o[T] = sX[0][T][lane];
-    // info / gate, row tile wv  ->  x = y + tanh(info) * sigmoid(gate)
-    {
-        f32x4 vi = ld4(w.infob + 16 * wv + 4 * q), vg = ld4(w.gateb + 16 * wv + 4 * q);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            vi = mfma_k16(vi, w.infoP[(wv * 4 + T) * 64 + lane], o[T]);
-            vg = mfma_k16(vg, w.gateP[(wv * 4 + T) * 64 + lane], o[T]);
-        }
-        f32x4 xr;
-        const f32x4 gw = wv == 0 ? y[0] : wv == 1 ? y[1] : wv == 2 ? y[2] : y[3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xr[r] = gw[r] + tanhf(vi[r]) * sigmoidf_(vg[r]);
-        sX[1][wv][lane] = xr;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int T = 0; T < 4; ++T) x[T] = sX[1][T][lane];
-    layernorm64(x, w.ln1w, w.ln1b, q);
-    // FFN: hidden tiles wv, wv+4, ... ; partial output in ff
-    f32x4 ff[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) ff[it] = splat4(0.f);
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-        f32x4 wc1[4], wc2[4];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) { wc1[T] = wn1[T]; wc2[T] = wn2[T]; }
-        f32x4 hid = hbn;
-        {
-            const int hn = (i + 1 < 16 ? i + 1 : i) * 4 + wv;
-#pragma unroll
-            for (int T = 0; T < 4; ++T) { wn1[T] = w.l1P[(hn * 4 + T) * 64 + lane]; wn2[T] = w.l2P[(T * 64 + hn) * 64 + lane]; }
-            hbn = ld4(w.l1b + 16 * hn + 4 * q);
-        }
-#pragma unroll
-        for (int T = 0; T < 4; ++T) hid = mfma_k16(hid, wc1[T], x[T]);
-        hid = relu4(hid);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) ff[it] = mfma_k16(ff[it], wc2[it], hid);
-    }
-    // sum the four partial FFN outputs through LDS (fixed order 0+1+2+3: deterministic)
-    __syncthreads();  // sX[0..3] reads above are complete in every wave before they are overwritten
-#pragma unroll
-    for (int it = 0; it < 4; ++it) sX[wv][it][lane] = ff[it];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const f32x4 t = ((sX[0][it][lane] + sX[1][it][lane]) + sX[2][it][lane]) + sX[3][it][lane];
-        x[it] = x[it] + (t + ld4(w.l2b + 16 * it + 4 * q));
-    }
-    layernorm64(x, w.ln2w, w.ln2b, q);
-}
-
-// ODE = false: the reference's integrator -- ONE explicit Euler step of size ode_time (ode_demo.py:186-190) with the attention output
-// given (any attention length).  ODE = true: `steps` steps of `method` (0 Euler, 1 torchdiffeq's fixed-grid rk4 = 3/8 rule,
-// 2 classical RK4) over [0, ode_time]; every stage needs the attention output of ITS state, which for attention length 1 (the
-// ETH/UCY/SDD path: softmax over one element) is just v(y) = W_v y + b_v and is computed here (vP, vb = value rows of the packed
-// in-projection).  With attention length > 1 a stage needs a pass over the whole group: op level (hypertransformer.ODEG_Encoder).
-// sX: [4][4][64] f32x4 exchange buffer (16 KiB of LDS); `tile` = the workgroup's 16-agent tile; waves 0..3 of the workgroup.
-template <bool ODE>
-__device__ __forceinline__ void post_attn_body(const PostW& w, const float* __restrict__ g,  // [n][64]
-                                               const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
-                                               float* __restrict__ pf,                       // [n][128]
-                                               int n, float ode_time, int method, int steps, const f32x4* __restrict__ vP,
-                                               const float* __restrict__ vb, int tile, f32x4 (*sX)[4][64]) {
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wv = threadIdx.x >> 6;
-    const int col = tile * 16 + c;
-    const int colc = col < n ? col : n - 1;
-    f32x4 a[4], gg[4], x[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) gg[T] = ld4(g + (size_t)colc * 64 + 16 * T + 4 * q);
-    f32x4 yo[4];  // integrated state
-    if (!ODE) {
-#pragma unroll
-        for (int T = 0; T < 4; ++T) a[T] = ld4(attn + (size_t)colc * ld_attn + 16 * T + 4 * q);
-        ode_rhs(w, sX, a, gg, x, lane, q, wv);
-        // torchdiffeq fixed-grid euler on t=[0,T]: y1 = y0 + T*f(y0) (ode_demo.py:188)
-#pragma unroll
-        for (int T = 0; T < 4; ++T) yo[T] = gg[T] + x[T] * ode_time;
-    } else {
-        auto F = [&](const f32x4 (&y)[4], f32x4 (&k)[4]) {
-            __syncthreads();  // previous stage's sX reads are done
-            {   // attention output for state y at attention length 1: v(y), row tile wv, exchanged through sX[2]
-                f32x4 v = ld4(vb + 16 * wv + 4 * q);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) v = mfma_k16(v, vP[(wv * 4 + T) * 64 + lane], y[T]);
-                sX[2][wv][lane] = v;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) a[T] = sX[2][T][lane];
-            __syncthreads();
-            ode_rhs(w, sX, a, y, k, lane, q, wv);
-        };
-        const float hstep = ode_time / (float)steps;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) yo[T] = gg[T];
-        for (int s = 0; s < steps; ++s) {
-            f32x4 k1[4], k2[4], k3[4], k4[4], t[4];
-            F(yo, k1);
-            if (method == 0) {
-#pragma unroll
-                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + k1[T] * hstep;
-            } else if (method == 1) {   // 3/8 rule (torchdiffeq rk4_alt_step_func)
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k1[T] * (hstep / 3.f);
-                F(t, k2);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + (k2[T] - k1[T] * (1.f / 3.f)) * hstep;
-                F(t, k3);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + (k1[T] - k2[T] + k3[T]) * hstep;
-                F(t, k4);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + (k1[T] + (k2[T] + k3[T]) * 3.f + k4[T]) * (hstep / 8.f);
-            } else {                    // classical RK4
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k1[T] * (hstep / 2.f);
-                F(t, k2);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k2[T] * (hstep / 2.f);
-                F(t, k3);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) t[T] = yo[T] + k3[T] * hstep;
-                F(t, k4);
-#pragma unroll
-                for (int T = 0; T < 4; ++T) yo[T] = yo[T] + (k1[T] + k2[T] * 2.f + k3[T] * 2.f + k4[T]) * (hstep / 6.f);
-            }
-        }
-    }
-    if (col < n) {
-        // pf = cat(ftraj_input, relu(ODE state at t = ode_time)) (ode_demo.py:231, model/STTODE.py:233-235); wave wv stores tile wv
-        const f32x4 go = wv == 0 ? gg[0] : wv == 1 ? gg[1] : wv == 2 ? gg[2] : gg[3];
-        const f32x4 xo = wv == 0 ? yo[0] : wv == 1 ? yo[1] : wv == 2 ? yo[2] : yo[3];
-        st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
-        st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
-    }
-}
-
 template <bool ODE>
 __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __restrict__ g, const float* __restrict__ attn, int ld_attn,
                                                         float* __restrict__ pf, int n, float ode_time, int method, int steps,
@@ -601,12 +326,16 @@ extern "C" int sttode_post_attn_ode(const float* outP, const float* outb, const 
     return 0;
 }
 
-// Internal (csrc/pipeline.hip): the fused per-agent stage above.  W = the model's weight table (enum SttodeWeight).  Returns -1 (nothing
-// launched) when the shape is outside the fused kernel's instantiation: the caller then takes the kernel-by-kernel path.
+// Internal (csrc/pipeline.hip): the fused per-agent stage above.  W = the model's weight table (enum SttodeWeight).
+// stt_agents_fused_covers is the ONE place that decides which shapes the fused kernel is instantiated for; the launcher refuses the rest.
+static size_t agents_fused_lds(int Tp) { return ((size_t)Tp * 256 + 512) * 16; }   // embed's need (>= post_attn's 16 KiB and the GRU's 12 KiB for Tp >= 2)
+bool stt_agents_fused_covers(int Tp, int TPX) {
+    return TPX == 1 && Tp >= 2 && agents_fused_lds(Tp) <= 64 * 1024 && agents_fused_lds(Tp) >= 16 * 1024;
+}
 int stt_agents_fused(const float* const* W, const float* enc_in, const int* last, float* g, float* qkv, float* pf, const float* xpad,
                      float* state0, int n, int Tp, int TPX, float ode_time, void* stream) {
-    const size_t lds = ((size_t)Tp * 256 + 512) * 16;          // embed's need (>= post_attn's 16 KiB and the GRU's 12 KiB for Tp >= 2)
-    if (TPX != 1 || lds > 64 * 1024 || lds < 16 * 1024) return -1;
+    STT_REQUIRE(stt_agents_fused_covers(Tp, TPX), "stt_agents_fused: shape outside the fused per-agent kernel (ask stt_agents_fused_covers first)");
+    const size_t lds = agents_fused_lds(Tp);
     AgentsFusedArgs a;
     a.ew.fc1P = W[STT_W_FC1P]; a.ew.fc1b = W[STT_W_FC1B]; a.ew.posP = (const f32x4*)W[STT_W_POSP]; a.ew.peb = W[STT_W_PEB];
     a.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; a.ew.fc2b = W[STT_W_FC2B]; a.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; a.ew.fc3b = W[STT_W_FC3B];

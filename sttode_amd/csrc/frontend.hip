@@ -4,12 +4,14 @@
 //              utils/metrics.py:7-26 (min-over-K ADE / FDE).
 // HBM-bound byte shuffling: one thread per scene / agent, coalesced over agents.
 #include "api_util.hpp"
+#include "../../include/sttode_hip.h"
 #include <string>
 
 static thread_local std::string g_err;
 void stt_set_error(const char* msg) { g_err = msg ? msg : ""; }
 extern "C" const char* sttode_last_error() { return g_err.c_str(); }
-extern "C" int sttode_abi_version() { return 1; }
+// bumped whenever an exported signature or an ABI enum (SttodeWeight / SttodeBuffer / SttodeStage) changes; capi.py checks it at load
+extern "C" int sttode_abi_version() { return STTODE_ABI_VERSION; }
 
 __global__ void scene_orig_kernel(const float* __restrict__ past, const int* __restrict__ scene_ptr, int S, int Tp,
                                   float* __restrict__ scene_orig, int* __restrict__ agent_scene) {

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <utility>
 #include <cstring>
+#include <mutex>
 
 #include <cstdlib>
 #define STT_MAX_PARTS 8
@@ -31,6 +32,7 @@ struct SttodeModel {
     // stream, so the grid tail of one part's kernel is filled by the next part's kernel (columns are independent).
     int col_parts;
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
+    int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
     int ode_method, ode_steps;  // integrator of the encoder ODE (0, 1 = one Euler step = the reference)
     int prog_len;
     hipStream_t part_stream[STT_MAX_PARTS];
@@ -47,6 +49,8 @@ struct SttodeModel {
     std::vector<TimRec> recs;
     std::vector<hipEvent_t> pool;
 };
+
+static std::mutex g_stream_mu;   // guards the creation of the process-wide streams (sA / sB / sB2 / side, per device)
 
 static inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // 256-byte alignment in floats
 
@@ -71,6 +75,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->chain_mode = -1;
     m->ode_method = 0; m->ode_steps = 1;
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
+    m->fused_mode = 1;
+    if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
     m->prog_len = sttode_chain_prog_len(Tp, Tf);
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
     if (const char* e = getenv("STTODE_COL_PARTS")) m->col_parts = atoi(e);
@@ -103,12 +109,15 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     static hipStream_t g_sA[STT_MAX_DEVICES] = {}, g_sB[STT_MAX_DEVICES] = {}, g_sB2[STT_MAX_DEVICES] = {};   // per device of this process
     int dev = 0;
     ok = ok && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STT_MAX_DEVICES;
-    if (ok && !g_sA[dev]) {
-        ok = mk_stream(&g_sA[dev], a_prio) && hipStreamCreateWithFlags(&g_sB[dev], hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithFlags(&g_sB2[dev], hipStreamNonBlocking) == hipSuccess;
-        if (!ok) g_sA[dev] = nullptr;
+    if (ok) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);   // models may be created from several host threads
+        if (!g_sA[dev]) {
+            ok = mk_stream(&g_sA[dev], a_prio) && hipStreamCreateWithFlags(&g_sB[dev], hipStreamNonBlocking) == hipSuccess &&
+                 hipStreamCreateWithFlags(&g_sB2[dev], hipStreamNonBlocking) == hipSuccess;
+            if (!ok) g_sA[dev] = nullptr;
+        }
+        if (ok) { m->sA = g_sA[dev]; m->sB = g_sB[dev]; m->sB2 = g_sB2[dev]; }
     }
-    if (ok) { m->sA = g_sA[dev]; m->sB = g_sB[dev]; m->sB2 = g_sB2[dev]; }
     ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
@@ -160,6 +169,7 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_YBUF, mm * 16 * m->NOY);
     put(STT_B_STATE1, mm * 96);
     put(STT_B_QUEUE, 64);
+    put(STT_B_FLAGS, (size_t)(n + 15) / 16 + 4);   // one flag per 16-agent tile + the time-out word (fused launch), zeroed per call
     *total_floats = (long)o;
     return 0;
 }
@@ -168,6 +178,13 @@ extern "C" int sttode_set_chain(SttodeModel* m, int mode) {
     STT_REQUIRE(m, "sttode_set_chain: null model");
     STT_REQUIRE(mode >= -1 && mode <= 1, "sttode_set_chain: mode must be -1 (auto), 0 or 1");
     m->chain_mode = mode;
+    return 0;
+}
+
+extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
+    STT_REQUIRE(m, "sttode_set_fused: null model");
+    STT_REQUIRE(mode == 0 || mode == 1, "sttode_set_fused: mode must be 0 or 1");
+    m->fused_mode = mode;
     return 0;
 }
 
@@ -244,7 +261,7 @@ struct StageTimer {
     StageTimer(SttodeModel* m_, int st, hipStream_t s_) : m(m_), stage(st), s(s_) {
         // the per-trajectory stages (two events per call) are bracketed on EVERY call while timing is enabled, so that overlapping launches
         // of consecutive calls are seen; the many short per-agent stages only on the sampled calls
-        on = m->timing || (m->timing_every > 0 && stage >= STT_STAGE_MLP0 && stage <= STT_STAGE_CHAIN);
+        on = m->timing || (m->timing_every > 0 && ((stage >= STT_STAGE_MLP0 && stage <= STT_STAGE_CHAIN) || stage == STT_STAGE_FUSED));
         if (on) { e0 = get_event(m); e1 = get_event(m); (void)hipEventRecord(e0, s); }
     }
     ~StageTimer() {
@@ -277,7 +294,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     static const bool fuse_on = !(getenv("STTODE_AGENTS_FUSED") && atoi(getenv("STTODE_AGENTS_FUSED")) == 0);
     static const int gru0_lat_p = getenv("STTODE_GRU0_LAT_TILES") ? atoi(getenv("STTODE_GRU0_LAT_TILES")) : 4096;
     const int ntiles = (n + 15) / 16;
-    if (fuse_on && attn_len == 1 && m->ode_method == 0 && m->ode_steps == 1 && TPX == 1 && Tp >= 2 &&
+    if (fuse_on && attn_len == 1 && m->ode_method == 0 && m->ode_steps == 1 && stt_agents_fused_covers(Tp, TPX) &&
         ntiles <= (use_side ? stt_gru_lat_tiles() : gru0_lat_p) && ntiles <= stt_enc_lat_tiles()) {
         RUN(STT_STAGE_AGENTS, s,
             stt_agents_fused(W, ws + off[STT_B_ENC_IN], (const int*)(ws + off[STT_B_LAST]), g, qkv, pf, xpad, state0, n, Tp, TPX, 12.0f, s));
@@ -294,8 +311,11 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         int dev = 0;
         STT_HIP(hipGetDevice(&dev));
         STT_REQUIRE(dev >= 0 && dev < STT_MAX_DEVICES, "sttode_inference_*: device index beyond STT_MAX_DEVICES");
-        if (!g_side[dev]) STT_HIP(hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking));
-        m->side = g_side[dev];
+        {
+            std::lock_guard<std::mutex> lk(g_stream_mu);
+            if (!g_side[dev]) STT_HIP(hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking));
+            m->side = g_side[dev];
+        }
     }
     hipStream_t gs = use_side ? m->side : s;
     if (use_side) {
@@ -418,6 +438,18 @@ static int frontend(SttodeModel* m, float* ws, const long* off, const float* pas
     return 0;
 }
 
+// Fused launch (csrc/chain32.hip, RoleArgs): scene batches (attention length 1) with the reference's integrator whose per-trajectory
+// stage takes the fused chain anyway; the per-agent stage then needs no launch, no stream and no free compute unit of its own.
+static bool use_fused(const SttodeModel* m, int n, bool scenes) {
+    const long ncols_all = (long)n * m->K;
+    const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
+    return m->fused_mode == 1 && scenes && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_agents_fused_covers(m->Tp, m->TPX);
+}
+static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, const float* z, float* pred, hipStream_t s) {
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(m->w, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, 2, s));
+    return 0;
+}
+
 // serial form: everything on the caller's stream
 static inline void arm_timing(SttodeModel* m) {
     m->timing = m->timing_every > 0 && (m->calls % m->timing_every) == 0;
@@ -430,6 +462,7 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
+    if (use_fused(m, n, scene_ptr != nullptr)) return stage_fused(m, ws, off, n, z, pred, s);
     if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
     return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
@@ -442,6 +475,18 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
+    if (use_fused(m, n, scene_ptr != nullptr)) {
+        // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
+        // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)
+        hipStream_t sf = (m->acalls % 3 == 0) ? m->sB : (m->acalls % 3 == 1) ? m->sB2 : m->sA;
+        ++m->acalls;
+        STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));
+        STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));   // the slot's previous user has drained
+        if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
+        if (int rc = stage_fused(m, ws, off, n, z, pred, sf)) return rc;
+        STT_HIP(hipEventRecord(m->evB_done[slot], sf));
+        return 0;
+    }
     STT_HIP(hipStreamWaitEvent(m->sA, m->ev_call, 0));
     STT_HIP(hipStreamWaitEvent(m->sA, m->evB_done[slot], 0));    // the slot's previous user (call i-2) has drained
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, m->sA)) return rc;

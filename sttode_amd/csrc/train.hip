@@ -916,11 +916,7 @@ extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* d
     STT_REQUIRE(qkv && dO && dqkv && L > 0 && Nb > 0, "sttode_mhgsa_attn_bwd: bad argument");
     STT_REQUIRE(L <= 1024, "sttode_mhgsa_attn_bwd: attention length must be <= 1024 for the training backward");
     const size_t shm = (size_t)L * (32 + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        STT_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    STT_SET_LDS_ONCE(attn_bwd_kernel, 160 * 1024);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(Nb * 8), dim3(L < 256 ? ((L + 63) / 64) * 64 : 256), shm, (hipStream_t)stream, qkv, dO, dqkv, L, Nb);
     STT_HIP(hipGetLastError());
     return 0;

@@ -503,13 +503,23 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         if ctx.ready is not None:                                  # graph replay already produced the gradients
-            flat, views = ctx.ready
+            flat, views, state = ctx.ready
+            _consume(state)
             flat.mul_(gout)
             G = views
         else:
             G = ctx.engine.run_backward(gout, ctx.step_id)
         _hand_over(G, ctx.names, ctx.params)
         return None, None, None, None, None, None
+
+
+def _consume(state):
+    """A graph-replay step hands its gradients over ONCE, through whichever path comes first (the direct one of _LossTensor.backward or
+    the autograd node): a second backward() raises like the eager step's consumed tape does, instead of silently doubling ``.grad``."""
+    if state['consumed']:
+        raise SttodeError('training backward: the tape of this forward() was already consumed (backward() called twice on a '
+                          'graph-replayed step); call forward() again')
+    state['consumed'] = True
 
 
 def _hand_over(G, names, params):
@@ -538,6 +548,7 @@ class _LossTensor(torch.Tensor):
         self._sttode_step = None
         engine, names, ready, params, step_id = fast
         if ready is not None:
+            _consume(ready[2])
             G = ready[1]                                           # graph replay already produced the gradients
         else:
             G = engine.run_backward(None, step_id)
@@ -596,7 +607,33 @@ class _GraphedStep:
             if k in G:
                 views[k] = flat[off: off + v.numel()].view(v.shape)
             off += ((v.numel() + 3) // 4) * 4
-        return losses.clone(), (flat, views)
+        return losses.clone(), (flat, views, {'consumed': False})
+
+
+def _names_params(eng, net):
+    """(names, parameters, pointer token) of ``net``, cached on the engine and VALIDATED on every call: each cached Parameter must still
+    be the object registered under its name in its module, and each module the one registered in its parent (~130 dict look-ups; walking
+    named_parameters() every step costs ~0.1 ms of a 1.3 ms step).  A replaced Parameter or sub-module rebuilds the cache, and the token
+    -- a hash of every parameter's storage pointer, part of the hipGraph key -- changes with it, so a captured graph is never replayed
+    against parameters it does not hold and ``.grad`` lands on the live objects."""
+    cache = getattr(eng, '_names_params', None)
+    if cache is not None:
+        names, params, token, pslots, mslots = cache
+        if all(m._parameters.get(k) is p for m, k, p in pslots) and all(pm._modules.get(k) is m for pm, k, m in mslots):
+            return names, params, token
+    names, params, pslots, mslots = [], [], [], []
+    for mname, mod in net.named_modules():
+        if mname:
+            parent, _, leaf = mname.rpartition('.')
+            mslots.append((net.get_submodule(parent) if parent else net, leaf, mod))
+    for name, p in net.named_parameters():
+        mname, _, leaf = name.rpartition('.')
+        names.append(name)
+        params.append(p)
+        pslots.append((net.get_submodule(mname) if mname else net, leaf, p))
+    token = hash(tuple(p.data_ptr() for p in params))
+    eng._names_params = (names, params, token, pslots, mslots)
+    return names, params, token
 
 
 def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
@@ -618,13 +655,10 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     if eng is None or eng.dev != dev:
         eng = net._engine = Engine(net)
         net._graphs, net._graph_seen = {}, set()
-    cache = getattr(eng, '_names_params', None)
-    if cache is None or cache[1][0] is not next(net.parameters()):
-        cache = eng._names_params = ([k for k, _ in net.named_parameters()], [p for _, p in net.named_parameters()])
-    names, params = cache
+    names, params, ptr_token = _names_params(eng, net)
     ready = None
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
-           params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
+           ptr_token, params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
            float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
     # launch-bound regime only (one scene, <= ~100 agents): at NBA batch sizes the kernels dominate and replay is no faster
     if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= 100:

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
     assert len(fns) >= 20
     for name in fns:
         assert hasattr(L, name), f'{name} declared in include/sttode_hip.h but not exported'
-    assert L.sttode_abi_version() == 1
+    assert L.sttode_abi_version() == capi.ABI_VERSION
 
 
 def test_ctypes_table_matches_header():

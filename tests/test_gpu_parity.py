@@ -39,7 +39,7 @@ def hip_model(dataset='eth', Tp=8, Tf=12, seed=1234):
 def test_library_loaded_and_fails_loudly_on_cpu():
     from sttode_amd import STTODENet, capi
     _gpu()
-    assert capi.lib().sttode_abi_version() == 1
+    assert capi.lib().sttode_abi_version() == capi.ABI_VERSION
     m = STTODENet(make_args(), 'cpu')
     m.set_data(None, torch.zeros(3, 2, 8), torch.zeros(3, 2, 12))
     with pytest.raises(capi.SttodeError):
@@ -434,6 +434,63 @@ def test_pmath_op_library_vs_reference_golden(golden):
     a, b = T(o['obl_a']), T(o['obl_b'])
     np.testing.assert_allclose(pm.oblique_proj(a).cpu().numpy(), o['obl_proj_a'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pm.oblique_dist(pm.oblique_proj(a), pm.oblique_proj(b)).cpu().numpy(), o['obl_dist'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('nsc', [61, 512])
+def test_fused_launch_is_bitwise_the_separate_per_agent_launches(nsc):
+    """Round 3: the per-agent stage as leading workgroups of the chain launch (csrc/chain32.hip agent_role; one flag per 16-agent tile,
+    sc1 payload stores, consumer poll + agent-scope acquire) against the separate per-agent launches: predictions AND every per-agent
+    intermediate (g, qkv, pf, state0, the three layer-1 tables) bit for bit.  The hand-off is exercised the way the guide asks
+    (uneven load, warm caches, every word): the SAME workspace is reused by back-to-back calls with DIFFERENT inputs, serially and with
+    three calls in flight, so a stale L1 / L2 line or a flag that overtakes its payload shows up as a mismatch."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(2000, 2000 + nsc), 'eth')
+    n, S = sb.n_agents, sb.n_scenes
+    variants = []
+    for v in range(4):                                    # same shapes (one workspace), different numbers
+        past = (sb.past * (1.0 + 0.03 * v) + 0.1 * v).astype(np.float32)
+        variants.append((torch.from_numpy(past).to(m.device), torch.from_numpy(sb.future).to(m.device),
+                         torch.from_numpy(sb.scene_ptr).to(m.device), torch.from_numpy(scenes.latents(300 + v, n)).to(m.device)))
+    names = (('g', 64), ('qkv', 192), ('pf', 128), ('state0', 96), ('A0x', 512), ('A0y', 512), ('A1y', 512))
+
+    def run(v, fused):
+        past, fut, ptr, z = variants[v]
+        m.native().set_fused(fused)
+        m.set_scene_batch(past, fut, ptr)
+        out = m.inference(None, z=z).clone()
+        buf, off = m._workspace(n, S)
+        inter = {k: m._view(buf, off, k, n, w).clone() for k, w in names}
+        return out, inter
+    try:
+        m.native().set_chain(1)                           # the 61-scene batch is below the automatic chain threshold
+        ref = [run(v, 0) for v in range(4)]
+        for rep in range(3):
+            for v in (0, 3, 1, 2):
+                out, inter = run(v, 1)
+                assert torch.isfinite(out).all()
+                assert torch.equal(out, ref[v][0]), f'variant {v} rep {rep}: fused launch != separate launches'
+                for k, _ in names:
+                    assert torch.equal(inter[k], ref[v][1][k]), f'variant {v} rep {rep}: {k} differs'
+        # three calls in flight on the pipeline's streams, workspace slots reused every third call
+        m.native().set_fused(1)
+        m.reset_async()
+        handles, outs, order = [], [], [0, 1, 2, 3, 2, 0, 3, 1, 1, 0]
+        for v in order:
+            past, fut, ptr, z = variants[v]
+            m.set_scene_batch(past, fut, ptr)
+            handles.append(m.inference_async(z=z))
+            if len(handles) >= 3:
+                outs.append(m.wait(handles.pop(0)).clone())
+        while handles:
+            outs.append(m.wait(handles.pop(0)).clone())
+        torch.cuda.synchronize()
+        for i, v in enumerate(order):
+            assert torch.equal(outs[i], ref[v][0]), f'pipelined call {i} (variant {v}): fused launch != separate launches'
+    finally:
+        m.native().set_fused(1)
+        m.native().set_chain(-1)
+        m.reset_async()
 
 
 def test_async_pipeline_is_bitwise_identical_to_serial():
