@@ -127,8 +127,16 @@ def selftest_dist(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt, total = float(tmax[0]), float(tt[1])
+    gather = None
+    if dist is not None and not args.no_gather_futures:            # the collective of gather_futures_leg on ragged host rows (gloo)
+        from sttode_amd import parallel
+        rows = torch.full((rank + 2, 4), float(rank))
+        allr = parallel.gather_futures(rows)
+        want_rows = sum(r + 2 for r in range(world))
+        gather = {'check': 'ok' if allr.shape[0] == want_rows and float(allr.sum()) == float(sum(4 * r * (r + 2) for r in range(world))) else 'MISMATCH',
+                  'gathered_rows': int(allr.shape[0]), 'ranks': world}
     if rank == 0:
-        print(json.dumps({'metric': 'selftest units/sec', 'value': total * args.steps / dt, 'n_gpus': world,
+        print(json.dumps({'metric': 'selftest units/sec', 'value': total * args.steps / dt, 'n_gpus': world, 'gather': gather,
                           'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'backend': 'gloo (selftest, no GPU)',
                           'self_launched': bool(os.environ.get('STTODE_BENCH_SELF_LAUNCHED')), 'steps': args.steps}))
     if dist is not None:
@@ -239,10 +247,13 @@ class Leg:
             out = self._finish(self.pending.pop(0))
         return out
 
-    def timed(self, steps, warmup, dist, time_every, serial=False, d2h=False):
+    def timed(self, steps, warmup, dist, time_every, serial=False, d2h=False, gather=False):
         """W untimed + exactly `steps` timed steps, barrier + synchronize on both sides, MAX over ranks.
-        d2h: additionally copy every step's futures to pinned host memory inside the timed region."""
+        d2h: additionally copy every step's futures to pinned host memory inside the timed region.
+        gather: additionally all-gather every step's futures [n_r, K, Tf, 2] over the ranks (parallel.gather_futures: RCCL over xGMI),
+        which is what the reference's metric path needs when the futures are wanted on one rank (test.py:194,526)."""
         import torch
+        from sttode_amd import parallel
         dev = self.dev
         hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H target
         acc = None
@@ -264,12 +275,16 @@ class Leg:
                 acc = r
                 if d2h:
                     hostbuf.copy_(self.last_pred, non_blocking=True)
+                if gather:
+                    self.gathered = parallel.gather_futures(self.last_pred)
         t_host = time.perf_counter() - t0                         # the host's share: enqueueing `steps` steps (no device sync inside)
         r = self.drain()                                          # every one of the K steps completes inside the timed region
         if r is not None:
             acc = r
             if d2h:
                 hostbuf.copy_(self.last_pred, non_blocking=True)
+            if gather:
+                self.gathered = parallel.gather_futures(self.last_pred)
         acc = self.sums(acc)                                      # the last step's per-agent best-of-K values -> (sum ADE, sum FDE, agents)
         if dist is not None:
             dist.all_reduce(acc)                                  # metrics of the last step over all ranks
@@ -397,6 +412,38 @@ class Leg:
         if self.kind == 'nba':
             c['attention_group'] = self.G
         return c
+
+
+def gather_futures_leg(head, dist, rank, world, acc, args):
+    """The one collective the north star names, under the process group the bench runs on (RCCL when launched on GPUs): all-gather of the
+    predicted futures [n_r, K, Tf, 2] of every rank (parallel.gather_futures; the reference's metric path wants the futures in one
+    place: test.py:194,526; its only distributed code: core/utils.py:370-389).  (1) correctness: the gathered futures and the gathered
+    ground truth give, on every rank, the SAME best-of-K ADE / FDE sums as the all-reduced per-rank sums of the timed run; (2) shard
+    balance: agents per rank; (3) value_incl_gather: the timed region once more with the gather inside every step."""
+    import torch
+    from sttode_amd import parallel
+    pred_all = parallel.gather_futures(head.last_pred)                               # [sum n_r, K, Tf, 2], rank order
+    gt_all = parallel.gather_futures(head.model._future.contiguous())                # [sum n_r, Tf, 2]
+    counts = [torch.zeros(1, dtype=torch.int64, device=head.dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([head.n], dtype=torch.int64, device=head.dev))
+    counts = [int(c) for c in counts]
+    ade, fde = head.model.best_of_k(pred_all, gt=gt_all)
+    got = torch.stack((ade.double().sum(), fde.double().sum())).cpu()
+    la, lf = head.model.best_of_k(head.last_pred, gt=head.model._future)             # the same futures, rank by rank: local sums, all-reduced
+    want = torch.stack((la.double().sum(), lf.double().sum()))
+    dist.all_reduce(want)
+    want = want.cpu()
+    rel = float(((got - want).abs() / want.abs().clamp_min(1e-12)).max())
+    ok = pred_all.shape[0] == sum(counts) and int(acc[2]) == sum(counts) and rel < 1e-6
+    r3 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, gather=True)
+    res = {'collective': 'all_gather of the futures [n_r, K, Tf, 2] fp32, padded to the largest shard (sttode_amd.parallel.gather_futures)',
+           'backend': dist.get_backend(), 'ranks': world, 'agents_per_rank': counts, 'gathered_rows': int(pred_all.shape[0]),
+           'bytes_per_rank_per_step': int(head.n * K * head.Tf * 2 * 4),
+           'sums_from_gathered_vs_allreduced_rel_err': rel, 'check': 'ok' if ok else 'MISMATCH',
+           'ms_per_step_incl_gather': r3['ms_per_step'], 'value_incl_gather': r3['value']}
+    if not ok:
+        sys.stderr.write(f'bench.py: gathered futures disagree with the all-reduced metric sums on rank {rank}: {res}\n')
+    return res
 
 
 def train_bench(args, rank, world, dev, dist, cpu=True):
@@ -529,6 +576,7 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--no-gather-futures', action='store_true', help='multi-rank runs: skip the all-gather of the futures (check + value_incl_gather)')
     ap.add_argument('--selftest-dist', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -577,6 +625,11 @@ def main():
     r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
     out['ms_per_step_incl_d2h'] = r2['ms_per_step']
+
+    if dist is not None and not args.no_gather_futures:
+        out['gather'] = gather_futures_leg(head, dist, rank, world, acc, args)
+        if rank == 0:
+            out['value_incl_gather'] = out['gather'].pop('value_incl_gather')
 
     want = [k for k in LEGS if k != 'eth_512'] if args.legs == 'all' else [] if args.legs == 'none' else args.legs.split(',')
     do_cpu = rank == 0 and world == 1 and not args.no_cpu

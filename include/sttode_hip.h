@@ -331,10 +331,11 @@ int sttode_set_col_parts(SttodeModel* m, int parts);
 /* per-trajectory stage: 1 = fused chain kernel (sttode_traj_chain), 0 = the three-kernel form (mlp_block0 -> gru_cols -> mlp_block1),
  * -1 = automatic (fused when the batch has >= 128 trajectories per workgroup slot to fill; default, or env STTODE_CHAIN). */
 int sttode_set_chain(SttodeModel* m, int mode);
-/* Scene batches whose per-trajectory stage takes the fused chain: 1 (default, or env STTODE_FUSED) = the per-agent stage (encoder, block-0
- * GRU, layer-1 pre-activation tables: PastEncoder.forward model/STTODE.py:214-236, DecomposeBlock.forward :62-75 of block 0) runs as the
- * leading workgroups of the chain launch, trajectory groups wait on one flag per 16-agent tile; 0 = separate launches on the pipeline's
- * per-agent stream.  Results are bitwise the same either way. */
+/* Calls whose per-trajectory stage takes the fused chain: 1 (default, or env STTODE_FUSED) = the per-agent stage (encoder, block-0 GRU,
+ * layer-1 pre-activation tables: PastEncoder.forward model/STTODE.py:214-236, DecomposeBlock.forward :62-75 of block 0) runs as the
+ * leading workgroups of the chain launch, trajectory groups wait on one flag per 16-agent tile (attention groups > 1, the NBA branch:
+ * the embedding and the attention stay launches in front, the roles start at the post-attention layer); 0 = separate launches on the
+ * pipeline's per-agent stream.  Results are bitwise the same either way. */
 int sttode_set_fused(SttodeModel* m, int mode);
 /* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
  * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */

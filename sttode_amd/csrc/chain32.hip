@@ -56,6 +56,8 @@ struct RoleArgs {
     const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
     const f32x4* WAx; const float* b1x; const f32x4* WAy; const float* b1y; const f32x4* WA1; const float* b11;
     float* A0x; float* A0y; float* A1y;
+    const float* attn; int ld_attn;   // attention output of an EARLIER launch (attention groups > 1, the NBA branch): the role then starts
+                                      // at the post-attention layer; nullptr: attention length 1, the role runs the embedding too
     unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
     int ntiles; float ode_time;
 };
@@ -380,16 +382,19 @@ __device__ __forceinline__ void agent_role(const ChainArgs& A, int tile, char* s
     // slower than alone (283 vs 150 us, profiles/r03/trace_*), holding a workgroup slot all the while.  Raised priority lets its few
     // instructions issue first; the chain wave loses the same handful of pipe cycles either way.
     __builtin_amdgcn_s_setprio(ROLE_PRIO);
-    embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, A.Tp, tile, reinterpret_cast<f32x4*>(smem));
-    __syncthreads();                              // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
+    if (R.attn == nullptr) {                      // (uniform) attention length 1: softmax over one key == 1, the attention output is v
+        embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, A.Tp, tile, reinterpret_cast<f32x4*>(smem));
+        __syncthreads();                          // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
+    }
     C32_TRACE_PHASE(0);
-    post_attn_body<false>(R.pw, R.g, R.qkv + 128, 192, R.pf, nag, R.ode_time, 0, 1, nullptr, nullptr, tile,
+    post_attn_body<false>(R.pw, R.g, R.attn ? R.attn : R.qkv + 128, R.attn ? R.ld_attn : 192, R.pf, nag, R.ode_time, 0, 1, nullptr, nullptr, tile,
                           reinterpret_cast<f32x4(*)[4][64]>(smem));
     __syncthreads();                              // pf of this tile is visible to the workgroup; LDS changes hands again
     C32_TRACE_PHASE(1);
     f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
-    const int cur = gru_lat4_body(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH,
-                                  reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64);
+    f32x4* sW45 = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
+    const int cur = A.ldx == 16 ? gru_lat4_body<1>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH, sW45)
+                                : gru_lat4_body<2>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH, sW45);
     C32_TRACE_PHASE(2);
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -770,18 +775,21 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
 
 // Internal (csrc/pipeline.hip): the fused launch -- per-agent roles + trajectory groups in ONE grid (see RoleArgs).  W = the model's
 // weight table (enum SttodeWeight), ws / off = the caller's workspace and its layout; the front-end (xpad, enc_in, cur, orig, last) has
-// run on `stream` before.  Covers what the stand-alone fused per-agent kernel covers (stt_agents_fused_covers: attention length 1, the
-// reference's one Euler step, 2*Tp <= 16).
+// run on `stream` before.  attn == nullptr: attention length 1 (scene batches), the roles run the embedding too; attn != nullptr (the NBA
+// branch: attention groups > 1): embed_qkv and mhgsa_attn have run on `stream` before, the roles start at the post-attention layer.
+// The reference's one Euler step only.
+bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, int wgs_per_cu, void* stream) {
+                    float ode_time, const float* attn, int ld_attn, int wgs_per_cu, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
-    STT_REQUIRE(n > 0 && K > 0 && stt_agents_fused_covers(Tp, 1) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
+    STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
+    STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
     STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "stt_chain_fused: chunk program length does not match (Tp, Tf)");
     STT_REQUIRE((long)n * K <= 0x7fffffffL, "stt_chain_fused: too many trajectories");
     ChainArgs a;
     a.A0x = ws + off[STT_B_A0X]; a.A0y = ws + off[STT_B_A0Y]; a.A1y = ws + off[STT_B_A1Y];
     a.pool = (const f32x4*)W[STT_W_CHAIN_POOL]; a.prog = (const int2*)W[STT_W_CHAIN_PROG]; a.prog_len = prog_len;
-    a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 16; a.cur = ws + off[STT_B_CUR];
+    a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.cur = ws + off[STT_B_CUR];
     a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
     a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0;
 #if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
@@ -803,6 +811,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     r.WAx = (const f32x4*)W[STT_W_B0_XWA]; r.b1x = W[STT_W_B0_XB1]; r.WAy = (const f32x4*)W[STT_W_B0_YWA]; r.b1y = W[STT_W_B0_YB1];
     r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
     r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
+    r.attn = attn; r.ld_attn = ld_attn;
     r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;

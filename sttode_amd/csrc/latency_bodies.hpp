@@ -386,6 +386,7 @@ __device__ __forceinline__ void st4_sc1(float* p, const f32x4 v) {
 // (sW45: [2][3 gates][8 k-tiles][64] f32x4 = 48 KiB, by LDS-DMA).  A split over output rows: every element of h is the k-ordered chain
 // of gru_lat_body / gru_cols_kernel, so the bits are those of the other forms.  Returns the index of the sH buffer that holds the final
 // hidden state (all six tiles, B-operand fragment layout), which the caller may feed straight into the next layer.
+template <int TPX>
 __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, const f32x4* __restrict__ convP, const float* __restrict__ convB,
                                              const f32x4* __restrict__ wihP, const f32x4* __restrict__ whhP, const float* __restrict__ gbias,
                                              float* __restrict__ state, int ncols, int Tp, int tile, f32x4 (*sH)[6][64], f32x4* sW45) {
@@ -414,13 +415,17 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
 #pragma unroll
     for (int g = 0; g < 4; ++g) { b0[g] = ld4(gbias + g * 96 + 16 * w + 4 * q); b1[g] = ld4(gbias + g * 96 + 16 * w2 + 4 * q); }
     const f32x4 cb0 = ld4(convB + 4 * q), cb1 = ld4(convB + 16 + 4 * q);
-    const f32x4 d = ld4(xin + (size_t)colc * 16 + 4 * q);
+    f32x4 d[TPX];
+#pragma unroll
+    for (int T = 0; T < TPX; ++T) d[T] = ld4(xin + (size_t)colc * (16 * TPX) + 16 * T + 4 * q);
     f32x4 hn = splat4(0.f), hn2 = splat4(0.f);
     sH[0][w][lane] = hn;
     if (w < 2) sH[0][4 + w][lane] = hn2;
-    f32x4 cw[2];
+    f32x4 cw[2][TPX];
 #pragma unroll
-    for (int io = 0; io < 2; ++io) cw[io] = convP[io * 64 + lane];
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed; the barrier publishes everybody's
     __syncthreads();
     const f32x4* wB = sW45 + (size_t)(w & 1) * (24 * 64) + lane;
@@ -429,11 +434,17 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
     for (int t = 0; t < Tp; ++t) {
         f32x4 e[2] = {cb0, cb1};
 #pragma unroll
-        for (int io = 0; io < 2; ++io) e[io] = relu4(mfma_k16(e[io], cw[io], d));
+        for (int io = 0; io < 2; ++io) {
+#pragma unroll
+            for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
+            e[io] = relu4(e[io]);
+        }
         {
             const int tn = (t + 1 < Tp) ? t + 1 : 0;
 #pragma unroll
-            for (int io = 0; io < 2; ++io) cw[io] = convP[(2 * tn + io) * 64 + lane];
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
         }
         {
             f32x4 ar = b0[0], az = b0[1], ai = b0[2], ah = b0[3];

@@ -438,15 +438,30 @@ static int frontend(SttodeModel* m, float* ws, const long* off, const float* pas
     return 0;
 }
 
-// Fused launch (csrc/chain32.hip, RoleArgs): scene batches (attention length 1) with the reference's integrator whose per-trajectory
-// stage takes the fused chain anyway; the per-agent stage then needs no launch, no stream and no free compute unit of its own.
-static bool use_fused(const SttodeModel* m, int n, bool scenes) {
+// Fused launch (csrc/chain32.hip, RoleArgs): calls with the reference's integrator whose per-trajectory stage takes the fused chain anyway;
+// the per-agent stage then needs no launch, no stream and no free compute unit of its own.  Attention groups > 1 (the NBA branch) keep
+// embed_qkv and mhgsa_attn as launches in front (the attention reads every agent of the group); the roles start behind them.
+static bool use_fused(const SttodeModel* m, int n) {
     const long ncols_all = (long)n * m->K;
     const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
-    return m->fused_mode == 1 && scenes && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_agents_fused_covers(m->Tp, m->TPX);
+    return m->fused_mode == 1 && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_chain_fused_covers(m->Tp);
 }
-static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, const float* z, float* pred, hipStream_t s) {
-    RUN(STT_STAGE_FUSED, s, stt_chain_fused(m->w, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, 2, s));
+static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z, float* pred, hipStream_t s) {
+    const float* const* W = m->w;
+    const float* attn = nullptr;
+    if (attn_len > 1) {
+        float* qkv = ws + off[STT_B_QKV];
+        RUN(STT_STAGE_EMBED, s,
+            sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
+                             W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],
+                             (const int*)(ws + off[STT_B_LAST]), ws + off[STT_B_G], qkv, n, m->Tp, s));
+        const long st_seq = (long)attn_slots * 192;   // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
+        RUN(STT_STAGE_ATTN, s,
+            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, ws + off[STT_B_ATTN], nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192,
+                              st_seq, 192, st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+        attn = ws + off[STT_B_ATTN];
+    }
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, 2, s));
     return 0;
 }
 
@@ -462,7 +477,7 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
-    if (use_fused(m, n, scene_ptr != nullptr)) return stage_fused(m, ws, off, n, z, pred, s);
+    if (use_fused(m, n)) return stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, s);
     if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
     return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
@@ -475,7 +490,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
-    if (use_fused(m, n, scene_ptr != nullptr)) {
+    if (use_fused(m, n)) {
         // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
         // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)
         hipStream_t sf = (m->acalls % 3 == 0) ? m->sB : (m->acalls % 3 == 1) ? m->sB2 : m->sA;
@@ -483,7 +498,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
         STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));
         STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));   // the slot's previous user has drained
         if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
-        if (int rc = stage_fused(m, ws, off, n, z, pred, sf)) return rc;
+        if (int rc = stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, sf)) return rc;
         STT_HIP(hipEventRecord(m->evB_done[slot], sf));
         return 0;
     }

@@ -94,3 +94,4 @@ def test_bench_self_launch_spawns_the_ranks():
     d = json.loads(line[0])
     assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['self_launched'] is True and d['steps'] == 3
     assert d['value'] > 0 and d['backend'].startswith('gloo')
+    assert d['gather'] == {'check': 'ok', 'gathered_rows': 5, 'ranks': 2}      # the futures all-gather of the multi-rank line, rehearsed on host rows
