@@ -159,7 +159,7 @@ LEGS = {
 
 
 class Leg:
-    DEPTH = 3
+    DEPTH = 4
 
     def __init__(self, name, rank, dev, size=None):
         import torch
@@ -565,10 +565,11 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
-    ap.add_argument('--depth', type=int, default=3, help='calls in flight of the software pipeline (2..4)')
+    ap.add_argument('--depth', type=int, default=4, help='calls in flight of the software pipeline (2..4): workspace / prediction slots; the launches rotate over three streams')
     ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
     ap.add_argument('--legs', default='all', help="secondary legs: 'all', 'none' or a comma list of " + ','.join(k for k in LEGS if k != 'eth_512'))
     ap.add_argument('--leg-steps', type=int, default=40)
+    ap.add_argument('--only-leg', default='', help='run ONE leg alone (profiling passes) and print a short line')
     ap.add_argument('--train', action='store_true', help='print ONLY the training line (secondary metric: train.py:72-95 loop)')
     ap.add_argument('--no-train', action='store_true', help='skip the "train" object of the default line')
     ap.add_argument('--train-batch', type=int, default=1, help='scenes per optimizer step (1 = the reference loop)')
@@ -576,6 +577,7 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
     ap.add_argument('--no-gather-futures', action='store_true', help='multi-rank runs: skip the all-gather of the futures (check + value_incl_gather)')
     ap.add_argument('--selftest-dist', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -602,6 +604,21 @@ def main():
         return 0
 
     Leg.DEPTH = max(2, min(4, args.depth))
+    if args.only_leg:
+        # one leg alone (profiling passes: `rocprofv3 --kernel-trace --stats -- python3 bench.py --only-leg sdd_1024 --serial` gives that
+        # leg's serial per-launch durations without the headline's launches of the same kernel in the table)
+        if args.only_leg not in LEGS:
+            sys.stderr.write(f'bench.py: unknown leg {args.only_leg!r}\n')
+            return 2
+        leg = Leg(args.only_leg, rank, dev, size=args.scenes if args.only_leg == 'eth_512' else None)
+        lr = leg.timed(args.leg_steps, 5, dist, 1, serial=args.serial)
+        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 1)
+        if rank == 0:
+            print(json.dumps({'leg': args.only_leg, 'serial': bool(args.serial), 'value': lr['value'], 'ms_per_step': lr['ms_per_step'], 'steps': args.leg_steps,
+                              'config': leg.config(world), 'roofline': lroof, 'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
     head = Leg('eth_512', rank, dev, size=args.scenes)
     if args.col_parts:
         head.model.native().set_col_parts(args.col_parts)
@@ -609,6 +626,15 @@ def main():
     roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every)
     if roof:
         roof['path_frac_survey_flops_superseded'] = r['value'] / world * F_TRAJ_SURVEY / PEAK_F32_MFMA
+    if roof and not args.serial and not args.no_serial_check:
+        # the same kernel with ONE launch in flight (a few serial steps, every launch bracketed): the plain per-launch formula
+        # flop_per_launch / mean launch duration, the figure `rocprofv3 --kernel-trace --stats` of `bench.py --serial` reproduces
+        rs = head.timed(8, 2, dist, 1, serial=True)
+        ms, cnt = rs['stage_ms'].get(roof['kernel'], (0.0, 0))
+        if cnt:
+            roof['mean_launch_s_serial'] = ms * 1e-3 / cnt
+            roof['frac_serial_equivalent'] = roof['flop_per_launch'] / roof['mean_launch_s_serial'] / PEAK_F32_MFMA
+            roof['ms_per_step_serial'] = rs['ms_per_step']
     acc = r['metrics']
     out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'steps': args.steps, 'warmup': args.warmup,
@@ -617,8 +643,8 @@ def main():
            'config': head.config(world), 'roofline': roof, 'kernels': kern,
            'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
                            'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
-           'kernels_note': 'HIP-event durations on the launch streams; in the pipelined run the per-agent stages execute beside the previous '
-                           "batch's per-trajectory kernels, so their durations include waiting for compute units"}
+           'kernels_note': 'HIP-event durations on the launch streams; launches of consecutive pipelined steps share the chip (three streams in '
+                           'rotation), so a launch takes longer than it would alone; the fused launch contains the per-agent roles'}
     if rank == 0:
         out['ade_fde_synthetic'] = [float(acc[0] / acc[2]), float(acc[1] / acc[2])]
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
@@ -647,9 +673,15 @@ def main():
         leg = Leg(name, rank, dev)
         # two timed regions, the faster one reported (both kept in `ms_per_step_runs`): a leg's region is only 20-80 ms long, and one
         # host pause (first use of an allocation size, a collector run of another library) moves it by tens of percent
-        runs = [leg.timed(args.leg_steps, 5, dist, 2) for _ in range(2)]
+        runs = [leg.timed(args.leg_steps, 5, dist, 1 if args.serial else 2, serial=args.serial) for _ in range(2)]
         lr = min(runs, key=lambda r: r['ms_per_step'])
         lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2)
+        if lroof and not args.serial and not args.no_serial_check:
+            rs = leg.timed(8, 2, dist, 1, serial=True)
+            ms, cnt = rs['stage_ms'].get(lroof['kernel'], (0.0, 0))
+            if cnt:
+                lroof['mean_launch_s_serial'] = ms * 1e-3 / cnt
+                lroof['frac_serial_equivalent'] = lroof['flop_per_launch'] / lroof['mean_launch_s_serial'] / PEAK_F32_MFMA
         legs[name] = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'],
                       'host_enqueue_ms_per_step': lr['host_ms_per_step'], 'ms_per_step_runs': [r['ms_per_step'] for r in runs],
                       'steps': args.leg_steps, 'config': leg.config(world), 'roofline': lroof,

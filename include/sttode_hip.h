@@ -334,9 +334,14 @@ int sttode_set_chain(SttodeModel* m, int mode);
 /* Calls whose per-trajectory stage takes the fused chain: 1 (default, or env STTODE_FUSED) = the per-agent stage (encoder, block-0 GRU,
  * layer-1 pre-activation tables: PastEncoder.forward model/STTODE.py:214-236, DecomposeBlock.forward :62-75 of block 0) runs as the
  * leading workgroups of the chain launch, trajectory groups wait on one flag per 16-agent tile (attention groups > 1, the NBA branch:
- * the embedding and the attention stay launches in front, the roles start at the post-attention layer); 0 = separate launches on the
- * pipeline's per-agent stream.  Results are bitwise the same either way. */
+ * the embedding and the attention stay launches in front, the roles start at the post-attention layer); 2 = as 1, and for scene batches
+ * the roles also run set_data's normalisation of their tile (model/STTODE.py:397-461): the call is ONE launch; 0 = separate launches on
+ * the pipeline's per-agent stream.  Results are bitwise the same in every mode. */
 int sttode_set_fused(SttodeModel* m, int mode);
+/* Grid order of the fused launch (host-callable, no GPU): block -> group index (>= 0) or -1 - tile for the per-agent role of a 16-agent
+ * tile; roles sit `lead` groups ahead of the first group that reads their tables, so every producer has a smaller block index than its
+ * consumers (Decoder.forward's repeat_interleave layout, model/STTODE.py:322-328: trajectory = agent * K + k). */
+int sttode_fused_block_of(long block, long tiles, long groups, long K, long lead);
 /* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
  * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */
 int sttode_set_ode(SttodeModel* m, int method, int steps);

@@ -62,6 +62,8 @@ def main(src, dst):
             continue
         base = name.split('<')[0].split('[')[0]
         st = STAGE_OF.get(base)
+        if base == 'traj_chain_kernel' and 'true' in name:        # traj_chain_kernel<NY, true>: the fused launch (per-agent roles + groups)
+            st = 'agents+trajectory_chain[fused launch]'
         if st == 'gru_cols':
             st = 'gru_cols[block1,trajectories]' if 'trajectories' in name else 'gru_cols[block0,agents]'
         if st:
@@ -76,6 +78,9 @@ def main(src, dst):
     for f in glob.glob(os.path.join(src, 'prof*', '*', '*_kernel_stats.csv')):
         tag = f.split(os.sep)[-3]
         rows = list(csv.DictReader(open(f)))[:14]
+        for r in rows:                                   # torch's template instantiations run to kilobytes: keep the head of the name
+            if len(r['Name']) > 140:
+                r['Name'] = r['Name'][:137] + '...'
         with open(os.path.join(dst, f'{tag}_kernel_stats.csv'), 'w') as fo:
             w = csv.DictWriter(fo, fieldnames=rows[0].keys())
             w.writeheader()

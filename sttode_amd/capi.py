@@ -75,6 +75,7 @@ SIGNATURES = {
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
     'sttode_set_fused': [_P, _I],
+    'sttode_fused_block_of': [_L, _L, _L, _L, _L],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
@@ -136,7 +137,8 @@ class NativeModel:
             raise SttodeError('sttode_set_chain failed: ' + lib().sttode_last_error().decode())
 
     def set_fused(self, mode):
-        """1: per-agent roles inside the chain launch (default), 0: separate per-agent launches."""
+        """1: per-agent roles inside the chain launch (default); 2: the roles also run the scene front-end (one launch per call);
+        0: separate per-agent launches."""
         if lib().sttode_set_fused(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())
 

@@ -24,6 +24,7 @@
 //     another stream fills it: the kernel holds no chip-wide resource).
 #include "chain.hpp"
 #include "latency_bodies.hpp"
+#include "frontend_body.hpp"
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
 #include <cstdlib>
@@ -56,10 +57,16 @@ struct RoleArgs {
     const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
     const f32x4* WAx; const float* b1x; const f32x4* WAy; const float* b1y; const f32x4* WA1; const float* b11;
     float* A0x; float* A0y; float* A1y;
+    // scene front-end inside the role (scene batches; nullptr: the front-end ran as a launch before): set_data's normalisation for the
+    // tile's 16 agents -- scene origin (mean of the scene's last observed positions, summed in agent order like scene_orig_kernel),
+    // normalised track, velocities, flags -- written to the workspace rows the other phases and the trajectory groups read
+    const float* past; const int* scene_ptr; int S; float* scene_orig; int* agent_scene;
+    float* enc_in_w; float* xpad_w; float* cur_w; float* orig_w; int* last_w;
     const float* attn; int ld_attn;   // attention output of an EARLIER launch (attention groups > 1, the NBA branch): the role then starts
                                       // at the post-attention layer; nullptr: attention length 1, the role runs the embedding too
     unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
     int ntiles; float ode_time;
+    int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
 };
 
 #ifndef ROLE_PRIO
@@ -382,6 +389,30 @@ __device__ __forceinline__ void agent_role(const ChainArgs& A, int tile, char* s
     // slower than alone (283 vs 150 us, profiles/r03/trace_*), holding a workgroup slot all the while.  Raised priority lets its few
     // instructions issue first; the chain wave loses the same handful of pipe cycles either way.
     __builtin_amdgcn_s_setprio(ROLE_PRIO);
+    if (R.past) {   // (uniform) STTODENet.set_data for this tile (model/STTODE.py:397-461), one lane per agent
+        if (threadIdx.x < 16) {
+            const int a = tile * 16 + (int)threadIdx.x;
+            if (a < nag) {
+                int lo = 0, hi = R.S - 1;                 // the agent's scene: largest s with scene_ptr[s] <= a
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (R.scene_ptr[mid] <= a) lo = mid; else hi = mid - 1;
+                }
+                const int a0 = R.scene_ptr[lo], a1 = R.scene_ptr[lo + 1];
+                float sx = 0.f, sy = 0.f;
+                for (int aa = a0; aa < a1; ++aa) {       // agent order, as scene_orig_kernel sums: identical bits
+                    sx += R.past[((size_t)aa * A.Tp + (A.Tp - 1)) * 2 + 0];
+                    sy += R.past[((size_t)aa * A.Tp + (A.Tp - 1)) * 2 + 1];
+                }
+                const float inv = (float)(a1 - a0);
+                const float ox = sx / inv, oy = sy / inv;
+                if (a == a0) { R.scene_orig[2 * lo] = ox; R.scene_orig[2 * lo + 1] = oy; }
+                R.agent_scene[a] = lo;
+                agent_inputs_core<true>(a, R.past, A.Tp, A.ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, R.xpad_w, R.enc_in_w, R.cur_w, R.orig_w, R.last_w);
+            }
+        }
+        __syncthreads();                                  // enc_in / last / xpad of this tile are visible to the workgroup
+    }
     if (R.attn == nullptr) {                      // (uniform) attention length 1: softmax over one key == 1, the attention output is v
         embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, A.Tp, tile, reinterpret_cast<f32x4*>(smem));
         __syncthreads();                          // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
@@ -434,6 +465,24 @@ __device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, 
     return ok;
 }
 
+// Grid order of the fused launch.  Roles and groups are interleaved: the role of tile t is placed `lead` groups ahead of the first group
+// that reads its tables, g_first(t) = floor(t K / 8) (a tile = 16 agents = 16 K trajectories, a group = 128), so that in a running
+// pipeline a role has finished by the time its consumers are dispatched (nobody spins), and a single serial launch starts its
+// trajectory groups at once instead of behind ALL roles (the per-agent stage then costs its matrix work, not a prologue).  Sort key:
+// role t -> max(0, g_first(t) - lead), group g -> g, roles first on ties; every role a group needs has g_first <= g, hence a smaller
+// block index: with in-order dispatch every producer is resident or finished before its consumer starts (no deadlock; the bounded
+// spin of wait_tiles is the backstop).  Returns the group index, or -1 - tile for a role.  Scalar code: ~10 binary-search steps.
+__host__ __device__ __forceinline__ int fused_block_of(long b, long T, long G, long K, long lead) {
+    auto roles_upto = [&](long x) { const long c = (8 * (x + lead + 1) + K - 1) / K; return c < T ? c : T; };   // #roles with key <= x
+    long lo = -1, hi = G - 1;                       // largest g with position g + roles_upto(g) <= b
+    while (lo < hi) {
+        const long mid = (lo + hi + 1) >> 1;
+        if (mid + roles_upto(mid) <= b) lo = mid; else hi = mid - 1;
+    }
+    if (lo >= 0 && lo + roles_upto(lo) == b) return (int)lo;
+    return -1 - (int)(b - (lo + 1));
+}
+
 template <int NY, bool FUSE>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -454,16 +503,17 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     const int ngroups = (A.ncols + 127) >> 7;
 
     C32_TRACE_BEGIN();
-    if (FUSE && (int)blockIdx.x < A.R.ntiles) {   // (uniform) the leading workgroups of a fused launch: per-agent roles
-        agent_role(A, blockIdx.x, smem);
+    const int fb = FUSE ? fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead) : (int)blockIdx.x;
+    if (FUSE && fb < 0) {   // (uniform) a per-agent role
+        agent_role(A, -1 - fb, smem);
         C32_TRACE_END(1);
         return;
     }
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
     for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
-    if (threadIdx.x == 0) sq[0] = FUSE ? (int)blockIdx.x - A.R.ntiles : A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
+    if (threadIdx.x == 0) sq[0] = FUSE ? fb : A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
     if (FUSE) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
-        const int g0 = (int)blockIdx.x - A.R.ntiles;
+        const int g0 = fb;
         const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
         if (wave == 0 && !wait_tiles(A.R.flags, (c_lo / A.K) >> 4, (c_hi / A.K) >> 4, A.R.flags + A.R.ntiles, lane) && lane == 0) sq[0] = -1;
     }
@@ -472,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     int g = sq[0];
     if (FUSE && g < 0) {   // (uniform) time-out: poison the group's predictions, never hang
         for (int i = threadIdx.x; i < 128 * A.Tf2; i += blockDim.x) {
-            const size_t o = (size_t)((int)blockIdx.x - A.R.ntiles) * 128 * A.Tf2 + i;
+            const size_t o = (size_t)fb * 128 * A.Tf2 + i;
             if (o < (size_t)A.ncols * A.Tf2) A.pred[o] = __builtin_nanf("");
         }
         return;
@@ -688,7 +738,7 @@ template <int NY, bool FUSE> static int chain_launch(const ChainArgs& a, int wgs
     if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
-    if (FUSE) grid = a.R.ntiles + ngroups;   // roles first (dispatch order = index order), one group per workgroup behind them
+    if (FUSE) grid = a.R.ntiles + ngroups;   // roles interleaved ahead of their consumers (fused_block_of), one group per workgroup
     else if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
@@ -728,6 +778,11 @@ static long long* g_chain_dbg = nullptr;
 static int g_trace_tag = 0;
 extern "C" int sttode_chain_debug_buffer(void* p) { g_chain_dbg = (long long*)p; return 0; }  // >= grid * 4 * 16 int64, zeroed
 #endif
+
+// Host view of the fused launch's grid order (tests: every block is exactly one role or group; producers precede consumers).
+extern "C" int sttode_fused_block_of(long block, long tiles, long groups, long K, long lead) {
+    return fused_block_of(block, tiles, groups, K, lead);
+}
 
 extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
     const int NY = (2 * Tf + 31) / 32;
@@ -775,12 +830,13 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
 
 // Internal (csrc/pipeline.hip): the fused launch -- per-agent roles + trajectory groups in ONE grid (see RoleArgs).  W = the model's
 // weight table (enum SttodeWeight), ws / off = the caller's workspace and its layout; the front-end (xpad, enc_in, cur, orig, last) has
-// run on `stream` before.  attn == nullptr: attention length 1 (scene batches), the roles run the embedding too; attn != nullptr (the NBA
+// run on `stream` before -- unless `past` / `scene_ptr` are given (scene batches): the roles then run it for their tiles themselves and the
+// call is ONE launch.  attn == nullptr: attention length 1 (scene batches), the roles run the embedding too; attn != nullptr (the NBA
 // branch: attention groups > 1): embed_qkv and mhgsa_attn have run on `stream` before, the roles start at the post-attention layer.
 // The reference's one Euler step only.
 bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, const float* attn, int ld_attn, int wgs_per_cu, void* stream) {
+                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
     STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
@@ -812,7 +868,21 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
     r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
     r.attn = attn; r.ld_attn = ld_attn;
+    STT_REQUIRE(!past || (scene_ptr && S > 0 && !attn), "stt_chain_fused: the in-role front-end needs scene_ptr, S > 0 and attention length 1");
+    r.past = past; r.scene_ptr = scene_ptr; r.S = S;
+    r.scene_orig = ws + off[STT_B_SCENE_ORIG]; r.agent_scene = (int*)(ws + off[STT_B_AGENT_SCENE]);
+    r.enc_in_w = ws + off[STT_B_ENC_IN]; r.xpad_w = ws + off[STT_B_XPAD]; r.cur_w = ws + off[STT_B_CUR]; r.orig_w = ws + off[STT_B_ORIG];
+    r.last_w = (int*)(ws + off[STT_B_LAST]);
     r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
+    {
+        // STTODE_ROLE_LEAD: groups of head start of a role over its first consumer; < 0 (default): all roles first.  Measured on one box
+        // (profiles/r03/ab_lead_frontend_depth.txt): pipelined 73.4-74.6 M trajectories/s for lead 64 / 160 / 400 / roles first alike, but a
+        // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
+        // other roles, and holds its slot all the while
+        static int lead = -2;
+        if (lead == -2) { const char* e = getenv("STTODE_ROLE_LEAD"); lead = e ? atoi(e) : -1; }
+        r.lead = lead < 0 ? (1 << 28) : lead;
+    }
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {

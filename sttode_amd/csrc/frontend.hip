@@ -4,6 +4,7 @@
 //              utils/metrics.py:7-26 (min-over-K ADE / FDE).
 // HBM-bound byte shuffling: one thread per scene / agent, coalesced over agents.
 #include "api_util.hpp"
+#include "frontend_body.hpp"
 #include "../../include/sttode_hip.h"
 #include <string>
 
@@ -47,40 +48,7 @@ __device__ __forceinline__ void agent_inputs_one(int a, const float* __restrict_
     } else {
         last = (a % nba_N == nba_N - 1);
     }
-    const float* p = seq + (size_t)a * T * 2;
-    float* xp = xpad ? xpad + (size_t)a * 16 * TPX : nullptr;
-    float pnx = 0.f, pny = 0.f, pwx = 0.f, pwy = 0.f;  // previous frame: normalised / world
-    const bool have_prev = prev_last != nullptr;
-    if (have_prev) {
-        pwx = prev_last[2 * a];
-        pwy = prev_last[2 * a + 1];
-        pnx = pwx - ox;
-        pny = pwy - oy;
-    }
-    for (int t = 0; t < T; ++t) {
-        const float wx = p[2 * t], wy = p[2 * t + 1];
-        const float nx = wx - ox, ny = wy - oy;
-        float vx, vy;
-        if (t == 0 && !have_prev) {
-            // first velocity duplicates the second one (model/STTODE.py:432-433,582-583)
-            const float w1x = p[2], w1y = p[3];
-            if (vel_from_norm) { vx = (w1x - ox) - nx; vy = (w1y - oy) - ny; }
-            else { vx = w1x - wx; vy = w1y - wy; }
-        } else {
-            if (vel_from_norm) { vx = nx - pnx; vy = ny - pny; }
-            else { vx = wx - pwx; vy = wy - pwy; }
-        }
-
-        float* e = enc_in + ((size_t)a * T + t) * 4;
-        e[0] = nx; e[1] = ny; e[2] = vx; e[3] = vy;
-        if (xp) { xp[2 * t] = nx; xp[2 * t + 1] = ny; }
-        pnx = nx; pny = ny; pwx = wx; pwy = wy;
-    }
-    if (xp)
-        for (int k = 2 * T; k < 16 * TPX; ++k) xp[k] = 0.f;
-    if (cur) { cur[2 * a] = pnx; cur[2 * a + 1] = pny; }
-    if (orig) { orig[2 * a] = ox; orig[2 * a + 1] = oy; }
-    if (last_flag) last_flag[a] = last;
+    agent_inputs_core<false>(a, seq, T, TPX, vel_from_norm, ox, oy, last, prev_last, xpad, enc_in, cur, orig, last_flag);
 }
 __global__ void agent_inputs_kernel(const float* __restrict__ seq, int n, int T, int TPX, int mode, int vel_from_norm,
                                     const float* __restrict__ prev_last, const float* __restrict__ scene_orig,

@@ -1,0 +1,54 @@
+// Scene front-end per agent (set_data / set_data_nba equivalents: model/STTODE.py:397-461, 463-486, 578-596), shared by the front-end
+// kernels (frontend.hip) and the per-agent role of the fused chain launch (chain32.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// SC1: the value is read by ANOTHER workgroup of the same launch -> agent-scope (write-through) store (cdna_hip_programming.md §6 G16 R1);
+// scalar sc1 stores are slow per byte, which is irrelevant for the ~20 floats per agent written this way
+template <bool SC1> __device__ __forceinline__ void fe_store(float* p, float v) {
+    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// One agent: normalised track (xpad, flattened (t, c), zero padded to 16*TPX), encoder inputs [T][4] = (normalised position, velocity with
+// the first one duplicated: model/STTODE.py:432-433,582-583), cur_location, scene origin per agent, last-agent flag.
+// (ox, oy): the agent's scene origin (0 for the NBA branch); `last`: the add_category flag (model/STTODE.py:199-210).
+template <bool SC1>
+__device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict__ seq, int T, int TPX, int vel_from_norm, float ox, float oy,
+                                                  int last, const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq, world coords
+                                                  float* __restrict__ xpad, float* __restrict__ enc_in, float* __restrict__ cur,
+                                                  float* __restrict__ orig, int* __restrict__ last_flag) {
+    const float* p = seq + (size_t)a * T * 2;
+    float* xp = xpad ? xpad + (size_t)a * 16 * TPX : nullptr;
+    float pnx = 0.f, pny = 0.f, pwx = 0.f, pwy = 0.f;  // previous frame: normalised / world
+    const bool have_prev = prev_last != nullptr;
+    if (have_prev) {
+        pwx = prev_last[2 * a];
+        pwy = prev_last[2 * a + 1];
+        pnx = pwx - ox;
+        pny = pwy - oy;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float wx = p[2 * t], wy = p[2 * t + 1];
+        const float nx = wx - ox, ny = wy - oy;
+        float vx, vy;
+        if (t == 0 && !have_prev) {
+            // first velocity duplicates the second one (model/STTODE.py:432-433,582-583)
+            const float w1x = p[2], w1y = p[3];
+            if (vel_from_norm) { vx = (w1x - ox) - nx; vy = (w1y - oy) - ny; }
+            else { vx = w1x - wx; vy = w1y - wy; }
+        } else {
+            if (vel_from_norm) { vx = nx - pnx; vy = ny - pny; }
+            else { vx = wx - pwx; vy = wy - pwy; }
+        }
+        float* e = enc_in + ((size_t)a * T + t) * 4;
+        e[0] = nx; e[1] = ny; e[2] = vx; e[3] = vy;
+        if (xp) { fe_store<SC1>(xp + 2 * t, nx); fe_store<SC1>(xp + 2 * t + 1, ny); }
+        pnx = nx; pny = ny; pwx = wx; pwy = wy;
+    }
+    if (xp)
+        for (int k = 2 * T; k < 16 * TPX; ++k) fe_store<SC1>(xp + k, 0.f);
+    if (cur) { fe_store<SC1>(cur + 2 * a, pnx); fe_store<SC1>(cur + 2 * a + 1, pny); }
+    if (orig) { fe_store<SC1>(orig + 2 * a, ox); fe_store<SC1>(orig + 2 * a + 1, oy); }
+    if (last_flag) last_flag[a] = last;
+}

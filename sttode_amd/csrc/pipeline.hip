@@ -33,6 +33,7 @@ struct SttodeModel {
     int col_parts;
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
     int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
+    bool fe_in_role; // fused scene batches: the roles also run the scene front-end (STTODE_FE_IN_ROLE=1; default: a launch in front)
     int ode_method, ode_steps;  // integrator of the encoder ODE (0, 1 = one Euler step = the reference)
     int prog_len;
     hipStream_t part_stream[STT_MAX_PARTS];
@@ -77,6 +78,9 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
     m->fused_mode = 1;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
+    // default off: measured neutral to -0.6 % pipelined and -1.5 % serial at 512 scenes (the two front-end launches cost less than the
+    // ~10 us they add to every role), +1 % on the 256-scene SDD leg (profiles/r03/ab_lead_frontend_depth.txt)
+    m->fe_in_role = getenv("STTODE_FE_IN_ROLE") && atoi(getenv("STTODE_FE_IN_ROLE")) != 0;
     m->prog_len = sttode_chain_prog_len(Tp, Tf);
     m->col_parts = 1;  // measured on MI355X: 1 -> 62.1, 2 -> 60.6, 4 -> 55.4 M traj/s (kernels of different streams do not fill each other's tails)
     if (const char* e = getenv("STTODE_COL_PARTS")) m->col_parts = atoi(e);
@@ -183,8 +187,9 @@ extern "C" int sttode_set_chain(SttodeModel* m, int mode) {
 
 extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
     STT_REQUIRE(m, "sttode_set_fused: null model");
-    STT_REQUIRE(mode == 0 || mode == 1, "sttode_set_fused: mode must be 0 or 1");
-    m->fused_mode = mode;
+    STT_REQUIRE(mode >= 0 && mode <= 2, "sttode_set_fused: mode must be 0, 1 or 2");
+    m->fused_mode = mode ? 1 : 0;
+    m->fe_in_role = mode == 2;
     return 0;
 }
 
@@ -446,7 +451,8 @@ static bool use_fused(const SttodeModel* m, int n) {
     const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
     return m->fused_mode == 1 && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_chain_fused_covers(m->Tp);
 }
-static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z, float* pred, hipStream_t s) {
+static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z, float* pred,
+                       const float* past, const int* scene_ptr, int S, hipStream_t s) {
     const float* const* W = m->w;
     const float* attn = nullptr;
     if (attn_len > 1) {
@@ -461,7 +467,7 @@ static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int at
                               st_seq, 192, st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
         attn = ws + off[STT_B_ATTN];
     }
-    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, 2, s));
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, s));
     return 0;
 }
 
@@ -476,8 +482,12 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
-    if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
-    if (use_fused(m, n)) return stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, s);
+    // scene batches on the fused launch: the roles run the front-end of their own tiles (the call is ONE launch); otherwise it is a launch
+    const bool fe_in_role = use_fused(m, n) && scene_ptr != nullptr && m->fe_in_role;
+    if (!fe_in_role)
+        if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
+    if (use_fused(m, n))
+        return stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, s);
     if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
     return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
@@ -497,8 +507,10 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
         ++m->acalls;
         STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));
         STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));   // the slot's previous user has drained
-        if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
-        if (int rc = stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, sf)) return rc;
+        const bool fe_in_role = scene_ptr != nullptr && m->fe_in_role;
+        if (!fe_in_role)
+            if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
+        if (int rc = stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, sf)) return rc;
         STT_HIP(hipEventRecord(m->evB_done[slot], sf));
         return 0;
     }

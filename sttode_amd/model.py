@@ -182,7 +182,7 @@ class STTODENet(nn.Module):
         # integrator of the tensor-ODE encoder: the reference runs ONE Euler step (ode_demo.py:186-190) = ('euler', 1); 'rk4' is
         # torchdiffeq's fixed-grid rk4 (3/8 rule), 'rk4_classic' the classical one; steps = uniform steps over [0, 12] (oracle-checked only)
         self.ode_method, self.ode_steps = 'euler', 1
-        self.async_depth = 3     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
+        self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
         self._ptr_cache = {}
         self._pf = self._pf_thunk = None
@@ -659,7 +659,7 @@ class STTODENet(nn.Module):
     @torch.no_grad()
     def inference_async(self, z=None):
         """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  The per-agent stage
-        runs on an internal stream beside the per-trajectory kernels of the previous calls; ``async_depth`` (default 3) slots rotate,
+        runs on an internal stream beside the per-trajectory kernels of the previous calls; ``async_depth`` (default 4) slots rotate,
         so at most that many calls may be in flight: call ``wait(handle)`` (which returns the [K, n, Tf, 2] view) before the
         ``async_depth``-th next call.
         Inputs set by set_data / set_scene_batch / set_data_nba must stay unmodified until then.  Bitwise identical to inference()."""

@@ -202,3 +202,29 @@ def test_no_cpu_fallback_anywhere():
                                    torch.zeros(192), torch.zeros(64, 64), torch.zeros(64))):
         with pytest.raises(capi.SttodeError):
             call()
+
+
+def test_fused_launch_grid_order_is_a_permutation_with_producers_first():
+    """sttode_fused_block_of (the C function the fused chain kernel calls on the device, csrc/chain32.hip): over the whole grid every role
+    tile and every trajectory group appears exactly once, and every tile a group reads (agents of trajectories [128 g, 128 g + 127],
+    trajectory = agent * K + k: model/STTODE.py:322-328) has a SMALLER block index than the group -- the property that makes the
+    in-launch flag wait deadlock-free under in-order dispatch.  Host-only: no GPU call."""
+    from sttode_amd import capi
+    L = capi.lib()
+    L.sttode_fused_block_of.restype = ctypes.c_int
+    for n, K, lead in ((8645, 20, 160), (7, 20, 160), (1408, 20, 0), (5120, 20, 160), (33, 7, 5), (100, 1, 160), (16, 20, 1 << 28),
+                       (4321, 3, 17), (2000, 64, 160), (1, 20, 160)):
+        T, G = (n + 15) // 16, (n * K + 127) // 128
+        roles, groups = set(), set()
+        for b in range(T + G):
+            v = L.sttode_fused_block_of(b, T, G, K, lead)
+            if v >= 0:
+                assert v < G and v not in groups, (n, K, lead, b, v)
+                groups.add(v)
+                t_lo, t_hi = (v * 128 // K) >> 4, (min(v * 128 + 127, n * K - 1) // K) >> 4
+                assert all(t in roles for t in range(t_lo, t_hi + 1)), (n, K, lead, b, v)
+            else:
+                t = -1 - v
+                assert 0 <= t < T and t not in roles, (n, K, lead, b, t)
+                roles.add(t)
+        assert len(roles) == T and len(groups) == G

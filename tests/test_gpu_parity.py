@@ -294,7 +294,22 @@ def test_fused_trajectory_chain_vs_three_kernel_form_and_oracle(case):
             a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
             obs, pred = sb.scene(s)
             assert_close(outs[1][:, a:b], oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20]), what=f'{case} scene {s} vs oracle')
-    elif case != 'k_not_20':
+    elif case == 'k_not_20':
+        # the reference's inference() hard-codes 20 samples (model/STTODE.py:600), so the oracle is driven through the components it is made
+        # of: PastEncoder.forward (:214-236) and Decoder.forward (:320-347) with sample_num = 7, scene by scene
+        from oracle.sttode_ref import first_diff_dup
+        for s in range(0, sb.n_scenes, 9):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            with torch.no_grad():
+                ora.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred))
+                pt = ora.past_traj
+                pf = ora.past_encoder(torch.cat((pt, first_diff_dup(pt)), dim=-1), 1, ora.agent_num)
+                out, _ = ora.decoder(pf.repeat_interleave(7, dim=0), torch.from_numpy(z[a * 7:b * 7]), pt, pt[:, -1:], sample_num=7, mode='inference')
+                ref = (out.permute(1, 0, 2, 3) + ora.scene_orig).numpy()
+            assert_close(outs[1][:, a:b], ref, what=f'{case} scene {s} vs oracle components')
+            assert_close(outs[0][:, a:b], ref, what=f'{case} scene {s} (three-kernel form) vs oracle components')
+    else:
         with torch.no_grad():
             ora.set_data_nba(data)
             ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
@@ -468,7 +483,8 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
             variants.append(({'past_traj': torch.from_numpy(d['past_traj']).to(m.device), 'future_traj': torch.from_numpy(d['future_traj']).to(m.device)},
                              torch.from_numpy(scenes.latents(300 + v, n)).to(m.device)))
         feed = lambda inp: m.set_data_nba(inp)
-    names = (('g', 64), ('qkv', 192), ('pf', 128), ('state0', 96), ('A0x', 512), ('A0y', 512), ('A1y', 512))
+    names = (('g', 64), ('qkv', 192), ('pf', 128), ('state0', 96), ('A0x', 512), ('A0y', 512), ('A1y', 512),
+             ('xpad', 16 * (1 if 2 * Tp <= 16 else 2)), ('enc_in', 4 * Tp), ('cur', 2), ('orig', 2))     # (scene batches: the roles run set_data too)
 
     def run(v, fused):
         inp, z = variants[v]
@@ -477,6 +493,8 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         out = m.inference(None, z=z).clone()
         buf, off = m._workspace(n, S)
         inter = {k: m._view(buf, off, k, n, w).clone() for k, w in names}
+        if S:
+            inter['scene_orig'] = m._view(buf, off, 'scene_orig', S, 2).clone()
         return out, inter
     # Tp > 8 (two 16-wide input tiles): the separate launches run block 0's GRU in its streaming 32-column form (another summation order),
     # the role in the 16-column latency form -> agreement to rounding there, bitwise everywhere else; the fused launch itself must
@@ -489,18 +507,18 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
             first = [run(v, 1) for v in range(4)]
             for v in range(4):
                 assert_close(first[v][0].cpu().numpy(), ref[v][0].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'{case} variant {v}: fused vs separate launches')
-                for k, _ in names:
+                for k in first[v][1]:
                     assert_close(first[v][1][k].cpu().numpy(), ref[v][1][k].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'{case} variant {v}: {k}')
             ref = first
         for rep in range(3):
             for v in (0, 3, 1, 2):
-                out, inter = run(v, 1)
+                out, inter = run(v, 1 + (rep + v) % 2)    # mode 2: the roles also run the scene front-end (one launch per call)
                 assert torch.isfinite(out).all()
                 assert torch.equal(out, ref[v][0]), f'{case} variant {v} rep {rep}: fused launch != separate launches'
-                for k, _ in names:
+                for k in inter:
                     assert torch.equal(inter[k], ref[v][1][k]), f'{case} variant {v} rep {rep}: {k} differs'
         # three calls in flight on the pipeline's streams, workspace slots reused every third call
-        m.native().set_fused(1)
+        m.native().set_fused(2)
         m.reset_async()
         handles, outs, order = [], [], [0, 1, 2, 3, 2, 0, 3, 1, 1, 0]
         for v in order:
@@ -1064,6 +1082,68 @@ def _compare_grads(got, ref, rtol=2e-4):
     return worst
 
 
+def _fp32_errs(g64, g32):
+    """name -> distance of an fp32 gradient from the float64 one, in units of max |g| (one sample of what fp32 rounding does there)."""
+    return {k: float((g32[k].double().cpu() - v.double().cpu()).abs().max()) / (float(v.double().abs().max()) + 1e-300)
+            for k, v in g64.items() if v is not None}
+
+
+def _grad_yardstick(got, g64, g32, what, digests=None, factor=2.0, floor=1e-4, more_ref_errs=None):
+    """Per-parameter float64 yardstick (the rule of the pmath boundary rows and of the L = 4096 attention test): the HIP gradient's
+    distance from the float64 evaluation of the same graph, in units of max |g|, may be at most `factor` x the distance of a CORRECT fp32
+    evaluation (torch's own fp32 autograd of the oracle: `g32`; with `digests`, the reference's own backward() as recorded in the golden
+    file: norm + first 48 entries) from that same float64 gradient, or `floor`, whichever is larger.  No flat band: a parameter whose
+    fp32 evaluation is tight must be tight here too.  Returns the table rows (also written to profiles/ by the caller's `dump`)."""
+    rows, bad = [], []
+    for name, r64 in g64.items():
+        gt = got[name]
+        if r64 is None:
+            assert gt is None, name
+            continue
+        assert gt is not None, name
+        r64 = r64.double().cpu()
+        scale = float(r64.abs().max()) + 1e-300
+        e_hip = float((gt.double().cpu() - r64).abs().max()) / scale
+        e_ref = float((g32[name].double().cpu() - r64).abs().max()) / scale
+        if more_ref_errs is not None:                            # a second sample of the fp32 rounding error on this parameter
+            e_ref = max(e_ref, more_ref_errs.get(name, 0.0))
+        bound = max(factor * e_ref, floor)
+        row = {'param': name, 'max_abs_g': scale, 'err_hip_vs_f64': e_hip, 'err_fp32_autograd_vs_f64': e_ref, 'bound': bound}
+        if digests is not None and name in digests:
+            dg = digests[name]                                   # [sum, norm, max|g|, first 48 entries] of the reference's fp32 gradient
+            f64 = r64.flatten()
+            n64 = float(f64.norm())
+            k = min(48, f64.numel())
+            hd = grad_digest(gt)
+            e_ref_norm, e_hip_norm = abs(dg[1] - n64) / (n64 + 1e-300), abs(hd[1] - n64) / (n64 + 1e-300)
+            e_ref_ent = float(np.abs(dg[3:3 + k] - f64[:k].numpy()).max()) / scale
+            e_hip_ent = float(np.abs(hd[3:3 + k] - f64[:k].numpy()).max()) / scale
+            row.update(err_hip_norm=e_hip_norm, err_reference_norm=e_ref_norm, err_hip_first48=e_hip_ent, err_reference_first48=e_ref_ent)
+            if e_hip_norm > max(factor * e_ref_norm, floor) or e_hip_ent > max(factor * e_ref_ent, floor):
+                bad.append((name, 'digest', e_hip_norm, e_ref_norm, e_hip_ent, e_ref_ent))
+        if e_hip > bound:
+            bad.append((name, 'entries', e_hip, e_ref, bound))
+        rows.append(row)
+    _dump_grad_table(what, rows)
+    assert not bad, f'{what}: gradients beyond max({factor} x fp32-vs-f64 error, {floor}) of max |g|: {bad[:6]}'
+    return rows
+
+
+def _dump_grad_table(what, rows):
+    """The per-parameter table of one gradient test, as text under gpurun_out/ (copied into profiles/ by the collection script)."""
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'grad_tables')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, what.replace(' ', '_').replace('/', '_') + '.txt'), 'w') as f:
+            keys = [k for k in rows[0] if k != 'param']
+            f.write('# ' + what + '\n# param ' + ' '.join(keys) + '\n')
+            for r in rows:
+                f.write(r['param'] + ' ' + ' '.join(f'{r[k]:.3e}' for k in keys) + '\n')
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize('tag,dataset,Tp,Tf', [('eth', 'eth', 8, 12), ('nba', 'nba', 5, 10)])
 def test_training_step_gradients_vs_reference_and_oracle(golden, tag, dataset, Tp, Tf):
     """forward() + total_loss.backward() on the HIP training kernels (train.py:81-85): losses and all 88 live parameter
@@ -1076,20 +1156,15 @@ def test_training_step_gradients_vs_reference_and_oracle(golden, tag, dataset, T
         if f'{tag}_nograd::{name}' in g:
             assert gr is None, name
             continue
-        ref = g[f'{tag}_grad::{name}']
-        got = grad_digest(gr)
-        # two fp32 evaluations of the same gradient: the reference's own autograd sits 0.8e-4 .. 4.6e-4 of max |g| from the float64
-        # evaluation of the graph (below), ours 1.8e-4 .. 2.1e-4 -- the digests are held to the same 5e-4 as the float64 comparison
-        assert abs(got[1] - ref[1]) <= 5e-4 * ref[1] + 1e-9, (name, got[1], ref[1])
-        assert np.abs(got[3:] - ref[3:]).max() <= 5e-4 * (ref[2] + 1e-12), (name, np.abs(got[3:] - ref[3:]).max(), ref[2])
-    # entry by entry: against the float64 evaluation of the same graph (torch's own fp32 autograd is 0.8e-4 .. 4.6e-4 of
-    # max |g| away from it on these cases, the HIP step 1.8e-4 .. 2.0e-4), and against the fp32 oracle
+    digests = {name: g[f'{tag}_grad::{name}'] for name in grads if f'{tag}_grad::{name}' in g}
+    # Entry by entry AND through the reference's own backward() digests, on the per-parameter float64 yardstick (_grad_yardstick): the
+    # float64 evaluation of the same graph is the truth, torch's fp32 autograd of the oracle / the reference's recorded fp32 gradient are
+    # the measure of what a correct fp32 evaluation can reach for THAT parameter
     g64, l64 = oracle_grads(tag, dataset, Tp, Tf, g, double=True)
     np.testing.assert_allclose(losses, l64, rtol=1e-4)
-    _compare_grads(grads, g64, rtol=5e-4)
     ograds, olosses = oracle_grads(tag, dataset, Tp, Tf, g)
     np.testing.assert_allclose(losses, olosses, rtol=1e-4)
-    _compare_grads(grads, ograds, rtol=1e-3)
+    _grad_yardstick(grads, g64, ograds, f'training step {tag}', digests=digests)
 
 
 def test_training_step_with_dropout_masks_vs_oracle(golden):
@@ -1101,9 +1176,13 @@ def test_training_step_with_dropout_masks_vs_oracle(golden):
     dp = torch.from_numpy(((rng.random((n * 8, 64)) < 0.9) / 0.9).astype(np.float32))
     df = torch.from_numpy(((rng.random((n * 12, 64)) < 0.9) / 0.9).astype(np.float32))
     grads, losses = _hip_grads('eth', 'eth', 8, 12, g, drop=(dp.to(dev), df.to(dev)), train_mode=True)
-    ograds, olosses = oracle_grads('eth', 'eth', 8, 12, g, drop=(dp, df), double=True)
+    g64, olosses = oracle_grads('eth', 'eth', 8, 12, g, drop=(dp, df), double=True)
     np.testing.assert_allclose(losses, olosses, rtol=1e-4)
-    _compare_grads(grads, ograds, rtol=5e-4)
+    g32, _ = oracle_grads('eth', 'eth', 8, 12, g, drop=(dp, df))
+    # block 1's conv / W_ih gradients: torch's fp32 autograd lands 1.6e-5 of max |g| from float64 WITH these masks and 7.9e-5 without
+    # them on the same scene (HIP: 1.26e-4 and 1.34e-4) -- both runs are samples of the same fp32 rounding, the yardstick takes the larger
+    more = _fp32_errs(oracle_grads('eth', 'eth', 8, 12, g, double=True)[0], oracle_grads('eth', 'eth', 8, 12, g)[0])
+    _grad_yardstick(grads, g64, g32, 'training step eth with dropout masks', more_ref_errs=more)
     assert abs(losses[0] - float(g['eth_losses'][0])) > 1e-3      # the masks really changed the objective
 
 
@@ -1359,7 +1438,8 @@ def test_training_step_edge_scene_sizes_vs_oracle(N):
     grads, losses = _hip_grads('eth', 'eth', 8, 12, g)             # first step of this shape: eager
     g64, l64 = oracle_grads('eth', 'eth', 8, 12, g, double=True)
     np.testing.assert_allclose(losses, l64, rtol=1e-4)
-    _compare_grads(grads, g64, rtol=5e-4)
+    g32, _ = oracle_grads('eth', 'eth', 8, 12, g)
+    _grad_yardstick(grads, g64, g32, f'training step eth N={N}')
     grads2, losses2 = _hip_grads('eth', 'eth', 8, 12, g)           # second step: captured + replayed hipGraph
     np.testing.assert_allclose(losses2, losses, rtol=1e-6)
     _compare_grads(grads2, {k: v for k, v in grads.items()}, rtol=1e-6)
@@ -1396,7 +1476,13 @@ def test_training_step_nba_shapes_vs_oracle(B, N, Tp, Tf):
     finally:
         torch.set_default_dtype(prev)
     np.testing.assert_allclose([float(out[0].detach())] + list(out[1:]), [float(v.detach()) for v in vals], rtol=1e-4)
-    _compare_grads(grads, {k: p.grad for k, p in o.named_parameters()}, rtol=5e-4)
+    o32 = oracle_model('nba', Tp, Tf)                       # the same graph in fp32 (torch autograd): what a correct fp32 evaluation reaches
+    o32.zero_grad()
+    o32.set_data_nba(data)
+    o32.forward_loss_tensors(*[torch.from_numpy(e) for e in eps])[0].backward()
+    g32 = {k: (p.grad.clone() if p.grad is not None else None) for k, p in o32.named_parameters()}
+    o32.zero_grad()
+    _grad_yardstick(grads, {k: p.grad for k, p in o.named_parameters()}, g32, f'training step nba B={B} N={N} Tp={Tp} Tf={Tf}')
 
 
 def test_pmath_autograd_functions_vs_reference_golden(golden):
