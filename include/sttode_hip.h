@@ -82,6 +82,17 @@ int sttode_post_attn_ode(const float* outP, const float* outb, const float* info
                          const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* inP, const float* inb,
                          const float* g, float* pf, int n, float ode_time, int method, int steps, void* stream);
 
+/* Right-hand side of the encoder's tensor ODE at ONE state y [n,64] for any attention length: k = LN2(h + FFN(h)), h = LN1(y + gate(out_proj(a)))
+ * with `a` [n, ld_attn] the attention output of state y (TransformerEncoder_ode.forward, ode_demo.py:25-72 = TransformerEncoderLayer.forward,
+ * hypertransformer.py:134-153).  The native pipeline integrates with it when a non-default integrator meets an attention group > 1:
+ * per stage in-projection of y (sttode_linear_cols) -> sttode_mhgsa_attn over the group -> this -> axpy combinations. */
+int sttode_post_attn_rhs(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                         const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                         const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* y,
+                         const float* attn, int ld_attn, float* kout, int n, void* stream);
+/* past_feature [n,128] = cat(ftraj_input g, relu(integrated ODE state y)) (ode_demo.py:231, model/STTODE.py:233-235) */
+int sttode_ode_state_to_pf(const float* g, const float* y, float* pf, int n, void* stream);
+
 /* DecomposeBlock front half (model/STTODE.py:62-69): conv1d(2->32,k3,pad1)+relu, GRU(32->96) final state.
  * xin [ncols,16*TPX] = flattened (x_true - x_hat) -> state [ncols,96]. */
 int sttode_gru_cols(const float* xin, const float* convP, const float* convB, const float* wihP, const float* whhP,
@@ -307,7 +318,8 @@ enum SttodeWeight {
 /* workspace buffers (offsets in floats from sttode_workspace_layout) */
 enum SttodeBuffer {
     STT_B_SCENE_ORIG, STT_B_AGENT_SCENE, STT_B_XPAD, STT_B_ENC_IN, STT_B_CUR, STT_B_ORIG, STT_B_LAST, STT_B_G, STT_B_QKV,
-    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_QUEUE, STT_B_FLAGS /* tile flags of the fused launch */, STT_B_COUNT
+    STT_B_ATTN, STT_B_PF, STT_B_STATE0, STT_B_A0X, STT_B_A0Y, STT_B_A1Y, STT_B_DBUF, STT_B_YBUF, STT_B_STATE1, STT_B_QUEUE, STT_B_FLAGS /* tile flags of the fused launch */,
+    STT_B_ODE /* [6][n][64]: state, k1..k4, scratch of the multi-stage integrator with attention groups > 1 */, STT_B_COUNT
 };
 
 /* pipeline stages reported by sttode_timing_read */
@@ -343,7 +355,9 @@ int sttode_set_fused(SttodeModel* m, int mode);
  * consumers (Decoder.forward's repeat_interleave layout, model/STTODE.py:322-328: trajectory = agent * K + k). */
 int sttode_fused_block_of(long block, long tiles, long groups, long K, long lead);
 /* integrator of the tensor-ODE encoder inside the native pipeline: method / steps as in sttode_post_attn_ode (default 0, 1 = reference).
- * Non-default settings need attention length 1 (scene batches); sttode_inference_nba then fails with a message. */
+ * Attention length 1 (scene batches): every stage inside the fused encoder kernel.  Attention groups > 1 (sttode_inference_nba): every
+ * stage is a pass over the group -- in-projection of the state, sttode_mhgsa_attn, sttode_post_attn_rhs, axpy combinations -- enqueued
+ * natively by the same call (odeint over TransformerEncoder_ode, ode_demo.py:186-190; parity unpinned: the reference only takes one Euler step). */
 int sttode_set_ode(SttodeModel* m, int method, int steps);
 /* every = 0: off; n > 0: bracket the stages of every n-th forward call with hipEvents recorded on the launch streams (the
  * per-trajectory stages are bracketed on every call while n > 0) */

@@ -24,6 +24,8 @@ SIGNATURES = {
     'sttode_mhgsa_attn': [_P, _P, _P, _P, _P, _P, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_post_attn_ode': [_P] * 16 + [_P, _P, _I, _F, _I, _I, _P],
+    'sttode_post_attn_rhs': [_P] * 14 + [_P, _P, _I, _P, _I, _P],
+    'sttode_ode_state_to_pf': [_P, _P, _P, _I, _P],
     'sttode_gru_cols': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'sttode_set_latency_tiles': [_I, _I, _I],
     'sttode_linear_cols': [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -97,7 +99,7 @@ TRUNK_PTRS = ('fc1_w', 'fc1_b', 'pos_w', 'pos_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc
               'gate_w', 'gate_b', 'ln1_w', 'ln1_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'ln2_w', 'ln2_b', 'enc_in', 'last', 'pe', 'drop', 'posin', 'tp',
               'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode')   # enum SttodeTrunkPtr
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
-           'A1y', 'dbuf', 'ybuf', 'state1', 'queue', 'flags')
+           'A1y', 'dbuf', 'ybuf', 'state1', 'queue', 'flags', 'ode')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',
           'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain', 'agents_fused[encoder+block0 GRU]', 'agents+trajectory_chain[fused launch]')
 

@@ -221,6 +221,38 @@ __global__ __launch_bounds__(256) void post_attn_kernel(PostW w, const float* __
     post_attn_body<ODE>(w, g, attn, ld_attn, pf, n, ode_time, method, steps, vP, vb, blockIdx.x, sX);
 }
 
+// Right-hand side of the tensor ODE at ONE state for ANY attention length: k = f(y) = LN2(h + FFN(h)), h = LN1(y + gate(out_proj(a))), with
+// `a` the attention output of state y computed by the caller (in-projection of y -> mhgsa_attn over the group).  The building block of
+// multi-step / Runge-Kutta integration with attention groups > 1 (the NBA branch), where every stage is a pass over the whole group
+// (TransformerEncoder_ode.forward, ode_demo.py:25-72; odeint over it: :186-190).  One workgroup per 16-agent tile; wave w stores row tile w.
+__global__ __launch_bounds__(256) void post_attn_rhs_kernel(PostW w, const float* __restrict__ y, const float* __restrict__ attn, int ld_attn,
+                                                            float* __restrict__ kout, int n) {
+    __shared__ f32x4 sX[4][4][64];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 a[4], yy[4], x[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        yy[T] = ld4(y + (size_t)colc * 64 + 16 * T + 4 * q);
+        a[T] = ld4(attn + (size_t)colc * ld_attn + 16 * T + 4 * q);
+    }
+    ode_rhs(w, sX, a, yy, x, lane, q, wv);
+    if (col < n) {
+        const f32x4 xo = wv == 0 ? x[0] : wv == 1 ? x[1] : wv == 2 ? x[2] : x[3];
+        st4(kout + (size_t)col * 64 + 16 * wv + 4 * q, xo);
+    }
+}
+// past_feature = cat(ftraj_input, relu(ODE state at t = ode_time)) (ode_demo.py:231, model/STTODE.py:233-235)
+__global__ void ode_state_to_pf_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ pf, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * 64) return;
+    const long a = i >> 6, f = i & 63;
+    pf[a * 128 + f] = g[i];
+    pf[a * 128 + 64 + f] = fmaxf(y[i], 0.f);
+}
+
 // The per-agent stage of a scene batch (attention length 1, the reference's one Euler step) in ONE launch: workgroup role 0 runs the
 // encoder of its 16-agent tile (embed_lat_body, then post_attn_body on what it just wrote: softmax over one key == 1, so the attention
 // output is the value projection), role 1 the block-0 conv + GRU of the same tile (gru_lat_body, six waves).  Replaces three launches and
@@ -301,6 +333,30 @@ extern "C" int sttode_post_attn(const float* outP, const float* outb, const floa
     w.ln2w = ln2w; w.ln2b = ln2b;
     hipLaunchKernelGGL(post_attn_kernel<false>, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, g, attn, ld_attn, pf, n, ode_time, 0,
                        1, (const f32x4*)nullptr, (const float*)nullptr);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// f(y) of the encoder's tensor ODE at one state, attention output given (any attention length): see post_attn_rhs_kernel.
+extern "C" int sttode_post_attn_rhs(const float* outP, const float* outb, const float* infoP, const float* infob, const float* gateP,
+                                    const float* gateb, const float* ln1w, const float* ln1b, const float* l1P, const float* l1b,
+                                    const float* l2P, const float* l2b, const float* ln2w, const float* ln2b, const float* y,
+                                    const float* attn, int ld_attn, float* kout, int n, void* stream) {
+    STT_REQUIRE(outP && outb && infoP && infob && gateP && gateb && ln1w && ln1b && l1P && l1b && l2P && l2b && ln2w && ln2b && y && attn && kout,
+                "sttode_post_attn_rhs: null pointer");
+    STT_REQUIRE(n > 0 && ld_attn >= 64 && ld_attn % 4 == 0, "sttode_post_attn_rhs: n must be > 0, ld_attn >= 64 and a multiple of 4");
+    PostW w;
+    w.outP = (const f32x4*)outP; w.outb = outb; w.infoP = (const f32x4*)infoP; w.infob = infob; w.gateP = (const f32x4*)gateP;
+    w.gateb = gateb; w.ln1w = ln1w; w.ln1b = ln1b; w.l1P = (const f32x4*)l1P; w.l1b = l1b; w.l2P = (const f32x4*)l2P; w.l2b = l2b;
+    w.ln2w = ln2w; w.ln2b = ln2b;
+    hipLaunchKernelGGL(post_attn_rhs_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, y, attn, ld_attn, kout, n);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+// pf [n,128] = cat(g, relu(y)) (model/STTODE.py:233-235 with the integrated state y)
+extern "C" int sttode_ode_state_to_pf(const float* g, const float* y, float* pf, int n, void* stream) {
+    STT_REQUIRE(g && y && pf && n > 0, "sttode_ode_state_to_pf: bad argument");
+    hipLaunchKernelGGL(ode_state_to_pf_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, y, pf, n);
     STT_HIP(hipGetLastError());
     return 0;
 }

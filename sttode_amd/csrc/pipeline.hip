@@ -174,6 +174,7 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_STATE1, mm * 96);
     put(STT_B_QUEUE, 64);
     put(STT_B_FLAGS, (size_t)(n + 15) / 16 + 4);   // one flag per 16-agent tile + the time-out word (fused launch), zeroed per call
+    put(STT_B_ODE, (size_t)6 * n * 64);   // multi-stage integrator with attention groups > 1 (always laid out: sttode_set_ode may come later)
     *total_floats = (long)o;
     return 0;
 }
@@ -362,9 +363,50 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         attn_src = attn;
         ld_attn = 64;
     }
-    if (m->ode_method != 0 || m->ode_steps != 1) {
-        STT_REQUIRE(attn_len == 1, "sttode_inference_nba: a non-default ODE integrator needs attention length 1 (every stage of an attention group > 1 "
-                                   "is a pass over the whole group: use the op-level hypertransformer.ODEG_Encoder)");
+    if ((m->ode_method != 0 || m->ode_steps != 1) && attn_len > 1) {
+        // Multi-step Euler / RK4 with an attention group > 1: every stage is a pass over the whole group.  y' = f(y), f = the encoder layer
+        // with the attention of state y (TransformerEncoder_ode, ode_demo.py:25-72), integrated over [0, 12] on a uniform grid exactly as
+        // hypertransformer.ode_integrate does at op level (same stage algebra and axpy order).  Launch-bound by construction.
+        float* ob = ws + off[STT_B_ODE];
+        const size_t nf = (size_t)n * 64;
+        float *y = ob, *k1 = ob + nf, *k2 = ob + 2 * nf, *k3 = ob + 3 * nf, *k4 = ob + 4 * nf, *t = ob + 5 * nf;
+        const long st_seq = (long)attn_slots * 192;
+        auto F = [&](const float* state, float* kout) -> int {
+            RUN(STT_STAGE_EMBED, s, sttode_linear_cols(state, 64, 64, nullptr, 0, 0, W[STT_W_INP], W[STT_W_INB], qkv, 192, n, 192, 0, s));
+            RUN(STT_STAGE_ATTN, s,
+                sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, attn, nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
+                                  st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+            RUN(STT_STAGE_POST, s,
+                sttode_post_attn_rhs(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
+                                     W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], state,
+                                     attn, 64, kout, n, s));
+            return 0;
+        };
+        auto copy = [&](float* dst, const float* src) -> int { STT_HIP(hipMemcpyAsync(dst, src, nf * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0; };
+        auto axpy = [&](float* yv, double a, const float* x) -> int {
+            return sttode_train_ewise(1, yv, x, nullptr, nullptr, nullptr, (long)nf, 0, (float)a, s);
+        };
+#define ODE_DO(call) do { if (int _rc = (call)) return _rc; } while (0)
+        ODE_DO(copy(y, g));
+        const double h = 12.0 / (double)m->ode_steps;
+        for (int st = 0; st < m->ode_steps; ++st) {
+            ODE_DO(F(y, k1));
+            if (m->ode_method == 0) { ODE_DO(axpy(y, h, k1)); continue; }
+            if (m->ode_method == 1) {   // torchdiffeq's fixed-grid rk4 = the 3/8 rule (rk4_alt_step_func)
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 3, k1)); ODE_DO(F(t, k2));
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k2)); ODE_DO(axpy(t, -h / 3, k1)); ODE_DO(F(t, k3));
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k1)); ODE_DO(axpy(t, -h, k2)); ODE_DO(axpy(t, h, k3)); ODE_DO(F(t, k4));
+                ODE_DO(axpy(y, h / 8, k1)); ODE_DO(axpy(y, 3 * h / 8, k2)); ODE_DO(axpy(y, 3 * h / 8, k3)); ODE_DO(axpy(y, h / 8, k4));
+            } else {                    // classical RK4
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 2, k1)); ODE_DO(F(t, k2));
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 2, k2)); ODE_DO(F(t, k3));
+                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k3)); ODE_DO(F(t, k4));
+                ODE_DO(axpy(y, h / 6, k1)); ODE_DO(axpy(y, h / 3, k2)); ODE_DO(axpy(y, h / 3, k3)); ODE_DO(axpy(y, h / 6, k4));
+            }
+        }
+#undef ODE_DO
+        RUN(STT_STAGE_POST, s, sttode_ode_state_to_pf(g, y, pf, n, s));
+    } else if (m->ode_method != 0 || m->ode_steps != 1) {
         RUN(STT_STAGE_POST, s,
             sttode_post_attn_ode(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
                                  W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B],

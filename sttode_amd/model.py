@@ -433,8 +433,24 @@ class STTODENet(nn.Module):
         pf = self._f(n, 128)
         if (self.ode_method, self.ode_steps) != ('euler', 1):
             if L > 1:
-                raise NotImplementedError('a non-default ODE integrator with an attention group > 1 needs a pass over the group per stage: '
-                                          'use the op-level sttode_amd.hypertransformer.ODEG_Encoder(method, steps)')
+                # every stage is a pass over the whole attention group: in-projection of the state -> geodesic attention -> f(y); the same
+                # stage algebra the native pipeline enqueues (csrc/pipeline.hip stage_agents) and hypertransformer.ode_integrate spells out
+                from .hypertransformer import ode_integrate
+                e = qkv.element_size()
+
+                def rhs(y):
+                    q2, a2, k = self._f(n, 192), self._f(n, 64), self._f(n, 64)
+                    capi.call('sttode_linear_cols', y, 64, 64, None, 0, 0, W['inP'], W['inb'], q2, 192, n, 192, 0, st)
+                    capi.call('sttode_mhgsa_attn', q2.data_ptr() + 64 * e, q2.data_ptr(), q2.data_ptr() + 128 * e, a2, None, None, L, L,
+                              Nslots, Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192, Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
+                    capi.call('sttode_post_attn_rhs', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
+                              W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], y, a2, 64, k, n, st)
+                    self._keep_ode = (q2, a2)
+                    return k
+                yT = ode_integrate(rhs, g, self.ODE_TIME, self.ode_method, int(self.ode_steps))
+                capi.call('sttode_ode_state_to_pf', g, yT, pf, n, st)
+                self._keep = (g, qkv)
+                return pf
             capi.call('sttode_post_attn_ode', W['outP'], W['outb'], W['infoP'], W['infob'], W['gateP'], W['gateb'], W['ln1w'], W['ln1b'],
                       W['l1P'], W['l1b'], W['l2P'], W['l2b'], W['ln2w'], W['ln2b'], W['inP'], W['inb'], g, pf, n, self.ODE_TIME,
                       self.ODE_METHODS[self.ode_method], int(self.ode_steps), st)

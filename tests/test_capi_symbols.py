@@ -175,8 +175,12 @@ def test_input_validation_on_host():
         m.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 4], np.int32))         # CSR does not end at n
     with pytest.raises(capi.SttodeError):
         m.inference(None)                                                                              # nothing set
-    with pytest.raises(NotImplementedError):
-        STTODENet(make_args(Tp=8, Tf=12).__class__(**{**vars(make_args()), 'num_decompose': 3}), 'cpu')
+    # model shapes outside the built kernel instantiations are refused in ONE place, STTODENet.__init__ (the reference derives every dimension
+    # from args, model/STTODE.py:179-196,246-254,350-366; its defaults -- and every checkpoint its CLI produces with them -- are what is built)
+    for bad in ({'num_decompose': 3}, {'num_decompose': 1}, {'hidden_dim': 128}, {'hidden_dim': 32}, {'zdim': 16}, {'zdim': 64},
+                {'past_length': 17}, {'future_length': 49}):
+        with pytest.raises(NotImplementedError):
+            STTODENet(make_args().__class__(**{**vars(make_args()), **bad}), 'cpu')
     a = make_args()
     a.learn_prior = True
     m2 = STTODENet(a, 'cpu')
