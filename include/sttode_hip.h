@@ -312,6 +312,7 @@ enum SttodeWeight {
     STT_W_B0_YB1, STT_W_B0_STREAM,
     STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
     STT_W_CHAIN_POOL, STT_W_CHAIN_PROG, STT_W_CHAIN_CONSTS, STT_W_G0_POOL, STT_W_G0_PROG, STT_W_G0_CONSTS,
+    STT_W_CHAINB3_POOL, STT_W_CHAINB3_PROG,   /* exploratory bf16-split stream of the fused launch (packing.chain_stream_b3) */
     STT_W_COUNT
 };
 
@@ -350,6 +351,11 @@ int sttode_set_chain(SttodeModel* m, int mode);
  * the roles also run set_data's normalisation of their tile (model/STTODE.py:397-461): the call is ONE launch; 0 = separate launches on
  * the pipeline's per-agent stream.  Results are bitwise the same in every mode. */
 int sttode_set_fused(SttodeModel* m, int mode);
+/* EXPLORATORY, opt-in, never the default (own dtype label in bench.py): 1 = the fused launch runs the two block-0 decoder MLPs
+ * (DecomposeBlock.forward model/STTODE.py:71-77 of block 0: 38 % of the per-trajectory FLOP) as a three-way bf16 split on the bf16
+ * matrix cores -- x = hi + mid + lo, six products, fp32 accumulate: fp32-class accuracy, held to the same golden vectors at the same
+ * 1e-4 -- instead of fp32 MFMAs; 0 (default, or env STTODE_BF16X3) = fp32 everywhere.  Applies to fused launches only. */
+int sttode_set_mfma_mode(SttodeModel* m, int mode);
 /* Grid order of the fused launch (host-callable, no GPU): block -> group index (>= 0) or -1 - tile for the per-agent role of a 16-agent
  * tile; roles sit `lead` groups ahead of the first group that reads their tables, so every producer has a smaller block index than its
  * consumers (Decoder.forward's repeat_interleave layout, model/STTODE.py:322-328: trajectory = agent * K + k). */

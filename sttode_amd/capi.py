@@ -77,6 +77,7 @@ SIGNATURES = {
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
     'sttode_set_fused': [_P, _I],
+    'sttode_set_mfma_mode': [_P, _I],
     'sttode_fused_block_of': [_L, _L, _L, _L, _L],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
@@ -94,7 +95,8 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                                        'ln2b')]
                 + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream')]
                 + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')]
-                + [('chain', k) for k in ('pool', 'prog', 'consts')] + [('gru0s', k) for k in ('pool', 'prog', 'consts')])
+                + [('chain', k) for k in ('pool', 'prog', 'consts')] + [('gru0s', k) for k in ('pool', 'prog', 'consts')]
+                + [('chain_b3', k) for k in ('pool', 'prog')])
 TRUNK_PTRS = ('fc1_w', 'fc1_b', 'pos_w', 'pos_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b', 'inproj_w', 'inproj_b', 'out_w', 'out_b', 'info_w', 'info_b',
               'gate_w', 'gate_b', 'ln1_w', 'ln1_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'ln2_w', 'ln2_b', 'enc_in', 'last', 'pe', 'drop', 'posin', 'tp',
               'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode')   # enum SttodeTrunkPtr
@@ -143,6 +145,11 @@ class NativeModel:
         0: separate per-agent launches."""
         if lib().sttode_set_fused(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())
+
+    def set_mfma_mode(self, mode):
+        """EXPLORATORY: 1 = block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix cores; 0 = fp32."""
+        if lib().sttode_set_mfma_mode(self.h, int(mode)) != 0:
+            raise SttodeError('sttode_set_mfma_mode failed: ' + lib().sttode_last_error().decode())
 
     def set_ode(self, method, steps):
         if lib().sttode_set_ode(self.h, int(method), int(steps)) != 0:

@@ -11,7 +11,7 @@ int stt_agents_fused(const float* const* W, const float* enc_in, const int* last
                      float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip
 bool stt_agents_fused_covers(int Tp, int TPX);                                          // encoder.hip: shapes the fused per-agent kernel is built for
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
+                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
 bool stt_chain_fused_covers(int Tp);                                                    // chain32.hip
 int stt_gru_lat_tiles();
 int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.hip: sttode_set_latency_tiles)

@@ -118,20 +118,25 @@ __device__ __forceinline__ f32x16 ldrows(const float* p, int h) {
     return r;
 }
 
-struct ChainStream {
+// BUF: f32x4 per ring buffer (= the largest chunk).  GEN = false: program entries are (first PK32 tile, tiles <= 3) of 4-KiB tiles;
+// GEN = true (exploratory bf16-split mode: tiles of 6 and 4 KiB in one pool): (offset in f32x4 units, number of 1-KiB pieces).
+template <int BUF, bool GEN>
+struct ChainStreamT {
+    static constexpr int kBuf = BUF;
     const f32x4* pool; const int2* lprog; f32x4* ring;  // lprog: the chunk program, copied to LDS at kernel start
     unsigned ring_addr;
     int len, p, par, lane, wave;
     int2 nxt_v;  // program entry of the chunk after the one in flight: read from LDS one step early, consumed at the next begin()
     __device__ __forceinline__ void dma(int2 ev, int buf) {
-        // a chunk of nt tiles = 4*nt pieces of 1 KiB; wave w moves pieces w, w+4, w+8
-        const int off = __builtin_amdgcn_readfirstlane(ev.x), nt = __builtin_amdgcn_readfirstlane(ev.y);
-        const f32x4* src = pool + (size_t)off * C32_TILE + lane;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)buf * (C32_CMAX * C32_TILE * 16) + (unsigned)wave * 1024);
+        // a chunk = `pieces` pieces of 1 KiB; wave w moves pieces w, w+4, w+8, ...
+        const int off = __builtin_amdgcn_readfirstlane(ev.x), cnt = __builtin_amdgcn_readfirstlane(ev.y);
+        const f32x4* src = pool + (GEN ? (size_t)off : (size_t)off * C32_TILE) + lane;
+        const int pieces = GEN ? cnt : 4 * cnt;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)buf * (BUF * 16) + (unsigned)wave * 1024);
 #ifndef C32_DIAG_NODMA
 #pragma unroll
-        for (int i = 0; i < C32_CMAX; ++i)
-            if (i < nt) glds16_asm(src + (4 * i + wave) * 64, dst + i * 4096);
+        for (int i = 0; i < (BUF / 64 + 3) / 4; ++i)
+            if (4 * i + wave < pieces) glds16_asm(src + (4 * i + wave) * 64, dst + i * 4096);
 #endif
     }
     __device__ __forceinline__ void init(const f32x4* pool_, const int2* lprog_, int len_, f32x4* ring_) {
@@ -152,7 +157,7 @@ struct ChainStream {
         nxt_v = lprog[q];
         __builtin_amdgcn_sched_barrier(0);
     }
-    __device__ __forceinline__ const f32x4* cur() const { return ring + par * (C32_CMAX * C32_TILE) + lane; }
+    __device__ __forceinline__ const f32x4* cur() const { return ring + par * BUF + lane; }
     // end of a chunk step: this wave's DMA pieces have landed (vmcnt), then everybody's (barrier)
     __device__ __forceinline__ void end() {
         __builtin_amdgcn_sched_barrier(0);
@@ -165,6 +170,7 @@ struct ChainStream {
         __builtin_amdgcn_sched_barrier(0);
     }
 };
+typedef ChainStreamT<C32_CMAX * C32_TILE, false> ChainStream;
 
 // acc += Atile (32 rows x 32 k, PK32) * B (32 k x 32 columns in accumulator layout)
 __device__ __forceinline__ void tile_mma(f32x16& acc, const f32x4* __restrict__ t, const f32x16& B) {
@@ -204,8 +210,8 @@ __device__ __forceinline__ void tile_mma2(f32x16& acc, const Frag& cur, const f3
 // whole group otherwise; the kernel has 256 and must not spill: a kernel with ANY scratch pays a scratch set-up per dispatch).
 // The per-agent pre-activation rows arrive through the wave's gather slot (4 x 16 B per lane per hidden tile, LDS-DMA):
 // a0 points at this lane's A0 row; a0_next at the row the NEXT phase starts with.
-template <int KH>
-__device__ __forceinline__ void mlp_l12(ChainStream& st, const f32x4* slot, const f32x4* zslot, const f32x16* Bh,
+template <int KH, class ST>
+__device__ __forceinline__ void mlp_l12(ST& st, const f32x4* slot, const f32x4* zslot, const f32x16* Bh,
                                         const float* __restrict__ a0, const float* __restrict__ a0_next, f32x16 (&acc2)[8], int lane, int h) {
     const unsigned slot_addr = __builtin_amdgcn_readfirstlane(lds_addr(slot));
     constexpr int KT1 = 1 + KH;
@@ -258,8 +264,8 @@ __device__ __forceinline__ void mlp_l12(ChainStream& st, const f32x4* slot, cons
 }
 
 // Layer 3: out[o] = b3 + W3[o] relu(acc2 + b2), NO output tiles of 32 rows; 8 k-tiles per output tile, chunks of 3 tiles.
-template <int NO>
-__device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const float* __restrict__ b2, const float* __restrict__ b3,
+template <int NO, class ST>
+__device__ __forceinline__ void mlp_l3(ST& st, f32x16 (&acc2)[8], const float* __restrict__ b2, const float* __restrict__ b3,
                                        f32x16 (&out)[NO], int h) {
 #pragma unroll
     for (int R = 0; R < 8; ++R) {
@@ -285,11 +291,170 @@ __device__ __forceinline__ void mlp_l3(ChainStream& st, f32x16 (&acc2)[8], const
     st.end();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// EXPLORATORY (round 3, opt-in, never the default): the two block-0 MLPs on the bf16 matrix cores with fp32-class accuracy.
+// x = hi + mid + lo (three bf16 values, 8 mantissa bits each: 24 bits, what fp32 holds), W likewise (split on the host, packing.pk32b_tile);
+// W x ~ lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi (the three dropped products are <= 2^-24 relative), fp32 accumulate:
+// six v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16-deep k block = 384 matrix-pipe cycles per 32 x 32 x 32 tile against 1 024 for
+// sixteen 32x32x2 fp32 MFMAs.  The fp32 accumulator layout of a layer is still the B layout of the next: k slot s of lane half h of
+// k block kb <-> accumulator register 8 kb + s.  Costs: the split of every activation tile (11 VALU instructions per pair of values),
+// 1.5x the A-operand bytes.  Measured in the chain's weight-stream structure: 252 vs 143 fp32-equivalent TFLOP/s
+// (profiles/r03/bf16x3_probe.json, csrc/diag/diag.hip shape 6).
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#define C32_TILE_B3 384                     // f32x4 per bf16-split tile (6 KiB)
+#define C32_BUF_B3 (C32_CMAX * C32_TILE_B3) // f32x4 per ring buffer in the exploratory mode (18 KiB)
+struct B3 { bf16x8 p[3][2]; };              // [plane: hi, mid, lo][k block]
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void split3(const f32x16& x, B3& o) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = x[8 * kb + 2 * q], x1 = x[8 * kb + 2 * q + 1];
+            const f32x2v v = {x0, x1};
+            hi[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+            const float r0 = x0 - bf_lo(hi[q]), r1 = x1 - bf_hi(hi[q]);
+            const f32x2v rv = {r0, r1};
+            mi[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, bf16x2));
+            const f32x2v qv = {r0 - bf_lo(mi[q]), r1 - bf_hi(mi[q])};
+            lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(qv, bf16x2));
+        }
+        const u32x4v H = {hi[0], hi[1], hi[2], hi[3]}, M = {mi[0], mi[1], mi[2], mi[3]}, L = {lo[0], lo[1], lo[2], lo[3]};
+        o.p[0][kb] = __builtin_bit_cast(bf16x8, H);
+        o.p[1][kb] = __builtin_bit_cast(bf16x8, M);
+        o.p[2][kb] = __builtin_bit_cast(bf16x8, L);
+    }
+}
+struct Frag6 { f32x4 a[6]; };               // [k block * 3 + plane]
+__device__ __forceinline__ void ldfrag6(Frag6& f, const f32x4* __restrict__ t) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f.a[i] = t[i * 64];
+}
+// acc += tile x B; the next tile's six fragments are requested halfway (tn != nullptr), like tile_mma2.  Small products first.
+__device__ __forceinline__ void tile_mma_b3(f32x16& acc, const Frag6& cur, const B3& B, Frag6& nxt, const f32x4* __restrict__ tn) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 1 && tn) {
+            ldfrag6(nxt, tn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, cur.a[kb * 3 + 0]), am = __builtin_bit_cast(bf16x8, cur.a[kb * 3 + 1]),
+                     al = __builtin_bit_cast(bf16x8, cur.a[kb * 3 + 2]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, B.p[0][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[2][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, B.p[1][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, B.p[0][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[1][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[0][kb], acc, 0, 0, 0);
+    }
+}
+// acc += tile x B without look-ahead: the tile's six fragments are read here (the register-tight block-1 form; the SIMD's other wave
+// covers the LDS latency)
+__device__ __forceinline__ void tile_mma_b3n(f32x16& acc, const f32x4* __restrict__ t, const B3& B) {
+    Frag6 f, dummy;
+    ldfrag6(f, t);
+    tile_mma_b3(acc, f, B, dummy, nullptr);
+}
+// mlp_l12<KH> on split tiles: per hidden tile 1 + KH layer-1 tiles (B = z, then the KH state tiles Bh: each split HERE from its fp32
+// registers -- keeping three more tiles as planes would cost 72 VGPRs the kernel does not have) + 8 layer-2 row tiles.
+// PRE: fragment look-ahead across tiles (KH = 0); without it 24 fewer VGPRs (KH = 3).
+template <int KH, bool PRE, class ST>
+__device__ __forceinline__ void mlp_l12_b3(ST& st, const f32x4* slot, const f32x4* zslot, const f32x16* Bh, const float* __restrict__ a0,
+                                           const float* __restrict__ a0_next, f32x16 (&acc2)[8], int lane, int h) {
+    const unsigned slot_addr = __builtin_amdgcn_readfirstlane(lds_addr(slot));
+    constexpr int KT1 = 1 + KH;
+    static_assert((KT1 + 8) % 3 == 0, "hidden tile must be a whole number of chunks");
+#pragma unroll
+    for (int R = 0; R < 8; ++R) acc2[R] = splat16(0.f);
+#pragma unroll 1
+    for (int ht = 0; ht < 16; ++ht) {
+        f32x16 h1, zb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 v = slot[a * 64 + lane];
+            h1[4 * a + 0] = v[0]; h1[4 * a + 1] = v[1]; h1[4 * a + 2] = v[2]; h1[4 * a + 3] = v[3];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 v = zslot[a * 64 + lane];
+            zb[4 * a + 0] = v[0]; zb[4 * a + 1] = v[1]; zb[4 * a + 2] = v[2]; zb[4 * a + 3] = v[3];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the gather issued next
+        __builtin_amdgcn_sched_barrier(0);
+        const float* nx = (ht + 1 < 16) ? a0 + 32 * (ht + 1) : a0_next;
+        B3 Bt;
+        split3(zb, Bt);
+        Frag6 fr[2];
+#pragma unroll
+        for (int i = 0; i < KT1 + 8; ++i) {
+            if (i % 3 == 0) {
+                if (i > 0) st.end();
+                if (PRE) ldfrag6(fr[i & 1], st.cur());
+                st.begin();
+                if (i == 0) {
+#ifndef C32_DIAG_NOGATHER
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) glds16_asm(nx + 8 * a + 4 * h, slot_addr + a * 1024);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const f32x4* tc = st.cur() + (i % 3) * C32_TILE_B3;
+            const f32x4* tn = (i % 3 < 2) ? tc + C32_TILE_B3 : nullptr;
+            if (i > 0 && i < KT1) {
+                STT_FENCE();
+                split3(Bh[i - 1], Bt);                // state tile i-1 of this wave's columns
+            }
+            f32x16& acc = i < KT1 ? h1 : acc2[i < KT1 ? 0 : i - KT1];
+            if (PRE) tile_mma_b3(acc, fr[i & 1], Bt, fr[(i + 1) & 1], tn);
+            else tile_mma_b3n(acc, tc, Bt);
+            if (i == KT1 - 1) {
+                h1 = relu16(h1);
+                split3(h1, Bt);                       // the hidden tile's planes take the registers of the layer-1 operand's
+            }
+        }
+        st.end();
+    }
+}
+// mlp_l3 on split tiles, k-tile major: activation tile T is split once and feeds all NO output tiles.
+template <int NO, class ST>
+__device__ __forceinline__ void mlp_l3_b3(ST& st, f32x16 (&acc2)[8], const float* __restrict__ b2, const float* __restrict__ b3,
+                                          f32x16 (&out)[NO], int h) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[o] = ldrows(b3 + 32 * o, h);
+    Frag6 fr[2];
+    B3 Bt;
+#pragma unroll
+    for (int i = 0; i < 8 * NO; ++i) {
+        if (i % NO == 0) {
+            STT_FENCE();
+            const f32x16 b = ldrows(b2 + 32 * (i / NO), h);
+            const f32x16 a = relu16(acc2[i / NO] + b);
+            split3(a, Bt);
+        }
+        if (i % 3 == 0) {
+            if (i > 0) st.end();
+            ldfrag6(fr[i & 1], st.cur());
+            st.begin();
+        }
+        const f32x4* tn = (i % 3 < 2 && i + 1 < 8 * NO) ? st.cur() + (i % 3 + 1) * C32_TILE_B3 : nullptr;
+        tile_mma_b3(out[i % NO], fr[i & 1], Bt, fr[(i + 1) & 1], tn);
+    }
+    st.end();
+}
+
 // conv1d(k=3) + relu + GRU(32 -> 96) over Tp steps for this wave's 32 columns, every weight tile streamed per step
 // (model/STTODE.py:62-69; gate rows pre-scaled, chain.hpp): d = the flattened (t, c) input rows in accumulator layout, hs = h (in/out),
 // gb = gate biases [4][96] (r, z, b_in, b_hn), cb = conv bias [32], both in LDS.  Per step: 1 conv tile (a chunk of its own) and 36
 // gate tiles = 12 chunks.  Shared by the fused chain (block 1, per trajectory) and gru32_kernel (block 0, per agent).
-__device__ __forceinline__ void gru32_steps(ChainStream& st, const float* gb, const float* cb, const f32x16& d, f32x16 (&hs)[3], int Tp, int h) {
+template <class ST>
+__device__ __forceinline__ void gru32_steps(ST& st, const float* gb, const float* cb, const f32x16& d, f32x16 (&hs)[3], int Tp, int h) {
 #pragma unroll 1
     for (int t = 0; t < Tp; ++t) {
         f32x16 e = ldrows(cb, h);
@@ -483,11 +648,12 @@ __host__ __device__ __forceinline__ int fused_block_of(long b, long T, long G, l
     return -1 - (int)(b - (lo + 1));
 }
 
-template <int NY, bool FUSE>
+template <int NY, bool FUSE, bool B3M>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
+    typedef ChainStreamT<B3M ? C32_BUF_B3 : C32_CMAX * C32_TILE, B3M> Stream;   // B3M: exploratory bf16-split mode (block-0 MLPs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
-    f32x4* slots = ring + C32_RING;
+    f32x4* slots = ring + 2 * Stream::kBuf;
     f32x4* zslots = slots + 4 * C32_SLOT;
     float* cst = reinterpret_cast<float*>(zslots + 4 * C32_SLOT);
     int2* lprog = reinterpret_cast<int2*>(cst + C32Const<NY>::total);
@@ -528,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         return;
     }
     if (g >= ngroups) return;  // (uniform) cannot happen with grid <= ngroups; nothing is in flight yet
-    ChainStream st;
+    Stream st;
     st.init(A.pool, lprog, A.prog_len, ring);
 
     auto col_of = [&](int gg) { int col = gg * 128 + wave * 32 + c; return col < A.ncols ? col : A.ncols - 1; };
@@ -561,9 +727,14 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         f32x16 d;
         {   // ---- block 0, decoder_x: x_hat0, d = x_true - x_hat0
             agent = opaque(agent);
-            mlp_l12<0>(st, slot, zslot, nullptr, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
             f32x16 xo[1];
-            mlp_l3<1>(st, acc2, cst + CO::b2x, cst + CO::b3x, xo, h);
+            if (B3M) {
+                mlp_l12_b3<0, true>(st, slot, zslot, nullptr, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
+                mlp_l3_b3<1>(st, acc2, cst + CO::b2x, cst + CO::b3x, xo, h);
+            } else {
+                mlp_l12<0>(st, slot, zslot, nullptr, A.A0x + (size_t)agent * 512, A.A0y + (size_t)agent * 512, acc2, lane, h);
+                mlp_l3<1>(st, acc2, cst + CO::b2x, cst + CO::b3x, xo, h);
+            }
             agent = opaque(agent);
             const float* xp = A.xpad + (size_t)agent * A.ldx;
 #pragma unroll
@@ -578,9 +749,14 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         C32_STAMP(1);
         {   // ---- block 0, decoder_y: y_hat0 parked in pred (re-read by the epilogue)
             agent = opaque(agent);
-            mlp_l12<0>(st, slot, zslot, nullptr, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
             f32x16 yo[NY];
-            mlp_l3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
+            if (B3M) {
+                mlp_l12_b3<0, true>(st, slot, zslot, nullptr, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
+                mlp_l3_b3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
+            } else {
+                mlp_l12<0>(st, slot, zslot, nullptr, A.A0y + (size_t)agent * 512, A.A1y + (size_t)agent * 512, acc2, lane, h);
+                mlp_l3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
+            }
             if (live) {
                 float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
 #pragma unroll
@@ -614,14 +790,16 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         {   // ---- block 1, decoder_y + epilogue
             agent = opaque(agent);
             const int cnx = col_of(gnext < ngroups ? gnext : g);
-            mlp_l12<3>(st, slot, zslot, hs, A.A1y + (size_t)agent * 512, A.A0x + (size_t)(cnx / A.K) * 512, acc2, lane, h);
+            if (B3M) mlp_l12_b3<3, false>(st, slot, zslot, hs, A.A1y + (size_t)agent * 512, A.A0x + (size_t)(cnx / A.K) * 512, acc2, lane, h);
+            else mlp_l12<3>(st, slot, zslot, hs, A.A1y + (size_t)agent * 512, A.A0x + (size_t)(cnx / A.K) * 512, acc2, lane, h);
             {   // z of the NEXT group into the z slot (this group's last read of it is behind us); lands during layer 3
                 const float* zp = A.z + (size_t)opaque(cnx) * 32;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) glds16_asm(zp + 8 * a + 4 * h, zslot_addr + a * 1024);
             }
             f32x16 yo[NY];
-            mlp_l3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
+            if (B3M) mlp_l3_b3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
+            else mlp_l3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
             if (live) {
                 agent = opaque(agent);
                 const float cx = A.cur[2 * agent], cy = A.cur[2 * agent + 1];
@@ -722,15 +900,15 @@ static int chain_cus() {
     }
     return n;
 }
-static int chain_lds(int NY, int prog_len) { return (C32_RING + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
+static int chain_lds(int NY, int prog_len, bool b3 = false) { return ((b3 ? 2 * C32_BUF_B3 : C32_RING) + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
 static int role_lds(int Tp) {   // agent_role's phases: embed (Tp*256 + 512 f32x4), GRU (h tiles 12 KiB + image of hidden tiles 4, 5: 48 KiB)
     const int e = (Tp * 256 + 512) * 16, g = (2 * 6 * 64 + 2 * 24 * 64) * 16;
     return e > g ? e : g;
 }
 
-template <int NY, bool FUSE> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
-    STT_SET_LDS_ONCE((traj_chain_kernel<NY, FUSE>), 96 * 1024);   // once per (instantiation, device)
+template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
+    STT_SET_LDS_ONCE((traj_chain_kernel<NY, FUSE, B3M>), 96 * 1024);   // once per (instantiation, device)
     const int ngroups = (a.ncols + 127) / 128;
     // STTODE_CHAIN_RESERVE=r leaves r of the chip's 2-per-CU workgroup slots to concurrently running kernels (the per-agent stage
     // of the next call in the pipelined form); the work queue makes the remaining workgroups absorb the groups
@@ -747,12 +925,12 @@ template <int NY, bool FUSE> static int chain_launch(const ChainArgs& a, int wgs
     static int wgs_env = -1;   // STTODE_CHAIN_WGS=1|2 overrides the caller's choice (experiments)
     if (wgs_env < 0) { const char* e = getenv("STTODE_CHAIN_WGS"); wgs_env = e ? atoi(e) : 0; }
     const int wgs = wgs_env > 0 ? wgs_env : wgs_per_cu;
-    int lds = chain_lds(NY, a.prog_len);
+    int lds = chain_lds(NY, a.prog_len, B3M);
     if (FUSE && lds < role_lds(a.Tp)) lds = role_lds(a.Tp);
     if (wgs == 1 && lds < 84 * 1024) lds = 84 * 1024;
     STT_REQUIRE(lds <= 96 * 1024, "sttode_traj_chain: dynamic LDS beyond the 96 KiB the kernel is registered for");
     if (FUSE) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
-    hipLaunchKernelGGL((traj_chain_kernel<NY, FUSE>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((traj_chain_kernel<NY, FUSE, B3M>), dim3(grid), dim3(256), lds, s, a);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -836,7 +1014,8 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
 // The reference's one Euler step only.
 bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, void* stream) {
+                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3,
+                    void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
     STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
@@ -844,7 +1023,8 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     STT_REQUIRE((long)n * K <= 0x7fffffffL, "stt_chain_fused: too many trajectories");
     ChainArgs a;
     a.A0x = ws + off[STT_B_A0X]; a.A0y = ws + off[STT_B_A0Y]; a.A1y = ws + off[STT_B_A1Y];
-    a.pool = (const f32x4*)W[STT_W_CHAIN_POOL]; a.prog = (const int2*)W[STT_W_CHAIN_PROG]; a.prog_len = prog_len;
+    a.pool = (const f32x4*)W[b3 ? STT_W_CHAINB3_POOL : STT_W_CHAIN_POOL]; a.prog = (const int2*)W[b3 ? STT_W_CHAINB3_PROG : STT_W_CHAIN_PROG];
+    a.prog_len = prog_len;
     a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.cur = ws + off[STT_B_CUR];
     a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
     a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0;
@@ -886,9 +1066,9 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {
-        case 1: return chain_launch<1, true>(a, wgs_per_cu, s);
-        case 2: return chain_launch<2, true>(a, wgs_per_cu, s);
-        case 3: return chain_launch<3, true>(a, wgs_per_cu, s);
+        case 1: return b3 ? chain_launch<1, true, true>(a, wgs_per_cu, s) : chain_launch<1, true>(a, wgs_per_cu, s);
+        case 2: return b3 ? chain_launch<2, true, true>(a, wgs_per_cu, s) : chain_launch<2, true>(a, wgs_per_cu, s);
+        case 3: return b3 ? chain_launch<3, true, true>(a, wgs_per_cu, s) : chain_launch<3, true>(a, wgs_per_cu, s);
         default: STT_REQUIRE(false, "stt_chain_fused: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;

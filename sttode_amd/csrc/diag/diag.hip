@@ -375,6 +375,131 @@ __global__ __launch_bounds__(256, 2) void diag_stream32i_kernel(const f32x4* __r
     if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// shape 6 / 7 (round 3, exploratory): the same weight-stream structure with the fp32 product replaced by a THREE-WAY bf16 SPLIT on the
+// bf16 matrix cores: x = hi + mid + lo (8 mantissa bits each), W likewise (split on the host), W x ~ hi.hi + hi.mid + mid.hi + hi.lo +
+// lo.hi + mid.mid (the dropped terms are <= 2^-24 relative): six v_mfma_f32_32x32x16_bf16 per 16-deep k block, fp32 accumulate.
+// A "tile" (32 rows x 32 k) = 2 k blocks x 3 planes x 1 KiB = 6 KiB, read by six ds_read_b128 per lane; per tile and wave 12 MFMAs
+// of 32 cycles = 384 matrix-pipe cycles against 1 024 for the sixteen 32x32x2 fp32 MFMAs of shape 1.  The accumulator layout of a
+// layer still IS the B layout of the next: k slot s of lane half h <-> accumulator register 8 kb + s (feature 16 kb + 8 (s / 4) + 4 h + s % 4),
+// a permutation inside the 16-block that the host applies to the weight columns.  Per hidden tile: tile 0 = layer 1 (B = z planes),
+// relu, SPLIT of the 32 x 32 activation tile into planes (11 VALU instructions per pair of values), tiles 1..8 = layer-2 row tiles.
+// FLOP are counted as fp32-EQUIVALENT (65 536 per tile and wave, as for shape 1), so the figure compares directly with shapes 1..5.
+// WPS = waves per SIMD the kernel is compiled for: 2 (256 VGPRs, two workgroups per CU) or 1 (512 VGPRs, one workgroup per CU).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+struct B3 { bf16x8 p[3][2]; };   // [plane][k block]
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void split3(const f32x16& x, B3& o) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float x0 = x[8 * kb + 2 * p], x1 = x[8 * kb + 2 * p + 1];
+            f32x2v v = {x0, x1};
+            const bf16x2 h = __builtin_convertvector(v, bf16x2);
+            hi[p] = __builtin_bit_cast(unsigned, h);
+            const float r0 = x0 - bf_lo(hi[p]), r1 = x1 - bf_hi(hi[p]);
+            f32x2v rv = {r0, r1};
+            const bf16x2 m = __builtin_convertvector(rv, bf16x2);
+            mi[p] = __builtin_bit_cast(unsigned, m);
+            f32x2v qv = {r0 - bf_lo(mi[p]), r1 - bf_hi(mi[p])};
+            const bf16x2 l = __builtin_convertvector(qv, bf16x2);
+            lo[p] = __builtin_bit_cast(unsigned, l);
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 H = {hi[0], hi[1], hi[2], hi[3]}, M = {mi[0], mi[1], mi[2], mi[3]}, Lo = {lo[0], lo[1], lo[2], lo[3]};
+        o.p[0][kb] = __builtin_bit_cast(bf16x8, H);
+        o.p[1][kb] = __builtin_bit_cast(bf16x8, M);
+        o.p[2][kb] = __builtin_bit_cast(bf16x8, Lo);
+    }
+}
+// acc += tile (6 fragments at t: [kb][plane][64 lanes]) x B
+__device__ __forceinline__ void tile_mma_b3(f32x16& acc, const f32x4* __restrict__ t, const B3& B) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, t[(kb * 3 + 0) * 64]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, t[(kb * 3 + 1) * 64]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, t[(kb * 3 + 2) * 64]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, B.p[0][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[2][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, B.p[1][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, B.p[0][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[1][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, B.p[0][kb], acc, 0, 0, 0);
+    }
+}
+template <int C, int WPS>
+__global__ __launch_bounds__(256, WPS) void diag_stream_b3_kernel(const f32x4* __restrict__ blob, int total_tiles, float* __restrict__ out,
+                                                                  int ngroups, float seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* lds = reinterpret_cast<f32x4*>(smem);
+    constexpr int TILE = 384;  // f32x4 per tile (6 KiB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto dma = [&](int chunk, int buf) {
+        const f32x4* src = blob + ((size_t)chunk * C % total_tiles) * TILE + lane;
+        f32x4* dst = lds + buf * (C * TILE);
+#pragma unroll
+        for (int i = 0; i < (6 * C + 3) / 4; ++i) {
+            const int idx = i * 4 + wave;
+            if (idx < 6 * C) glds16(src + idx * 64, dst + idx * 64);
+        }
+    };
+    f32x16 acc2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = seed * (float)(i + 1);
+    f32x16 zf;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zf[e] = 1.0f - 0.002f * (float)(lane + e);
+    B3 Bz, Bh;
+    split3(zf, Bz);
+    Bh = Bz;
+    f32x16 h1;
+    dma(blockIdx.x, 0);
+    __syncthreads();
+    int chunk = 0;
+    for (int grp = 0; grp < ngroups; ++grp) {
+#pragma unroll
+        for (int cc = 0; cc < 9; ++cc) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma(blockIdx.x + chunk + 1, (chunk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4* buf = lds + (chunk & 1) * (C * TILE) + lane;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                const int ti = (cc * C + t) % 9;  // 0: layer 1, 1..8: layer 2 row tile ti-1
+                if (ti == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) h1[e] = 0.f;
+                    tile_mma_b3(h1, buf + t * TILE, Bz);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) h1[e] = fmaxf(h1[e], 0.f);
+                    split3(h1, Bh);
+                } else {
+                    tile_mma_b3(acc2[ti - 1], buf + t * TILE, Bh);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            ++chunk;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc2[i][e];
+    if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 struct StreamCtx { int shape, grid, lds, n, total; const f32x4* blob; float* scratch; hipStream_t s; };
 static void stream_go(void* p) {
     StreamCtx* c = (StreamCtx*)p;
@@ -385,7 +510,9 @@ static void stream_go(void* p) {
         case 2: hipLaunchKernelGGL((diag_stream32_kernel<3, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
         case 3: hipLaunchKernelGGL((diag_stream32_kernel<9, 0>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
         case 4: hipLaunchKernelGGL((diag_stream32_kernel<9, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
-        default: hipLaunchKernelGGL(diag_stream32i_kernel, g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
+        case 5: hipLaunchKernelGGL(diag_stream32i_kernel, g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
+        case 6: hipLaunchKernelGGL((diag_stream_b3_kernel<3, 2>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
+        default: hipLaunchKernelGGL((diag_stream_b3_kernel<3, 1>), g, b, c->lds, c->s, c->blob, c->total, c->scratch, c->n, 0.5f); break;
     }
 }
 
@@ -395,7 +522,7 @@ static void stream_go(void* p) {
 // 9-chunk groups (others) per workgroup.
 extern "C" int sttode_diag_stream(int shape, int wgs_per_cu, int n, int repeats, const float* blob, long blob_floats, float* scratch,
                                   double* tflops, void* stream) {
-    DIAG_REQUIRE(blob && scratch && tflops && n > 0 && repeats > 0 && shape >= 0 && shape <= 5, "sttode_diag_stream: bad arguments");
+    DIAG_REQUIRE(blob && scratch && tflops && n > 0 && repeats > 0 && shape >= 0 && shape <= 7, "sttode_diag_stream: bad arguments");
     DIAG_REQUIRE(wgs_per_cu >= 1 && wgs_per_cu <= (shape == 0 ? 3 : 2), "sttode_diag_stream: too many workgroups per CU");
     DIAG_REQUIRE(blob_floats >= 512 * 1024, "sttode_diag_stream: blob must hold >= 2 MiB");
     StreamCtx c;
@@ -405,6 +532,12 @@ extern "C" int sttode_diag_stream(int shape, int wgs_per_cu, int n, int repeats,
         c.lds = 2 * S0_CHW * 16; c.total = (int)(blob_floats / 4 / S0_CHW);
         flop_per_wg = 4.0 * n * 72.0 * 2048.0;
         DIAG_HIP(hipFuncSetAttribute((const void*)diag_stream16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
+    } else if (shape >= 6) {   // bf16 three-way split: 6 KiB tiles, 18 KiB chunks; FLOP counted as fp32-equivalent (65 536 per tile and wave)
+        const int C = 3;
+        c.lds = 2 * C * 6144; c.total = (int)(blob_floats / 4 / 384) / C * C;
+        flop_per_wg = 4.0 * n * 9.0 * C * 16.0 * 4096.0;
+        const void* f = shape == 6 ? (const void*)diag_stream_b3_kernel<3, 2> : (const void*)diag_stream_b3_kernel<3, 1>;
+        DIAG_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
     } else {
         const int C = shape <= 2 ? 3 : 9;
         c.lds = 2 * C * 4096; c.total = (int)(blob_floats / 4 / 256) / C * C;

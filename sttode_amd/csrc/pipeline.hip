@@ -33,6 +33,7 @@ struct SttodeModel {
     int col_parts;
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
     int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
+    int b3;          // exploratory: block-0 MLPs of the fused launch as a three-way bf16 split (sttode_set_mfma_mode)
     bool fe_in_role; // fused scene batches: the roles also run the scene front-end (STTODE_FE_IN_ROLE=1; default: a launch in front)
     int ode_method, ode_steps;  // integrator of the encoder ODE (0, 1 = one Euler step = the reference)
     int prog_len;
@@ -41,6 +42,8 @@ struct SttodeModel {
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB, sB2;
+    hipStream_t sX[3];   // extra streams of the fused rotation (STTODE_FUSED_STREAMS = 4..6; experiments: they share the runtime's hardware queues)
+    int fused_streams;
     int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate calls between sB and sB2
     long acalls;
     hipEvent_t ev_call, evA_done[STT_MAX_SLOTS], evB_done[STT_MAX_SLOTS];
@@ -77,6 +80,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->ode_method = 0; m->ode_steps = 1;
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
     m->fused_mode = 1;
+    m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
     // default off: measured neutral to -0.6 % pipelined and -1.5 % serial at 512 scenes (the two front-end launches cost less than the
     // ~10 us they add to every role), +1 % on the 256-scene SDD leg (profiles/r03/ab_lead_frontend_depth.txt)
@@ -121,6 +125,13 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
             if (!ok) g_sA[dev] = nullptr;
         }
         if (ok) { m->sA = g_sA[dev]; m->sB = g_sB[dev]; m->sB2 = g_sB2[dev]; }
+        m->fused_streams = 3;
+        if (const char* e = getenv("STTODE_FUSED_STREAMS")) m->fused_streams = atoi(e) < 1 ? 1 : atoi(e) > 6 ? 6 : atoi(e);
+        static hipStream_t g_sX[STT_MAX_DEVICES][3] = {};
+        for (int i = 0; ok && i < m->fused_streams - 3; ++i) {
+            if (!g_sX[dev][i]) ok = hipStreamCreateWithFlags(&g_sX[dev][i], hipStreamNonBlocking) == hipSuccess;
+            m->sX[i] = g_sX[dev][i];
+        }
     }
     ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
@@ -191,6 +202,13 @@ extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
     STT_REQUIRE(mode >= 0 && mode <= 2, "sttode_set_fused: mode must be 0, 1 or 2");
     m->fused_mode = mode ? 1 : 0;
     m->fe_in_role = mode == 2;
+    return 0;
+}
+
+extern "C" int sttode_set_mfma_mode(SttodeModel* m, int mode) {
+    STT_REQUIRE(m, "sttode_set_mfma_mode: null model");
+    STT_REQUIRE(mode == 0 || mode == 1, "sttode_set_mfma_mode: mode must be 0 (fp32) or 1 (three-way bf16 split, exploratory)");
+    m->b3 = mode;
     return 0;
 }
 
@@ -509,7 +527,7 @@ static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int at
                               st_seq, 192, st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
         attn = ws + off[STT_B_ATTN];
     }
-    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, s));
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, m->b3, s));
     return 0;
 }
 
@@ -545,7 +563,8 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     if (use_fused(m, n)) {
         // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
         // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)
-        hipStream_t sf = (m->acalls % 3 == 0) ? m->sB : (m->acalls % 3 == 1) ? m->sB2 : m->sA;
+        const int si = (int)(m->acalls % m->fused_streams);
+        hipStream_t sf = si == 0 ? m->sB : si == 1 ? m->sB2 : si == 2 ? m->sA : m->sX[si - 3];
         ++m->acalls;
         STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));
         STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));   // the slot's previous user has drained

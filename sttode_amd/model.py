@@ -182,6 +182,9 @@ class STTODENet(nn.Module):
         # integrator of the tensor-ODE encoder: the reference runs ONE Euler step (ode_demo.py:186-190) = ('euler', 1); 'rk4' is
         # torchdiffeq's fixed-grid rk4 (3/8 rule), 'rk4_classic' the classical one; steps = uniform steps over [0, 12] (oracle-checked only)
         self.ode_method, self.ode_steps = 'euler', 1
+        # EXPLORATORY, opt-in: 'bf16x3' runs the two block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix
+        # cores (fp32-class accuracy, fp32 accumulate; csrc/chain32.hip B3M); 'f32' (default) = fp32 MFMA everywhere.  env STTODE_BF16X3=1
+        self.mfma_mode = 'bf16x3' if os.environ.get('STTODE_BF16X3', '0') not in ('', '0') else 'f32'
         self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
         self._ptr_cache = {}
@@ -229,6 +232,7 @@ class STTODENet(nn.Module):
                     'future': packing.pack_trunk(sd, 'future_encoder.', a.future_length),
                     'post': packing.pack_posterior(sd),
                     'chain': packing.chain_stream(sd, a.past_length, a.future_length),
+                    'chain_b3': packing.chain_stream_b3(sd, a.past_length, a.future_length),
                     'gru0s': packing.gru32_stream(sd, 0, a.past_length)}
             self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
                                 for k, v in d.items()} for g, d in host.items()}
@@ -252,6 +256,11 @@ class STTODENet(nn.Module):
         if self._native is not None and getattr(self._native, '_ode', (0, 1)) != ode:
             self._native.set_ode(*ode)
             self._native._ode = ode
+        if self._native is not None and getattr(self._native, '_mfma', None) != self.mfma_mode:
+            if self.mfma_mode not in ('f32', 'bf16x3'):
+                raise ValueError("mfma_mode must be 'f32' or 'bf16x3'")
+            self._native.set_mfma_mode(1 if self.mfma_mode == 'bf16x3' else 0)
+            self._native._mfma = self.mfma_mode
         return self._native
 
     def _workspace(self, n, S):

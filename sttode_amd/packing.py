@@ -197,6 +197,45 @@ def pk32_tiles(W):
     return np.stack([np.stack([pk32_tile(Wp[32 * i:32 * i + 32, 32 * j:32 * j + 32]) for j in range(Kp // 32)]) for i in range(Np // 32)])
 
 
+def _bf16_rne(x):
+    """float32 array -> (bf16 bit patterns uint16, the same values widened back to float32); round to nearest even."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    return r, (r.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def pk32b_tile(Wb):
+    """[32, 32] block -> 1536 float32-sized words holding the THREE-WAY bf16 SPLIT of the block in v_mfma_f32_32x32x16_bf16 A-operand
+    order (exploratory mode, csrc/chain32.hip B3): W = hi + mid + lo with 8 mantissa bits each (round to nearest even at every level).
+    Layout [k block kb (2)][plane (3: hi, mid, lo)][lane (64)][8 bf16]: lane l holds row l & 31, k slot s of half h = l >> 5 is
+    column 16 kb + 8 (s // 4) + 4 h + s % 4 -- the feature that accumulator register 8 kb + s of the producing layer holds for that lane,
+    so the fp32 accumulator layout of a layer is still the B layout of the next."""
+    Wb = np.asarray(Wb, np.float32)
+    assert Wb.shape == (32, 32)
+    hi_b, hi_f = _bf16_rne(Wb)
+    mi_b, mi_f = _bf16_rne(Wb - hi_f)
+    lo_b, _ = _bf16_rne((Wb - hi_f) - mi_f)
+    out = np.zeros((2, 3, 64, 8), np.uint16)
+    lane = np.arange(64)
+    row, h = lane & 31, lane >> 5
+    for kb in range(2):
+        for s_ in range(8):
+            col = 16 * kb + 8 * (s_ // 4) + 4 * h + s_ % 4
+            for pl, src in enumerate((hi_b, mi_b, lo_b)):
+                out[kb, pl, :, s_] = src[row, col]
+    return np.ascontiguousarray(out).reshape(-1).view(np.float32)
+
+
+def pk32b_tiles(W):
+    """[N, K] (zero padded to multiples of 32) -> [N/32, K/32, 1536] (pk32b_tile of every block)."""
+    W = np.asarray(W, np.float32)
+    N, K = W.shape
+    Np, Kp = (N + 31) // 32 * 32, (K + 31) // 32 * 32
+    Wp = np.zeros((Np, Kp), np.float32)
+    Wp[:N, :K] = W
+    return np.stack([np.stack([pk32b_tile(Wp[32 * i:32 * i + 32, 32 * j:32 * j + 32]) for j in range(Kp // 32)]) for i in range(Np // 32)])
+
+
 def tiles_y32(Tf):
     return (2 * Tf + 31) // 32
 
@@ -204,6 +243,50 @@ def tiles_y32(Tf):
 def chain_prog_len(Tp, Tf):
     l3y = (8 * tiles_y32(Tf) + 2) // 3
     return (48 + 3) + (48 + l3y) + 13 * Tp + (64 + l3y)
+
+
+def chain_stream_b3(sd, Tp, Tf):
+    """Exploratory mode (csrc/chain32.hip, traj_chain_kernel<NY, FUSE, true>): the same consumption order as chain_stream, but the three
+    decoder MLPs (block-0 decoder_x and decoder_y, block-1 decoder_y: 63 % of the chain's FLOP) as three-way bf16 split tiles
+    (pk32b_tile, 6 KiB) for the bf16 matrix cores; block 1's conv + GRU stays fp32 PK32.  One flat pool with tiles of both sizes; the program holds
+    (offset in 16-byte units, number of 1-KiB pieces) per chunk of <= 3 tiles.  Layer 3 of the split MLPs is laid out k-tile major
+    (every activation tile is split once and feeds all output tiles)."""
+    f = chain_stream(sd, Tp, Tf)
+    NY = tiles_y32(Tf)
+    g = lambda k: np.asarray(sd[k], np.float32)
+    words, prog = [], []
+    pos = 0
+
+    def add(ts):
+        nonlocal pos
+        for o in range(0, len(ts), 3):
+            grp = ts[o:o + 3]
+            prog.append((pos // 4, sum(t.size for t in grp) // 256))
+            for t in grp:
+                words.append(t)
+                pos += t.size
+
+    def mlp_b3(prefix, kcols, NO, n_out):
+        W1, W2, W3 = g(prefix + 'layers.0.weight'), g(prefix + 'layers.1.weight'), g(prefix + 'layers.2.weight')
+        P1, P2 = pk32b_tiles(W1[:, kcols]), pk32b_tiles(W2)
+        W3p = np.zeros((32 * NO, 256), np.float32)
+        W3p[:n_out] = W3
+        P3 = pk32b_tiles(W3p)
+        for ht in range(16):
+            add(list(P1[ht]) + [P2[R, ht] for R in range(8)])
+        add([P3[o, T] for T in range(8) for o in range(NO)])          # k-tile major
+
+    mlp_b3('decoder.decompose.0.decoder_x.', slice(128, 160), 1, 2 * Tp)
+    mlp_b3('decoder.decompose.0.decoder_y.', slice(128, 160), NY, 2 * Tf)
+    n_b3 = len(prog)
+    l3y = (8 * NY + 2) // 3
+    assert n_b3 == (48 + 3) + (48 + l3y)
+    for first, cnt in f['prog'][n_b3:n_b3 + 13 * Tp]:                      # block-1 conv + GRU: the fp32 tiles, in the fp32 stream's own order
+        add([f['pool'][first + i] for i in range(cnt)])
+    mlp_b3('decoder.decompose.1.decoder_y.', slice(128, 256), NY, 2 * Tf)   # block-1 decoder_y: k = [z | state1]
+    assert len(prog) == f['prog_len']
+    return {'pool': np.ascontiguousarray(np.concatenate(words)), 'prog': np.ascontiguousarray(np.asarray(prog, np.int32)),
+            'consts': f['consts'], 'prog_len': len(prog)}
 
 
 def chain_stream(sd, Tp, Tf):

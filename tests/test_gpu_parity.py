@@ -538,6 +538,53 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         m.reset_async()
 
 
+@pytest.mark.parametrize('case', ['eth_512', 'eth_61', 'sdd', 'nba_128', 'nba_long'])
+def test_exploratory_bf16x3_mode_vs_fp32_and_oracle(case):
+    """EXPLORATORY opt-in mode (STTODENet.mfma_mode = 'bf16x3', sttode_set_mfma_mode): the two block-0 decoder MLPs of the fused launch as a
+    three-way bf16 split on the bf16 matrix cores (six products, fp32 accumulate).  Held to the SAME bar as the fp32 path: the CPU oracle
+    at rtol 1e-4 + atol 1e-4 on sampled scenes / the whole NBA batch, and against the fp32 mode of the same launch (agreement far inside
+    that bar is expected: the split carries 24 mantissa bits).  Deterministic: two runs give the same bits."""
+    from sttode_amd import scenes
+    if case in ('eth_512', 'eth_61', 'sdd'):
+        m, ora = hip_model('eth', 8, 12), oracle_model('eth', 8, 12)
+        sb = scenes.make_scene_batch(range(3000, 3512), 'eth') if case == 'eth_512' else \
+            scenes.make_scene_batch(range(3000, 3061), 'eth') if case == 'eth_61' else scenes.make_scene_batch(range(0, 96), 'sdd')
+        z = scenes.latents(55, sb.n_agents)
+        feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    else:
+        Tp, Tf, B, N = (5, 10, 128, 11) if case == 'nba_128' else (10, 40, 48, 10)
+        m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+        d = scenes.nba_batch(91, B, N=N, obs_len=Tp, pred_len=Tf)
+        z = scenes.latents(56, B * N)
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        feed = lambda: m.set_data_nba(data)
+    outs = {}
+    try:
+        m.native().set_chain(1)
+        for mode in ('f32', 'bf16x3'):
+            m.mfma_mode = mode
+            feed()
+            outs[mode] = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+            feed()
+            assert np.array_equal(m.inference(None, z=torch.from_numpy(z)).cpu().numpy(), outs[mode]), f'{case} {mode}: not deterministic'
+    finally:
+        m.mfma_mode = 'f32'
+        m.native().set_chain(-1)
+    assert np.isfinite(outs['bf16x3']).all()
+    assert not np.array_equal(outs['bf16x3'], outs['f32'])           # the mode really ran (different summation: not the same bits)
+    assert_close(outs['bf16x3'], outs['f32'], rtol=2e-5, atol=2e-5, what=f'{case}: bf16x3 vs fp32 mode')
+    if case in ('eth_512', 'eth_61', 'sdd'):
+        for s in range(0, sb.n_scenes, 37 if case == 'eth_512' else 11):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            assert_close(outs['bf16x3'][:, a:b], oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20]), what=f'{case} scene {s}: bf16x3 vs oracle')
+    else:
+        with torch.no_grad():
+            ora.set_data_nba(data)
+            ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
+        assert_close(outs['bf16x3'], ref, what=f'{case}: bf16x3 vs oracle')
+
+
 def test_async_pipeline_is_bitwise_identical_to_serial():
     """sttode_inference_scenes_async (two-slot cross-call pipeline) == serial inference(), bit for bit, over several
     back-to-back calls with different batches in flight."""
