@@ -128,6 +128,20 @@ def selftest_dist(args):
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt, total = float(tmax[0]), float(tt[1])
     gather = None
+    if not args.no_exploratory:
+        # EXPLORATORY, never the headline: the same timed region with the per-trajectory chain as a three-way bf16 split on the bf16 matrix
+        # cores (fp32 accumulate; STTODENet.mfma_mode = 'bf16x3').  Its own key and dtype label; parity sample below (same 1e-4 bar).
+        head.model.mfma_mode = 'bf16x3'
+        rx = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial)
+        out['exploratory_bf16x3'] = {
+            'value': rx['value'], 'unit': 'trajectories/s', 'ms_per_step': rx['ms_per_step'],
+            'dtype': 'bf16x3: operands of the decoder MLPs and GRU split three ways into bf16 (x = hi + mid + lo, six products per k block on '
+                     'v_mfma_f32_32x32x16_bf16), fp32 accumulate, everything else f32',
+            'speedup_vs_f32_headline': rx['value'] / r['value'],
+            'fp32_equivalent_frac_of_fp32_mfma_peak': (rx['value'] / world) * head.F['path_per_traj'] / PEAK_F32_MFMA,
+            'note': 'opt-in mode, not the product default and not `value`; held to the same golden vectors and oracle at rtol 1e-4 + atol 1e-4 '
+                    '(tests/test_gpu_parity.py::test_exploratory_bf16x3_*)'}
+        head.model.mfma_mode = 'f32'
     if dist is not None and not args.no_gather_futures:            # the collective of gather_futures_leg on ragged host rows (gloo)
         from sttode_amd import parallel
         rows = torch.full((rank + 2, 4), float(rank))
@@ -577,6 +591,7 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--no-exploratory', action='store_true', help='skip the exploratory bf16x3 region (key exploratory_bf16x3)')
     ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
     ap.add_argument('--no-gather-futures', action='store_true', help='multi-rank runs: skip the all-gather of the futures (check + value_incl_gather)')
     ap.add_argument('--selftest-dist', action='store_true', help=argparse.SUPPRESS)
@@ -700,6 +715,10 @@ def main():
         cb['sample_1_thread'] = cb1['sample']
         out['cpu_baseline'], out['parity'] = cb, par
         out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
+        if 'exploratory_bf16x3' in out:
+            head.model.mfma_mode = 'bf16x3'
+            _, out['exploratory_bf16x3']['parity'] = head.cpu_sample(min(2.0, args.cpu_seconds), nthr)
+            head.model.mfma_mode = 'f32'
         for name, leg in leg_objs.items():
             legs[name]['cpu_baseline'], legs[name]['parity'] = leg.cpu_sample(args.leg_cpu_seconds, nthr)
     del head, leg_objs

@@ -351,10 +351,11 @@ int sttode_set_chain(SttodeModel* m, int mode);
  * the roles also run set_data's normalisation of their tile (model/STTODE.py:397-461): the call is ONE launch; 0 = separate launches on
  * the pipeline's per-agent stream.  Results are bitwise the same in every mode. */
 int sttode_set_fused(SttodeModel* m, int mode);
-/* EXPLORATORY, opt-in, never the default (own dtype label in bench.py): 1 = the fused launch runs the two block-0 decoder MLPs
- * (DecomposeBlock.forward model/STTODE.py:71-77 of block 0: 38 % of the per-trajectory FLOP) as a three-way bf16 split on the bf16
- * matrix cores -- x = hi + mid + lo, six products, fp32 accumulate: fp32-class accuracy, held to the same golden vectors at the same
- * 1e-4 -- instead of fp32 MFMAs; 0 (default, or env STTODE_BF16X3) = fp32 everywhere.  Applies to fused launches only. */
+/* EXPLORATORY, opt-in, never the default (own dtype label in bench.py): 1 = the per-trajectory chain (the three decoder MLPs and block 1's
+ * conv + GRU: DecomposeBlock.forward model/STTODE.py:51-77, Decoder.forward :320-347) runs its matrix products as a three-way bf16
+ * split on the bf16 matrix cores -- x = hi + mid + lo, six products per k block, fp32 accumulate: fp32-class accuracy, held to the same
+ * golden vectors at the same 1e-4 -- instead of fp32 MFMAs; 0 (default, or env STTODE_BF16X3) = fp32 everywhere.  The per-agent stage,
+ * the attention and every call below the chain threshold stay fp32 in both modes. */
 int sttode_set_mfma_mode(SttodeModel* m, int mode);
 /* Grid order of the fused launch (host-callable, no GPU): block -> group index (>= 0) or -1 - tile for the per-agent role of a 16-agent
  * tile; roles sit `lead` groups ahead of the first group that reads their tables, so every producer has a smaller block index than its

@@ -449,6 +449,93 @@ __device__ __forceinline__ void mlp_l3_b3(ST& st, f32x16 (&acc2)[8], const float
     st.end();
 }
 
+// planes -> fp32 (hi + mid + lo; within 2^-25 relative of the value that was split): the previous state for the GRU's blend
+__device__ __forceinline__ f32x16 b3_to_f32(const B3& b) {
+    f32x16 r;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const u32x4v H = __builtin_bit_cast(u32x4v, b.p[0][kb]), M = __builtin_bit_cast(u32x4v, b.p[1][kb]), L = __builtin_bit_cast(u32x4v, b.p[2][kb]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[8 * kb + 2 * q] = (bf_lo(H[q]) + bf_lo(M[q])) + bf_lo(L[q]);
+            r[8 * kb + 2 * q + 1] = (bf_hi(H[q]) + bf_hi(M[q])) + bf_hi(L[q]);
+        }
+    }
+    return r;
+}
+// gru32_steps on split tiles (exploratory mode): the step's B operands -- conv input d (constant over the steps), conv output e, the
+// three state tiles -- are split ONCE per step (each feeds 9 gate tiles); the new state is kept fp32 until the step ends, then split.
+// Same tile order as the fp32 stream: per step 1 conv tile (a chunk of its own), then per j: r:[e h0 h1 h2] z:[e h0 h1 h2] n_h:[h0 h1 h2]
+// n_i:[e] = 4 chunks of 3 tiles.  No fragment look-ahead (registers: 96 + 24 of planes, 48 of new state, up to 48 of gates).
+template <class ST>
+__device__ __forceinline__ void gru32_steps_b3(ST& st, const float* gb, const float* cb, const f32x16& d, f32x16 (&hs)[3], int Tp, int h) {
+    B3 dB, hB[3];
+    split3(d, dB);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) split3(hs[j], hB[j]);
+    constexpr int T = C32_TILE_B3;
+#pragma unroll 1
+    for (int t = 0; t < Tp; ++t) {
+        B3 eB;
+        {
+            f32x16 e = ldrows(cb, h);
+            st.begin();
+            tile_mma_b3n(e, st.cur(), dB);
+            e = relu16(e);
+            st.end();
+            split3(e, eB);
+        }
+        f32x16 hn[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            STT_FENCE();
+            f32x16 ar = ldrows(gb + 0 * 96 + 32 * j, h);
+            st.begin();
+            tile_mma_b3n(ar, st.cur(), eB);
+            tile_mma_b3n(ar, st.cur() + T, hB[0]);
+            tile_mma_b3n(ar, st.cur() + 2 * T, hB[1]);
+            st.end(); st.begin();
+            tile_mma_b3n(ar, st.cur(), hB[2]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ar[r] = C32_SIG(ar[r]);          // r gate
+            STT_FENCE();
+            f32x16 az = ldrows(gb + 1 * 96 + 32 * j, h);
+            tile_mma_b3n(az, st.cur() + T, eB);
+            tile_mma_b3n(az, st.cur() + 2 * T, hB[0]);
+            st.end(); st.begin();
+            tile_mma_b3n(az, st.cur(), hB[1]);
+            tile_mma_b3n(az, st.cur() + T, hB[2]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) az[r] = C32_SIG(az[r]);          // z gate
+            STT_FENCE();
+            f32x16 an = ldrows(gb + 3 * 96 + 32 * j, h);
+            tile_mma_b3n(an, st.cur() + 2 * T, hB[0]);
+            st.end(); st.begin();
+            tile_mma_b3n(an, st.cur(), hB[1]);
+            tile_mma_b3n(an, st.cur() + T, hB[2]);
+            {
+                const f32x16 bi = ldrows(gb + 2 * 96 + 32 * j, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) an[r] = fmaf(ar[r], an[r], bi[r]);     // b_in + r * (W_hn h + b_hn)
+            }
+            STT_FENCE();
+            tile_mma_b3n(an, st.cur() + 2 * T, eB);                                 // + W_in e
+            st.end();
+            const f32x16 hp = b3_to_f32(hB[j]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ng = C32_TANH(an[r]);
+                hn[j][r] = fmaf(az[r], hp[r] - ng, ng);  // (1-z) n + z h
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            hs[j] = hn[j];
+            split3(hn[j], hB[j]);
+        }
+    }
+}
+
 // conv1d(k=3) + relu + GRU(32 -> 96) over Tp steps for this wave's 32 columns, every weight tile streamed per step
 // (model/STTODE.py:62-69; gate rows pre-scaled, chain.hpp): d = the flattened (t, c) input rows in accumulator layout, hs = h (in/out),
 // gb = gate biases [4][96] (r, z, b_in, b_hn), cb = conv bias [32], both in LDS.  Per step: 1 conv tile (a chunk of its own) and 36
@@ -782,7 +869,8 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         {   // ---- block 1: conv1d + relu + GRU over Tp steps, weights streamed per step
 #pragma unroll
             for (int j = 0; j < 3; ++j) hs[j] = splat16(0.f);
-            gru32_steps(st, cst + CO::gb, cst + CO::cb, d, hs, A.Tp, h);
+            if (B3M) gru32_steps_b3(st, cst + CO::gb, cst + CO::cb, d, hs, A.Tp, h);
+            else gru32_steps(st, cst + CO::gb, cst + CO::cb, d, hs, A.Tp, h);
         }
         STT_FENCE();
         C32_STAMP(3);
@@ -968,6 +1056,7 @@ extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
     return (48 + 3) + (48 + l3y) + 13 * Tp + (64 + l3y);
 }
 
+static thread_local bool g_traj_chain_b3 = false;   // set only by stt_traj_chain_b3 around its call
 // Fused per-trajectory chain of Decoder.forward (model/STTODE.py:320-347) for K samples per agent; see the file header.
 extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                                  const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
@@ -997,6 +1086,15 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
 #endif
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
+    if (g_traj_chain_b3) {   // internal (pipeline.hip, exploratory mode): pool / prog are packing.chain_stream_b3's
+        a.persistent = 0;
+        switch (NY) {
+            case 1: return chain_launch<1, false, true>(a, wgs_per_cu, s);
+            case 2: return chain_launch<2, false, true>(a, wgs_per_cu, s);
+            case 3: return chain_launch<3, false, true>(a, wgs_per_cu, s);
+            default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
+        }
+    }
     switch (NY) {
         case 1: return chain_launch<1, false>(a, wgs_per_cu, s);
         case 2: return chain_launch<2, false>(a, wgs_per_cu, s);
@@ -1004,6 +1102,15 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
         default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;
+}
+// Internal (pipeline.hip): the chain without roles on the exploratory bf16-split stream (pool / prog = packing.chain_stream_b3).
+int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
+                      const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
+                      float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream) {
+    g_traj_chain_b3 = true;
+    const int rc = sttode_traj_chain(A0x, A0y, A1y, pool, prog, prog_len, consts, z, xpad, ldx, cur, orig, pred, counter, ncols, K, Tp, Tf, wgs_per_cu, stream);
+    g_traj_chain_b3 = false;
+    return rc;
 }
 
 // Internal (csrc/pipeline.hip): the fused launch -- per-agent roles + trajectory groups in ONE grid (see RoleArgs).  W = the model's

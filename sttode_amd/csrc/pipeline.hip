@@ -454,6 +454,13 @@ static int stage_trajectories(SttodeModel* m, float* ws, const long* off, int n,
     const long ncols_all = (long)n * K;
     const bool fused = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
     if (fused) {
+        if (m->b3) {   // exploratory mode: the same chain on the three-way bf16 split stream
+            RUN(STT_STAGE_CHAIN, s,
+                stt_traj_chain_b3(A0x, A0y, A1y, W[STT_W_CHAINB3_POOL], (const int*)W[STT_W_CHAINB3_PROG], m->prog_len, W[STT_W_CHAIN_CONSTS], z,
+                                  xpad, 16 * TPX, ws + off[STT_B_CUR], ws + off[STT_B_ORIG], pred, (int*)(ws + off[STT_B_QUEUE]), (int)ncols_all, K,
+                                  Tp, Tf, pipelined ? 1 : 2, s));
+            return 0;
+        }
         RUN(STT_STAGE_CHAIN, s,
             sttode_traj_chain(A0x, A0y, A1y, W[STT_W_CHAIN_POOL], (const int*)W[STT_W_CHAIN_PROG], m->prog_len, W[STT_W_CHAIN_CONSTS], z,
                               xpad, 16 * TPX, ws + off[STT_B_CUR], ws + off[STT_B_ORIG], pred, (int*)(ws + off[STT_B_QUEUE]), (int)ncols_all, K,

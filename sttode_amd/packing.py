@@ -246,9 +246,8 @@ def chain_prog_len(Tp, Tf):
 
 
 def chain_stream_b3(sd, Tp, Tf):
-    """Exploratory mode (csrc/chain32.hip, traj_chain_kernel<NY, FUSE, true>): the same consumption order as chain_stream, but the three
-    decoder MLPs (block-0 decoder_x and decoder_y, block-1 decoder_y: 63 % of the chain's FLOP) as three-way bf16 split tiles
-    (pk32b_tile, 6 KiB) for the bf16 matrix cores; block 1's conv + GRU stays fp32 PK32.  One flat pool with tiles of both sizes; the program holds
+    """Exploratory mode (csrc/chain32.hip, traj_chain_kernel<NY, FUSE, true>): the same consumption order as chain_stream, with every
+    tile -- the three decoder MLPs and block 1's conv + GRU -- as a three-way bf16 split (pk32b_tile, 6 KiB) for the bf16 matrix cores.  One flat pool with tiles of both sizes; the program holds
     (offset in 16-byte units, number of 1-KiB pieces) per chunk of <= 3 tiles.  Layer 3 of the split MLPs is laid out k-tile major
     (every activation tile is split once and feeds all output tiles)."""
     f = chain_stream(sd, Tp, Tf)
@@ -281,8 +280,28 @@ def chain_stream_b3(sd, Tp, Tf):
     n_b3 = len(prog)
     l3y = (8 * NY + 2) // 3
     assert n_b3 == (48 + 3) + (48 + l3y)
-    for first, cnt in f['prog'][n_b3:n_b3 + 13 * Tp]:                      # block-1 conv + GRU: the fp32 tiles, in the fp32 stream's own order
-        add([f['pool'][first + i] for i in range(cnt)])
+    # block-1 conv + GRU: gate rows pre-scaled exactly as in chain_stream, same tile order; the tiles are re-streamed every step
+    p_ = 'decoder.decompose.1.'
+    L2E = np.float32(1.4426950408889634)
+    sc = np.concatenate([np.full(192, -L2E, np.float32), np.full(96, 2 * L2E, np.float32)])
+    Pih = pk32b_tiles(g(p_ + 'encoder_past.weight_ih_l0') * sc[:, None])
+    Phh = pk32b_tiles(g(p_ + 'encoder_past.weight_hh_l0') * sc[:, None])
+    conv = pk32b_tiles(toeplitz_conv(g(p_ + 'conv_past.weight'), Tp, 2))
+    gru = []
+    for j in range(3):
+        gru += [Pih[j, 0], Phh[j, 0], Phh[j, 1], Phh[j, 2], Pih[3 + j, 0], Phh[3 + j, 0], Phh[3 + j, 1], Phh[3 + j, 2],
+                Phh[6 + j, 0], Phh[6 + j, 1], Phh[6 + j, 2], Pih[6 + j, 0]]
+    gru_off = pos // 4
+    for t_ in gru:
+        words.append(t_)
+        pos += t_.size
+    conv_off = pos // 4
+    for t in range(Tp):
+        words.append(conv[t, 0])
+        pos += conv[t, 0].size
+    for t in range(Tp):
+        prog.append((conv_off + 384 * t, 6))
+        prog.extend((gru_off + 3 * 384 * c, 18) for c in range(12))
     mlp_b3('decoder.decompose.1.decoder_y.', slice(128, 256), NY, 2 * Tf)   # block-1 decoder_y: k = [z | state1]
     assert len(prog) == f['prog_len']
     return {'pool': np.ascontiguousarray(np.concatenate(words)), 'prog': np.ascontiguousarray(np.asarray(prog, np.int32)),

@@ -538,6 +538,50 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         m.reset_async()
 
 
+@pytest.mark.parametrize('case', ['eth_N2', 'eth_N7', 'eth_N32', 'sdd_ragged', 'nba_B4', 'nba_B32', 'nba_B128', 'nba_long_B8'])
+def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
+    """The exploratory mode against the REFERENCE's own vectors (tests/golden/*.npz), at the same rtol 1e-4 + atol 1e-4 as the fp32 path:
+    every golden inference case pushed through the fused chain launch (forced: these batches are below the automatic threshold) with the
+    three-way bf16 split -- ETH N = 2 / 7 / 32, the four ragged SDD scenes in one batch, NBA B = 4 / 32 / 128, the long horizon."""
+    from sttode_amd import scenes
+    g = golden(case)
+    if case.startswith('eth_N'):
+        m = hip_model('eth', 8, 12)
+        feed = lambda: m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
+        z, check = g['z'], lambda out: assert_close(out, g['out'], what=f'{case}: bf16x3 vs reference')
+    elif case == 'sdd_ragged':
+        m = hip_model('eth', 8, 12)
+        past = np.concatenate([g[f's{i}_obs'].transpose(0, 2, 1) for i in range(4)])
+        fut = np.concatenate([g[f's{i}_pred'].transpose(0, 2, 1) for i in range(4)])
+        z = np.concatenate([g[f's{i}_z'] for i in range(4)])
+        ptr = np.cumsum([0] + [g[f's{i}_obs'].shape[0] for i in range(4)]).astype(np.int32)
+        feed = lambda: m.set_scene_batch(past, fut, ptr)
+
+        def check(out):
+            for i in range(4):
+                assert_close(out[:, ptr[i]:ptr[i + 1]], g[f's{i}_out'], what=f'{case} scene {i}: bf16x3 vs reference')
+    else:
+        Tp, Tf, N = (10, 40, 10) if case == 'nba_long_B8' else (5, 10, 11)
+        m = hip_model('nba', Tp, Tf)
+        if case == 'nba_long_B8':
+            d, z, st = scenes.nba_batch(8, 8, N=10, obs_len=10, pred_len=40), scenes.latents(4100, 80), 1
+        else:
+            B = int(case[5:])
+            d, z, st = scenes.nba_batch(int(g['nba_seed']), B), scenes.latents(int(g['z_seed']), B * 11), int(g['stride'])
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        feed = lambda: m.set_data_nba(data)
+        check = lambda out: assert_close(out[:, ::st], g['out'], what=f'{case}: bf16x3 vs reference')
+    try:
+        m.native().set_chain(1)
+        m.mfma_mode = 'bf16x3'
+        feed()
+        out = m.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+    finally:
+        m.mfma_mode = 'f32'
+        m.native().set_chain(-1)
+    check(out)
+
+
 @pytest.mark.parametrize('case', ['eth_512', 'eth_61', 'sdd', 'nba_128', 'nba_long'])
 def test_exploratory_bf16x3_mode_vs_fp32_and_oracle(case):
     """EXPLORATORY opt-in mode (STTODENet.mfma_mode = 'bf16x3', sttode_set_mfma_mode): the two block-0 decoder MLPs of the fused launch as a
