@@ -128,20 +128,6 @@ def selftest_dist(args):
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt, total = float(tmax[0]), float(tt[1])
     gather = None
-    if not args.no_exploratory:
-        # EXPLORATORY, never the headline: the same timed region with the per-trajectory chain as a three-way bf16 split on the bf16 matrix
-        # cores (fp32 accumulate; STTODENet.mfma_mode = 'bf16x3').  Its own key and dtype label; parity sample below (same 1e-4 bar).
-        head.model.mfma_mode = 'bf16x3'
-        rx = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial)
-        out['exploratory_bf16x3'] = {
-            'value': rx['value'], 'unit': 'trajectories/s', 'ms_per_step': rx['ms_per_step'],
-            'dtype': 'bf16x3: operands of the decoder MLPs and GRU split three ways into bf16 (x = hi + mid + lo, six products per k block on '
-                     'v_mfma_f32_32x32x16_bf16), fp32 accumulate, everything else f32',
-            'speedup_vs_f32_headline': rx['value'] / r['value'],
-            'fp32_equivalent_frac_of_fp32_mfma_peak': (rx['value'] / world) * head.F['path_per_traj'] / PEAK_F32_MFMA,
-            'note': 'opt-in mode, not the product default and not `value`; held to the same golden vectors and oracle at rtol 1e-4 + atol 1e-4 '
-                    '(tests/test_gpu_parity.py::test_exploratory_bf16x3_*)'}
-        head.model.mfma_mode = 'f32'
     if dist is not None and not args.no_gather_futures:            # the collective of gather_futures_leg on ragged host rows (gloo)
         from sttode_amd import parallel
         rows = torch.full((rank + 2, 4), float(rank))
@@ -667,6 +653,20 @@ def main():
     out['value_incl_d2h'] = r2['value']
     out['ms_per_step_incl_d2h'] = r2['ms_per_step']
 
+    if not args.no_exploratory:
+        # EXPLORATORY, never the headline: the same timed region with the per-trajectory chain as a three-way bf16 split on the bf16 matrix
+        # cores (fp32 accumulate; STTODENet.mfma_mode = 'bf16x3').  Its own key and dtype label; parity sample below (same 1e-4 bar).
+        head.model.mfma_mode = 'bf16x3'
+        rx = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial)
+        out['exploratory_bf16x3'] = {
+            'value': rx['value'], 'unit': 'trajectories/s', 'ms_per_step': rx['ms_per_step'],
+            'dtype': 'bf16x3: operands of the decoder MLPs and GRU split three ways into bf16 (x = hi + mid + lo, six products per k block on '
+                     'v_mfma_f32_32x32x16_bf16), fp32 accumulate, everything else f32',
+            'speedup_vs_f32_headline': rx['value'] / r['value'],
+            'fp32_equivalent_frac_of_fp32_mfma_peak': (rx['value'] / world) * head.F['path_per_traj'] / PEAK_F32_MFMA,
+            'note': 'opt-in mode, not the product default and not `value`; held to the same golden vectors and oracle at rtol 1e-4 + atol 1e-4 '
+                    '(tests/test_gpu_parity.py::test_exploratory_bf16x3_*)'}
+        head.model.mfma_mode = 'f32'
     if dist is not None and not args.no_gather_futures:
         out['gather'] = gather_futures_leg(head, dist, rank, world, acc, args)
         if rank == 0:
