@@ -515,6 +515,24 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
                                                        '(rotation + positional dropout), torch.optim.Adam lr 1e-4 (' + args.train_adam + ')',
                                            'parallelism': f'scenes x{world}' + (' + flat gradient all-reduce' if world > 1 else '')}}
+    if args.train_adam == 'fused':
+        # the same steps with torch's DEFAULT optimizer form (foreach; what the reference's train.py:122 constructs): a second optimizer on
+        # the same parameters, its own warm-up, the same timed loop -- reported beside the fused figure, never instead of it
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        for i in range(nsc):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        out['ms_per_step_foreach_adam'] = 1e3 * dtf / steps
+        out['steps_per_s_foreach_adam'] = world * steps / dtf
     if cpu and rank == 0 and world == 1 and not args.no_cpu:
         train_cpu_baseline(args, out)
     return out
@@ -727,7 +745,8 @@ def main():
     if train is not None:
         if do_cpu:
             train_cpu_baseline(args, train)
-        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'steps', 'config', 'cpu_baseline', 'speedup_vs_cpu_baseline') if k in train}
+        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config',
+                                              'cpu_baseline', 'speedup_vs_cpu_baseline') if k in train}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -349,7 +349,8 @@ int sttode_set_chain(SttodeModel* m, int mode);
  * leading workgroups of the chain launch, trajectory groups wait on one flag per 16-agent tile (attention groups > 1, the NBA branch:
  * the embedding and the attention stay launches in front, the roles start at the post-attention layer); 2 = as 1, and for scene batches
  * the roles also run set_data's normalisation of their tile (model/STTODE.py:397-461): the call is ONE launch; 0 = separate launches on
- * the pipeline's per-agent stream.  Results are bitwise the same in every mode. */
+ * the pipeline's per-agent stream; 3 = as 1 with the roles interleaved 160 groups ahead of their consumers in the grid instead of all
+ * in front (sttode_fused_block_of; measured neutral pipelined, slower serial).  Results are bitwise the same in every mode. */
 int sttode_set_fused(SttodeModel* m, int mode);
 /* EXPLORATORY, opt-in, never the default (own dtype label in bench.py): 1 = the per-trajectory chain (the three decoder MLPs and block 1's
  * conv + GRU: DecomposeBlock.forward model/STTODE.py:51-77, Decoder.forward :320-347) runs its matrix products as a three-way bf16

@@ -19,12 +19,21 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 for k,v in d['configs'].items(): print('fused=$F', k, round(v['value']/1e6,2), 'M traj/s', round(v['ms_per_step'],3), 'ms', (v.get('roofline') or {}).get('kernel'), round((v.get('roofline') or {}).get('frac',0),3))"
   done > $O/legs_fused_vs_unfused.txt
   # batch-size sweep (pipelined, as the headline)
+  timeout -k 10 200 python bench.py --legs none --no-cpu --steps 10 > /dev/null 2>&1     # (first process after a pause: discarded)
   for S in 128 256 512 1024 2048 4096; do
-    timeout -k 10 200 python bench.py --legs none --no-cpu --scenes $S --steps 40 > $O/sweep_s$S.json 2>/dev/null || echo "sweep $S failed"
+    timeout -k 10 200 python bench.py --legs none --no-cpu --scenes $S --steps 40 --no-exploratory > $O/sweep_s$S.json 2>/dev/null || echo "sweep $S failed"
   done
   # block-level trace (diagnostic build): who ran where and when
-  STTODE_HIP_LIB=$R/sttode_amd/lib/variants/lib_trace.so TRACE_NAME=c timeout -k 10 200 python profiles/exp_r03_trace.py 512 30 > $O/trace_pipelined_fused.txt 2>&1
-  STTODE_HIP_LIB=$R/sttode_amd/lib/variants/lib_trace.so TRACE_NAME=c timeout -k 10 200 python profiles/exp_r03_trace.py 512 10 serial > $O/trace_serial_fused.txt 2>&1
+  F="launches, |steady|roles:|groups:|per-CU|clock|role phases"
+  STTODE_HIP_LIB=$R/sttode_amd/lib/variants/lib_trace.so TRACE_NAME=c timeout -k 10 200 python profiles/exp_r03_trace.py 512 30 2>&1 | grep -E "$F" > $O/trace_pipelined_fused.txt
+  STTODE_HIP_LIB=$R/sttode_amd/lib/variants/lib_trace.so TRACE_NAME=c timeout -k 10 200 python profiles/exp_r03_trace.py 512 10 serial 2>&1 | grep -E "$F" > $O/trace_serial_fused.txt
+  STTODE_BF16X3=1 STTODE_HIP_LIB=$R/sttode_amd/lib/variants/lib_trace.so TRACE_NAME=c timeout -k 10 200 python profiles/exp_r03_trace.py 512 30 2>&1 | grep -E "$F" > $O/trace_pipelined_fused_bf16x3.txt
+  timeout -k 10 200 python bench.py --legs none --no-cpu --steps 10 > /dev/null 2>&1
+  for i in 1 2 3; do
+    echo "f32: $(timeout -k 10 200 python bench.py --legs none --no-cpu --steps 40 --no-exploratory 2>/dev/null | line)"
+    echo "bf16x3: $(STTODE_BF16X3=1 timeout -k 10 200 python bench.py --legs none --no-cpu --steps 40 --no-exploratory 2>/dev/null | line)"
+  done > $O/bf16x3_ab.txt
+  timeout -k 10 200 python profiles/exp_r03_bf16x3_probe.py $O/bf16x3_probe.json > /dev/null 2>&1
   timeout -k 10 300 python profiles/exp_per_scene_latency.py > $O/per_scene_latency.txt 2>&1
   exit 0
 fi

@@ -1122,7 +1122,7 @@ int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, cons
 bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
                     float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3,
-                    void* stream) {
+                    int lead, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
     STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
@@ -1161,15 +1161,11 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     r.enc_in_w = ws + off[STT_B_ENC_IN]; r.xpad_w = ws + off[STT_B_XPAD]; r.cur_w = ws + off[STT_B_CUR]; r.orig_w = ws + off[STT_B_ORIG];
     r.last_w = (int*)(ws + off[STT_B_LAST]);
     r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
-    {
-        // STTODE_ROLE_LEAD: groups of head start of a role over its first consumer; < 0 (default): all roles first.  Measured on one box
-        // (profiles/r03/ab_lead_frontend_depth.txt): pipelined 73.4-74.6 M trajectories/s for lead 64 / 160 / 400 / roles first alike, but a
-        // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
-        // other roles, and holds its slot all the while
-        static int lead = -2;
-        if (lead == -2) { const char* e = getenv("STTODE_ROLE_LEAD"); lead = e ? atoi(e) : -1; }
-        r.lead = lead < 0 ? (1 << 28) : lead;
-    }
+    // grid order: `lead` groups of head start of a role over its first consumer; < 0 (default): all roles first.  Measured on one box
+    // (profiles/r03/ab_lead_frontend_depth.txt): pipelined 73.4-74.6 M trajectories/s for lead 64 / 160 / 400 / roles first alike, but a
+    // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
+    // other roles, and holds its slot all the while
+    r.lead = lead < 0 ? (1 << 28) : lead;
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {

@@ -512,7 +512,7 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
             ref = first
         for rep in range(3):
             for v in (0, 3, 1, 2):
-                out, inter = run(v, 1 + (rep + v) % 2)    # mode 2: the roles also run the scene front-end (one launch per call)
+                out, inter = run(v, 1 + (rep + v) % 3)    # mode 2: the roles also run the scene front-end; mode 3: roles interleaved in the grid
                 assert torch.isfinite(out).all()
                 assert torch.equal(out, ref[v][0]), f'{case} variant {v} rep {rep}: fused launch != separate launches'
                 for k in inter:
