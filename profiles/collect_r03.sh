@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/r03c
 mkdir -p $O
+if [ "$1" != b ]; then rm -rf $O/prof_* $O/pmc_* $O/tl_*; fi   # (stale passes of earlier calls would be merged into the same directories)
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(round(d['value']/1e6,2), round(d['ms_per_step'],3), r['kernel'], round(r['frac'],3), round(r.get('frac_serial_equivalent', 0),3), round(r['launches_in_flight'],2))"; }
 if [ "$1" = b ]; then
   # fused launch vs the round-2 pipeline (separate per-agent launches, one chain workgroup per CU), alternating on this box; legs likewise
@@ -40,19 +41,19 @@ fi
 timeout -k 10 600 python bench.py > $O/final_bench.json 2> $O/final_bench.err || { echo "bench failed"; tail -5 $O/final_bench.err; exit 1; }
 cd /tmp
 # (1) SERIAL kernel stats, no counters: flop_per_launch / AverageNs / 157.3e12 is the plain per-launch roofline fraction
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial_headline -- python3 $R/bench.py --serial --legs none --no-cpu --steps 20 --warmup 3 > $O/prof_serial_headline.log 2>&1 || { echo "serial prof failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial_headline -- python3 $R/bench.py --serial --legs none --no-cpu --no-exploratory --steps 20 --warmup 3 > $O/prof_serial_headline.log 2>&1 || { echo "serial prof failed"; exit 1; }
 for L in ucy_2048 sdd_1024 nba_128 nba_long_4096; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial_leg_$L -- python3 $R/bench.py --only-leg $L --serial --leg-steps 16 > $O/prof_serial_leg_$L.log 2>&1 || echo "serial leg $L prof failed"
 done
 # (2) PIPELINED kernel trace: stats + union of the launch intervals from the trace's own timestamps (cross-check of the HIP-event union)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined_headline -- python3 $R/bench.py --legs none --no-cpu --steps 20 --warmup 3 > $O/prof_pipelined_headline.log 2>&1 || echo "pipelined prof failed"
-timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl_pipelined -o tl -- python3 $R/bench.py --legs none --no-cpu --steps 20 --warmup 3 --no-serial-check > $O/tl_pipelined.log 2>&1 \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined_headline -- python3 $R/bench.py --legs none --no-cpu --no-exploratory --steps 20 --warmup 3 > $O/prof_pipelined_headline.log 2>&1 || echo "pipelined prof failed"
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl_pipelined -o tl -- python3 $R/bench.py --legs none --no-cpu --no-exploratory --steps 20 --warmup 3 --no-serial-check > $O/tl_pipelined.log 2>&1 \
   && python3 $R/profiles/summarize_timeline.py $O/tl_pipelined/tl_results.db traj_chain 36 4 > $O/timeline_pipelined.txt
 # (3) counters, serial bench, separate passes
 for P in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
          "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   T=$(echo $P | cut -d" " -f1)
-  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pmc_$T -- python3 $R/bench.py --legs none --no-cpu --steps 3 --warmup 1 --serial > $O/pmc_$T.log 2>&1 || { echo "pmc $T failed"; exit 1; }
+  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pmc_$T -- python3 $R/bench.py --legs none --no-cpu --no-exploratory --steps 3 --warmup 1 --serial > $O/pmc_$T.log 2>&1 || { echo "pmc $T failed"; exit 1; }
 done
 cd $R
 python - <<'PY'

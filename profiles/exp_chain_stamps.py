@@ -18,7 +18,7 @@ for S in [int(a) for a in sys.argv[1:]] or [128]:
     for _ in range(3):
         m.inference(None)
     ngroups = (sb.n_agents * 20 + 127) // 128
-    nwg = max(512, ngroups)                      # non-persistent launches use one workgroup per group
+    nwg = max(512, ngroups + (sb.n_agents + 15) // 16)   # one workgroup per group (+ the roles of a fused launch: group blocks come after them)
     dbg = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=dev)
     L.sttode_chain_debug_buffer.argtypes = [ctypes.c_void_p]
     L.sttode_chain_debug_buffer(dbg.data_ptr())

@@ -75,8 +75,12 @@ def main(src, dst):
         allt = {'round1_three_kernel_form': allt}
     allt['eth_512'] = traffic
     json.dump(allt, open(tp, 'w'), indent=1, sort_keys=True)
-    for f in glob.glob(os.path.join(src, 'prof*', '*', '*_kernel_stats.csv')):
+    stats = {}
+    for f in glob.glob(os.path.join(src, 'prof*', '*', '*_kernel_stats.csv')):   # gpurun merges runs into one directory: newest pass per tag
         tag = f.split(os.sep)[-3]
+        if tag not in stats or os.path.getmtime(f) > os.path.getmtime(stats[tag]):
+            stats[tag] = f
+    for tag, f in stats.items():
         rows = list(csv.DictReader(open(f)))[:14]
         for r in rows:                                   # torch's template instantiations run to kilobytes: keep the head of the name
             if len(r['Name']) > 140:
