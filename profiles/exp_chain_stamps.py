@@ -37,5 +37,7 @@ for S in [int(a) for a in sys.argv[1:]] or [128]:
     t0 = ns[:, 0, 0][valid[:, 0]]
     print(f'  group total us median {np.median(tot) / 1e3:.1f} min {tot.min() / 1e3:.1f} max {tot.max() / 1e3:.1f}; first-group start spread {(t0.max() - t0.min()) / 1e3:.1f} us; '
           f'kernel span {(ns[:, :, 4][valid].max() - t0.min()) / 1e3:.1f} us')
-    ideal = {'mlp0x': 152 * 16 * 64, 'mlp0y': 152 * 16 * 64, 'gru': 8 * 37 * 16 * 64, 'mlp1': 200 * 16 * 64}
-    print('  MFMA-only cycles per phase:', ideal)
+    b3 = os.environ.get('STTODE_BF16X3', '0') not in ('', '0')
+    per_tile = 12 * 32 if b3 else 16 * 64      # matrix-pipe cycles per 32 x 32 x 32 tile: six bf16 MFMAs per k block vs sixteen fp32 MFMAs
+    ideal = {'mlp0x': 152 * per_tile, 'mlp0y': 152 * per_tile, 'gru': 8 * 37 * per_tile, 'mlp1': 200 * per_tile}
+    print('  MFMA-only cycles per phase (' + ('bf16x3' if b3 else 'f32') + '):', ideal)

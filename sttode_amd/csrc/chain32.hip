@@ -372,24 +372,41 @@ __device__ __forceinline__ void mlp_l12_b3(ST& st, const f32x4* slot, const f32x
     static_assert((KT1 + 8) % 3 == 0, "hidden tile must be a whole number of chunks");
 #pragma unroll
     for (int R = 0; R < 8; ++R) acc2[R] = splat16(0.f);
-#pragma unroll 1
-    for (int ht = 0; ht < 16; ++ht) {
-        f32x16 h1, zb;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const f32x4 v = slot[a * 64 + lane];
-            h1[4 * a + 0] = v[0]; h1[4 * a + 1] = v[1]; h1[4 * a + 2] = v[2]; h1[4 * a + 3] = v[3];
-        }
+    // KH == 0 (block 0): z's planes are made ONCE per phase and stay in registers (24 VGPRs this form can afford: 16 splits and 64 LDS
+    // reads fewer per phase); KH == 3 (block 1) has no registers to spare and re-splits z from its fp32 LDS slot per hidden tile
+    B3 Bz;
+    if (KH == 0) {
+        f32x16 zb;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const f32x4 v = zslot[a * 64 + lane];
             zb[4 * a + 0] = v[0]; zb[4 * a + 1] = v[1]; zb[4 * a + 2] = v[2]; zb[4 * a + 3] = v[3];
         }
+        split3(zb, Bz);
+    }
+#pragma unroll 1
+    for (int ht = 0; ht < 16; ++ht) {
+        f32x16 h1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 v = slot[a * 64 + lane];
+            h1[4 * a + 0] = v[0]; h1[4 * a + 1] = v[1]; h1[4 * a + 2] = v[2]; h1[4 * a + 3] = v[3];
+        }
+        B3 Bt;
+        if (KH == 0) {
+            Bt = Bz;
+        } else {
+            f32x16 zb;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = zslot[a * 64 + lane];
+                zb[4 * a + 0] = v[0]; zb[4 * a + 1] = v[1]; zb[4 * a + 2] = v[2]; zb[4 * a + 3] = v[3];
+            }
+            split3(zb, Bt);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is re-filled by the gather issued next
         __builtin_amdgcn_sched_barrier(0);
         const float* nx = (ht + 1 < 16) ? a0 + 32 * (ht + 1) : a0_next;
-        B3 Bt;
-        split3(zb, Bt);
         Frag6 fr[2];
 #pragma unroll
         for (int i = 0; i < KT1 + 8; ++i) {
@@ -1056,11 +1073,10 @@ extern "C" int sttode_chain_prog_len(int Tp, int Tf) {
     return (48 + 3) + (48 + l3y) + 13 * Tp + (64 + l3y);
 }
 
-static thread_local bool g_traj_chain_b3 = false;   // set only by stt_traj_chain_b3 around its call
-// Fused per-trajectory chain of Decoder.forward (model/STTODE.py:320-347) for K samples per agent; see the file header.
-extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
-                                 const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
-                                 float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream) {
+// The chain without roles; b3: the exploratory bf16-split stream (pool / prog = packing.chain_stream_b3's) instead of the fp32 one.
+static int traj_chain_impl(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
+                           const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
+                           float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, bool b3, void* stream) {
     STT_REQUIRE(A0x && A0y && A1y && pool && prog && consts && z && xpad && cur && orig && pred && counter, "sttode_traj_chain: null pointer");
     STT_REQUIRE(ncols > 0 && K > 0 && Tp >= 1 && 2 * Tp <= 32 && Tf >= 1, "sttode_traj_chain: bad ncols/K/Tp/Tf");
     STT_REQUIRE(ldx == 16 || ldx == 32, "sttode_traj_chain: ldx must be 16 or 32");
@@ -1086,7 +1102,7 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
 #endif
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
-    if (g_traj_chain_b3) {   // internal (pipeline.hip, exploratory mode): pool / prog are packing.chain_stream_b3's
+    if (b3) {
         a.persistent = 0;
         switch (NY) {
             case 1: return chain_launch<1, false, true>(a, wgs_per_cu, s);
@@ -1103,14 +1119,17 @@ extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float
     }
     return 0;
 }
-// Internal (pipeline.hip): the chain without roles on the exploratory bf16-split stream (pool / prog = packing.chain_stream_b3).
+// Fused per-trajectory chain of Decoder.forward (model/STTODE.py:320-347) for K samples per agent; see the file header.
+extern "C" int sttode_traj_chain(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
+                                 const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
+                                 float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream) {
+    return traj_chain_impl(A0x, A0y, A1y, pool, prog, prog_len, consts, z, xpad, ldx, cur, orig, pred, counter, ncols, K, Tp, Tf, wgs_per_cu, false, stream);
+}
+// Internal (pipeline.hip): the same on the exploratory bf16-split stream.
 int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                       const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
                       float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream) {
-    g_traj_chain_b3 = true;
-    const int rc = sttode_traj_chain(A0x, A0y, A1y, pool, prog, prog_len, consts, z, xpad, ldx, cur, orig, pred, counter, ncols, K, Tp, Tf, wgs_per_cu, stream);
-    g_traj_chain_b3 = false;
-    return rc;
+    return traj_chain_impl(A0x, A0y, A1y, pool, prog, prog_len, consts, z, xpad, ldx, cur, orig, pred, counter, ncols, K, Tp, Tf, wgs_per_cu, true, stream);
 }
 
 // Internal (csrc/pipeline.hip): the fused launch -- per-agent roles + trajectory groups in ONE grid (see RoleArgs).  W = the model's
