@@ -1,6 +1,5 @@
-line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline'] or {}; print(round(d['value']/1e6,2), round(d['ms_per_step'],3), round(r.get('frac',0),3))"; }
+export STTODE_HIP_LIB=$PWD/sttode_amd/lib/variants/lib_trace.so
+F="launches, |steady|roles:|groups:|per-CU|clock|role phases"
 timeout -k 10 200 python bench.py --legs none --no-cpu --steps 10 --no-exploratory > /dev/null 2>&1
-for i in 1 2 3; do
-echo "f32: $(timeout -k 10 200 python bench.py --legs none --no-cpu --steps 40 --no-exploratory 2>/dev/null | line)"
-echo "bf16x3: $(STTODE_BF16X3=1 timeout -k 10 200 python bench.py --legs none --no-cpu --steps 40 --no-exploratory 2>/dev/null | line)"
-done
+echo "== SDD-256 pipelined"; LEG=sdd_1024 TRACE_NAME=sdd timeout -k 10 200 python profiles/exp_r03_trace.py 256 60 2>&1 | grep -E "$F"
+echo "== NBA-128 pipelined"; LEG=nba_128 TRACE_NAME=nba timeout -k 10 200 python profiles/exp_r03_trace.py 128 60 2>&1 | grep -E "$F"

@@ -14,7 +14,8 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 serial = len(sys.argv) > 3 and sys.argv[3] == 'serial'
 dev = torch.device('cuda:0')
-leg = bench.Leg('eth_512', 0, dev, size=S)
+LEG = os.environ.get('LEG', 'eth_512')          # any bench leg (sdd_1024, nba_128, ...: S is then ignored unless LEG is eth_512)
+leg = bench.Leg(LEG, 0, dev, size=S if LEG == 'eth_512' else None)
 L = capi.lib()
 L.sttode_chain_debug_buffer.argtypes = [ctypes.c_void_p]
 NO_RANDN, NO_BOK = bool(os.environ.get('NO_RANDN')), bool(os.environ.get('NO_BOK'))   # diagnostic: reuse one z / skip best-of-K
