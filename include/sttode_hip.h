@@ -358,6 +358,11 @@ int sttode_set_fused(SttodeModel* m, int mode);
  * golden vectors at the same 1e-4 -- instead of fp32 MFMAs; 0 (default, or env STTODE_BF16X3) = fp32 everywhere.  The per-agent stage,
  * the attention and every call below the chain threshold stay fp32 in both modes. */
 int sttode_set_mfma_mode(SttodeModel* m, int mode);
+/* Fault injection for tests of the in-launch hand-off's give-up path: in fused launches the per-agent role of 16-agent tile `tile` computes
+ * its tables but never publishes its flag (-1: off, the default).  The trajectory groups that read that tile then run into the bound of
+ * their spin (~1 s), write NaN into their predictions and set the time-out word (workspace buffer STT_B_FLAGS, word [tiles]) -- the
+ * launch ends, it never hangs; every other group is unaffected. */
+int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
 /* Grid order of the fused launch (host-callable, no GPU): block -> group index (>= 0) or -1 - tile for the per-agent role of a 16-agent
  * tile; roles sit `lead` groups ahead of the first group that reads their tables, so every producer has a smaller block index than its
  * consumers (Decoder.forward's repeat_interleave layout, model/STTODE.py:322-328: trajectory = agent * K + k). */

@@ -78,6 +78,7 @@ SIGNATURES = {
     'sttode_set_chain': [_P, _I],
     'sttode_set_fused': [_P, _I],
     'sttode_set_mfma_mode': [_P, _I],
+    'sttode_debug_drop_role_flag': [_P, _I],
     'sttode_fused_block_of': [_L, _L, _L, _L, _L],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],

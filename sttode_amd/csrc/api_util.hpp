@@ -11,7 +11,7 @@ int stt_agents_fused(const float* const* W, const float* enc_in, const int* last
                      float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip
 bool stt_agents_fused_covers(int Tp, int TPX);                                          // encoder.hip: shapes the fused per-agent kernel is built for
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, int lead, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
+                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, int lead, int drop_tile, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
 bool stt_chain_fused_covers(int Tp);
 int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                       const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,

@@ -67,6 +67,7 @@ struct RoleArgs {
     unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
     int ntiles; float ode_time;
     int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
+    int drop_tile;       // fault injection (tests): the role of this tile never publishes its flag (-1: none) -- exercises the give-up path
 };
 
 #ifndef ROLE_PRIO
@@ -711,7 +712,7 @@ __device__ __forceinline__ void agent_role(const ChainArgs& A, int tile, char* s
     // publish (guide §6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(R.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && tile != R.drop_tile) __hip_atomic_store(R.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Consumer side: wave 0 polls the flags of tiles [t_lo, t_hi] (relaxed agent-scope loads, one lane per tile, s_sleep between polls), then
@@ -1141,7 +1142,7 @@ int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, cons
 bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
                     float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3,
-                    int lead, void* stream) {
+                    int lead, int drop_tile, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
     STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
@@ -1185,6 +1186,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
     // other roles, and holds its slot all the while
     r.lead = lead < 0 ? (1 << 28) : lead;
+    r.drop_tile = drop_tile;
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {

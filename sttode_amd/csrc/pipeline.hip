@@ -34,6 +34,7 @@ struct SttodeModel {
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
     int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
     int role_lead;   // fused launch's grid order: groups of head start of a role over its first consumer, < 0 = all roles first (default)
+    int drop_tile;   // fault injection (tests): the role of this 16-agent tile does not publish its flag in fused launches (-1: none)
     int b3;          // exploratory: block-0 MLPs of the fused launch as a three-way bf16 split (sttode_set_mfma_mode)
     bool fe_in_role; // fused scene batches: the roles also run the scene front-end (STTODE_FE_IN_ROLE=1; default: a launch in front)
     int ode_method, ode_steps;  // integrator of the encoder ODE (0, 1 = one Euler step = the reference)
@@ -83,6 +84,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->fused_mode = 1;
     m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;
+    m->drop_tile = -1;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
     // default off: measured neutral to -0.6 % pipelined and -1.5 % serial at 512 scenes (the two front-end launches cost less than the
     // ~10 us they add to every role), +1 % on the 256-scene SDD leg (profiles/r03/ab_lead_frontend_depth.txt)
@@ -205,6 +207,12 @@ extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
     m->fused_mode = mode ? 1 : 0;
     m->fe_in_role = mode == 2;
     m->role_lead = mode == 3 ? 160 : -1;
+    return 0;
+}
+
+extern "C" int sttode_debug_drop_role_flag(SttodeModel* m, int tile) {
+    STT_REQUIRE(m && tile >= -1, "sttode_debug_drop_role_flag: bad arguments");
+    m->drop_tile = tile;
     return 0;
 }
 
@@ -537,7 +545,7 @@ static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int at
                               st_seq, 192, st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
         attn = ws + off[STT_B_ATTN];
     }
-    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, m->b3, m->role_lead, s));
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, m->b3, m->role_lead, m->drop_tile, s));
     return 0;
 }
 

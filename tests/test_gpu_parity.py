@@ -629,6 +629,52 @@ def test_exploratory_bf16x3_mode_vs_fp32_and_oracle(case):
         assert_close(outs['bf16x3'], ref, what=f'{case}: bf16x3 vs oracle')
 
 
+def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals():
+    """The exit condition of the in-launch hand-off: with the flag of ONE 16-agent tile withheld (fault injection,
+    sttode_debug_drop_role_flag) the trajectory groups that read that tile run into the bound of their spin (~1 s), poison THEIR
+    predictions with NaN and set the time-out word; the launch ends, every other group's predictions are the bits of a healthy run, and
+    the next healthy launch on the same workspace is clean again."""
+    import time
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(4000, 4061), 'eth')
+    n, S, K = sb.n_agents, sb.n_scenes, 20
+    z = torch.from_numpy(scenes.latents(77, n)).to(m.device)
+    try:
+        m.native().set_chain(1)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        good = m.inference(None, z=z).clone()
+        tile = 3                                              # agents 48..63
+        capi.call('sttode_debug_drop_role_flag', m.native().h, tile)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        t0 = time.perf_counter()
+        bad = m.inference(None, z=z).clone()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 30.0, f'the launch took {dt:.1f} s: the spin is not bounded'
+        buf, off = m._workspace(n, S)
+        ntiles = (n + 15) // 16
+        flags = m._view(buf, off, 'flags', ntiles + 1, dtype=torch.int32).cpu().numpy()
+        assert flags[ntiles] == 1 and flags[tile] == 0 and (np.delete(flags[:ntiles], tile) == 1).all()
+        # groups of 128 trajectories (= agents*K): the poisoned ones are exactly those whose agents touch the withheld tile
+        a_lo, a_hi = 16 * tile, min(16 * tile + 15, n - 1)
+        g_lo, g_hi = (a_lo * K) // 128, (a_hi * K + K - 1) // 128
+        flat_bad, flat_good = bad.permute(1, 0, 2, 3).reshape(n * K, -1), good.permute(1, 0, 2, 3).reshape(n * K, -1)
+        rows = torch.arange(n * K, device=m.device)
+        hit = (rows // 128 >= g_lo) & (rows // 128 <= g_hi)
+        assert torch.isnan(flat_bad[hit]).all()
+        assert torch.equal(flat_bad[~hit], flat_good[~hit])
+    finally:
+        capi.call('sttode_debug_drop_role_flag', m.native().h, -1)
+        m.native().set_chain(-1)
+    m.native().set_chain(1)
+    try:
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        assert torch.equal(m.inference(None, z=z), good)
+    finally:
+        m.native().set_chain(-1)
+
+
 def test_async_pipeline_is_bitwise_identical_to_serial():
     """sttode_inference_scenes_async (two-slot cross-call pipeline) == serial inference(), bit for bit, over several
     back-to-back calls with different batches in flight."""
