@@ -750,6 +750,32 @@ def test_random_latents_follow_torch_generator():
     assert tuple(a.shape) == (20, 5, 12, 2) and bool(torch.isfinite(a).all())
 
 
+def test_async_latents_follow_the_same_generator_sequence_as_serial_calls():
+    """inference_async(z=None) draws its latents from torch's generator at call time, like inference(None): the same seed gives the same
+    predictions call by call, whether the calls are pipelined or serial."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(5000, 5012), 'eth')
+    feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    torch.manual_seed(11)
+    serial = []
+    for _ in range(4):
+        feed()
+        serial.append(m.inference(None).clone())
+    torch.manual_seed(11)
+    m.reset_async()
+    hs = []
+    for _ in range(4):
+        feed()
+        hs.append(m.inference_async())
+    outs = [m.wait(h).clone() for h in hs]
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(outs[i], serial[i]), f'call {i}: async latents differ from the serial sequence'
+    assert not torch.equal(outs[0], outs[1])
+    m.reset_async()
+
+
 def test_nba_group_spanning_two_ranks_matches_single_rank():
     """one attention group sharded over ranks, with an all-gather of q|k|v.  Two ranks are simulated in one
     process (the gather is injected); every rank's slice must equal the single-rank result."""
