@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 /* Version of this header: the library returns it from sttode_abi_version(); a binding compares before its first call (round 1-2: 1). */
-#define STTODE_ABI_VERSION 3
+#define STTODE_ABI_VERSION 4
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
@@ -363,6 +363,16 @@ int sttode_set_mfma_mode(SttodeModel* m, int mode);
  * their spin (~1 s), write NaN into their predictions and set the time-out word (workspace buffer STT_B_FLAGS, word [tiles]) -- the
  * launch ends, it never hangs; every other group is unaffected. */
 int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
+/* Host staging of one scene for the one-scene-per-call loop (test.py:171-188 -> set_data, model/STTODE.py:397-404): pre [N][2][Tp] and
+ * fut [N][2][Tf] (HOST pointers, the loader's layout; fut may be NULL with Tf = 0) are transposed into a pinned ring slot and copied to
+ * dev [N*Tp*2 + N*Tf*2] (DEVICE: past [N][Tp][2] followed by future [N][Tf][2]) with one asynchronous copy on `stream`. */
+int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream);
+/* Serial scene calls (sttode_inference_scenes) below the chain threshold -- the reference's evaluation loop hands over ONE scene per call
+ * (test.py:171-188) -- run as ONE launch whose workgroups take the roles front-end + per-agent stage / block-0 decoder_y / block-0
+ * decoder_x -> block-1 GRU -> block-1 decoder_y and hand tables over through flags (csrc/scene_lat.hip), when the call has at most
+ * `max_tiles` 16-trajectory tiles: -1 = default (128, or env STTODE_SCENE_LAUNCH), 0 = never (six launches, as round 2).  Bitwise the
+ * same predictions either way.  Replaces: model/STTODE.py:397-461 + :553-627 for one scene. */
+int sttode_set_scene_launch(SttodeModel* m, int max_tiles);
 /* Grid order of the fused launch (host-callable, no GPU): block -> group index (>= 0) or -1 - tile for the per-agent role of a 16-agent
  * tile; roles sit `lead` groups ahead of the first group that reads their tables, so every producer has a smaller block index than its
  * consumers (Decoder.forward's repeat_interleave layout, model/STTODE.py:322-328: trajectory = agent * K + k). */

@@ -11,7 +11,7 @@ _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 3   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
+ABI_VERSION = 4   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
@@ -79,6 +79,8 @@ SIGNATURES = {
     'sttode_set_fused': [_P, _I],
     'sttode_set_mfma_mode': [_P, _I],
     'sttode_debug_drop_role_flag': [_P, _I],
+    'sttode_set_scene_launch': [_P, _I],
+    'sttode_stage_scene': [_P, _P, _I, _I, _I, _P, _P],
     'sttode_fused_block_of': [_L, _L, _L, _L, _L],
     'sttode_set_ode': [_P, _I, _I],
     'sttode_timing_enable': [_P, _I],
@@ -140,6 +142,11 @@ class NativeModel:
         """1: fused per-trajectory chain kernel, 0: three-kernel form, -1: automatic."""
         if lib().sttode_set_chain(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_chain failed: ' + lib().sttode_last_error().decode())
+
+    def set_scene_launch(self, max_tiles):
+        """Serial scene calls with at most `max_tiles` 16-trajectory tiles run as ONE launch (csrc/scene_lat.hip); -1: default (128),
+        0: never (the six-launch form).  Bitwise the same predictions either way."""
+        call('sttode_set_scene_launch', self.h, int(max_tiles))
 
     def set_fused(self, mode):
         """1: per-agent roles inside the chain launch (default); 2: the roles also run the scene front-end (one launch per call);
@@ -238,5 +245,10 @@ def call(name, *args, tag=None):
 
 
 def stream_ptr():
+    """Raw hipStream_t of torch's current stream on the current device (the C accessor: torch.cuda.current_stream() builds a Stream object
+    through three Python layers, ~9 us, twice per one-scene call)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream

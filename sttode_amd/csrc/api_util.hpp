@@ -13,6 +13,9 @@ bool stt_agents_fused_covers(int Tp, int TPX);                                  
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
                     float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, int lead, int drop_tile, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
 bool stt_chain_fused_covers(int Tp);
+int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int TPX, int NOY, int n_chunks0, int n_chunks1,
+                  const float* z, float* pred, float ode_time, const float* past, const int* scene_ptr, int S, int drop_tile, void* stream);   // scene_lat.hip: a scene call as ONE launch
+bool stt_scene_lat_covers(int Tp, int TPX, int NOY);
 int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                       const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,
                       float* pred, int* counter, int ncols, int K, int Tp, int Tf, int wgs_per_cu, void* stream);   // chain32.hip                                                    // chain32.hip

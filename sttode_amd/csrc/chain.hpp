@@ -85,6 +85,12 @@ __device__ __forceinline__ void layernorm64(f32x4 (&x)[4], const float* __restri
 }
 
 // LDS byte address of a pointer into shared memory (generic -> address space 3)
+// Workgroup barrier for LDS exchange ONLY: LDS operations complete (lgkmcnt), global loads in flight stay in flight.  __syncthreads()
+// carries a workgroup-scope fence, i.e. `s_waitcnt vmcnt(0)` in front of every s_barrier: a weight prefetch issued groups ahead would be
+// drained at the next exchange and every loop iteration would expose a full L2 round trip (measured in the latency forms: 1.8 us per
+// 0.97-us group of MFMAs).  Not for hand-offs through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }

@@ -29,6 +29,26 @@
 #include "../../include/sttode_hip.h"
 #include <cstdlib>
 
+// C32_DIAG_TRACE (diagnostic build, profiles/exp_r03_trace.py): every workgroup appends one record {launch tag, block, kind, start, end (100 MHz
+// s_memrealtime), HW_ID, XCC_ID} to the debug buffer -- who ran where and when, across overlapping launches
+#ifdef C32_DIAG_TRACE
+__shared__ long long g_tr_ph[4];   // role phase stamps (thread 0)
+#define C32_TRACE_BEGIN() long long _tr_t0 = 0, _tr_c0 = 0; if (threadIdx.x == 0 && A.dbg) { _tr_t0 = __builtin_amdgcn_s_memrealtime(); _tr_c0 = __builtin_amdgcn_s_memtime(); }
+#define C32_TRACE_END(kind) do { if (threadIdx.x == 0 && A.dbg) { \
+        const long long _t1 = __builtin_amdgcn_s_memrealtime(); unsigned _hw, _xcc; \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(_hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(_xcc)); \
+        const unsigned long long _r = atomicAdd((unsigned long long*)A.dbg, 1ull); if ((long long)_r >= A.dbg[1]) break; /* dbg[1] = capacity in records */ \
+        long long* _p = A.dbg + 8 + _r * 12; _p[0] = A.trace_tag; _p[1] = blockIdx.x; _p[2] = (kind); _p[3] = _tr_t0; _p[4] = _t1; _p[5] = _hw; _p[6] = _xcc; \
+        _p[8] = g_tr_ph[0]; _p[9] = g_tr_ph[1]; _p[10] = g_tr_ph[2]; _p[7] = __builtin_amdgcn_s_memtime() - _tr_c0; _p[11] = g_tr_ph[3]; } } while (0)
+#define C32_TRACE_PHASE(i) do { if (threadIdx.x == 0) g_tr_ph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C32_TRACE_PHASE(i) do { } while (0)
+#define C32_TRACE_BEGIN() do { } while (0)
+#define C32_TRACE_END(kind) do { } while (0)
+#endif
+
+#include "role_body.hpp"
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // diagnostic builds (profiles/exp_chain_variants.sh; never shipped): -DC32_DIAG_NODMA / _NOGATHER / _NOBARRIER / _NOGATES
@@ -44,35 +64,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define C32_CMAX 3                          // tiles per chunk
 #define C32_RING (2 * C32_CMAX * C32_TILE)  // f32x4 in the double buffer (24 KiB)
 #define C32_SLOT 256                        // f32x4 per wave gather slot (4 KiB)
-
-// Per-agent ROLE of the fused launch (round 3): the first `ntiles` workgroups of the grid run, for one 16-agent tile each, the whole
-// per-agent stage -- encoder (embed_lat_body -> post_attn_body), block-0 conv + GRU (gru_lat4_body) and the three layer-1 pre-activation
-// tables (preact_rows) -- and publish ONE flag per tile; the trajectory groups behind them in the grid wait for the flags of the tiles
-// their agents live in.  Why: as separate launches on their own stream these kernels were starved by the running chain (its queue keeps
-// every freed workgroup slot until its grid is fully dispatched: 1.85 ms for a 0.1 ms stage, profiles/r03/timeline_default.txt), which
-// forced ONE chain workgroup per CU in the pipelined path; inside the launch nothing needs a chain-free CU.
-struct RoleArgs {
-    EmbedW ew; PostW pw;
-    const float* enc_in; const int* last; float* g; float* qkv; float* pf;
-    const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
-    const f32x4* WAx; const float* b1x; const f32x4* WAy; const float* b1y; const f32x4* WA1; const float* b11;
-    float* A0x; float* A0y; float* A1y;
-    // scene front-end inside the role (scene batches; nullptr: the front-end ran as a launch before): set_data's normalisation for the
-    // tile's 16 agents -- scene origin (mean of the scene's last observed positions, summed in agent order like scene_orig_kernel),
-    // normalised track, velocities, flags -- written to the workspace rows the other phases and the trajectory groups read
-    const float* past; const int* scene_ptr; int S; float* scene_orig; int* agent_scene;
-    float* enc_in_w; float* xpad_w; float* cur_w; float* orig_w; int* last_w;
-    const float* attn; int ld_attn;   // attention output of an EARLIER launch (attention groups > 1, the NBA branch): the role then starts
-                                      // at the post-attention layer; nullptr: attention length 1, the role runs the embedding too
-    unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
-    int ntiles; float ode_time;
-    int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
-    int drop_tile;       // fault injection (tests): the role of this tile never publishes its flag (-1: none) -- exercises the give-up path
-};
-
-#ifndef ROLE_PRIO
-#define ROLE_PRIO 3
-#endif
 
 struct ChainArgs {
     const float* A0x; const float* A0y; const float* A1y;  // [nagents][512] per-agent layer-1 pre-activations (b1 included)
@@ -623,117 +614,12 @@ __device__ __forceinline__ void gru32_steps(ST& st, const float* gb, const float
 // being computed once at the top of the group and kept live (64-bit pointers held across phases were what spilled)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
-// C32_DIAG_TRACE (diagnostic build, profiles/exp_r03_trace.py): every workgroup appends one record {launch tag, block, kind, start, end (100 MHz
-// s_memrealtime), HW_ID, XCC_ID} to the debug buffer -- who ran where and when, across overlapping launches
-#ifdef C32_DIAG_TRACE
-__shared__ long long g_tr_ph[4];   // role phase stamps (thread 0)
-#define C32_TRACE_BEGIN() long long _tr_t0 = 0, _tr_c0 = 0; if (threadIdx.x == 0 && A.dbg) { _tr_t0 = __builtin_amdgcn_s_memrealtime(); _tr_c0 = __builtin_amdgcn_s_memtime(); }
-#define C32_TRACE_END(kind) do { if (threadIdx.x == 0 && A.dbg) { \
-        const long long _t1 = __builtin_amdgcn_s_memrealtime(); unsigned _hw, _xcc; \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(_hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(_xcc)); \
-        const unsigned long long _r = atomicAdd((unsigned long long*)A.dbg, 1ull); if ((long long)_r >= A.dbg[1]) break; /* dbg[1] = capacity in records */ \
-        long long* _p = A.dbg + 8 + _r * 12; _p[0] = A.trace_tag; _p[1] = blockIdx.x; _p[2] = (kind); _p[3] = _tr_t0; _p[4] = _t1; _p[5] = _hw; _p[6] = _xcc; \
-        _p[8] = g_tr_ph[0]; _p[9] = g_tr_ph[1]; _p[10] = g_tr_ph[2]; _p[7] = __builtin_amdgcn_s_memtime() - _tr_c0; _p[11] = g_tr_ph[3]; } } while (0)
-#define C32_TRACE_PHASE(i) do { if (threadIdx.x == 0) g_tr_ph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define C32_TRACE_PHASE(i) do { } while (0)
-#define C32_TRACE_BEGIN() do { } while (0)
-#define C32_TRACE_END(kind) do { } while (0)
-#endif
-
 #ifdef C32_DIAG_STAMPS
 #define C32_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && gi < 4) { A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k)] = __builtin_amdgcn_s_memtime(); \
                                                                     A.dbg[((size_t)blockIdx.x * 4 + gi) * 16 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define C32_STAMP(k) do { } while (0)
 #endif
-
-// The per-agent stage of ONE 16-agent tile on a chain workgroup's resources (4 waves, <= 256 VGPRs, the chain's dynamic LDS).  The
-// bodies are the stand-alone kernels' code (latency_bodies.hpp), so g / qkv / pf / state0 / A0x / A0y / A1y carry the bits the separate
-// launches produce.  LDS: [0, 40 KiB) embed, then [0, 16 KiB) post-attention exchange, then [0, 12 KiB) h tiles + [12, 60 KiB) GRU image.
-__device__ __forceinline__ void agent_role(const ChainArgs& A, int tile, char* smem) {
-    const RoleArgs& R = A.R;
-    const int nag = (A.ncols + A.K - 1) / A.K;   // == ncols / K: agents
-    // The role is a short chain of DEPENDENT steps (barriers, L2 round trips, 32-cycle MFMAs) sharing each SIMD with a chain wave that has
-    // a 64-cycle MFMA ready every cycle it is asked: at equal priority the older chain wave wins every arbitration and the role ran 2x
-    // slower than alone (283 vs 150 us, profiles/r03/trace_*), holding a workgroup slot all the while.  Raised priority lets its few
-    // instructions issue first; the chain wave loses the same handful of pipe cycles either way.
-    __builtin_amdgcn_s_setprio(ROLE_PRIO);
-    if (R.past) {   // (uniform) STTODENet.set_data for this tile (model/STTODE.py:397-461), one lane per agent
-        if (threadIdx.x < 16) {
-            const int a = tile * 16 + (int)threadIdx.x;
-            if (a < nag) {
-                int lo = 0, hi = R.S - 1;                 // the agent's scene: largest s with scene_ptr[s] <= a
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (R.scene_ptr[mid] <= a) lo = mid; else hi = mid - 1;
-                }
-                const int a0 = R.scene_ptr[lo], a1 = R.scene_ptr[lo + 1];
-                float sx = 0.f, sy = 0.f;
-                for (int aa = a0; aa < a1; ++aa) {       // agent order, as scene_orig_kernel sums: identical bits
-                    sx += R.past[((size_t)aa * A.Tp + (A.Tp - 1)) * 2 + 0];
-                    sy += R.past[((size_t)aa * A.Tp + (A.Tp - 1)) * 2 + 1];
-                }
-                const float inv = (float)(a1 - a0);
-                const float ox = sx / inv, oy = sy / inv;
-                if (a == a0) { R.scene_orig[2 * lo] = ox; R.scene_orig[2 * lo + 1] = oy; }
-                R.agent_scene[a] = lo;
-                agent_inputs_core<true>(a, R.past, A.Tp, A.ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, R.xpad_w, R.enc_in_w, R.cur_w, R.orig_w, R.last_w);
-            }
-        }
-        __syncthreads();                                  // enc_in / last / xpad of this tile are visible to the workgroup
-    }
-    if (R.attn == nullptr) {                      // (uniform) attention length 1: softmax over one key == 1, the attention output is v
-        embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, A.Tp, tile, reinterpret_cast<f32x4*>(smem));
-        __syncthreads();                          // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
-    }
-    C32_TRACE_PHASE(0);
-    post_attn_body<false>(R.pw, R.g, R.attn ? R.attn : R.qkv + 128, R.attn ? R.ld_attn : 192, R.pf, nag, R.ode_time, 0, 1, nullptr, nullptr, tile,
-                          reinterpret_cast<f32x4(*)[4][64]>(smem));
-    __syncthreads();                              // pf of this tile is visible to the workgroup; LDS changes hands again
-    C32_TRACE_PHASE(1);
-    f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
-    f32x4* sW45 = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
-    const int cur = A.ldx == 16 ? gru_lat4_body<1>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH, sW45)
-                                : gru_lat4_body<2>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, A.Tp, tile, sH, sW45);
-    C32_TRACE_PHASE(2);
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = tile * 16 + c;
-    const int colc = col < nag ? col : nag - 1;
-    f32x4 B[14];                                  // [pf | state0] of this lane's agent as B-operand fragments
-#pragma unroll
-    for (int T = 0; T < 8; ++T) B[T] = ld4(R.pf + (size_t)colc * 128 + 16 * T + 4 * q);
-#pragma unroll
-    for (int T = 0; T < 6; ++T) B[8 + T] = sH[cur][T][lane];
-    preact_rows<14, true>(R.WAx, R.b1x, R.A0x, B, col, col < nag, lane, q, wv);
-    preact_rows<14, true>(R.WAy, R.b1y, R.A0y, B, col, col < nag, lane, q, wv);
-    preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < nag, lane, q, wv);
-    // publish (guide §6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0 && tile != R.drop_tile) __hip_atomic_store(R.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Consumer side: wave 0 polls the flags of tiles [t_lo, t_hi] (relaxed agent-scope loads, one lane per tile, s_sleep between polls), then
-// ONE agent-scope acquire drops this CU's stale L1 lines; the caller's barrier releases the other waves.  The spin is bounded (~1 s): a
-// producer that never arrives -- it cannot, in-order dispatch puts every producer in front of its consumers -- would poison this group's
-// predictions with NaN and set the time-out word instead of hanging the device.
-__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane) {
-    bool ok = true;
-    for (int t = t_lo + lane; t <= t_hi; t += 64) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 20)) { ok = false; break; }
-        }
-    }
-    ok = __all(ok);
-    if (!ok && lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return ok;
-}
 
 // Grid order of the fused launch.  Roles and groups are interleaved: the role of tile t is placed `lead` groups ahead of the first group
 // that reads its tables, g_first(t) = floor(t K / 8) (a tile = 16 agents = 16 K trajectories, a group = 128), so that in a running
@@ -776,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     C32_TRACE_BEGIN();
     const int fb = FUSE ? fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead) : (int)blockIdx.x;
     if (FUSE && fb < 0) {   // (uniform) a per-agent role
-        agent_role(A, -1 - fb, smem);
+        agent_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, -1 - fb, smem);
         C32_TRACE_END(1);
         return;
     }
@@ -1009,7 +895,7 @@ static int chain_cus() {
 static int chain_lds(int NY, int prog_len, bool b3 = false) { return ((b3 ? 2 * C32_BUF_B3 : C32_RING) + 8 * C32_SLOT) * 16 + (1216 + 64 * NY) * 4 + prog_len * 8 + 16; }
 
 static int role_lds(int Tp) {   // agent_role's phases: embed (Tp*256 + 512 f32x4), GRU (h tiles 12 KiB + image of hidden tiles 4, 5: 48 KiB)
-    const int e = (Tp * 256 + 512) * 16, g = (2 * 6 * 64 + 2 * 24 * 64) * 16;
+    const int e = (Tp * 256 + 512) * 16, g = (2 * 6 * 64 + 2 * 24 * 64 + 2 * 4 * 64) * 16;   // h tiles 12 KiB + image 48 KiB + gate hand-off 8 KiB
     return e > g ? e : g;
 }
 

@@ -516,125 +516,7 @@ __global__ __launch_bounds__(256, 3) void mlp_block1_kernel(
 // the 16-quad chain of output tile o.  Same summation order as the throughput kernels everywhere: identical bits.
 // MODE 0: block-0 decoder_x (dbuf = x_true - x_hat0) | 1: block-0 decoder_y (ybuf) | 2: block-1 decoder_y + epilogue (pred)
 // ---------------------------------------------------------------------------------------------------
-struct MlpLatArgs {
-    const float* A0; const f32x4* blob; const float* z; const float* state; const float* xpad; const float* ybuf; const float* cur;
-    const float* orig; float* out; int ncols, K, Tf2;
-};
-template <int KTV>
-struct MlpLatFrag {            // one group's operands of one wave
-    f32x4 a0;                  // A0[agent][16 (4g + w) + 4q ..]
-    f32x4 w1[KTV];             // W1v tiles of chunk 4g + w
-    f32x4 w2[4][4];            // [chunk of the group][own row tile]
-};
-template <int KTV, int NO, int MODE>
-__device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* sH1, f32x4* sH2, int tile) {
-    constexpr int CHW = (KTV + 16) * 64;            // f32x4 per chunk
-    constexpr int NR = (NO + 3) / 4;                 // output tiles this wave finishes: o = wave, wave + 4
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = tile * 16 + c;
-    const int colc = col < a.ncols ? col : a.ncols - 1;
-    const int agent = colc / a.K;
-    const float* arow = a.A0 + (size_t)agent * 512 + 4 * q;
-    const f32x4* wl = a.blob + lane;
-    auto fetch = [&](MlpLatFrag<KTV>& f, int g) {
-        f.a0 = ld4(arow + 16 * (4 * g + wave));
-        const f32x4* own = wl + (size_t)(4 * g + wave) * CHW;
-#pragma unroll
-        for (int T = 0; T < KTV; ++T) f.w1[T] = own[T * 64];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f.w2[cc][i] = wl[(size_t)(4 * g + cc) * CHW + (KTV + 4 * wave + i) * 64];
-    };
-    f32x4 B[KTV];
-    B[0] = ld4(a.z + (size_t)colc * 32 + 4 * q);
-    B[1] = ld4(a.z + (size_t)colc * 32 + 16 + 4 * q);
-    if (KTV == 8) {
-#pragma unroll
-        for (int T = 0; T < 6; ++T) B[2 + (T < KTV - 2 ? T : 0)] = ld4(a.state + (size_t)colc * 96 + 16 * T + 4 * q);
-    }
-    f32x4 acc2[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc2[i] = splat4(0.f);
-    auto group = [&](const MlpLatFrag<KTV>& f, int g) {
-        f32x4 h1 = f.a0;
-#pragma unroll
-        for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, f.w1[T], B[T]);
-        f32x4* hb = sH1 + (g & 1) * 256;
-        hb[wave * 64 + lane] = relu4(h1);
-        __syncthreads();
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const f32x4 hv = hb[cc * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc2[i] = mfma_k16(acc2[i], f.w2[cc][i], hv);
-        }
-    };
-    MlpLatFrag<KTV> fa, fb;
-    fetch(fa, 0);
-#pragma unroll 1
-    for (int g = 0; g < 6; g += 2) {
-        fetch(fb, g + 1);
-        group(fa, g);
-        fetch(fa, g + 2);
-        group(fb, g + 1);
-    }
-    fetch(fb, 7);
-    group(fa, 6);
-    // layer 3 operands travel during the last group: b2 sits behind the first layer-3 chunk's 16 tiles and its b3 (packing.mlp_stream)
-    const f32x4* l3 = a.blob + (size_t)32 * CHW;
-    f32x4 w3[NR][16], b3v[NR], b2v[4];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int o = wave + 4 * i < NO ? wave + 4 * i : NO - 1;
-#pragma unroll
-        for (int T = 0; T < 16; ++T) w3[i][T] = l3[(size_t)o * CHW + T * 64 + lane];
-        b3v[i] = ld4(reinterpret_cast<const float*>(l3 + (size_t)o * CHW + 16 * 64) + 4 * q);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b2v[i] = ld4(reinterpret_cast<const float*>(l3 + 16 * 64) + 16 + 16 * (4 * wave + i) + 4 * q);
-    group(fb, 7);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sH2[(4 * wave + i) * 64 + lane] = relu4(acc2[i] + b2v[i]);
-    __syncthreads();                                 // the whole 256-wide layer-2 activation as B-operand fragments
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int o = wave + 4 * i;
-        if (o >= NO) continue;
-        f32x4 v = b3v[i];
-#pragma unroll
-        for (int T = 0; T < 16; ++T) v = mfma_k16(v, w3[i][T], sH2[T * 64 + lane]);
-        if (col >= a.ncols) continue;
-        if (MODE == 0) {
-            const f32x4 xt = ld4(a.xpad + (size_t)agent * (16 * NO) + 16 * o + 4 * q);
-            st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, xt - v);
-        } else if (MODE == 1) {
-            st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, v);
-        } else {
-            const int row0 = 16 * o + 4 * q;
-            if (row0 < a.Tf2) {
-                const float cx = a.cur[2 * agent], cy = a.cur[2 * agent + 1];
-                const float ox = a.orig[2 * agent], oy = a.orig[2 * agent + 1];
-                const f32x4 y0 = ld4(a.ybuf + (size_t)col * (16 * NO) + row0);
-                f32x4 r;
-                r[0] = ((y0[0] + v[0]) + cx) + ox;
-                r[1] = ((y0[1] + v[1]) + cy) + oy;
-                r[2] = ((y0[2] + v[2]) + cx) + ox;
-                r[3] = ((y0[3] + v[3]) + cy) + oy;
-                float* pp = a.out + (size_t)col * a.Tf2 + row0;
-                if (row0 + 3 < a.Tf2 && (a.Tf2 & 3) == 0) {
-                    st4(pp, r);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (row0 + e < a.Tf2) pp[e] = r[e];
-                }
-            }
-        }
-    }
-}
-
+// MlpLatArgs / mlp_lat_run: latency_bodies.hpp (shared with the one-launch scene path, scene_lat.hip)
 // block 0: blockIdx.y = role (0: decoder_x, 1: decoder_y); block 1: one role
 template <int TPX, int NOY>
 __global__ __launch_bounds__(256) void mlp0_lat_kernel(MlpLatArgs ax, MlpLatArgs ay) {
@@ -839,7 +721,7 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     if ((ncols + 15) / 16 <= mlp_lat_tiles()) {   // few columns: latency form (four waves share one 16-column tile)
         MlpLatArgs ax, ay;
         ax.A0 = A0x; ax.blob = (const f32x4*)stream; ax.z = z; ax.state = nullptr; ax.xpad = xpad; ax.ybuf = nullptr; ax.cur = nullptr;
-        ax.orig = nullptr; ax.out = dbuf; ax.ncols = ncols; ax.K = K; ax.Tf2 = 0;
+        ax.orig = nullptr; ax.out = dbuf; ax.ncols = ncols; ax.K = K; ax.Tf2 = 0; ax.out_lds = nullptr; ax.state_lds = nullptr; ax.a0_lds = nullptr;
         ay = ax;
         ay.A0 = A0y; ay.blob = (const f32x4*)stream + (size_t)(32 + TPX) * MLP0_CHW; ay.out = ybuf;
         const dim3 g((ncols + 15) / 16, 2);
@@ -892,7 +774,7 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
     if ((ncols + 15) / 16 <= mlp_lat_tiles()) {   // few columns: latency form
         MlpLatArgs a;
         a.A0 = A1y; a.blob = (const f32x4*)stream; a.z = z; a.state = state1; a.xpad = nullptr; a.ybuf = ybuf; a.cur = cur; a.orig = orig;
-        a.out = pred; a.ncols = ncols; a.K = K; a.Tf2 = 2 * Tf;
+        a.out = pred; a.ncols = ncols; a.K = K; a.Tf2 = 2 * Tf; a.out_lds = nullptr; a.state_lds = nullptr; a.a0_lds = nullptr;
         const dim3 g((ncols + 15) / 16);
         hipStream_t sl = (hipStream_t)stream_;
 #define L1L(NY)                                                                                   \

@@ -208,3 +208,49 @@ extern "C" int sttode_best_of_k(const float* pred, const float* gt, int n, int K
     STT_HIP(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Host staging of ONE scene for the reference's one-scene-per-call loop (test.py:171-188 -> STTODENet.set_data, model/STTODE.py:397-404):
+// the loader's pageable [N][2][T] tracks are transposed into a pinned ring slot as [N][T][2] (past, then future) and travel to the device
+// in ONE asynchronous copy on the caller's stream.  A ring of four slots per device, each guarded by an event: the slot is reused only
+// once the copy that last read it has completed (normally long ago).  Replaces a dozen torch calls (~35 us of host time per scene).
+// ---------------------------------------------------------------------------------------------------
+#include <mutex>
+struct StageSlot { float* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
+static StageSlot g_stage[STT_ATTR_DEVICES][4];
+static int g_stage_k[STT_ATTR_DEVICES];
+static std::mutex g_stage_mu;
+
+extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream) {
+    STT_REQUIRE(pre && dev, "sttode_stage_scene: null pointer");
+    STT_REQUIRE(N > 0 && Tp > 0 && Tf >= 0 && (fut || Tf == 0), "sttode_stage_scene: bad N/Tp/Tf");
+    int d = 0;
+    STT_HIP(hipGetDevice(&d));
+    STT_REQUIRE(d >= 0 && d < STT_ATTR_DEVICES, "sttode_stage_scene: device index beyond the staging table");
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    StageSlot& s = g_stage[d][g_stage_k[d] = (g_stage_k[d] + 1) & 3];
+    const size_t need = (size_t)N * (Tp + Tf) * 2;
+    if (s.ev) STT_HIP(hipEventSynchronize(s.ev));   // the copy that last read this slot is done
+    else STT_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    if (s.cap < need) {
+        if (s.host) STT_HIP(hipHostFree(s.host));
+        s.host = nullptr;
+        s.cap = need < 4096 ? 4096 : 2 * need;
+        STT_HIP(hipHostMalloc((void**)&s.host, s.cap * sizeof(float), hipHostMallocDefault));
+    }
+    float* h = s.host;
+    for (int a = 0; a < N; ++a)
+        for (int t = 0; t < Tp; ++t) {
+            h[((size_t)a * Tp + t) * 2] = pre[((size_t)a * 2) * Tp + t];
+            h[((size_t)a * Tp + t) * 2 + 1] = pre[((size_t)a * 2 + 1) * Tp + t];
+        }
+    float* hf = h + (size_t)N * Tp * 2;
+    for (int a = 0; a < N; ++a)
+        for (int t = 0; t < Tf; ++t) {
+            hf[((size_t)a * Tf + t) * 2] = fut[((size_t)a * 2) * Tf + t];
+            hf[((size_t)a * Tf + t) * 2 + 1] = fut[((size_t)a * 2 + 1) * Tf + t];
+        }
+    STT_HIP(hipMemcpyAsync(dev, h, need * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    STT_HIP(hipEventRecord(s.ev, (hipStream_t)stream));
+    return 0;
+}

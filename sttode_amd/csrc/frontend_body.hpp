@@ -13,7 +13,9 @@ template <bool SC1> __device__ __forceinline__ void fe_store(float* p, float v) 
 // One agent: normalised track (xpad, flattened (t, c), zero padded to 16*TPX), encoder inputs [T][4] = (normalised position, velocity with
 // the first one duplicated: model/STTODE.py:432-433,582-583), cur_location, scene origin per agent, last-agent flag.
 // (ox, oy): the agent's scene origin (0 for the NBA branch); `last`: the add_category flag (model/STTODE.py:199-210).
-template <bool SC1>
+// TMAX > 0 (T <= TMAX): the track is read into registers first and the frame loop is unrolled -- with stores between the loads (atomic ones
+// when SC1) every frame otherwise costs a memory round trip, 4-5 us for 8 frames on the critical path of a one-scene call.
+template <bool SC1, int TMAX = 0>
 __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict__ seq, int T, int TPX, int vel_from_norm, float ox, float oy,
                                                   int last, const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq, world coords
                                                   float* __restrict__ xpad, float* __restrict__ enc_in, float* __restrict__ cur,
@@ -28,21 +30,31 @@ __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict
         pnx = pwx - ox;
         pny = pwy - oy;
     }
-    for (int t = 0; t < T; ++t) {
-        const float wx = p[2 * t], wy = p[2 * t + 1];
+    float2 wb[TMAX > 0 ? TMAX : 1];
+    if (TMAX > 0) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) wb[t] = reinterpret_cast<const float2*>(p)[t];
+    }
+#pragma unroll
+    for (int t = 0; t < (TMAX > 0 ? TMAX : T); ++t) {
+        if (TMAX > 0 && t >= T) break;
+        const float wx = TMAX > 0 ? wb[t].x : p[2 * t], wy = TMAX > 0 ? wb[t].y : p[2 * t + 1];
         const float nx = wx - ox, ny = wy - oy;
         float vx, vy;
         if (t == 0 && !have_prev) {
             // first velocity duplicates the second one (model/STTODE.py:432-433,582-583)
-            const float w1x = p[2], w1y = p[3];
+            const float w1x = TMAX > 0 ? wb[1 < TMAX ? 1 : 0].x : p[2], w1y = TMAX > 0 ? wb[1 < TMAX ? 1 : 0].y : p[3];
             if (vel_from_norm) { vx = (w1x - ox) - nx; vy = (w1y - oy) - ny; }
             else { vx = w1x - wx; vy = w1y - wy; }
         } else {
             if (vel_from_norm) { vx = nx - pnx; vy = ny - pny; }
             else { vx = wx - pwx; vy = wy - pwy; }
         }
-        float* e = enc_in + ((size_t)a * T + t) * 4;
-        e[0] = nx; e[1] = ny; e[2] = vx; e[3] = vy;
+        if (enc_in) {
+            float* e = enc_in + ((size_t)a * T + t) * 4;
+            e[0] = nx; e[1] = ny; e[2] = vx; e[3] = vy;
+        }
         if (xp) { fe_store<SC1>(xp + 2 * t, nx); fe_store<SC1>(xp + 2 * t + 1, ny); }
         pnx = nx; pny = ny; pwx = wx; pwy = wy;
     }

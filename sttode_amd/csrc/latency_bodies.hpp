@@ -89,6 +89,14 @@ __device__ __forceinline__ void gru_lat_body(const float* __restrict__ xin, cons
 }
 
 
+// 16-byte agent-scope (sc1, write-through) store: the payload form of an in-launch hand-off to ANOTHER workgroup -- no release fence is
+// needed behind it (cdna_hip_programming.md §6 Guideline 16, R1).  hipcc does not count an asm store: every storing wave runs
+// `s_waitcnt vmcnt(0)` itself before the workgroup's flag is published.  (`s_nop 1`: §5.7 item 1 -- the data registers may otherwise be
+// overwritten before the store has read them.)
+__device__ __forceinline__ void st4_sc1(float* p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // encoder (PastEncoder trunk): model/STTODE.py:214-236, hypertransformer.py:55-89,134-153, ode_demo.py:186-190,223-231
 // ---------------------------------------------------------------------------------------------------
@@ -288,7 +296,7 @@ __device__ __forceinline__ void ode_rhs(const PostW& w, f32x4 (*sX)[4][64], cons
 // ETH/UCY/SDD path: softmax over one element) is just v(y) = W_v y + b_v and is computed here (vP, vb = value rows of the packed
 // in-projection).  With attention length > 1 a stage needs a pass over the whole group: op level (hypertransformer.ODEG_Encoder).
 // sX: [4][4][64] f32x4 exchange buffer (16 KiB of LDS); `tile` = the workgroup's 16-agent tile; waves 0..3 of the workgroup.
-template <bool ODE>
+template <bool ODE, bool SC1 = false>   // SC1: pf is read by OTHER workgroups of the same launch (write-through stores)
 __device__ __forceinline__ void post_attn_body(const PostW& w, const float* __restrict__ g,  // [n][64]
                                                const float* __restrict__ attn, int ld_attn,  // [n][ld] attention output (pre out_proj)
                                                float* __restrict__ pf,                       // [n][128]
@@ -364,32 +372,35 @@ __device__ __forceinline__ void post_attn_body(const PostW& w, const float* __re
         // pf = cat(ftraj_input, relu(ODE state at t = ode_time)) (ode_demo.py:231, model/STTODE.py:233-235); wave wv stores tile wv
         const f32x4 go = wv == 0 ? gg[0] : wv == 1 ? gg[1] : wv == 2 ? gg[2] : gg[3];
         const f32x4 xo = wv == 0 ? yo[0] : wv == 1 ? yo[1] : wv == 2 ? yo[2] : yo[3];
-        st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
-        st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
+        if (SC1) {
+            st4_sc1(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
+            st4_sc1(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
+        } else {
+            st4(pf + (size_t)col * 128 + 16 * wv + 4 * q, go);
+            st4(pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(xo));
+        }
     }
 }
+
 
 
 // ---------------------------------------------------------------------------------------------------
 // Bodies used only by the per-agent ROLE of the fused chain launch (chain32.hip): a 256-thread workgroup with <= 256 VGPRs per wave
 // ---------------------------------------------------------------------------------------------------
-// 16-byte agent-scope (sc1, write-through) store: the payload form of an in-launch hand-off to ANOTHER workgroup -- no release fence is
-// needed behind it (cdna_hip_programming.md §6 Guideline 16, R1).  hipcc does not count an asm store: every storing wave runs
-// `s_waitcnt vmcnt(0)` itself before the workgroup's flag is published.  (`s_nop 1`: §5.7 item 1 -- the data registers may otherwise be
-// overwritten before the store has read them.)
-__device__ __forceinline__ void st4_sc1(float* p, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-
 // Four-wave form of gru_lat_body (block-0 conv + GRU of ONE 16-agent tile): wave w keeps the 24 weight fragments of hidden tile w in
 // registers for all steps; hidden tiles 4 and 5 are computed by waves 0 and 1 as well, from fragments staged once in LDS
-// (sW45: [2][3 gates][8 k-tiles][64] f32x4 = 48 KiB, by LDS-DMA).  A split over output rows: every element of h is the k-ordered chain
+// (sW45: [2][3 gates][8 k-tiles][64] f32x4 = 48 KiB, by LDS-DMA, + 8 KiB behind it for the raw gate sums handed to waves 2, 3 = 56 KiB).  A split over output rows: every element of h is the k-ordered chain
 // of gru_lat_body / gru_cols_kernel, so the bits are those of the other forms.  Returns the index of the sH buffer that holds the final
 // hidden state (all six tiles, B-operand fragment layout), which the caller may feed straight into the next layer.
-template <int TPX>
+struct GruNoPre { __device__ __forceinline__ void operator()() const {} };
+// PRE: called once every weight load of the prologue is in flight and before the tile's input is read (a workgroup whose input is made by
+// its own front-end runs it there, under the weights' latency)
+template <int TPX, bool DLDS = false, bool SC1 = false, class PRE = GruNoPre>   // SC1: state is read by OTHER workgroups of the same launch
 __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, const f32x4* __restrict__ convP, const float* __restrict__ convB,
                                              const f32x4* __restrict__ wihP, const f32x4* __restrict__ whhP, const float* __restrict__ gbias,
-                                             float* __restrict__ state, int ncols, int Tp, int tile, f32x4 (*sH)[6][64], f32x4* sW45) {
+                                             float* __restrict__ state, int ncols, int Tp, int tile, f32x4 (*sH)[6][64], f32x4* sW45,
+                                             const f32x4* d_lds = nullptr, PRE pre = PRE()) {
+    // DLDS: the tile's input comes from d_lds (B-operand fragments [TPX][64] in LDS) instead of xin, and the final state stays in sH only
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = tile * 16 + c;
@@ -411,25 +422,45 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
 #pragma unroll
         for (int T = 0; T < 6; ++T) wh[g][T] = whhP[((g * 6 + w) * 6 + T) * 64 + lane];
     }
-    const int w2 = w < 2 ? 4 + w : 4;   // second hidden tile of waves 0 and 1
+    const int w2 = w < 2 ? 4 + w : 4;   // second hidden tile of waves 0 and 1 (its gate functions run on waves 2 and 3)
 #pragma unroll
     for (int g = 0; g < 4; ++g) { b0[g] = ld4(gbias + g * 96 + 16 * w + 4 * q); b1[g] = ld4(gbias + g * 96 + 16 * w2 + 4 * q); }
     const f32x4 cb0 = ld4(convB + 4 * q), cb1 = ld4(convB + 16 + 4 * q);
-    f32x4 d[TPX];
-#pragma unroll
-    for (int T = 0; T < TPX; ++T) d[T] = ld4(xin + (size_t)colc * (16 * TPX) + 16 * T + 4 * q);
-    f32x4 hn = splat4(0.f), hn2 = splat4(0.f);
-    sH[0][w][lane] = hn;
-    if (w < 2) sH[0][4 + w][lane] = hn2;
     f32x4 cw[2][TPX];
 #pragma unroll
     for (int io = 0; io < 2; ++io)
 #pragma unroll
         for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
+    pre();
+    f32x4 d[TPX];
+#pragma unroll
+    for (int T = 0; T < TPX; ++T) d[T] = DLDS ? d_lds[T * 64 + lane] : ld4(xin + (size_t)colc * (16 * TPX) + 16 * T + 4 * q);
+    f32x4 hn = splat4(0.f), hn2 = splat4(0.f);
+    sH[0][w][lane] = hn;
+    if (w < 2) sH[0][4 + w][lane] = hn2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed; the barrier publishes everybody's
     __syncthreads();
     const f32x4* wB = sW45 + (size_t)(w & 1) * (24 * 64) + lane;
+    f32x4* sG = sW45 + 2 * 24 * 64;                    // [2 tiles][4][64]: raw gate sums of hidden tiles 4, 5 (8 KiB behind the image)
     int cur = 0;
+    // One step = two halves around an LDS hand-off.  The matrix work of hidden tiles 4, 5 sits on waves 0, 1 (from the LDS image), but their
+    // gate functions (12 exp / rcp evaluations per lane, ~560 cycles with the matrix pipe idle) move to waves 2, 3, which have nothing
+    // else left by then; waves 2, 3 likewise keep their own tile's gate functions for the second half.  First half: every wave runs 104
+    // MFMAs; second half: waves 0, 1 their own tile (96 MFMAs + gates), waves 2, 3 gates only.  Same sums, same functions: same bits.
+    auto gates = [&](const f32x4& ar, const f32x4& az, const f32x4& ai, const f32x4& ah, const f32x4& hp) {
+        f32x4 o;
+#ifdef LAT_DIAG_NO_GATES    // (diagnostic builds only)
+        return ar * 1e-3f + az * 1e-3f + ai * 1e-3f + ah * 1e-3f + hp * 0.5f;
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rg = sigmoid_prescaled(ar[r]);
+            const float zg = sigmoid_prescaled(az[r]);
+            const float ng = tanh_prescaled(fmaf(rg, ah[r], ai[r]));
+            o[r] = fmaf(zg, hp[r] - ng, ng);  // (1-z) n + z h
+        }
+        return o;
+    };
 #pragma unroll 1
     for (int t = 0; t < Tp; ++t) {
         f32x4 e[2] = {cb0, cb1};
@@ -446,15 +477,15 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
 #pragma unroll
                 for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
         }
-        {
-            f32x4 ar = b0[0], az = b0[1], ai = b0[2], ah = b0[3];
+        f32x4 ar, az, ai, ah;
+        auto own_sums = [&]() {                        // hidden tile w from the register fragments
+            ar = b0[0]; az = b0[1]; ai = b0[2]; ah = b0[3];
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 ar = mfma_k16(ar, wi[0][T], e[T]);
                 az = mfma_k16(az, wi[1][T], e[T]);
                 ai = mfma_k16(ai, wi[2][T], e[T]);
             }
-            const f32x4 hp = sH[cur][w][lane];
 #pragma unroll
             for (int T = 0; T < 6; ++T) {
                 const f32x4 hb = sH[cur][T][lane];
@@ -462,47 +493,51 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
                 az = mfma_k16(az, wh[1][T], hb);
                 ah = mfma_k16(ah, wh[2][T], hb);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = sigmoid_prescaled(ar[r]);
-                const float zg = sigmoid_prescaled(az[r]);
-                const float ng = tanh_prescaled(fmaf(rg, ah[r], ai[r]));
-                hn[r] = fmaf(zg, hp[r] - ng, ng);  // (1-z) n + z h
-            }
-        }
-        if (w < 2) {   // wave-uniform: hidden tile 4 + w from the LDS image
-            STT_FENCE();
-            f32x4 ar = b1[0], az = b1[1], ai = b1[2], ah = b1[3];
+        };
+        if (w < 2) {   // (wave-uniform) first half: hidden tile 4 + w from the LDS image, raw sums handed to wave 2 + w
+            f32x4 br = b1[0], bz = b1[1], bi = b1[2], bh = b1[3];
+#ifndef LAT_DIAG_NO_TILEB   // (diagnostic builds only: timing without the second tile's matrix work; results are garbage)
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
-                ar = mfma_k16(ar, wB[(0 * 8 + T) * 64], e[T]);
-                az = mfma_k16(az, wB[(1 * 8 + T) * 64], e[T]);
-                ai = mfma_k16(ai, wB[(2 * 8 + T) * 64], e[T]);
+                br = mfma_k16(br, wB[(0 * 8 + T) * 64], e[T]);
+                bz = mfma_k16(bz, wB[(1 * 8 + T) * 64], e[T]);
+                bi = mfma_k16(bi, wB[(2 * 8 + T) * 64], e[T]);
             }
-            const f32x4 hp = sH[cur][4 + w][lane];
 #pragma unroll
             for (int T = 0; T < 6; ++T) {
                 const f32x4 hb = sH[cur][T][lane];
-                ar = mfma_k16(ar, wB[(0 * 8 + 2 + T) * 64], hb);
-                az = mfma_k16(az, wB[(1 * 8 + 2 + T) * 64], hb);
-                ah = mfma_k16(ah, wB[(2 * 8 + 2 + T) * 64], hb);
+                br = mfma_k16(br, wB[(0 * 8 + 2 + T) * 64], hb);
+                bz = mfma_k16(bz, wB[(1 * 8 + 2 + T) * 64], hb);
+                bh = mfma_k16(bh, wB[(2 * 8 + 2 + T) * 64], hb);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = sigmoid_prescaled(ar[r]);
-                const float zg = sigmoid_prescaled(az[r]);
-                const float ng = tanh_prescaled(fmaf(rg, ah[r], ai[r]));
-                hn2[r] = fmaf(zg, hp[r] - ng, ng);
-            }
-            sH[cur ^ 1][4 + w][lane] = hn2;
+#endif
+            f32x4* g = sG + (size_t)w * 256 + lane;
+            g[0] = br; g[64] = bz; g[128] = bi; g[192] = bh;
+        } else {
+            own_sums();
+        }
+        lds_barrier();
+        if (w < 2) {   // second half
+            own_sums();
+            hn = gates(ar, az, ai, ah, sH[cur][w][lane]);
+        } else {
+            hn = gates(ar, az, ai, ah, sH[cur][w][lane]);
+            const f32x4* g = sG + (size_t)(w - 2) * 256 + lane;
+            hn2 = gates(g[0], g[64], g[128], g[192], sH[cur][2 + w][lane]);
+            sH[cur ^ 1][2 + w][lane] = hn2;
         }
         sH[cur ^ 1][w][lane] = hn;
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
-    if (col < ncols) {
-        st4(state + (size_t)col * 96 + 16 * w + 4 * q, hn);
-        if (w < 2) st4(state + (size_t)col * 96 + 16 * (4 + w) + 4 * q, hn2);
+    if (!DLDS && col < ncols) {
+        if (SC1) {
+            st4_sc1(state + (size_t)col * 96 + 16 * w + 4 * q, hn);
+            if (w >= 2) st4_sc1(state + (size_t)col * 96 + 16 * (2 + w) + 4 * q, hn2);
+        } else {
+            st4(state + (size_t)col * 96 + 16 * w + 4 * q, hn);
+            if (w >= 2) st4(state + (size_t)col * 96 + 16 * (2 + w) + 4 * q, hn2);
+        }
     }
     return cur;
 }
@@ -513,9 +548,11 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
 // Wave w computes row tiles w, w+4, .., w+28 in two groups of four; the fragments of the next two k-tiles are in flight while one feeds the
 // MFMAs (the weights come straight from L2: every fragment is used by exactly one wave).  Each output element is linear_cols_kernel's
 // k-ordered chain: identical bits.  SC1: store the rows write-through for a consumer in ANOTHER workgroup of the same launch.
+// out_lds != nullptr: the rows go to LDS as fragments [row tile][lane] instead (the one-launch scene path: the COLUMNS are then a
+// trajectory tile's agents and the table feeds mlp_lat_run's layer 1 of the same workgroup; wave w reads back exactly what it wrote).
 template <int KT, bool SC1>
 __device__ __forceinline__ void preact_rows(const f32x4* __restrict__ WP, const float* __restrict__ bias, float* __restrict__ out,
-                                            const f32x4 (&B)[14], int col, bool live, int lane, int q, int wv) {
+                                            const f32x4 (&B)[14], int col, bool live, int lane, int q, int wv, f32x4* out_lds = nullptr) {
     constexpr int D = 4;   // k-tiles of weight fragments in flight per row tile (L2 latency under load ~2-3 us vs 0.25 us of MFMAs per k-tile)
 #pragma unroll 1
     for (int rg = 0; rg < 2; ++rg) {
@@ -541,7 +578,10 @@ __device__ __forceinline__ void preact_rows(const f32x4* __restrict__ WP, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = mfma_k16(acc[i], wc[i], B[T]);
         }
-        if (live) {
+        if (out_lds) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out_lds[(wv + 4 * (4 * rg + i)) * 64 + lane] = acc[i];
+        } else if (live) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float* p = out + (size_t)col * 512 + 16 * (wv + 4 * (4 * rg + i)) + 4 * q;
@@ -551,3 +591,188 @@ __device__ __forceinline__ void preact_rows(const f32x4* __restrict__ WP, const 
         }
     }
 }
+
+// The same rows for a TRAJECTORY tile's own columns, in two passes (the one-launch scene form: pf arrives ~8 us before state0): k-tiles
+// [T0, T1) of all 32 row tiles (wave w: row tiles w, w+4, ..; acc[8] carries them across the passes, initialised with the bias by the
+// caller) as ONE pipeline of 2 (T1 - T0) steps -- step s = (row-tile quad s / N, k-tile T0 + s % N) -- with D steps of weight fragments
+// in flight; preact_prime issues the first D steps (weights only: callable BEFORE the data the pass multiplies has arrived).  Each
+// element is still bias, then k-tiles 0..13 in order: preact_rows' bits.
+template <int KT, int T0, int T1, int D>
+__device__ __forceinline__ void preact_load(const f32x4* __restrict__ WP, f32x4 (&w)[4], int s, int lane, int wv) {
+    constexpr int N = T1 - T0;
+    const int rg = s / N, T = s % N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = WP[((size_t)(wv + 4 * (4 * rg + i)) * KT + T0 + T) * 64 + lane];
+}
+template <int KT, int T0, int T1, int D>
+__device__ __forceinline__ void preact_prime(const f32x4* __restrict__ WP, f32x4 (&w)[D][4], int lane, int wv) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) preact_load<KT, T0, T1, D>(WP, w[s], s, lane, wv);
+}
+template <int KT, int T0, int T1, int D>
+__device__ __forceinline__ void preact_run(const f32x4* __restrict__ WP, f32x4 (&w)[D][4], f32x4 (&acc)[8], const f32x4 (&B)[14], int lane, int wv) {
+    constexpr int N = T1 - T0, S = 2 * N;
+    static_assert(D <= S, "prefetch depth beyond the pass");
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        f32x4 wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[s % D][i];
+        if (s + D < S) preact_load<KT, T0, T1, D>(WP, w[s % D], s + D, lane, wv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * (s / N) + i] = mfma_k16(acc[4 * (s / N) + i], wc[i], B[T0 + s % N]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Latency form of the decoder MLPs (see the comment at the kernels in decoder.hip)
+// ---------------------------------------------------------------------------------------------------
+struct MlpLatArgs {
+    const float* A0; const f32x4* blob; const float* z; const float* state; const float* xpad; const float* ybuf; const float* cur;
+    const float* orig; float* out; int ncols, K, Tf2;
+    // LDSIO forms (the one-launch scene path keeps a tile's d and GRU state in LDS, as B-operand fragments [k-tile][lane]):
+    f32x4* out_lds;            // MODE 0: d = x_true - x_hat0 goes here instead of `out`
+    const f32x4* state_lds;    // MODE 2: the block-1 GRU state comes from here instead of `state`
+    const f32x4* a0_lds;       // != nullptr: layer-1 pre-activations of THIS tile's columns as fragments [32 row tiles][64] instead of A0[agent]
+};
+template <int KTV>
+struct MlpLatFrag {            // one group's operands of one wave
+    f32x4 a0;                  // A0[agent][16 (4g + w) + 4q ..]
+    f32x4 w1[KTV];             // W1v tiles of chunk 4g + w
+    f32x4 w2[4][4];            // [chunk of the group][own row tile]
+};
+// DEEP: weight fragments travel TWO groups ahead (three register sets; a workgroup that has the CU to itself, 512 VGPRs per wave): one group
+// of MFMAs (~1 us) does not cover an L2 round trip plus the group's 72-100 KiB at the CU's 64 B/clk, two do.  Same arithmetic, same order.
+template <int KTV, int NO, int MODE, bool SC1 = false, bool LDSIO = false, bool DEEP = false>
+__device__ __forceinline__ void mlp_lat_run(const MlpLatArgs& a, f32x4* sH1, f32x4* sH2, int tile) {
+    constexpr int CHW = (KTV + 16) * 64;            // f32x4 per chunk
+    constexpr int NR = (NO + 3) / 4;                 // output tiles this wave finishes: o = wave, wave + 4
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = tile * 16 + c;
+    const int colc = col < a.ncols ? col : a.ncols - 1;
+    const int agent = colc / a.K;
+    const float* arow = a.A0 + (size_t)agent * 512 + 4 * q;
+    const f32x4* wl = a.blob + lane;
+    auto fetch = [&](MlpLatFrag<KTV>& f, int g) {
+        f.a0 = (LDSIO && a.a0_lds) ? a.a0_lds[(4 * g + wave) * 64 + lane] : ld4(arow + 16 * (4 * g + wave));
+        const f32x4* own = wl + (size_t)(4 * g + wave) * CHW;
+#pragma unroll
+        for (int T = 0; T < KTV; ++T) f.w1[T] = own[T * 64];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f.w2[cc][i] = wl[(size_t)(4 * g + cc) * CHW + (KTV + 4 * wave + i) * 64];
+    };
+    f32x4 B[KTV];
+    B[0] = ld4(a.z + (size_t)colc * 32 + 4 * q);
+    B[1] = ld4(a.z + (size_t)colc * 32 + 16 + 4 * q);
+    if (KTV == 8) {
+#pragma unroll
+        for (int T = 0; T < 6; ++T)
+            B[2 + (T < KTV - 2 ? T : 0)] = LDSIO ? a.state_lds[T * 64 + lane] : ld4(a.state + (size_t)colc * 96 + 16 * T + 4 * q);
+    }
+    f32x4 acc2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc2[i] = splat4(0.f);
+    auto group = [&](const MlpLatFrag<KTV>& f, int g) {
+        f32x4 h1 = f.a0;
+#pragma unroll
+        for (int T = 0; T < KTV; ++T) h1 = mfma_k16(h1, f.w1[T], B[T]);
+        f32x4* hb = sH1 + (g & 1) * 256;
+        hb[wave * 64 + lane] = relu4(h1);
+        lds_barrier();                                // (not __syncthreads: the next groups' weight loads stay in flight)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const f32x4 hv = hb[cc * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[i] = mfma_k16(acc2[i], f.w2[cc][i], hv);
+        }
+    };
+    const f32x4* l3 = a.blob + (size_t)32 * CHW;
+    f32x4 w3[NR][16], b3v[NR], b2v[4];
+    // layer 3 operands travel during the last group(s): b2 sits behind the first layer-3 chunk's 16 tiles and its b3 (packing.mlp_stream)
+    auto fetch3 = [&]() {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int o = wave + 4 * i < NO ? wave + 4 * i : NO - 1;
+#pragma unroll
+            for (int T = 0; T < 16; ++T) w3[i][T] = l3[(size_t)o * CHW + T * 64 + lane];
+            b3v[i] = ld4(reinterpret_cast<const float*>(l3 + (size_t)o * CHW + 16 * 64) + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b2v[i] = ld4(reinterpret_cast<const float*>(l3 + 16 * 64) + 16 + 16 * (4 * wave + i) + 4 * q);
+    };
+    if (DEEP) {
+        MlpLatFrag<KTV> f0, f1, f2;
+        fetch(f0, 0); fetch(f1, 1); STT_FENCE();
+        fetch(f2, 2); STT_FENCE(); group(f0, 0); STT_FENCE();
+        fetch(f0, 3); STT_FENCE(); group(f1, 1); STT_FENCE();
+        fetch(f1, 4); STT_FENCE(); group(f2, 2); STT_FENCE();
+        fetch(f2, 5); STT_FENCE(); group(f0, 3); STT_FENCE();
+        fetch(f0, 6); STT_FENCE(); group(f1, 4); STT_FENCE();
+        fetch(f1, 7); STT_FENCE(); group(f2, 5); STT_FENCE();
+        fetch3();     STT_FENCE(); group(f0, 6); STT_FENCE();
+        group(f1, 7);
+    } else {
+        MlpLatFrag<KTV> fa, fb;
+        fetch(fa, 0);
+#pragma unroll 1
+        for (int g = 0; g < 6; g += 2) {
+            fetch(fb, g + 1);
+            group(fa, g);
+            fetch(fa, g + 2);
+            group(fb, g + 1);
+        }
+        fetch(fb, 7);
+        group(fa, 6);
+        fetch3();
+        group(fb, 7);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sH2[(4 * wave + i) * 64 + lane] = relu4(acc2[i] + b2v[i]);
+    lds_barrier();                                   // the whole 256-wide layer-2 activation as B-operand fragments
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int o = wave + 4 * i;
+        if (o >= NO) continue;
+        f32x4 v = b3v[i];
+#pragma unroll
+        for (int T = 0; T < 16; ++T) v = mfma_k16(v, w3[i][T], sH2[T * 64 + lane]);
+        if (MODE == 0 && LDSIO) {                    // (columns past the end carry the last column's values: never stored anywhere)
+            const f32x4 dv = ld4(a.xpad + (size_t)agent * (16 * NO) + 16 * o + 4 * q) - v;
+            a.out_lds[o * 64 + lane] = dv;
+            if (a.out && col < a.ncols) st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, dv);   // the workspace copy (diagnostic views)
+            continue;
+        }
+        if (col >= a.ncols) continue;
+        if (MODE == 0) {
+            const f32x4 xt = ld4(a.xpad + (size_t)agent * (16 * NO) + 16 * o + 4 * q);
+            st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, xt - v);
+        } else if (MODE == 1) {
+            if (SC1) st4_sc1(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, v);
+            else st4(a.out + (size_t)col * (16 * NO) + 16 * o + 4 * q, v);
+        } else {
+            const int row0 = 16 * o + 4 * q;
+            if (row0 < a.Tf2) {
+                const float cx = a.cur[2 * agent], cy = a.cur[2 * agent + 1];
+                const float ox = a.orig[2 * agent], oy = a.orig[2 * agent + 1];
+                const f32x4 y0 = ld4(a.ybuf + (size_t)col * (16 * NO) + row0);
+                f32x4 r;
+                r[0] = ((y0[0] + v[0]) + cx) + ox;
+                r[1] = ((y0[1] + v[1]) + cy) + oy;
+                r[2] = ((y0[2] + v[2]) + cx) + ox;
+                r[3] = ((y0[3] + v[3]) + cy) + oy;
+                float* pp = a.out + (size_t)col * a.Tf2 + row0;
+                if (row0 + 3 < a.Tf2 && (a.Tf2 & 3) == 0) {
+                    st4(pp, r);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row0 + e < a.Tf2) pp[e] = r[e];
+                }
+            }
+        }
+    }
+}
+

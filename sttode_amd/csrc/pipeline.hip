@@ -34,6 +34,7 @@ struct SttodeModel {
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
     int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
     int role_lead;   // fused launch's grid order: groups of head start of a role over its first consumer, < 0 = all roles first (default)
+    int scene_launch; // largest number of 16-trajectory tiles a serial scene call runs as ONE launch (scene_lat.hip); 0: never
     int drop_tile;   // fault injection (tests): the role of this 16-agent tile does not publish its flag in fused launches (-1: none)
     int b3;          // exploratory: block-0 MLPs of the fused launch as a three-way bf16 split (sttode_set_mfma_mode)
     bool fe_in_role; // fused scene batches: the roles also run the scene front-end (STTODE_FE_IN_ROLE=1; default: a launch in front)
@@ -85,6 +86,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;
     m->drop_tile = -1;
+    m->scene_launch = 128;
+    if (const char* e = getenv("STTODE_SCENE_LAUNCH")) m->scene_launch = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
     // default off: measured neutral to -0.6 % pipelined and -1.5 % serial at 512 scenes (the two front-end launches cost less than the
     // ~10 us they add to every role), +1 % on the 256-scene SDD leg (profiles/r03/ab_lead_frontend_depth.txt)
@@ -188,7 +191,8 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_YBUF, mm * 16 * m->NOY);
     put(STT_B_STATE1, mm * 96);
     put(STT_B_QUEUE, 64);
-    put(STT_B_FLAGS, (size_t)(n + 15) / 16 + 4);   // one flag per 16-agent tile + the time-out word (fused launch), zeroed per call
+    // one flag per 16-agent tile + the time-out word (fused launches); three per agent tile + one per 16-trajectory tile (one-launch scene form); zeroed per call
+    put(STT_B_FLAGS, (size_t)3 * ((n + 15) / 16) + 4 + (mm + 15) / 16);
     put(STT_B_ODE, (size_t)6 * n * 64);   // multi-stage integrator with attention groups > 1 (always laid out: sttode_set_ode may come later)
     *total_floats = (long)o;
     return 0;
@@ -213,6 +217,13 @@ extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
 extern "C" int sttode_debug_drop_role_flag(SttodeModel* m, int tile) {
     STT_REQUIRE(m && tile >= -1, "sttode_debug_drop_role_flag: bad arguments");
     m->drop_tile = tile;
+    return 0;
+}
+
+extern "C" int sttode_set_scene_launch(SttodeModel* m, int max_tiles) {
+    STT_REQUIRE(m, "sttode_set_scene_launch: null model");
+    STT_REQUIRE(max_tiles >= -1, "sttode_set_scene_launch: max_tiles must be -1 (default), 0 (off) or a tile count");
+    m->scene_launch = max_tiles < 0 ? 128 : max_tiles;
     return 0;
 }
 
@@ -529,6 +540,14 @@ static bool use_fused(const SttodeModel* m, int n) {
     const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
     return m->fused_mode == 1 && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_chain_fused_covers(m->Tp);
 }
+// Serial scene calls below the chain threshold (the reference's one-scene-per-call evaluation loop, test.py:171-188): front-end, per-agent
+// stage and per-trajectory stage as roles of one launch.  Reference integrator only (the roles run one Euler step, like the fused launch).
+static bool use_scene_launch(const SttodeModel* m, int n, const int* scene_ptr) {
+    const long ncols_all = (long)n * m->K;
+    const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
+    return scene_ptr != nullptr && !chain && m->scene_launch > 0 && (ncols_all + 15) / 16 <= m->scene_launch && m->ode_method == 0 &&
+           m->ode_steps == 1 && m->col_parts <= 1 && stt_scene_lat_covers(m->Tp, m->TPX, m->NOY);
+}
 static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z, float* pred,
                        const float* past, const int* scene_ptr, int S, hipStream_t s) {
     const float* const* W = m->w;
@@ -560,6 +579,12 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    if (use_scene_launch(m, n, scene_ptr)) {   // a scene or a few: the whole call as ONE launch of cooperating workgroups (scene_lat.hip)
+        RUN(STT_STAGE_FUSED, s,
+            stt_scene_lat(m->w, ws, off, n, m->K, m->Tp, m->Tf, m->TPX, m->NOY, m->n_chunks0, m->n_chunks1, z, pred, 12.0f, past, scene_ptr, S,
+                          m->drop_tile, s));
+        return 0;
+    }
     // scene batches on the fused launch: the roles run the front-end of their own tiles (the call is ONE launch); otherwise it is a launch
     const bool fe_in_role = use_fused(m, n) && scene_ptr != nullptr && m->fe_in_role;
     if (!fe_in_role)

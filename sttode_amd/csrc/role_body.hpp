@@ -1,0 +1,135 @@
+// The per-agent ROLE shared by the fused launches (chain32.hip: roles + trajectory groups; scene_lat.hip: roles + 16-column tiles of a
+// single scene) and the tile-flag hand-off between workgroups of ONE launch.
+#pragma once
+#include "latency_bodies.hpp"
+#include "frontend_body.hpp"
+
+#ifndef C32_TRACE_PHASE
+#define C32_TRACE_PHASE(i) do { } while (0)
+#endif
+
+// Per-agent ROLE of the fused launch (round 3): the first `ntiles` workgroups of the grid run, for one 16-agent tile each, the whole
+// per-agent stage -- encoder (embed_lat_body -> post_attn_body), block-0 conv + GRU (gru_lat4_body) and the three layer-1 pre-activation
+// tables (preact_rows) -- and publish ONE flag per tile; the trajectory groups behind them in the grid wait for the flags of the tiles
+// their agents live in.  Why: as separate launches on their own stream these kernels were starved by the running chain (its queue keeps
+// every freed workgroup slot until its grid is fully dispatched: 1.85 ms for a 0.1 ms stage, profiles/r03/timeline_default.txt), which
+// forced ONE chain workgroup per CU in the pipelined path; inside the launch nothing needs a chain-free CU.
+struct RoleArgs {
+    EmbedW ew; PostW pw;
+    const float* enc_in; const int* last; float* g; float* qkv; float* pf;
+    const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias; float* state0;
+    const f32x4* WAx; const float* b1x; const f32x4* WAy; const float* b1y; const f32x4* WA1; const float* b11;
+    float* A0x; float* A0y; float* A1y;
+    // scene front-end inside the role (scene batches; nullptr: the front-end ran as a launch before): set_data's normalisation for the
+    // tile's 16 agents -- scene origin (mean of the scene's last observed positions, summed in agent order like scene_orig_kernel),
+    // normalised track, velocities, flags -- written to the workspace rows the other phases and the trajectory groups read
+    const float* past; const int* scene_ptr; int S; float* scene_orig; int* agent_scene;
+    float* enc_in_w; float* xpad_w; float* cur_w; float* orig_w; int* last_w;
+    const float* attn; int ld_attn;   // attention output of an EARLIER launch (attention groups > 1, the NBA branch): the role then starts
+                                      // at the post-attention layer; nullptr: attention length 1, the role runs the embedding too
+    unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
+    int ntiles; float ode_time;
+    int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
+    int drop_tile;       // fault injection (tests): the role of this tile never publishes its flag (-1: none) -- exercises the give-up path
+};
+
+#ifndef ROLE_PRIO
+#define ROLE_PRIO 3
+#endif
+
+// STTODENet.set_data for ONE 16-agent tile (model/STTODE.py:397-461), one lane per agent: scene origin (mean of the scene's last observed
+// positions, summed in agent order like scene_orig_kernel: identical bits), then the agent's inputs.  enc: the encoder's inputs (enc_in,
+// last flag, scene_orig, agent_scene); traj: the decoder's (xpad, cur, orig).  The caller's barrier publishes them to the workgroup.
+__device__ __forceinline__ void role_frontend(const RoleArgs& R, int nag, int Tp, int ldx, int tile, bool enc, bool traj) {
+    if (threadIdx.x < 16) {
+        const int a = tile * 16 + (int)threadIdx.x;
+        if (a < nag) {
+            int lo = 0, hi = R.S - 1;                 // the agent's scene: largest s with scene_ptr[s] <= a
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (R.scene_ptr[mid] <= a) lo = mid; else hi = mid - 1;
+            }
+            const int a0 = R.scene_ptr[lo], a1 = R.scene_ptr[lo + 1];
+            float sx = 0.f, sy = 0.f;
+            for (int aa = a0; aa < a1; ++aa) {       // agent order, as scene_orig_kernel sums
+                sx += R.past[((size_t)aa * Tp + (Tp - 1)) * 2 + 0];
+                sy += R.past[((size_t)aa * Tp + (Tp - 1)) * 2 + 1];
+            }
+            const float inv = (float)(a1 - a0);
+            const float ox = sx / inv, oy = sy / inv;
+            if (enc) {
+                if (a == a0) { R.scene_orig[2 * lo] = ox; R.scene_orig[2 * lo + 1] = oy; }
+                R.agent_scene[a] = lo;
+            }
+            agent_inputs_core<true, 16>(a, R.past, Tp, ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, traj ? R.xpad_w : nullptr, enc ? R.enc_in_w : nullptr,
+                                    traj ? R.cur_w : nullptr, traj ? R.orig_w : nullptr, enc ? R.last_w : nullptr);
+        }
+    }
+}
+
+// The per-agent stage of ONE 16-agent tile on a chain workgroup's resources (4 waves, <= 256 VGPRs, the chain's dynamic LDS).  The
+// bodies are the stand-alone kernels' code (latency_bodies.hpp), so g / qkv / pf / state0 / A0x / A0y / A1y carry the bits the separate
+// launches produce.  LDS: [0, 40 KiB) embed, then [0, 16 KiB) post-attention exchange, then [0, 12 KiB) h tiles + [12, 60 KiB) GRU image + [60, 68 KiB) gate hand-off.
+// nag: agents; Tp: observed frames; ldx: row stride of xpad (16 or 32)
+__device__ __forceinline__ void agent_role(const RoleArgs& R, int nag, int Tp, int ldx, const float* __restrict__ xpad, int tile, char* smem) {
+    // The role is a short chain of DEPENDENT steps (barriers, L2 round trips, 32-cycle MFMAs) sharing each SIMD with a chain wave that has
+    // a 64-cycle MFMA ready every cycle it is asked: at equal priority the older chain wave wins every arbitration and the role ran 2x
+    // slower than alone (283 vs 150 us, profiles/r03/trace_*), holding a workgroup slot all the while.  Raised priority lets its few
+    // instructions issue first; the chain wave loses the same handful of pipe cycles either way.
+    __builtin_amdgcn_s_setprio(ROLE_PRIO);
+    if (R.past) {   // (uniform) STTODENet.set_data for this tile
+        role_frontend(R, nag, Tp, ldx, tile, true, true);
+        __syncthreads();                                  // enc_in / last / xpad of this tile are visible to the workgroup
+    }
+    if (R.attn == nullptr) {                      // (uniform) attention length 1: softmax over one key == 1, the attention output is v
+        embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, Tp, tile, reinterpret_cast<f32x4*>(smem));
+        __syncthreads();                          // g / qkv of this tile are visible to the workgroup; the LDS region changes hands
+    }
+    C32_TRACE_PHASE(0);
+    post_attn_body<false>(R.pw, R.g, R.attn ? R.attn : R.qkv + 128, R.attn ? R.ld_attn : 192, R.pf, nag, R.ode_time, 0, 1, nullptr, nullptr, tile,
+                          reinterpret_cast<f32x4(*)[4][64]>(smem));
+    __syncthreads();                              // pf of this tile is visible to the workgroup; LDS changes hands again
+    C32_TRACE_PHASE(1);
+    f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
+    f32x4* sW45 = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
+    const int cur = ldx == 16 ? gru_lat4_body<1>(xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, Tp, tile, sH, sW45)
+                                : gru_lat4_body<2>(xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, Tp, tile, sH, sW45);
+    C32_TRACE_PHASE(2);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = tile * 16 + c;
+    const int colc = col < nag ? col : nag - 1;
+    f32x4 B[14];                                  // [pf | state0] of this lane's agent as B-operand fragments
+#pragma unroll
+    for (int T = 0; T < 8; ++T) B[T] = ld4(R.pf + (size_t)colc * 128 + 16 * T + 4 * q);
+#pragma unroll
+    for (int T = 0; T < 6; ++T) B[8 + T] = sH[cur][T][lane];
+    preact_rows<14, true>(R.WAx, R.b1x, R.A0x, B, col, col < nag, lane, q, wv);
+    preact_rows<14, true>(R.WAy, R.b1y, R.A0y, B, col, col < nag, lane, q, wv);
+    preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < nag, lane, q, wv);
+    // publish (guide §6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && tile != R.drop_tile) __hip_atomic_store(R.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer side: wave 0 polls the flags of tiles [t_lo, t_hi] (relaxed agent-scope loads, one lane per tile, s_sleep between polls), then
+// ONE agent-scope acquire drops this CU's stale L1 lines; the caller's barrier releases the other waves.  The spin is bounded (~1 s): a
+// producer that never arrives -- it cannot, in-order dispatch puts every producer in front of its consumers -- would poison this group's
+// predictions with NaN and set the time-out word instead of hanging the device.
+__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane) {
+    bool ok = true;
+    for (int t = t_lo + lane; t <= t_hi; t += 64) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 20)) { ok = false; break; }
+        }
+    }
+    ok = __all(ok);
+    if (!ok && lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return ok;
+}
+

@@ -203,6 +203,17 @@ class STTODENet(nn.Module):
     def past_feature(self, value):
         self._pf, self._pf_thunk = value, None
 
+    # per-call state (tensors of the current batch, views of the workspace): plain attributes.  nn.Module.__setattr__ walks its
+    # Parameter / Module / buffer checks on every assignment (~1.5 us each, ~17 per one-scene call of the evaluation loop)
+    _PLAIN = frozenset(('_past', '_future', '_scene_ptr', '_mode', 'batch_size', 'agent_num', '_S', '_N', 'pre_motion_mask', 'fut_motion_mask',
+                        'scene_orig', '_pf', '_pf_thunk', '_ws', '_dbg', 'diverse_pred', '_plist'))
+
+    def __setattr__(self, name, value):
+        if name in STTODENet._PLAIN:
+            self.__dict__[name] = value
+        else:
+            super().__setattr__(name, value)
+
     def set_device(self, device):
         self.device = torch.device(device)
         self.to(self.device)
@@ -330,7 +341,7 @@ class STTODENet(nn.Module):
         if N == 0:
             raise ValueError('empty scene')
         ptr = self._ptr_cache.get(N)                             # device-resident [0, N] CSR, built once per scene size
-        if ptr is None or ptr.device != torch.device(dev):
+        if ptr is None or not _on(ptr, dev):
             ptr = self._ptr_cache[N] = torch.tensor([0, N], dtype=torch.int32).to(dev)
         self.set_scene_batch(past, fut, ptr)
         self.batch_size = 1
@@ -338,26 +349,17 @@ class STTODENet(nn.Module):
 
     def _stage_scene(self, pre, fut):
         """Host tensors of one scene (loader layout [N,2,T]) -> device [N,T,2] tensors through ONE asynchronous H2D copy: both tracks
-        are transposed into a pinned staging buffer (a ring of four, each guarded by an event) and travel together.  ``.to(device)`` of
+        are transposed into a pinned staging buffer (a ring of four, each guarded by an event; native) and travel together.  ``.to(device)`` of
         a pageable tensor is a synchronous copy that also waits for the stream's earlier kernels -- two of them per scene were a third
         of the per-scene loop of test.py:171-188."""
         N, Tp = pre.shape[0], pre.shape[2]
         Tf = fut.shape[2] if fut is not None else 0
+        if N == 0:
+            raise ValueError('empty scene')
         need = N * (Tp + Tf) * 2
-        ring = self.__dict__.setdefault('_stage_ring', {'bufs': [None] * 4, 'events': [None] * 4, 'k': 0})
-        k = ring['k'] = (ring['k'] + 1) % 4
-        if ring['bufs'][k] is None or ring['bufs'][k].numel() < need:
-            ring['bufs'][k] = torch.empty(max(need, 4096), dtype=torch.float32).pin_memory()
-            ring['events'][k] = torch.cuda.Event()
-        else:
-            ring['events'][k].synchronize()                      # the copy that last read this buffer has completed (long ago, normally)
-        host = ring['bufs'][k][:need]
-        host[:N * Tp * 2].view(N, Tp, 2).copy_(pre.permute(0, 2, 1))
-        if fut is not None:
-            host[N * Tp * 2:].view(N, Tf, 2).copy_(fut.permute(0, 2, 1))
         dev = torch.empty(need, dtype=torch.float32, device=self.device)
-        dev.copy_(host, non_blocking=True)
-        ring['events'][k].record()
+        # transposes into a pinned ring slot + ONE asynchronous H2D copy, natively (csrc/frontend.hip: sttode_stage_scene)
+        capi.call('sttode_stage_scene', pre.contiguous(), fut.contiguous() if fut is not None else None, N, Tp, Tf, dev, capi.stream_ptr())
         return dev[:N * Tp * 2].view(N, Tp, 2), (dev[N * Tp * 2:].view(N, Tf, 2) if fut is not None else None)
 
     def set_scene_batch(self, past, future, scene_ptr):

@@ -750,6 +750,115 @@ def test_random_latents_follow_torch_generator():
     assert tuple(a.shape) == (20, 5, 12, 2) and bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize('case', ['one_agent', 'two_agents', 'eth_scene', 'tile_edge_16', 'tile_edge_17', 'three_scenes', 'sdd_like_40', 'k_7',
+                                  'long_16_24', 'short_4_6'])
+def test_one_launch_scene_form_is_bitwise_the_six_launch_form(case):
+    """A serial scene call below the chain threshold -- the reference's evaluation loop hands over ONE scene per call (test.py:171-188) --
+    runs as ONE launch whose workgroups take the roles front-end + per-agent stage / block-0 decoder_y / block-0 decoder_x -> block-1 GRU
+    -> block-1 decoder_y (csrc/scene_lat.hip).  Its bodies are the six launches' code and sum every element in the same order, so the
+    predictions must be the SAME BITS as the six-launch form (which the golden-vector and oracle tests pin), not merely close; and the
+    oracle comparison of the result itself at 1e-4."""
+    from sttode_amd import scenes
+    Tp, Tf, K = 8, 12, 20
+    if case == 'one_agent':
+        ids = None
+    elif case == 'two_agents':
+        ids = [s for s in range(6000, 6400) if scenes.eth_scene(s)[0].shape[0] == 2][:1] or [6001]
+    elif case == 'eth_scene':
+        ids = [6002]
+    elif case in ('tile_edge_16', 'tile_edge_17', 'sdd_like_40'):
+        ids = None
+    elif case == 'three_scenes':
+        ids = [6003, 6004, 6005]
+    else:
+        ids = [6006, 6007]
+    if case == 'k_7':
+        K = 7
+    if case == 'long_16_24':
+        Tp, Tf = 16, 24
+    if case == 'short_4_6':
+        Tp, Tf = 4, 6
+    m = hip_model('eth', Tp, Tf)
+    if K != 20:
+        from sttode_amd import STTODENet
+        a7 = make_args('eth', Tp, Tf)
+        a7.sample_k = K
+        m7 = STTODENet(a7, _gpu()).eval()
+        m7.load_state_dict(m.state_dict(), strict=True)
+        m = m7
+    if ids is None:     # scenes accumulated until the agent count is exactly the wanted one (the last scene is cut): tile edges
+        want = {'one_agent': 1, 'tile_edge_16': 16, 'tile_edge_17': 17, 'sdd_like_40': 40}[case]
+        sb = scenes.make_scene_batch(range(6100, 6140), 'eth', Tp, Tf)
+        ptr = [int(p) for p in sb.scene_ptr if int(p) < want] + [want]
+        past, fut, ptr = sb.past[:want], sb.future[:want], np.asarray(ptr, dtype=np.int32)
+    else:
+        sb = scenes.make_scene_batch(ids, 'eth', Tp, Tf)
+        past, fut, ptr = sb.past, sb.future, sb.scene_ptr
+    n = past.shape[0]
+    z = torch.from_numpy(scenes.latents(31, n, K=K)).to(m.device) if K != 20 else torch.from_numpy(scenes.latents(31, n)).to(m.device)
+    nat = m.native()
+    outs = {}
+    try:
+        for mode in (0, -1, 0, -1):
+            nat.set_scene_launch(mode)
+            m.set_scene_batch(past, fut, ptr)
+            outs.setdefault(mode, []).append(m.inference(None, z=z).clone())
+    finally:
+        nat.set_scene_launch(-1)
+    assert torch.equal(outs[-1][0], outs[-1][1]), 'one-launch form is not reproducible run to run'
+    assert torch.equal(outs[0][0], outs[0][1])
+    assert bool(torch.isfinite(outs[-1][0]).all())
+    if Tp <= 8:
+        assert torch.equal(outs[-1][0], outs[0][0]), f'one-launch form differs from the six launches: max |d| = {(outs[-1][0] - outs[0][0]).abs().max().item():.3e}'
+    else:   # Tp > 8: the six-launch form takes the STREAMING conv + GRU (gru32, another summation order); the one-launch form the 16-column one
+        assert_close(outs[-1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'{case}: one-launch vs six-launch form')
+    buf, off = m._workspace(n, len(ptr) - 1)
+    A = (n + 15) // 16
+    C = (n * K + 15) // 16
+    flags = m._view(buf, off, 'flags', 3 * A + 1 + C, dtype=torch.int32).cpu().numpy()
+    assert flags[A] == 0 and (np.delete(flags, A) == 1).all(), 'every producer published (E, G, E2 per agent tile, Y per trajectory tile), nobody timed out'
+    if case in ('eth_scene', 'three_scenes'):      # and against the CPU oracle, scene by scene (reference call pattern)
+        ora = oracle_model('eth', 8, 12)
+        out = outs[-1][0].cpu().numpy()
+        zz = z.cpu().numpy()
+        for si in range(sb.n_scenes):
+            a, b = int(sb.scene_ptr[si]), int(sb.scene_ptr[si + 1])
+            obs, pred = sb.scene(si)
+            assert_close(out[:, a:b], oracle_scene_inference(ora, obs, pred, zz[a * 20:b * 20]), what=f'{case} scene {si}: one-launch form vs oracle')
+
+
+def test_one_launch_scene_form_gives_up_instead_of_hanging():
+    """Fault injection on the one-launch scene form: the per-agent role of tile 1 never publishes; the trajectory tiles that read agents
+    16.. poison their predictions with NaN and set the time-out word, the others carry the bits of a healthy run, the launch ends."""
+    import time
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(6200, 6204), 'eth')
+    n, K = sb.n_agents, 20
+    assert 20 < n <= 100, n                                   # two or more agent tiles, and few enough trajectory tiles for the one-launch form
+    z = torch.from_numpy(scenes.latents(5, n)).to(m.device)
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    good = m.inference(None, z=z).clone()
+    try:
+        capi.call('sttode_debug_drop_role_flag', m.native().h, 1)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        t0 = time.perf_counter()
+        bad = m.inference(None, z=z).clone()
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 30.0
+    finally:
+        capi.call('sttode_debug_drop_role_flag', m.native().h, -1)
+    flat_bad, flat_good = bad.permute(1, 0, 2, 3).reshape(n * K, -1), good.permute(1, 0, 2, 3).reshape(n * K, -1)
+    rows = torch.arange(n * K, device=m.device)
+    t_lo, t_hi = rows // 16 * 16, torch.clamp(rows // 16 * 16 + 15, max=n * K - 1)
+    hit = ((t_hi // K) // 16 >= 1) & ((t_lo // K) // 16 <= 1)       # the tile's agent range touches agent tile 1
+    assert bool(hit.any()) and bool((~hit).any())
+    assert torch.isnan(flat_bad[hit]).all()
+    assert torch.equal(flat_bad[~hit], flat_good[~hit])
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    assert torch.equal(m.inference(None, z=z), good)
+
+
 def test_async_latents_follow_the_same_generator_sequence_as_serial_calls():
     """inference_async(z=None) draws its latents from torch's generator at call time, like inference(None): the same seed gives the same
     predictions call by call, whether the calls are pipelined or serial."""
