@@ -168,6 +168,17 @@ __global__ __launch_bounds__(384) void gru_cols_lat_kernel(const float* __restri
     gru_lat_body<TPX>(xin, convP, convB, wihP, whhP, gbias, state, ncols, Tp, blockIdx.x, sH);
 }
 
+// Balanced latency form (round 3): four waves, every wave 144 of a step's 576 gate-sum MFMAs and a quarter of the gate functions
+// (latency_bodies.hpp: gru_bal_body): 22 instead of 29 us for 8 steps.
+template <int TPX>
+__global__ __launch_bounds__(256) void gru_cols_bal_kernel(const float* __restrict__ xin, const f32x4* __restrict__ convP,
+                                                           const float* __restrict__ convB, const f32x4* __restrict__ wihP,
+                                                           const f32x4* __restrict__ whhP, const float* __restrict__ gbias,
+                                                           float* __restrict__ state, int ncols, int Tp) {
+    __shared__ f32x4 sH[2][6][64], sX[2 * 5 * 64];
+    gru_bal_body<TPX>(xin, convP, convB, wihP, whhP, gbias, state, ncols, Tp, blockIdx.x, sH, sX);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // generic per-column linear:  out[col][0:N] = act( W * [X1 | X2] + b ), up to 3 independent jobs per launch
 // (blockIdx.z).  Each wave: 16 columns x RT row tiles; all B tiles are loaded up front and the A fragments of
@@ -626,12 +637,19 @@ int stt_gru_cols_form(const float* xin, const float* convP, const float* convB, 
     STT_REQUIRE(ncols > 0 && Tp > 0 && (TPX == 1 || TPX == 2) && 2 * Tp <= 16 * TPX, "sttode_gru_cols: bad ncols/Tp/TPX");
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (ncols + 15) / 16;
-    if (ntiles <= (lat_max_tiles > 0 ? lat_max_tiles : gru_lat_tiles())) {   // few columns: one tile per workgroup, hidden units split over six waves (latency form)
-        if (TPX == 1)
-            hipLaunchKernelGGL(gru_cols_lat_kernel<1>, dim3(ntiles), dim3(384), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
+    if (ntiles <= (lat_max_tiles > 0 ? lat_max_tiles : gru_lat_tiles())) {   // few columns: one tile per workgroup, gate sums split evenly over four waves (latency form)
+        if (lat_max_tiles > 0) {   // beside a chain workgroup of another stream: the six-wave form (<= 128 VGPRs per wave); the balanced one needs 270-290
+            if (TPX == 1)
+                hipLaunchKernelGGL(gru_cols_lat_kernel<1>, dim3(ntiles), dim3(384), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
+                                   (const f32x4*)whhP, gbias, state, ncols, Tp);
+            else
+                hipLaunchKernelGGL(gru_cols_lat_kernel<2>, dim3(ntiles), dim3(384), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
+                                   (const f32x4*)whhP, gbias, state, ncols, Tp);
+        } else if (TPX == 1)
+            hipLaunchKernelGGL(gru_cols_bal_kernel<1>, dim3(ntiles), dim3(256), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
                                (const f32x4*)whhP, gbias, state, ncols, Tp);
         else
-            hipLaunchKernelGGL(gru_cols_lat_kernel<2>, dim3(ntiles), dim3(384), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
+            hipLaunchKernelGGL(gru_cols_bal_kernel<2>, dim3(ntiles), dim3(256), 0, s, xin, (const f32x4*)convP, convB, (const f32x4*)wihP,
                                (const f32x4*)whhP, gbias, state, ncols, Tp);
         STT_HIP(hipGetLastError());
         return 0;

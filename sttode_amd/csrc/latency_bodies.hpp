@@ -542,6 +542,168 @@ __device__ __forceinline__ int gru_lat4_body(const float* __restrict__ xin, cons
     return cur;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BALANCED four-wave form of the same conv + GRU, for a workgroup that has the CU to itself (one wave per SIMD, 512 VGPRs): the one-launch
+// scene form (scene_lat.hip), where two of these 8-step recurrences are more than half of a call's critical path.
+// A step is 576 fp32 16x16x4 MFMAs of gate sums + the gate functions.  Split by hidden tile (gru_lat4_body) two waves carry 200 MFMAs and
+// two carry 104; here the unit is a GATE SUM of one hidden tile -- r_j, z_j: 8 k-tiles (32 MFMAs) each; the candidate's two halves
+// ni_j = b + W_in e (2 k-tiles) and nh_j = b + W_hn h (6 k-tiles), which the GRU keeps apart anyway -- and every wave gets exactly 144:
+//     wave pair p = 0, 1 owns hidden tiles A = 2p, B = 2p + 1, C = 4 + p
+//     even wave:  r_A, z_A, r_C, nh_A, nh_C                      odd wave:  r_B, z_B, z_C, nh_B, ni_A, ni_B, ni_C
+// One LDS exchange per step hands the five sums a partner needs across (ni_A, z_C, ni_C one way; r_C, nh_C the other), then the gate
+// functions run balanced too: even wave tile A and registers 0, 1 of tile C, odd wave tile B and registers 2, 3 of tile C.  All 36
+// weight fragments of a wave stay in registers for all steps (no LDS image).  Every sum is bias, then W_i k-tiles, then W_h k-tiles in
+// order, every gate function the same expression: the bits of gru_cols_kernel / gru_lat_body / gru_lat4_body.
+// sH: [2][6][64] f32x4 (h as B-operand fragments), sX: [2 pairs][5][64] f32x4 exchange.  Returns the sH buffer holding the final state.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gru_gate(float ar, float az, float ai, float ah, float hp) {
+    const float rg = sigmoid_prescaled(ar);
+    const float zg = sigmoid_prescaled(az);
+    const float ng = tanh_prescaled(fmaf(rg, ah, ai));
+    return fmaf(zg, hp - ng, ng);  // (1-z) n + z h
+}
+template <int TPX, bool DLDS, bool ODD, class PRE>
+__device__ __forceinline__ int gru_bal_half(const float* __restrict__ xin, const f32x4* __restrict__ convP, const float* __restrict__ convB,
+                                            const f32x4* __restrict__ wihP, const f32x4* __restrict__ whhP, const float* __restrict__ gbias,
+                                            int ncols, int Tp, int tile, f32x4 (*sH)[6][64], f32x4* sX, const f32x4* d_lds, PRE& pre) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    const int col = tile * 16 + c;
+    const int colc = col < ncols ? col : ncols - 1;
+    const int tA = 2 * p, tB = 2 * p + 1, tC = 4 + p;
+    const int tO = ODD ? tB : tA;                          // the tile whose gate functions this wave runs in full
+    // full units (bias, 2 W_i k-tiles, 6 W_h k-tiles): even (r, A) (z, A) (r, C);  odd (r, B) (z, B) (z, C)
+    const int fg[3] = {0, 1, ODD ? 1 : 0};
+    const int fj[3] = {tO, tO, tC};
+    f32x4 fw[3][8], fb[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) fw[u][T] = wihP[((fg[u] * 6 + fj[u]) * 2 + T) * 64 + lane];
+#pragma unroll
+        for (int T = 0; T < 6; ++T) fw[u][2 + T] = whhP[((fg[u] * 6 + fj[u]) * 6 + T) * 64 + lane];
+        fb[u] = ld4(gbias + fg[u] * 96 + 16 * fj[u] + 4 * q);
+    }
+    // candidate halves: nh (6 W_h k-tiles): even A and C, odd B;  ni (2 W_i k-tiles): odd A, B, C
+    constexpr int NH = ODD ? 1 : 2, NI = ODD ? 3 : 1;
+    const int hj[2] = {tO, tC};
+    const int ij[3] = {tA, tB, tC};
+    f32x4 hw[NH][6], hbias[NH], iw[NI][2], ibias[NI];
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+#pragma unroll
+        for (int T = 0; T < 6; ++T) hw[u][T] = whhP[((2 * 6 + hj[u]) * 6 + T) * 64 + lane];
+        hbias[u] = ld4(gbias + 3 * 96 + 16 * hj[u] + 4 * q);
+    }
+    if (ODD) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T) iw[u][T] = wihP[((2 * 6 + ij[u]) * 2 + T) * 64 + lane];
+            ibias[u] = ld4(gbias + 2 * 96 + 16 * ij[u] + 4 * q);
+        }
+    }
+    const f32x4 cb0 = ld4(convB + 4 * q), cb1 = ld4(convB + 16 + 4 * q);
+    f32x4 cw[2][TPX];
+#pragma unroll
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int T = 0; T < TPX; ++T) cw[io][T] = convP[(io * TPX + T) * 64 + lane];
+    pre();
+    f32x4 d[TPX];
+#pragma unroll
+    for (int T = 0; T < TPX; ++T) d[T] = DLDS ? d_lds[T * 64 + lane] : ld4(xin + (size_t)colc * (16 * TPX) + 16 * T + 4 * q);
+    sH[0][tO][lane] = splat4(0.f);
+    if (!ODD) sH[0][tC][lane] = splat4(0.f);
+    lds_barrier();
+    f32x4* X = sX + (size_t)p * 5 * 64 + lane;            // [0] r_C  [1] nh_C  (from even)   [2] ni_A  [3] z_C  [4] ni_C  (from odd)
+    int cur = 0;
+#pragma unroll 1
+    for (int t = 0; t < Tp; ++t) {
+        f32x4 e[2] = {cb0, cb1};
+#pragma unroll
+        for (int io = 0; io < 2; ++io) {
+#pragma unroll
+            for (int T = 0; T < TPX; ++T) e[io] = mfma_k16(e[io], cw[io][T], d[T]);
+            e[io] = relu4(e[io]);
+        }
+        {
+            const int tn = (t + 1 < Tp) ? t + 1 : 0;
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int T = 0; T < TPX; ++T) cw[io][T] = convP[((2 * tn + io) * TPX + T) * 64 + lane];
+        }
+        f32x4 a[3] = {fb[0], fb[1], fb[2]}, nh[NH], ni[NI];
+#pragma unroll
+        for (int u = 0; u < NH; ++u) nh[u] = hbias[u];
+        if (ODD) {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) ni[u] = ibias[u];
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) a[u] = mfma_k16(a[u], fw[u][T], e[T]);
+            if (ODD) {
+#pragma unroll
+                for (int u = 0; u < NI; ++u) ni[u] = mfma_k16(ni[u], iw[u][T], e[T]);
+            }
+        }
+#pragma unroll
+        for (int T = 0; T < 6; ++T) {
+            const f32x4 hb = sH[cur][T][lane];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) a[u] = mfma_k16(a[u], fw[u][2 + T], hb);
+#pragma unroll
+            for (int u = 0; u < NH; ++u) nh[u] = mfma_k16(nh[u], hw[u][T], hb);
+        }
+        if (ODD) { X[2 * 64] = ni[0]; X[3 * 64] = a[2]; X[4 * 64] = ni[2]; }
+        else { X[0 * 64] = a[2]; X[1 * 64] = nh[1]; }
+        lds_barrier();
+        const f32x4 hpO = sH[cur][tO][lane], hpC = sH[cur][tC][lane];
+        f32x4 hn;
+        float* hc = reinterpret_cast<float*>(&sH[cur ^ 1][tC][lane]);
+        if (ODD) {   // tile B in full (all four sums are this wave's); registers 2, 3 of tile C
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[r] = gru_gate(a[0][r], a[1][r], ni[1][r], nh[0][r], hpO[r]);
+            const f32x4 rC = X[0 * 64], nhC = X[1 * 64];
+            hc[2] = gru_gate(rC[2], a[2][2], ni[2][2], nhC[2], hpC[2]);
+            hc[3] = gru_gate(rC[3], a[2][3], ni[2][3], nhC[3], hpC[3]);
+        } else {     // tile A in full (ni_A from the partner); registers 0, 1 of tile C
+            const f32x4 niA = X[2 * 64], zC = X[3 * 64], niC = X[4 * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[r] = gru_gate(a[0][r], a[1][r], niA[r], nh[0][r], hpO[r]);
+            hc[0] = gru_gate(a[2][0], zC[0], niC[0], nh[1][0], hpC[0]);
+            hc[1] = gru_gate(a[2][1], zC[1], niC[1], nh[1][1], hpC[1]);
+        }
+        sH[cur ^ 1][tO][lane] = hn;
+        lds_barrier();
+        cur ^= 1;
+    }
+    return cur;
+}
+template <int TPX, bool DLDS = false, bool SC1 = false, class PRE = GruNoPre>
+__device__ __forceinline__ int gru_bal_body(const float* __restrict__ xin, const f32x4* __restrict__ convP, const float* __restrict__ convB,
+                                            const f32x4* __restrict__ wihP, const f32x4* __restrict__ whhP, const float* __restrict__ gbias,
+                                            float* __restrict__ state, int ncols, int Tp, int tile, f32x4 (*sH)[6][64], f32x4* sX,
+                                            const f32x4* d_lds = nullptr, PRE pre = PRE()) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cur = (w & 1) ? gru_bal_half<TPX, DLDS, true, PRE>(xin, convP, convB, wihP, whhP, gbias, ncols, Tp, tile, sH, sX, d_lds, pre)
+                            : gru_bal_half<TPX, DLDS, false, PRE>(xin, convP, convB, wihP, whhP, gbias, ncols, Tp, tile, sH, sX, d_lds, pre);
+    if (!DLDS) {   // final state to memory: wave w stores hidden tile w, waves 0 and 1 also tiles 4 and 5 (the last barrier published them)
+        const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+        const int col = tile * 16 + c;
+        if (col < ncols) {
+            float* p0 = state + (size_t)col * 96 + 16 * w + 4 * q;
+            float* p1 = state + (size_t)col * 96 + 16 * (4 + (w & 1)) + 4 * q;
+            if (SC1) { st4_sc1(p0, sH[cur][w][lane]); if (w < 2) st4_sc1(p1, sH[cur][4 + (w & 1)][lane]); }
+            else { st4(p0, sH[cur][w][lane]); if (w < 2) st4(p1, sH[cur][4 + (w & 1)][lane]); }
+        }
+    }
+    return cur;
+}
+
 // Per-agent layer-1 pre-activations of the decoder for ONE 16-agent tile -- the rows sttode_agent_preact computes with linear_cols_kernel
 // (Decoder.forward's cat(past_feature, z) / DecomposeBlock's cat(hidden, state) hoisted to per-agent work: model/STTODE.py:323-328,71-75):
 //     out[col][0:512] = W [B_0 .. B_{KT-1}] + b        KT = 14: [pf | state0] (A0x, A0y);  KT = 8: pf only (A1y)
@@ -592,11 +754,11 @@ __device__ __forceinline__ void preact_rows(const f32x4* __restrict__ WP, const 
     }
 }
 
-// The same rows for a TRAJECTORY tile's own columns, in two passes (the one-launch scene form: pf arrives ~8 us before state0): k-tiles
-// [T0, T1) of all 32 row tiles (wave w: row tiles w, w+4, ..; acc[8] carries them across the passes, initialised with the bias by the
-// caller) as ONE pipeline of 2 (T1 - T0) steps -- step s = (row-tile quad s / N, k-tile T0 + s % N) -- with D steps of weight fragments
-// in flight; preact_prime issues the first D steps (weights only: callable BEFORE the data the pass multiplies has arrived).  Each
-// element is still bias, then k-tiles 0..13 in order: preact_rows' bits.
+// The same rows for a TRAJECTORY tile's own columns (the one-launch scene form; two passes there: pf arrives before state0): k-tiles
+// [T0, T1) of all 32 row tiles (wave w: row tiles
+// w, w+4, ..; acc[8], initialised with the bias by the caller) as ONE pipeline of 2 (T1 - T0) steps -- step s = (row-tile quad s / N,
+// k-tile T0 + s % N) -- with D steps of weight fragments in flight; preact_prime issues the first D steps (weights only: callable BEFORE
+// the data the pass multiplies has arrived).  Each element is still bias, then k-tiles in order: preact_rows' bits.
 template <int KT, int T0, int T1, int D>
 __device__ __forceinline__ void preact_load(const f32x4* __restrict__ WP, f32x4 (&w)[4], int s, int lane, int wv) {
     constexpr int N = T1 - T0;

@@ -38,17 +38,17 @@ struct SceneLatArgs {
     long long* dbg;             // diagnostic build only (SL_DIAG_TRACE): [block][8] phase stamps (100 MHz)
 };
 
-// LDS of a workgroup (bytes).  X role: layer-1 pre-activation fragments 32 KiB | MLP exchange 24 KiB | GRU h tiles 12 KiB | GRU image of
-// hidden tiles 4, 5 + gate hand-off: 56 KiB | d tiles 2 KiB;  E role: embedding (Tp*256 + 512) * 16 B, then 16 KiB;  G role: h tiles + image from 0.
+// LDS of a workgroup (bytes).  X role: layer-1 pre-activation fragments 32 KiB | MLP exchange 24 KiB | GRU h tiles 12 KiB | GRU gate-sum
+// exchange 10 KiB | d tiles 2 KiB;  E role: embedding (Tp*256 + 512) * 16 B, then 16 KiB;  G role: h tiles + exchange from 0.
 #define SL_A0 0
 #define SL_MLP (32 * 1024)
 #define SL_SH (56 * 1024)
-#define SL_W45 (68 * 1024)
-#define SL_D (124 * 1024)
-#define SL_TOTAL (126 * 1024)          // + 16 B: the workgroup's go / time-out word
+#define SL_GX (68 * 1024)
+#define SL_D (78 * 1024)
+#define SL_TOTAL (80 * 1024)          // + 16 B: the workgroup's go / time-out word
 
 #ifdef SL_DIAG_TRACE
-#define SL_STAMP(k) do { if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SL_STAMP(k) do { if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SL_STAMP(k) do { } while (0)
 #endif
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SL_STAMP(0);
 #ifdef SL_DIAG_TRACE
-    if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();   // core-clock counter at the start
+    if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + 7] = __builtin_amdgcn_s_memtime();   // core-clock counter at the start
 #endif
     if (b < 2 * A_tiles) {   // (uniform) per-agent roles
         const int tile = b >> 1;
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             SL_STAMP(3);
         } else {             // G: block-0 conv + GRU
             f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
-            f32x4* sW45 = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
+            f32x4* sX = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
             auto fe = [&]() {                         // the front-end runs under the latency of the GRU's weight loads
                 role_frontend(R, A.n, A.Tp, A.ldx, tile, false, true);
                 __syncthreads();                      // xpad of this tile is visible to the workgroup
                 SL_STAMP(1);
             };
-            gru_lat4_body<TPX, false, true, decltype(fe)>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, A.n, A.Tp, tile, sH, sW45,
-                                                          nullptr, fe);
+            gru_bal_body<TPX, false, true, decltype(fe)>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, A.n, A.Tp, tile, sH, sX,
+                                                         nullptr, fe);
             sl_publish(A.gflags + tile, true);
             SL_STAMP(2);
         }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     }
     if (s_ok) {
         f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem + SL_SH);
-        f32x4* sW45 = reinterpret_cast<f32x4*>(smem + SL_W45);
+        f32x4* sX = reinterpret_cast<f32x4*>(smem + SL_GX);
         f32x4* sD = reinterpret_cast<f32x4*>(smem + SL_D);
         MlpLatArgs x0 = A.x0;
         x0.out_lds = sD;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
         mlp_lat_run<2, TPX, 0, false, true, true>(x0, sH1, sH2, tile);
         __syncthreads();                               // d tiles are visible to the workgroup
         SL_STAMP(3);
-        const int cur = gru_lat4_body<TPX, true>(nullptr, A.convP, A.convB, A.wihP, A.whhP, A.gbias, nullptr, ncols, A.Tp, tile, sH, sW45, sD);
+        const int cur = gru_bal_body<TPX, true>(nullptr, A.convP, A.convB, A.wihP, A.whhP, A.gbias, nullptr, ncols, A.Tp, tile, sH, sX, sD);
         SL_STAMP(4);
         if (wave == 0) {   // A1y rows of this tile's agents and y_hat0 of this tile (both producers started long ago)
             const bool ok = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane) & wait_tiles(A.yflags, tile, tile, A.tmo, lane);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             mlp_lat_run<8, NOY, 2, false, true, true>(y1, sH1, sH2, tile);
             SL_STAMP(6);
 #ifdef SL_DIAG_TRACE
-            if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - A.dbg[(size_t)blockIdx.x * 8 + 7];   // core clocks of this workgroup
+            if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + 7] = __builtin_amdgcn_s_memtime() - A.dbg[(size_t)b * 8 + 7];   // core clocks of this workgroup
 #endif
             return;
         }

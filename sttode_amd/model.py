@@ -13,6 +13,7 @@ All compute runs in hand-written HIP kernels (sttode_amd/csrc); PyTorch only own
 stream.  There is no eager / CPU fallback: a missing library or a CPU tensor raises.
 """
 import os
+import operator
 
 import numpy as np
 import torch
@@ -120,6 +121,10 @@ class _Decoder(nn.Module):  # model/STTODE.py:303-318
                                        for _ in range(args.num_decompose))
 
 
+_DATA_PTR = torch.Tensor.data_ptr
+_VERSION = operator.attrgetter('_version')
+
+
 def _on(t, device):
     device = torch.device(device)
     return t.device.type == device.type and (device.index is None or t.device.index == device.index)
@@ -225,7 +230,8 @@ class STTODENet(nn.Module):
     def _weights_key(self):
         if getattr(self, '_plist', None) is None:
             self._plist = list(self.parameters()) + list(self.buffers())
-        return (self.device.index,) + tuple([(p.data_ptr(), p._version) for p in self._plist])
+        # (C-level maps: this runs on every call of the one-scene evaluation loop)
+        return (self.device.index, tuple(map(_DATA_PTR, self._plist)), tuple(map(_VERSION, self._plist)))
 
     def _apply(self, fn, *a, **k):
         self._plist = None  # .to()/.cuda() may replace parameter storage
