@@ -572,6 +572,38 @@ def train_cpu_baseline(args, out):
     out['speedup_vs_cpu_baseline'] = out['steps_per_s'] / out['cpu_baseline']['value']
 
 
+def per_scene_leg(dev, n_scenes=256):
+    """The reference's evaluation call pattern (test.py:171-188): ONE scene per call -- set_data (host tensors in, the loader's layout),
+    inference (latents drawn on device), .cpu() of the futures -- in a plain loop.  Milliseconds per scene, synchronised by the D2H of every
+    call; a latency figure beside the throughput headline."""
+    import time
+    import torch
+    from helpers import make_args
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    m = STTODENet(make_args('eth', 8, 12), dev).eval()
+    m.load_state_dict(to_torch_state_dict(make_weights(1234)))
+    data = [scenes.eth_scene(300000 + i) for i in range(n_scenes)]
+    data = [(torch.from_numpy(o), torch.from_numpy(p)) for o, p in data]
+
+    def loop():
+        tot = 0
+        for o, p in data:
+            m.set_data(None, o, p, None, None)
+            tot += m.inference(None).cpu().shape[1] * K
+        return tot
+    loop()
+    best, tot = None, 0
+    for _ in range(3):
+        t = time.perf_counter()
+        tot = loop()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return {'ms_per_scene': 1e3 * best / n_scenes, 'trajectories_per_s': tot / best, 'scenes': n_scenes, 'agents_per_scene': '2-32',
+            'pattern': 'set_data(host tensors) + inference() + .cpu() per scene, unbatched (test.py:171-188); best of 3 passes',
+            'form': 'one launch of cooperating workgroups per call (csrc/scene_lat.hip)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -595,6 +627,7 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--no-per-scene', action='store_true', help='skip the one-scene-per-call latency loop (key per_scene)')
     ap.add_argument('--no-exploratory', action='store_true', help='skip the exploratory bf16x3 region (key exploratory_bf16x3)')
     ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
     ap.add_argument('--no-gather-futures', action='store_true', help='multi-rank runs: skip the all-gather of the futures (check + value_incl_gather)')
@@ -747,6 +780,8 @@ def main():
             train_cpu_baseline(args, train)
         out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config',
                                               'cpu_baseline', 'speedup_vs_cpu_baseline') if k in train}
+    if rank == 0 and world == 1 and not args.no_per_scene and not args.only_leg:
+        out['per_scene'] = per_scene_leg(dev)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
