@@ -350,7 +350,9 @@ int sttode_set_chain(SttodeModel* m, int mode);
  * the embedding and the attention stay launches in front, the roles start at the post-attention layer); 2 = as 1, and for scene batches
  * the roles also run set_data's normalisation of their tile (model/STTODE.py:397-461): the call is ONE launch; 0 = separate launches on
  * the pipeline's per-agent stream; 3 = as 1 with the roles interleaved 160 groups ahead of their consumers in the grid instead of all
- * in front (sttode_fused_block_of; measured neutral pipelined, slower serial).  Results are bitwise the same in every mode. */
+ * in front (sttode_fused_block_of; measured neutral pipelined, slower serial); 4 = as 1 with a tile's stage split into FIVE role workgroups
+ * -- encoder beside block-0 GRU, then one per layer-1 table: latency max(E, G) + one table instead of their sum; measured -1 % at 512
+ * scenes, +3 % on the NBA-128 leg, not the default.  Results are bitwise the same in every mode. */
 int sttode_set_fused(SttodeModel* m, int mode);
 /* EXPLORATORY, opt-in, never the default (own dtype label in bench.py): 1 = the per-trajectory chain (the three decoder MLPs and block 1's
  * conv + GRU: DecomposeBlock.forward model/STTODE.py:51-77, Decoder.forward :320-347) runs its matrix products as a three-way bf16
@@ -360,7 +362,8 @@ int sttode_set_fused(SttodeModel* m, int mode);
 int sttode_set_mfma_mode(SttodeModel* m, int mode);
 /* Fault injection for tests of the in-launch hand-off's give-up path: in fused launches the per-agent role of 16-agent tile `tile` computes
  * its tables but never publishes its flag (-1: off, the default).  The trajectory groups that read that tile then run into the bound of
- * their spin (~1 s), write NaN into their predictions and set the time-out word (workspace buffer STT_B_FLAGS, word [tiles]) -- the
+ * their spin (~1 s), write NaN into their predictions and set the time-out word (workspace buffer STT_B_FLAGS, word [tiles]; with the split roles of
+ * mode 4 the flag words are E [tiles] | time-out | G [tiles] | tables [3 tiles] and the withheld flags are the tile's three table flags) -- the
  * launch ends, it never hangs; every other group is unaffected. */
 int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
 /* Host staging of one scene for the one-scene-per-call loop (test.py:171-188 -> set_data, model/STTODE.py:397-404): pre [N][2][Tp] and

@@ -150,7 +150,8 @@ class NativeModel:
 
     def set_fused(self, mode):
         """1: per-agent roles inside the chain launch (default); 2: the roles also run the scene front-end (one launch per call);
-        3: as 1 with the roles interleaved 160 groups ahead of their consumers in the grid; 0: separate per-agent launches.
+        3: as 1 with the roles interleaved 160 groups ahead of their consumers in the grid; 4: as 1 with five role workgroups per tile
+        (E | G | three tables) instead of one; 0: separate per-agent launches.
         Results are bitwise the same in every mode."""
         if lib().sttode_set_fused(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())

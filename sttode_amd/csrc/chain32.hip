@@ -660,7 +660,13 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     const int ngroups = (A.ncols + 127) >> 7;
 
     C32_TRACE_BEGIN();
-    const int fb = FUSE ? fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead) : (int)blockIdx.x;
+    if (FUSE && A.R.split && (int)blockIdx.x < 5 * A.R.ntiles) {   // (uniform) split per-agent roles, all in front of the groups
+        split_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, blockIdx.x, smem);
+        C32_TRACE_END(1);
+        return;
+    }
+    const int fb = !FUSE ? (int)blockIdx.x : A.R.split ? (int)blockIdx.x - 5 * A.R.ntiles
+                                                      : fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead);
     if (FUSE && fb < 0) {   // (uniform) a per-agent role
         agent_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, -1 - fb, smem);
         C32_TRACE_END(1);
@@ -672,7 +678,12 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     if (FUSE) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
         const int g0 = fb;
         const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
-        if (wave == 0 && !wait_tiles(A.R.flags, (c_lo / A.K) >> 4, (c_hi / A.K) >> 4, A.R.flags + A.R.ntiles, lane) && lane == 0) sq[0] = -1;
+        const int t_lo = (c_lo / A.K) >> 4, t_hi = (c_hi / A.K) >> 4;
+        if (wave == 0) {
+            const bool ok = A.R.split ? wait_tiles(A.R.pflags, 3 * t_lo, 3 * t_hi + 2, A.R.flags + A.R.ntiles, lane)   // the three tables of every tile
+                                      : wait_tiles(A.R.flags, t_lo, t_hi, A.R.flags + A.R.ntiles, lane);
+            if (!ok && lane == 0) sq[0] = -1;
+        }
     }
     __syncthreads();
     C32_TRACE_PHASE(3);   // (groups) flags seen
@@ -908,7 +919,7 @@ template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const Cha
     if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
-    if (FUSE) grid = a.R.ntiles + ngroups;   // roles interleaved ahead of their consumers (fused_block_of), one group per workgroup
+    if (FUSE) grid = (a.R.split ? 5 : 1) * a.R.ntiles + ngroups;   // roles ahead of their consumers, one group per workgroup
     else if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
@@ -921,7 +932,7 @@ template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const Cha
     if (FUSE && lds < role_lds(a.Tp)) lds = role_lds(a.Tp);
     if (wgs == 1 && lds < 84 * 1024) lds = 84 * 1024;
     STT_REQUIRE(lds <= 96 * 1024, "sttode_traj_chain: dynamic LDS beyond the 96 KiB the kernel is registered for");
-    if (FUSE) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
+    if (FUSE) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)(a.R.split ? 5 : 1) * a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
     hipLaunchKernelGGL((traj_chain_kernel<NY, FUSE, B3M>), dim3(grid), dim3(256), lds, s, a);
     STT_HIP(hipGetLastError());
     return 0;
@@ -1046,32 +1057,18 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     a.trace_tag = g_trace_tag++;
 #endif
     RoleArgs& r = a.R;
-    r.ew.fc1P = W[STT_W_FC1P]; r.ew.fc1b = W[STT_W_FC1B]; r.ew.posP = (const f32x4*)W[STT_W_POSP]; r.ew.peb = W[STT_W_PEB];
-    r.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; r.ew.fc2b = W[STT_W_FC2B]; r.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; r.ew.fc3b = W[STT_W_FC3B];
-    r.ew.fc3last = W[STT_W_FC3LAST]; r.ew.inP = (const f32x4*)W[STT_W_INP]; r.ew.inb = W[STT_W_INB];
-    r.pw.outP = (const f32x4*)W[STT_W_OUTP]; r.pw.outb = W[STT_W_OUTB]; r.pw.infoP = (const f32x4*)W[STT_W_INFOP]; r.pw.infob = W[STT_W_INFOB];
-    r.pw.gateP = (const f32x4*)W[STT_W_GATEP]; r.pw.gateb = W[STT_W_GATEB]; r.pw.ln1w = W[STT_W_LN1W]; r.pw.ln1b = W[STT_W_LN1B];
-    r.pw.l1P = (const f32x4*)W[STT_W_L1P]; r.pw.l1b = W[STT_W_L1B]; r.pw.l2P = (const f32x4*)W[STT_W_L2P]; r.pw.l2b = W[STT_W_L2B];
-    r.pw.ln2w = W[STT_W_LN2W]; r.pw.ln2b = W[STT_W_LN2B];
-    r.enc_in = ws + off[STT_B_ENC_IN]; r.last = (const int*)(ws + off[STT_B_LAST]); r.g = ws + off[STT_B_G]; r.qkv = ws + off[STT_B_QKV];
-    r.pf = ws + off[STT_B_PF];
-    r.convP = (const f32x4*)W[STT_W_B0_CONVP]; r.convB = W[STT_W_B0_CONVB]; r.wihP = (const f32x4*)W[STT_W_B0_WIHP];
-    r.whhP = (const f32x4*)W[STT_W_B0_WHHP]; r.gbias = W[STT_W_B0_GBIAS]; r.state0 = ws + off[STT_B_STATE0];
-    r.WAx = (const f32x4*)W[STT_W_B0_XWA]; r.b1x = W[STT_W_B0_XB1]; r.WAy = (const f32x4*)W[STT_W_B0_YWA]; r.b1y = W[STT_W_B0_YB1];
-    r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
-    r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
+    role_args_fill(r, W, ws, off);
     r.attn = attn; r.ld_attn = ld_attn;
     STT_REQUIRE(!past || (scene_ptr && S > 0 && !attn), "stt_chain_fused: the in-role front-end needs scene_ptr, S > 0 and attention length 1");
     r.past = past; r.scene_ptr = scene_ptr; r.S = S;
-    r.scene_orig = ws + off[STT_B_SCENE_ORIG]; r.agent_scene = (int*)(ws + off[STT_B_AGENT_SCENE]);
-    r.enc_in_w = ws + off[STT_B_ENC_IN]; r.xpad_w = ws + off[STT_B_XPAD]; r.cur_w = ws + off[STT_B_CUR]; r.orig_w = ws + off[STT_B_ORIG];
-    r.last_w = (int*)(ws + off[STT_B_LAST]);
     r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
     // grid order: `lead` groups of head start of a role over its first consumer; < 0 (default): all roles first.  Measured on one box
     // (profiles/r03/ab_lead_frontend_depth.txt): pipelined 73.4-74.6 M trajectories/s for lead 64 / 160 / 400 / roles first alike, but a
     // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
     // other roles, and holds its slot all the while
     r.lead = lead < 0 ? (1 << 28) : lead;
+    r.split = lead == -2;   // -2: roles first, each tile's role split into E | G | three table workgroups (default); -1: one workgroup per tile
+    r.gflags = r.flags + r.ntiles + 1; r.pflags = r.gflags + r.ntiles;
     r.drop_tile = drop_tile;
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;

@@ -84,7 +84,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
     m->fused_mode = 1;
     m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
-    m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;
+    m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
     m->scene_launch = 128;
     if (const char* e = getenv("STTODE_SCENE_LAUNCH")) m->scene_launch = atoi(e) > 0 ? atoi(e) : 0;
@@ -191,8 +191,9 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_YBUF, mm * 16 * m->NOY);
     put(STT_B_STATE1, mm * 96);
     put(STT_B_QUEUE, 64);
-    // one flag per 16-agent tile + the time-out word (fused launches); three per agent tile + one per 16-trajectory tile (one-launch scene form); zeroed per call
-    put(STT_B_FLAGS, (size_t)3 * ((n + 15) / 16) + 4 + (mm + 15) / 16);
+    // fused launches: five flags per 16-agent tile (E, G, three tables) + the time-out word; one-launch scene form: three per agent tile + one per
+    // 16-trajectory tile; zeroed per call
+    put(STT_B_FLAGS, (size_t)5 * ((n + 15) / 16) + 4 + (mm + 15) / 16);
     put(STT_B_ODE, (size_t)6 * n * 64);   // multi-stage integrator with attention groups > 1 (always laid out: sttode_set_ode may come later)
     *total_floats = (long)o;
     return 0;
@@ -207,10 +208,10 @@ extern "C" int sttode_set_chain(SttodeModel* m, int mode) {
 
 extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
     STT_REQUIRE(m, "sttode_set_fused: null model");
-    STT_REQUIRE(mode >= 0 && mode <= 3, "sttode_set_fused: mode must be 0, 1, 2 or 3");
+    STT_REQUIRE(mode >= 0 && mode <= 4, "sttode_set_fused: mode must be 0 .. 4");
     m->fused_mode = mode ? 1 : 0;
     m->fe_in_role = mode == 2;
-    m->role_lead = mode == 3 ? 160 : -1;
+    m->role_lead = mode == 3 ? 160 : mode == 4 ? -2 : -1;
     return 0;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "latency_bodies.hpp"
 #include "frontend_body.hpp"
+#include "../../include/sttode_hip.h"
 
 #ifndef C32_TRACE_PHASE
 #define C32_TRACE_PHASE(i) do { } while (0)
@@ -31,6 +32,10 @@ struct RoleArgs {
     int ntiles; float ode_time;
     int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
     int drop_tile;       // fault injection (tests): the role of this tile never publishes its flag (-1: none) -- exercises the give-up path
+    // split roles (fused chain launch, default): a tile's per-agent stage as FIVE workgroups instead of one -- E (encoder -> pf) beside
+    // G (block-0 conv + GRU -> state0), then P_0 P_1 P_2 (one layer-1 table each) -- so its latency is max(E, G) + one table (~70 us)
+    // instead of their sum (~150 us): calls with fewer groups than workgroup slots are bound by exactly that latency.
+    int split; unsigned* gflags; unsigned* pflags;   // flags: E [T] | time-out | G [T] | P [3 T]
 };
 
 #ifndef ROLE_PRIO
@@ -133,3 +138,92 @@ __device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, 
     return ok;
 }
 
+// publish (guide section 6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
+__device__ __forceinline__ void role_publish(unsigned* flag, bool really) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && really) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Split roles of the fused chain launch (RoleArgs::split).  Block r < 2 T: tile r / 2, E (even) or G (odd); 2 T <= r < 5 T: table
+// (r - 2 T) % 3 of tile (r - 2 T) / 3.  Same bodies, same sums as agent_role: the tables carry the same bits.
+__device__ __forceinline__ void split_role(const RoleArgs& R, int nag, int Tp, int ldx, const float* __restrict__ xpad, int r, char* smem) {
+    __builtin_amdgcn_s_setprio(ROLE_PRIO);
+    const int T = R.ntiles;
+    if (r < 2 * T) {
+        const int tile = r >> 1;
+        if ((r & 1) == 0) {   // E: encoder
+            if (R.past) {
+                role_frontend(R, nag, Tp, ldx, tile, true, false);
+                __syncthreads();
+            }
+            if (R.attn == nullptr) {
+                embed_lat_body(R.ew, R.enc_in, R.last, R.g, R.qkv, nag, Tp, tile, reinterpret_cast<f32x4*>(smem));
+                __syncthreads();
+            }
+            C32_TRACE_PHASE(0);
+            post_attn_body<false, true>(R.pw, R.g, R.attn ? R.attn : R.qkv + 128, R.attn ? R.ld_attn : 192, R.pf, nag, R.ode_time, 0, 1, nullptr,
+                                        nullptr, tile, reinterpret_cast<f32x4(*)[4][64]>(smem));
+            C32_TRACE_PHASE(1);
+            role_publish(R.flags + tile, true);
+        } else {              // G: block-0 conv + GRU
+            if (R.past) {
+                role_frontend(R, nag, Tp, ldx, tile, false, true);
+                __syncthreads();
+            }
+            f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
+            f32x4* sW45 = reinterpret_cast<f32x4*>(smem) + 2 * 6 * 64;
+            if (ldx == 16) gru_lat4_body<1, false, true>(xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, Tp, tile, sH, sW45);
+            else gru_lat4_body<2, false, true>(xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, nag, Tp, tile, sH, sW45);
+            C32_TRACE_PHASE(2);
+            role_publish(R.gflags + tile, true);
+        }
+        return;
+    }
+    const int tile = (r - 2 * T) / 3, k = (r - 2 * T) % 3;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* ok = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) *ok = 1;
+    __syncthreads();
+    if (wv == 0) {
+        bool o = wait_tiles(R.flags, tile, tile, R.flags + T, lane);
+        if (k < 2) o = wait_tiles(R.gflags, tile, tile, R.flags + T, lane) && o;
+        if (!o && lane == 0) *ok = 0;
+    }
+    __syncthreads();
+    if (!*ok) return;         // (uniform) time-out: the flag stays down, the tile's groups give up in turn
+    const int col = tile * 16 + c;
+    const int colc = col < nag ? col : nag - 1;
+    f32x4 B[14];
+#pragma unroll
+    for (int Tt = 0; Tt < 8; ++Tt) B[Tt] = ld4(R.pf + (size_t)colc * 128 + 16 * Tt + 4 * q);
+#pragma unroll
+    for (int Tt = 0; Tt < 6; ++Tt) B[8 + Tt] = k < 2 ? ld4(R.state0 + (size_t)colc * 96 + 16 * Tt + 4 * q) : B[0];
+    if (k == 0) preact_rows<14, true>(R.WAx, R.b1x, R.A0x, B, col, col < nag, lane, q, wv);
+    else if (k == 1) preact_rows<14, true>(R.WAy, R.b1y, R.A0y, B, col, col < nag, lane, q, wv);
+    else preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < nag, lane, q, wv);
+    role_publish(R.pflags + 3 * tile + k, tile != R.drop_tile);
+}
+
+// Host side: the weight fragments (model table W, STT_W_*) and workspace rows (ws + off[STT_B_*]) every launch that carries per-agent
+// roles hands to them; the caller sets what differs (attention input, scene front-end inputs, flags, fault injection).
+static inline void role_args_fill(RoleArgs& r, const float* const* W, float* ws, const long* off) {
+    r.ew.fc1P = W[STT_W_FC1P]; r.ew.fc1b = W[STT_W_FC1B]; r.ew.posP = (const f32x4*)W[STT_W_POSP]; r.ew.peb = W[STT_W_PEB];
+    r.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; r.ew.fc2b = W[STT_W_FC2B]; r.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; r.ew.fc3b = W[STT_W_FC3B];
+    r.ew.fc3last = W[STT_W_FC3LAST]; r.ew.inP = (const f32x4*)W[STT_W_INP]; r.ew.inb = W[STT_W_INB];
+    r.pw.outP = (const f32x4*)W[STT_W_OUTP]; r.pw.outb = W[STT_W_OUTB]; r.pw.infoP = (const f32x4*)W[STT_W_INFOP]; r.pw.infob = W[STT_W_INFOB];
+    r.pw.gateP = (const f32x4*)W[STT_W_GATEP]; r.pw.gateb = W[STT_W_GATEB]; r.pw.ln1w = W[STT_W_LN1W]; r.pw.ln1b = W[STT_W_LN1B];
+    r.pw.l1P = (const f32x4*)W[STT_W_L1P]; r.pw.l1b = W[STT_W_L1B]; r.pw.l2P = (const f32x4*)W[STT_W_L2P]; r.pw.l2b = W[STT_W_L2B];
+    r.pw.ln2w = W[STT_W_LN2W]; r.pw.ln2b = W[STT_W_LN2B];
+    r.enc_in = ws + off[STT_B_ENC_IN]; r.last = (const int*)(ws + off[STT_B_LAST]); r.g = ws + off[STT_B_G]; r.qkv = ws + off[STT_B_QKV];
+    r.pf = ws + off[STT_B_PF];
+    r.convP = (const f32x4*)W[STT_W_B0_CONVP]; r.convB = W[STT_W_B0_CONVB]; r.wihP = (const f32x4*)W[STT_W_B0_WIHP];
+    r.whhP = (const f32x4*)W[STT_W_B0_WHHP]; r.gbias = W[STT_W_B0_GBIAS]; r.state0 = ws + off[STT_B_STATE0];
+    r.WAx = (const f32x4*)W[STT_W_B0_XWA]; r.b1x = W[STT_W_B0_XB1]; r.WAy = (const f32x4*)W[STT_W_B0_YWA]; r.b1y = W[STT_W_B0_YB1];
+    r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
+    r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
+    r.scene_orig = ws + off[STT_B_SCENE_ORIG]; r.agent_scene = (int*)(ws + off[STT_B_AGENT_SCENE]);
+    r.enc_in_w = ws + off[STT_B_ENC_IN]; r.xpad_w = ws + off[STT_B_XPAD]; r.cur_w = ws + off[STT_B_CUR]; r.orig_w = ws + off[STT_B_ORIG];
+    r.last_w = (int*)(ws + off[STT_B_LAST]);
+}

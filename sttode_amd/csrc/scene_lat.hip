@@ -217,30 +217,14 @@ int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int 
     STT_REQUIRE(n_chunks0 == 64 + TPX + NOY && n_chunks1 == 32 + NOY, "stt_scene_lat: weight streams do not match (TPX, NOY)");
     SceneLatArgs a;
     RoleArgs& r = a.R;
-    r.ew.fc1P = W[STT_W_FC1P]; r.ew.fc1b = W[STT_W_FC1B]; r.ew.posP = (const f32x4*)W[STT_W_POSP]; r.ew.peb = W[STT_W_PEB];
-    r.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; r.ew.fc2b = W[STT_W_FC2B]; r.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; r.ew.fc3b = W[STT_W_FC3B];
-    r.ew.fc3last = W[STT_W_FC3LAST]; r.ew.inP = (const f32x4*)W[STT_W_INP]; r.ew.inb = W[STT_W_INB];
-    r.pw.outP = (const f32x4*)W[STT_W_OUTP]; r.pw.outb = W[STT_W_OUTB]; r.pw.infoP = (const f32x4*)W[STT_W_INFOP]; r.pw.infob = W[STT_W_INFOB];
-    r.pw.gateP = (const f32x4*)W[STT_W_GATEP]; r.pw.gateb = W[STT_W_GATEB]; r.pw.ln1w = W[STT_W_LN1W]; r.pw.ln1b = W[STT_W_LN1B];
-    r.pw.l1P = (const f32x4*)W[STT_W_L1P]; r.pw.l1b = W[STT_W_L1B]; r.pw.l2P = (const f32x4*)W[STT_W_L2P]; r.pw.l2b = W[STT_W_L2B];
-    r.pw.ln2w = W[STT_W_LN2W]; r.pw.ln2b = W[STT_W_LN2B];
-    r.enc_in = ws + off[STT_B_ENC_IN]; r.last = (const int*)(ws + off[STT_B_LAST]); r.g = ws + off[STT_B_G]; r.qkv = ws + off[STT_B_QKV];
-    r.pf = ws + off[STT_B_PF];
-    r.convP = (const f32x4*)W[STT_W_B0_CONVP]; r.convB = W[STT_W_B0_CONVB]; r.wihP = (const f32x4*)W[STT_W_B0_WIHP];
-    r.whhP = (const f32x4*)W[STT_W_B0_WHHP]; r.gbias = W[STT_W_B0_GBIAS]; r.state0 = ws + off[STT_B_STATE0];
-    r.WAx = (const f32x4*)W[STT_W_B0_XWA]; r.b1x = W[STT_W_B0_XB1]; r.WAy = (const f32x4*)W[STT_W_B0_YWA]; r.b1y = W[STT_W_B0_YB1];
-    r.WA1 = (const f32x4*)W[STT_W_B1_YWA]; r.b11 = W[STT_W_B1_YB1];
-    r.A0x = ws + off[STT_B_A0X]; r.A0y = ws + off[STT_B_A0Y]; r.A1y = ws + off[STT_B_A1Y];
+    role_args_fill(r, W, ws, off);
     r.attn = nullptr; r.ld_attn = 0;
     r.past = past; r.scene_ptr = scene_ptr; r.S = S;
-    r.scene_orig = ws + off[STT_B_SCENE_ORIG]; r.agent_scene = (int*)(ws + off[STT_B_AGENT_SCENE]);
-    r.enc_in_w = ws + off[STT_B_ENC_IN]; r.xpad_w = ws + off[STT_B_XPAD]; r.cur_w = ws + off[STT_B_CUR]; r.orig_w = ws + off[STT_B_ORIG];
-    r.last_w = (int*)(ws + off[STT_B_LAST]);
     const int A_tiles = (n + 15) / 16;
     const long ncols = (long)n * K;
     STT_REQUIRE(ncols <= 0x3fffffffL, "stt_scene_lat: too many trajectories");
     const int C_tiles = (int)((ncols + 15) / 16);
-    r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = A_tiles; r.ode_time = ode_time; r.lead = 0; r.drop_tile = drop_tile;
+    r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = A_tiles; r.ode_time = ode_time; r.lead = 0; r.drop_tile = drop_tile; r.split = 0; r.gflags = nullptr; r.pflags = nullptr;
     a.tmo = r.flags + A_tiles; a.gflags = a.tmo + 1; a.e2flags = a.gflags + A_tiles; a.yflags = a.e2flags + A_tiles;
     a.dbg = nullptr;
 #ifdef SL_DIAG_TRACE

@@ -510,9 +510,9 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
                 for k in first[v][1]:
                     assert_close(first[v][1][k].cpu().numpy(), ref[v][1][k].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'{case} variant {v}: {k}')
             ref = first
-        for rep in range(3):
+        for rep in range(4):
             for v in (0, 3, 1, 2):
-                out, inter = run(v, 1 + (rep + v) % 3)    # mode 2: the roles also run the scene front-end; mode 3: roles interleaved in the grid
+                out, inter = run(v, 1 + (rep + v) % 4)    # 1: default; 2: + scene front-end in the roles; 3: roles interleaved in the grid; 4: five role workgroups per tile (E | G | three tables)
                 assert torch.isfinite(out).all()
                 assert torch.equal(out, ref[v][0]), f'{case} variant {v} rep {rep}: fused launch != separate launches'
                 for k in inter:
@@ -629,7 +629,8 @@ def test_exploratory_bf16x3_mode_vs_fp32_and_oracle(case):
         assert_close(outs['bf16x3'], ref, what=f'{case}: bf16x3 vs oracle')
 
 
-def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals():
+@pytest.mark.parametrize('mode', [1, 4])
+def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals(mode):
     """The exit condition of the in-launch hand-off: with the flag of ONE 16-agent tile withheld (fault injection,
     sttode_debug_drop_role_flag) the trajectory groups that read that tile run into the bound of their spin (~1 s), poison THEIR
     predictions with NaN and set the time-out word; the launch ends, every other group's predictions are the bits of a healthy run, and
@@ -642,6 +643,7 @@ def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals(
     z = torch.from_numpy(scenes.latents(77, n)).to(m.device)
     try:
         m.native().set_chain(1)
+        m.native().set_fused(mode)                                # 4: five role workgroups per tile; the tile's three table flags are withheld
         m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
         good = m.inference(None, z=z).clone()
         tile = 3                                              # agents 48..63
@@ -654,8 +656,13 @@ def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals(
         assert dt < 30.0, f'the launch took {dt:.1f} s: the spin is not bounded'
         buf, off = m._workspace(n, S)
         ntiles = (n + 15) // 16
-        flags = m._view(buf, off, 'flags', ntiles + 1, dtype=torch.int32).cpu().numpy()
-        assert flags[ntiles] == 1 and flags[tile] == 0 and (np.delete(flags[:ntiles], tile) == 1).all()
+        flags = m._view(buf, off, 'flags', 5 * ntiles + 1, dtype=torch.int32).cpu().numpy()
+        assert flags[ntiles] == 1
+        if mode == 1:
+            assert flags[tile] == 0 and (np.delete(flags[:ntiles], tile) == 1).all()
+        else:                                                 # E [T] | time-out | G [T] | tables [3 T]
+            tables = flags[2 * ntiles + 1:].reshape(ntiles, 3)
+            assert (tables[tile] == 0).all() and (np.delete(tables, tile, axis=0) == 1).all() and (flags[:ntiles] == 1).all()
         # groups of 128 trajectories (= agents*K): the poisoned ones are exactly those whose agents touch the withheld tile
         a_lo, a_hi = 16 * tile, min(16 * tile + 15, n - 1)
         g_lo, g_hi = (a_lo * K) // 128, (a_hi * K + K - 1) // 128
@@ -666,6 +673,7 @@ def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals(
         assert torch.equal(flat_bad[~hit], flat_good[~hit])
     finally:
         capi.call('sttode_debug_drop_role_flag', m.native().h, -1)
+        m.native().set_fused(1)
         m.native().set_chain(-1)
     m.native().set_chain(1)
     try:
