@@ -160,6 +160,8 @@ LEGS = {
 
 class Leg:
     DEPTH = 4
+    ASYNC_METRICS = False
+    AHEAD = 0
 
     def __init__(self, name, rank, dev, size=None):
         import torch
@@ -221,25 +223,51 @@ class Leg:
 
     def _finish(self, h):
         import torch
-        pred = self.model.wait(h)                               # [K, n, Tf, 2] (a permuted view of the contiguous [n, K, Tf, 2] buffer)
         self.last_pred = h['pred']
-        return self.model.best_of_k(pred.permute(1, 0, 2, 3), gt=h['gt'])   # per-agent (ade, fde); summed ONCE, after the last step
+        if Leg.ASYNC_METRICS:
+            # best-of-K on the call's own pipeline stream (it starts the moment the call's launch drains; as a kernel on the caller's stream it
+            # queued ~0.5 ms for workgroup slots on a chip full of other calls' chains, with the next call's inputs behind it).  Nothing goes
+            # onto the caller's stream here; whoever needs the call's outputs or its slot waits for the event (settle()).
+            self.unsettled = h
+            return self.model.best_of_k_async(h, gt=h['gt'])   # per-agent (ade, fde) of the slot; summed ONCE, after the last step
+        pred = self.model.wait(h)                               # [K, n, Tf, 2] (a permuted view of the contiguous [n, K, Tf, 2] buffer)
+        return self.model.best_of_k(pred.permute(1, 0, 2, 3), gt=h['gt'])
+
+    def settle(self):
+        """(an event wait on the caller's stream, no kernel) the latest finished call's launch and metrics are complete: its futures may be
+        copied, its metric values read, and the input slot it used may be overwritten."""
+        h, self.unsettled = getattr(self, 'unsettled', None), None
+        if h is not None:
+            self.model.wait(h)
 
     def sums(self, af):
         import torch
+        self.settle()
         return torch.stack((af[0].sum(), af[1].sum(), self.n_dev))   # local sums; ONE all-reduce after the last step
 
     def step(self, serial=False):
         import torch
-        self._load()
         if serial:
+            self._load()
             pred = self.model.inference(None)
             self.last_pred = self.model.diverse_pred            # contiguous [n, K, Tf, 2]
             return self.model.best_of_k(pred.permute(1, 0, 2, 3))
-        h = self.model.inference_async()                        # z is drawn on device exactly like Normal.rsample in the reference
+        if not Leg.ASYNC_METRICS:
+            self._load()
+            h = self.model.inference_async()                    # z is drawn on device exactly like Normal.rsample in the reference
+            h['gt'] = self.model._future
+            self.pending.append(h)
+            return self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
+        # Order of a pipelined step k (depth 4, three pipeline streams in rotation): the call finished in step k-1 (k-4) is settled, so its
+        # input slot -- this step's -- may be overwritten; the metrics of call k-3 go onto ITS stream, which is also call k's, BEFORE
+        # call k's launch is enqueued there (behind it they would wait for call k to finish and hold call k+1's slot).
+        self.settle()
+        self._load()
+        out = self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth - 1 else None
+        h = self.model.inference_async()
         h['gt'] = self.model._future
         self.pending.append(h)
-        return self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
+        return out
 
     def drain(self):
         out = None
@@ -269,10 +297,20 @@ class Leg:
         gc.collect()
         gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
         t0 = time.perf_counter()
+        ahead = []                                                # host-side flow control: at most Leg.AHEAD steps enqueued beyond the device
         for _ in range(steps):
+            if Leg.AHEAD > 0 and not serial:
+                if len(ahead) >= Leg.AHEAD:
+                    ahead.pop(0).synchronize()
+                ev = torch.cuda.Event()
             r = self.step(serial)
+            if Leg.AHEAD > 0 and not serial:
+                ev.record()
+                ahead.append(ev)
             if r is not None:
                 acc = r
+                if d2h or gather:
+                    self.settle()                                 # the futures about to be copied are complete
                 if d2h:
                     hostbuf.copy_(self.last_pred, non_blocking=True)
                 if gather:
@@ -281,6 +319,8 @@ class Leg:
         r = self.drain()                                          # every one of the K steps completes inside the timed region
         if r is not None:
             acc = r
+            if d2h or gather:
+                self.settle()
             if d2h:
                 hostbuf.copy_(self.last_pred, non_blocking=True)
             if gather:
@@ -627,6 +667,8 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--ahead', type=int, default=0, help='host-side flow control: steps the host may enqueue beyond the device (0 = unbounded)')
+    ap.add_argument('--async-metrics', action='store_true', help='best-of-K on the call\'s own pipeline stream (model.best_of_k_async) instead of a kernel on the caller\'s stream; measured neutral')
     ap.add_argument('--no-per-scene', action='store_true', help='skip the one-scene-per-call latency loop (key per_scene)')
     ap.add_argument('--no-exploratory', action='store_true', help='skip the exploratory bf16x3 region (key exploratory_bf16x3)')
     ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
@@ -656,6 +698,8 @@ def main():
         return 0
 
     Leg.DEPTH = max(2, min(4, args.depth))
+    Leg.ASYNC_METRICS = args.async_metrics
+    Leg.AHEAD = max(0, args.ahead)
     if args.only_leg:
         # one leg alone (profiling passes: `rocprofv3 --kernel-trace --stats -- python3 bench.py --only-leg sdd_1024 --serial` gives that
         # leg's serial per-launch durations without the headline's launches of the same kernel in the table)

@@ -370,6 +370,12 @@ int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
  * fut [N][2][Tf] (HOST pointers, the loader's layout; fut may be NULL with Tf = 0) are transposed into a pinned ring slot and copied to
  * dev [N*Tp*2 + N*Tf*2] (DEVICE: past [N][Tp][2] followed by future [N][Tf][2]) with one asynchronous copy on `stream`. */
 int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream);
+/* Best-of-K ADE / FDE of an asynchronous call's predictions (utils/metrics.py:7-26, as sttode_best_of_k) enqueued on the pipeline stream
+ * the call of `slot` runs on: the metrics start the moment the call's launch drains, in stream order.  Re-records the slot's completion
+ * event behind them (sttode_wait(slot) then covers the metrics).  gt must have been written before the sttode_inference_*_async call
+ * (its stream waits for the caller's stream at that point). */
+int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade,
+                           float* fde);
 /* Serial scene calls (sttode_inference_scenes) below the chain threshold -- the reference's evaluation loop hands over ONE scene per call
  * (test.py:171-188) -- run as ONE launch whose workgroups take the roles front-end + per-agent stage / block-0 decoder_y / block-0
  * decoder_x -> block-1 GRU -> block-1 decoder_y and hand tables over through flags (csrc/scene_lat.hip), when the call has at most

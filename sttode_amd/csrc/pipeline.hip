@@ -34,6 +34,7 @@ struct SttodeModel {
     int chain_mode;  // 1 fused chain kernel, 0 three-kernel form, -1 automatic
     int fused_mode;  // 1 per-agent roles inside the chain launch wherever the shape is covered, 0 separate per-agent launches
     int role_lead;   // fused launch's grid order: groups of head start of a role over its first consumer, < 0 = all roles first (default)
+    hipStream_t slot_stream[STT_MAX_SLOTS];   // the pipeline stream the slot's latest asynchronous call ran on (its follow-up work goes there)
     int scene_launch; // largest number of 16-trajectory tiles a serial scene call runs as ONE launch (scene_lat.hip); 0: never
     int drop_tile;   // fault injection (tests): the role of this 16-agent tile does not publish its flag in fused launches (-1: none)
     int b3;          // exploratory: block-0 MLPs of the fused launch as a three-way bf16 split (sttode_set_mfma_mode)
@@ -86,6 +87,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
+    for (int p = 0; p < STT_MAX_SLOTS; ++p) m->slot_stream[p] = nullptr;
     m->scene_launch = 128;
     if (const char* e = getenv("STTODE_SCENE_LAUNCH")) m->scene_launch = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
@@ -617,6 +619,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
             if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
         if (int rc = stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, sf)) return rc;
         STT_HIP(hipEventRecord(m->evB_done[slot], sf));
+        m->slot_stream[slot] = sf;
         return 0;
     }
     STT_HIP(hipStreamWaitEvent(m->sA, m->ev_call, 0));
@@ -631,6 +634,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     STT_HIP(hipStreamWaitEvent(sb, m->evA_done[slot], 0));
     if (int rc = stage_trajectories(m, ws, off, n, z, pred, sb, true)) return rc;
     STT_HIP(hipEventRecord(m->evB_done[slot], sb));
+    m->slot_stream[slot] = sb;
     return 0;
 }
 
@@ -660,6 +664,19 @@ extern "C" int sttode_inference_nba_async(SttodeModel* m, const float* past, int
     STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba_async: null pointer");
     STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba_async: B and N must be positive");
     return run_async(m, past, nullptr, B * N, 0, B, N, z, workspace, pred, slot, (hipStream_t)stream);
+}
+
+// Follow-up work of an asynchronous call ON THE CALL'S OWN pipeline stream: best-of-K metrics of its predictions (utils/metrics.py:7-26) run
+// the moment its launch drains -- in stream order, no event, no workgroup slots to fight for on a chip full of other calls' chains (on the
+// caller's stream that 8-us kernel sat 0.5 ms in the queue and held the next call's inputs behind it).  The slot's completion event is
+// re-recorded behind it: sttode_wait(slot) and the slot's next user wait for the metrics too.
+extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pred, const float* gt, int n, int K, int Tf, float scale,
+                                      float* ade, float* fde) {
+    STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_best_of_k: bad model / slot");
+    STT_REQUIRE(m->slot_stream[slot] != nullptr, "sttode_async_best_of_k: no asynchronous call has used this slot");
+    if (int rc = sttode_best_of_k(pred, gt, n, K, Tf, scale, ade, fde, m->slot_stream[slot])) return rc;
+    STT_HIP(hipEventRecord(m->evB_done[slot], m->slot_stream[slot]));
+    return 0;
 }
 
 // make `stream` wait until the async call that used `slot` has produced its predictions

@@ -192,6 +192,7 @@ class STTODENet(nn.Module):
         self.mfma_mode = 'bf16x3' if os.environ.get('STTODE_BF16X3', '0') not in ('', '0') else 'f32'
         self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
+        self._async_metrics = {}
         self._ptr_cache = {}
         self._pf = self._pf_thunk = None
         self.to(self.device)
@@ -724,16 +725,36 @@ class STTODENet(nn.Module):
             capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, st)
         else:
             capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, st)
-        return {'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None))}
+        mb = self._async_metrics.get(key)
+        if mb is None:                                           # per-slot best-of-K outputs (best_of_k_async): no allocation per call
+            t = torch.empty(2, n, dtype=torch.float32, device=self.device)
+            mb = self._async_metrics[key] = (t[0], t[1])
+        return {'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None)), 'metrics': mb,
+                'gt_default': self._future}
 
     def wait(self, handle):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
         capi.call('sttode_wait', self.native().h, handle['slot'], capi.stream_ptr())
         return handle['pred'].permute(1, 0, 2, 3)
 
+    def best_of_k_async(self, handle, gt=None, scale=1.0):
+        """Min-over-K ADE / FDE per agent of an inference_async() call, enqueued on the pipeline stream the call runs on (they start the
+        moment the call's launch drains; nothing goes onto the caller's stream).  Returns (ade [n], fde [n]): views of the slot's metric
+        buffers, valid after ``wait(handle)`` and until the slot's next call.  ``gt`` [n, Tf, 2] must have been written before the
+        inference_async() call (default: the futures set with the batch)."""
+        gt = handle.get('gt_default') if gt is None else gt
+        if not (isinstance(gt, torch.Tensor) and gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous()):
+            raise ValueError('best_of_k_async needs a contiguous float32 device tensor gt [n, Tf, 2] that was written before the call')
+        pred = handle['pred']                                    # contiguous [n, K, Tf, 2]
+        n, K, Tf = pred.shape[:3]
+        mb = handle['metrics']
+        capi.call('sttode_async_best_of_k', self.native().h, handle['slot'], pred, gt, n, K, Tf, float(scale), mb[0], mb[1])
+        return mb[0], mb[1]
+
     def reset_async(self):
         torch.cuda.synchronize(self.device)
         self._async_bufs = {}
+        self._async_metrics = {}
 
     @torch.no_grad()
     def best_of_k(self, pred_nk, gt=None, scale=1.0):

@@ -867,6 +867,51 @@ def test_one_launch_scene_form_gives_up_instead_of_hanging():
     assert torch.equal(m.inference(None, z=z), good)
 
 
+def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_stream():
+    """best_of_k_async: the metrics of a pipelined call enqueued on the call's own pipeline stream (behind its launch, in stream order) are
+    the bits of best_of_k on the waited predictions; the slot's completion event covers them, so a slot reused four calls later never sees
+    its metric buffers or its ground truth overwritten early (ten calls through four slots, three batches of one shape in rotation)."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    batches = []
+    for v in range(3):
+        sb = scenes.make_scene_batch(range(7000, 7064), 'eth')
+        past = torch.from_numpy((sb.past * (1.0 + 0.05 * v)).astype(np.float32)).to(m.device)
+        fut = torch.from_numpy((sb.future * (1.0 + 0.05 * v)).astype(np.float32)).to(m.device)
+        batches.append((past, fut, torch.from_numpy(sb.scene_ptr).to(m.device), torch.from_numpy(scenes.latents(40 + v, sb.n_agents)).to(m.device)))
+    ref = []
+    for past, fut, ptr, z in batches:
+        m.set_scene_batch(past, fut, ptr)
+        out = m.inference(None, z=z)
+        a, f = m.best_of_k(out.permute(1, 0, 2, 3), gt=fut)
+        ref.append((a.clone(), f.clone()))
+    m.reset_async()
+    pend, got = [], []
+    for i in range(10):
+        v = (2 * i + i // 3) % 3
+        past, fut, ptr, z = batches[v]
+        m.set_scene_batch(past, fut, ptr)
+        h = m.inference_async(z=z)
+        pend.append((v, h, fut))
+        if len(pend) >= 4:
+            vv, hh, ff = pend.pop(0)
+            a, f = m.best_of_k_async(hh, gt=ff)
+            m.wait(hh)
+            got.append((vv, a.clone(), f.clone()))
+    while pend:
+        vv, hh, ff = pend.pop(0)
+        a, f = m.best_of_k_async(hh)                          # default ground truth: the futures set with the batch
+        m.wait(hh)
+        got.append((vv, a.clone(), f.clone()))
+    torch.cuda.synchronize()
+    assert len(got) == 10
+    for i, (vv, a, f) in enumerate(got):
+        assert torch.equal(a, ref[vv][0]) and torch.equal(f, ref[vv][1]), f'call {i} (batch {vv}): metrics on the call\'s stream differ'
+    with pytest.raises(ValueError):
+        m.best_of_k_async(h, gt=np.zeros((3, 12, 2), np.float32))
+    m.reset_async()
+
+
 def test_async_latents_follow_the_same_generator_sequence_as_serial_calls():
     """inference_async(z=None) draws its latents from torch's generator at call time, like inference(None): the same seed gives the same
     predictions call by call, whether the calls are pipelined or serial."""
