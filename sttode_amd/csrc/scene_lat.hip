@@ -53,13 +53,6 @@ struct SceneLatArgs {
 #define SL_STAMP(k) do { } while (0)
 #endif
 
-// publish (guide section 6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
-__device__ __forceinline__ void sl_publish(unsigned* flag, bool really) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0 && really) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int TPX, int NOY>
 __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +75,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             SL_STAMP(1);
             post_attn_body<false, true>(R.pw, R.g, R.qkv + 128, 192, R.pf, A.n, R.ode_time, 0, 1, nullptr, nullptr, tile,
                                         reinterpret_cast<f32x4(*)[4][64]>(smem));
-            sl_publish(R.flags + tile, tile != R.drop_tile);
+            role_publish(R.flags + tile, tile != R.drop_tile);
             SL_STAMP(2);
             // block-1 layer-1 table of the tile's agents: off the critical path (its readers first run block 0 and the GRU)
             const int col = tile * 16 + c;
@@ -93,7 +86,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
 #pragma unroll
             for (int T = 8; T < 14; ++T) B[T] = B[0];
             preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < A.n, lane, q, wave);
-            sl_publish(A.e2flags + tile, true);
+            role_publish(A.e2flags + tile, true);
             SL_STAMP(3);
         } else {             // G: block-0 conv + GRU
             f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
@@ -105,7 +98,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             };
             gru_bal_body<TPX, false, true, decltype(fe)>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, A.n, A.Tp, tile, sH, sX,
                                                          nullptr, fe);
-            sl_publish(A.gflags + tile, true);
+            role_publish(A.gflags + tile, true);
             SL_STAMP(2);
         }
         return;
@@ -159,7 +152,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             mlp_lat_run<2, NOY, 1, true, true, true>(y0, sH1, sH2, tile);
         }
         // (after a time-out the flag is still published: the X role has seen the same time-out and poisons the tile)
-        sl_publish(A.yflags + tile, true);
+        role_publish(A.yflags + tile, true);
         SL_STAMP(3);
         return;
     }
