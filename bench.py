@@ -162,6 +162,7 @@ class Leg:
     DEPTH = 4
     ASYNC_METRICS = False
     AHEAD = 0
+    OWN_STREAM = False
 
     def __init__(self, name, rank, dev, size=None):
         import torch
@@ -224,7 +225,7 @@ class Leg:
     def _finish(self, h):
         import torch
         self.last_pred = h['pred']
-        if Leg.ASYNC_METRICS:
+        if Leg.ASYNC_METRICS or Leg.OWN_STREAM:
             # best-of-K on the call's own pipeline stream (it starts the moment the call's launch drains; as a kernel on the caller's stream it
             # queued ~0.5 ms for workgroup slots on a chip full of other calls' chains, with the next call's inputs behind it).  Nothing goes
             # onto the caller's stream here; whoever needs the call's outputs or its slot waits for the event (settle()).
@@ -252,6 +253,19 @@ class Leg:
             pred = self.model.inference(None)
             self.last_pred = self.model.diverse_pred            # contiguous [n, K, Tf, 2]
             return self.model.best_of_k(pred.permute(1, 0, 2, 3))
+        if Leg.OWN_STREAM:
+            # everything of call k on ITS pipeline stream, in order: metrics of the stream's previous call (k-3), H2D of the inputs, the latents,
+            # the launch -- no cross-stream event anywhere (depth 3 = the three streams: a slot is only ever reused by its own stream)
+            out = self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
+            st = self.model.next_async_stream(self.n)
+            if st is None:
+                raise RuntimeError('--own-stream needs the one-stream fused form')
+            with torch.cuda.stream(st):
+                self._load()
+                h = self.model.inference_async()
+            h['gt'] = self.model._future
+            self.pending.append(h)
+            return out
         if not Leg.ASYNC_METRICS:
             self._load()
             h = self.model.inference_async()                    # z is drawn on device exactly like Normal.rsample in the reference
@@ -667,6 +681,8 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
+    ap.add_argument('--no-sustained', action='store_true', help='skip the 80-step own-stream run (key sustained)')
+    ap.add_argument('--own-stream', action='store_true', help='experiment: H2D, latents, launch and metrics of a call all on its pipeline stream (use with --depth 3)')
     ap.add_argument('--ahead', type=int, default=0, help='host-side flow control: steps the host may enqueue beyond the device (0 = unbounded)')
     ap.add_argument('--async-metrics', action='store_true', help='best-of-K on the call\'s own pipeline stream (model.best_of_k_async) instead of a kernel on the caller\'s stream; measured neutral')
     ap.add_argument('--no-per-scene', action='store_true', help='skip the one-scene-per-call latency loop (key per_scene)')
@@ -700,6 +716,7 @@ def main():
     Leg.DEPTH = max(2, min(4, args.depth))
     Leg.ASYNC_METRICS = args.async_metrics
     Leg.AHEAD = max(0, args.ahead)
+    Leg.OWN_STREAM = args.own_stream
     if args.only_leg:
         # one leg alone (profiling passes: `rocprofv3 --kernel-trace --stats -- python3 bench.py --only-leg sdd_1024 --serial` gives that
         # leg's serial per-launch durations without the headline's launches of the same kernel in the table)
@@ -746,6 +763,20 @@ def main():
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
     r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
+    if not args.serial and not args.no_sustained:
+        # the same workload as a LONG run in the form a serving loop would use: every call's H2D, latents, launch and metrics on the call's own
+        # pipeline stream (model.next_async_stream), depth 3 -- 80 steps, so that filling and draining the pipeline weigh 1/4 of what they
+        # do in the 20-step contract run.  A second figure beside `value`, never `value` itself.
+        keep = (Leg.OWN_STREAM, head.depth, head.model.async_depth)
+        Leg.OWN_STREAM, head.depth, head.model.async_depth = True, 3, 3
+        head.model.reset_async()
+        try:
+            r3 = head.timed(80, 5, dist, 0)
+        finally:
+            Leg.OWN_STREAM, head.depth, head.model.async_depth = keep
+            head.model.reset_async()
+        out['sustained'] = {'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'steps': 80, 'warmup': 5,
+                            'form': 'H2D + latents + launch + best-of-K of a call all on its own pipeline stream, three streams, depth 3'}
     out['ms_per_step_incl_d2h'] = r2['ms_per_step']
 
     if not args.no_exploratory:

@@ -370,6 +370,9 @@ int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
  * fut [N][2][Tf] (HOST pointers, the loader's layout; fut may be NULL with Tf = 0) are transposed into a pinned ring slot and copied to
  * dev [N*Tp*2 + N*Tf*2] (DEVICE: past [N][Tp][2] followed by future [N][Tf][2]) with one asynchronous copy on `stream`. */
 int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream);
+/* The pipeline stream the next sttode_inference_*_async call of n agents will run on (*stream; NULL when the call will not take the
+ * one-stream fused form).  Inputs prepared on that stream, and the call issued from it, need no cross-stream event. */
+int sttode_async_next_stream(SttodeModel* m, int n, void** stream);
 /* Best-of-K ADE / FDE of an asynchronous call's predictions (utils/metrics.py:7-26, as sttode_best_of_k) enqueued on the pipeline stream
  * the call of `slot` runs on: the metrics start the moment the call's launch drains, in stream order.  Re-records the slot's completion
  * event behind them (sttode_wait(slot) then covers the metrics).  gt must have been written before the sttode_inference_*_async call

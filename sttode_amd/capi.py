@@ -81,6 +81,7 @@ SIGNATURES = {
     'sttode_debug_drop_role_flag': [_P, _I],
     'sttode_set_scene_launch': [_P, _I],
     'sttode_stage_scene': [_P, _P, _I, _I, _I, _P, _P],
+    'sttode_async_next_stream': [_P, _I, _P],
     'sttode_async_best_of_k': [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P],
     'sttode_fused_block_of': [_L, _L, _L, _L, _L],
     'sttode_set_ode': [_P, _I, _I],

@@ -679,6 +679,18 @@ extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pre
     return 0;
 }
 
+// The pipeline stream the NEXT asynchronous call of n agents will run on (fused launches: one stream per call, three in rotation), or NULL
+// when that call is not of the one-stream form.  A caller that prepares the call's inputs ON that stream (H2D copy, latents) and issues the
+// call from it needs no cross-stream event at all: the call's wait for the caller's stream is then a wait for itself.
+extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
+    STT_REQUIRE(m && stream && n > 0, "sttode_async_next_stream: bad arguments");
+    *stream = nullptr;
+    if (!use_fused(m, n)) return 0;
+    const int si = (int)(m->acalls % m->fused_streams);
+    *stream = si == 0 ? m->sB : si == 1 ? m->sB2 : si == 2 ? m->sA : m->sX[si - 3];
+    return 0;
+}
+
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");

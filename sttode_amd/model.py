@@ -193,6 +193,7 @@ class STTODENet(nn.Module):
         self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
         self._async_bufs = {}
         self._async_metrics = {}
+        self._ext_streams = {}
         self._ptr_cache = {}
         self._pf = self._pf_thunk = None
         self.to(self.device)
@@ -736,6 +737,20 @@ class STTODENet(nn.Module):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
         capi.call('sttode_wait', self.native().h, handle['slot'], capi.stream_ptr())
         return handle['pred'].permute(1, 0, 2, 3)
+
+    def next_async_stream(self, n):
+        """torch stream (an ExternalStream over the pipeline's own) the next inference_async() call of ``n`` agents will run on, or None
+        when that call will not take the one-stream fused form.  Work enqueued there before the call -- the H2D copy of its inputs, the
+        latents -- is ordered in front of it without any cross-stream event:  ``with torch.cuda.stream(s): load(); h = m.inference_async()``."""
+        import ctypes
+        out = ctypes.c_void_p(0)
+        capi.call('sttode_async_next_stream', self.native().h, int(n), ctypes.addressof(out))
+        if not out.value:
+            return None
+        st = self._ext_streams.get(out.value)
+        if st is None:
+            st = self._ext_streams[out.value] = torch.cuda.ExternalStream(out.value, device=self.device)
+        return st
 
     def best_of_k_async(self, handle, gt=None, scale=1.0):
         """Min-over-K ADE / FDE per agent of an inference_async() call, enqueued on the pipeline stream the call runs on (they start the

@@ -912,6 +912,58 @@ def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_s
     m.reset_async()
 
 
+def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial():
+    """next_async_stream: the H2D copy of a call's inputs, its latents and the call itself all enqueued on the pipeline stream the call
+    will run on (no cross-stream event anywhere), metrics on that stream too -- nine calls over the three streams, depth 3 -- give the
+    predictions and best-of-K values of the serial calls, bit for bit, with latents from the same generator sequence."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    old_depth = m.async_depth
+    host = []
+    for v in range(3):
+        sb = scenes.make_scene_batch(range(7200 + 70 * v, 7270 + 70 * v), 'eth')
+        host.append((torch.from_numpy(sb.past).pin_memory(), torch.from_numpy(sb.future).pin_memory(), torch.from_numpy(sb.scene_ptr).to(m.device)))
+    try:
+        m.native().set_chain(1)
+        torch.manual_seed(21)
+        ref = []
+        for i in range(9):
+            past, fut, ptr = host[i % 3]
+            m.set_scene_batch(past.to(m.device), fut.to(m.device), ptr)
+            out = m.inference(None)
+            a, f = m.best_of_k(out.permute(1, 0, 2, 3))
+            ref.append((out.clone(), a.clone(), f.clone()))
+        m.reset_async()
+        m.async_depth = 3
+        torch.manual_seed(21)
+        pend, got = [], []
+        for i in range(9):
+            past, fut, ptr = host[i % 3]
+            if len(pend) >= 3:
+                h = pend.pop(0)
+                got.append((h, m.best_of_k_async(h)))             # on the stream of call i-3 == the stream of call i, ahead of it
+            st = m.next_async_stream(past.shape[0])
+            assert st is not None
+            with torch.cuda.stream(st):
+                m.set_scene_batch(past.to(m.device, non_blocking=True), fut.to(m.device, non_blocking=True), ptr)
+                pend.append(m.inference_async())
+        while pend:
+            h = pend.pop(0)
+            got.append((h, m.best_of_k_async(h)))
+        for h, _ in got:
+            m.wait(h)
+        torch.cuda.synchronize()
+        # slots are reused every third call: only the last three calls' buffers still hold their own results
+        for i in (6, 7, 8):
+            h, (a, f) = got[i]
+            assert torch.equal(h['pred'].permute(1, 0, 2, 3), ref[i][0]), f'call {i}: predictions differ'
+            assert torch.equal(a, ref[i][1]) and torch.equal(f, ref[i][2]), f'call {i}: metrics differ'
+    finally:
+        m.async_depth = old_depth
+        m.native().set_chain(-1)
+        m.reset_async()
+
+
 def test_async_latents_follow_the_same_generator_sequence_as_serial_calls():
     """inference_async(z=None) draws its latents from torch's generator at call time, like inference(None): the same seed gives the same
     predictions call by call, whether the calls are pipelined or serial."""
