@@ -79,6 +79,7 @@ struct ChainArgs {
     int persistent;  // 1: workgroups pull groups from the work queue until it is empty; 0: one group per workgroup (grid = groups)
     long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS / C32_DIAG_TRACE): per-workgroup stamps
     int trace_tag;   // diagnostic builds only: launch number
+    int xcd_map;     // fused launch, roles in front: group blocks b, b + 8, b + 16, .. (dispatched to ONE XCD) take consecutive group ids
     RoleArgs R;      // fused launch only (traj_chain_kernel<NY, true>)
 };
 
@@ -639,6 +640,16 @@ __host__ __device__ __forceinline__ int fused_block_of(long b, long T, long G, l
     return -1 - (int)(b - (lo + 1));
 }
 
+// XCD-aware group order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  A 16-agent tile's
+// table rows (3 x 2 KiB per agent, written through to memory by its role) are read by the 2-3 trajectory groups of its 320 trajectories; in
+// plain block order those are consecutive blocks = different XCDs, and every one of them fetches the rows from the fabric again.  With
+// group id = (blocks of one XCD get a contiguous range) the sharers run behind the same L2.  A permutation of which block computes which
+// group: results unchanged; producers (roles) still precede every group.
+__host__ __device__ __forceinline__ int xcd_group(int b, int G) {
+    const int x = b & 7, i = b >> 3, q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + i;
+}
+
 template <int NY, bool FUSE, bool B3M>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     typedef ChainStreamT<B3M ? C32_BUF_B3 : C32_CMAX * C32_TILE, B3M> Stream;   // B3M: exploratory bf16-split mode (block-0 MLPs)
@@ -665,8 +676,9 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         C32_TRACE_END(1);
         return;
     }
-    const int fb = !FUSE ? (int)blockIdx.x : A.R.split ? (int)blockIdx.x - 5 * A.R.ntiles
-                                                      : fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead);
+    int fb = !FUSE ? (int)blockIdx.x : A.R.split ? (int)blockIdx.x - 5 * A.R.ntiles
+                                                : fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead);
+    if (FUSE && A.xcd_map && fb >= 0) fb = xcd_group(fb, ngroups);   // (roles in front: fb was the group block's position in dispatch order)
     if (FUSE && fb < 0) {   // (uniform) a per-agent role
         agent_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, -1 - fb, smem);
         C32_TRACE_END(1);
@@ -985,7 +997,7 @@ static int traj_chain_impl(const float* A0x, const float* A0y, const float* A1y,
     a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
     a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
     a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
-    a.dbg = nullptr; a.trace_tag = 0;
+    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0;
     a.R = RoleArgs();   // unused by the unfused instantiation
     {
         static int pers = -1;   // default 0: one group per workgroup (slots free up continuously, so kernels of other streams -- the next
@@ -1051,7 +1063,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     a.prog_len = prog_len;
     a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.cur = ws + off[STT_B_CUR];
     a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
-    a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0;
+    a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0;
 #if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
     a.dbg = g_chain_dbg;
     a.trace_tag = g_trace_tag++;
@@ -1067,6 +1079,11 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside
     // other roles, and holds its slot all the while
     r.lead = lead < 0 ? (1 << 28) : lead;
+    {   // XCD-aware group order whenever all roles sit in front of the groups (STTODE_XCD_MAP=0: plain block order, for A/B)
+        static int xm = -1;
+        if (xm < 0) { const char* e = getenv("STTODE_XCD_MAP"); xm = e ? atoi(e) != 0 : 1; }
+        a.xcd_map = xm && lead < 0;
+    }
     r.split = lead == -2;   // -2: roles first, each tile's role split into E | G | three table workgroups (default); -1: one workgroup per tile
     r.gflags = r.flags + r.ntiles + 1; r.pflags = r.gflags + r.ntiles;
     r.drop_tile = drop_tile;
