@@ -759,7 +759,7 @@ def test_random_latents_follow_torch_generator():
 
 
 @pytest.mark.parametrize('case', ['one_agent', 'two_agents', 'eth_scene', 'tile_edge_16', 'tile_edge_17', 'three_scenes', 'sdd_like_40', 'k_7',
-                                  'long_16_24', 'short_4_6'])
+                                  'long_16_24', 'short_4_6', 'twenty_small_scenes'])
 def test_one_launch_scene_form_is_bitwise_the_six_launch_form(case):
     """A serial scene call below the chain threshold -- the reference's evaluation loop hands over ONE scene per call (test.py:171-188) --
     runs as ONE launch whose workgroups take the roles front-end + per-agent stage / block-0 decoder_y / block-0 decoder_x -> block-1 GRU
@@ -794,12 +794,23 @@ def test_one_launch_scene_form_is_bitwise_the_six_launch_form(case):
         m7 = STTODENet(a7, _gpu()).eval()
         m7.load_state_dict(m.state_dict(), strict=True)
         m = m7
+    if case == 'twenty_small_scenes':   # 20 scenes of 1-4 agents each (61 agents): every 16-agent tile spans several scenes, the roles' scene search runs deep
+        parts, ptr = [], [0]
+        for i, sid in enumerate(range(6300, 6320)):
+            o, p_ = scenes.eth_scene(sid)
+            k = 1 + (i * 7) % 4
+            parts.append((o[:k].transpose(0, 2, 1), p_[:k].transpose(0, 2, 1)))
+            ptr.append(ptr[-1] + k)
+        past = np.ascontiguousarray(np.concatenate([a for a, _ in parts]))
+        fut = np.ascontiguousarray(np.concatenate([b for _, b in parts]))
+        ptr = np.asarray(ptr, dtype=np.int32)
+        ids, sb = 'built', None
     if ids is None:     # scenes accumulated until the agent count is exactly the wanted one (the last scene is cut): tile edges
         want = {'one_agent': 1, 'tile_edge_16': 16, 'tile_edge_17': 17, 'sdd_like_40': 40}[case]
         sb = scenes.make_scene_batch(range(6100, 6140), 'eth', Tp, Tf)
         ptr = [int(p) for p in sb.scene_ptr if int(p) < want] + [want]
         past, fut, ptr = sb.past[:want], sb.future[:want], np.asarray(ptr, dtype=np.int32)
-    else:
+    elif ids != 'built':
         sb = scenes.make_scene_batch(ids, 'eth', Tp, Tf)
         past, fut, ptr = sb.past, sb.future, sb.scene_ptr
     n = past.shape[0]
