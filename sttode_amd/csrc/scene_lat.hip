@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
         const int cur = gru_bal_body<TPX, true>(nullptr, A.convP, A.convB, A.wihP, A.whhP, A.gbias, nullptr, ncols, A.Tp, tile, sH, sX, sD);
         SL_STAMP(4);
         if (wave == 0) {   // A1y rows of this tile's agents and y_hat0 of this tile (both producers started long ago)
-            const bool ok = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane) & wait_tiles(A.yflags, tile, tile, A.tmo, lane);
+            const bool ok1 = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane);   // (both waits run: each ends with the acquire its data needs)
+            const bool ok = wait_tiles(A.yflags, tile, tile, A.tmo, lane) && ok1;
             if (!ok && lane == 0) s_ok = 0;
         }
         __syncthreads();
