@@ -21,7 +21,11 @@ The JSON line carries
   parity       : HIP vs oracle on the sampled scenes with injected latents (max relative coordinate error, ADE/FDE);
   configs      : secondary legs for BASELINE configs 2-5 at the per-GPU share each config implies (UCY-mixed 2048/8 = 256 scenes,
                  SDD 1024/4 = 256 scenes, NBA B=128 x 11 agents (test.py:616-622), NBA long horizon 4096/8 = 512 scenes x 10 agents,
-                 obs 10 / pred 40), each with ms_per_step, trajectories/s, its dominant kernel's roofline and a short CPU sample.
+                 obs 10 / pred 40), each with ms_per_step, trajectories/s, its dominant kernel's roofline and a short CPU sample;
+  sustained    : the headline workload as an 80-step run in the form a serving loop would use (every call's H2D, latents, launch and
+                 metrics on the call's own pipeline stream; model.next_async_stream) -- a second figure, never `value`;
+  per_scene    : the reference's evaluation call pattern, ONE scene per call (set_data + inference + .cpu(), test.py:171-188): ms per scene;
+  train        : training steps/s of the train.py loop, with its own CPU baseline.
 """
 import argparse
 import json
