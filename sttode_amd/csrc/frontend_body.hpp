@@ -19,7 +19,8 @@ template <bool SC1, int TMAX = 0>
 __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict__ seq, int T, int TPX, int vel_from_norm, float ox, float oy,
                                                   int last, const float* __restrict__ prev_last,  // optional [n][2]: frame preceding seq, world coords
                                                   float* __restrict__ xpad, float* __restrict__ enc_in, float* __restrict__ cur,
-                                                  float* __restrict__ orig, int* __restrict__ last_flag) {
+                                                  float* __restrict__ orig, int* __restrict__ last_flag,
+                                                  const float2* __restrict__ preloaded = nullptr) {   // TMAX > 0: the track, read by the caller ahead of time
     const float* p = seq + (size_t)a * T * 2;
     float* xp = xpad ? xpad + (size_t)a * 16 * TPX : nullptr;
     float pnx = 0.f, pny = 0.f, pwx = 0.f, pwy = 0.f;  // previous frame: normalised / world
@@ -34,7 +35,7 @@ __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict
     if (TMAX > 0) {
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
-            if (t < T) wb[t] = reinterpret_cast<const float2*>(p)[t];
+            if (t < T) wb[t] = preloaded ? preloaded[t] : reinterpret_cast<const float2*>(p)[t];
     }
 #pragma unroll
     for (int t = 0; t < (TMAX > 0 ? TMAX : T); ++t) {
