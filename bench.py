@@ -767,7 +767,7 @@ def main():
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
     r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
-    if not args.serial and not args.no_sustained:
+    if not args.serial and not args.no_sustained and world == 1:   # (single-GPU figure; the multi-rank runs keep to the contract's regions)
         # the same workload as a LONG run in the form a serving loop would use: every call's H2D, latents, launch and metrics on the call's own
         # pipeline stream (model.next_async_stream), depth 3 -- 80 steps, so that filling and draining the pipeline weigh 1/4 of what they
         # do in the 20-step contract run.  A second figure beside `value`, never `value` itself.
