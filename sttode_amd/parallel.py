@@ -4,8 +4,8 @@ The ETH/UCY/SDD path shards embarrassingly: scenes are independent units (pedest
 own scene's origin and last-agent flag; the reference's attention length is 1), so ranks take
 contiguous scene ranges balanced by agent count and run the whole hot path locally with replicated weights.  There
 is NO data-path collective.  Only the results are exchanged:
-  * gather_futures: one variable-size all-gather of the predicted futures [n_r, K, Tf, 2] (padded to the largest
-    shard; over xGMI every rank writes its shard to its 7 peers directly), or
+  * gather_futures: ONE all_gather_into_tensor of the predicted futures [n_r, K, Tf, 2] (padded to the largest shard, preallocated
+    receive buffer, no count exchange when the partition is deterministic; over xGMI every rank writes its shard to its 7 peers directly), or
   * reduce_metrics: a 3-scalar all-reduce of (sum ADE, sum FDE, agents) when only metrics are needed.
 NBA path: the independent unit is the forward-call batch ("attention group", e.g. 128 scenes, test.py:618): whole
 groups go to ranks (shard_groups); results then match the reference exactly.
@@ -34,22 +34,62 @@ def _coll_device(t, group=None):
     return torch.device('cpu') if dist.get_backend(group) == 'gloo' else t.device
 
 
-def gather_futures(pred_local, group=None):
-    """All-gather of per-rank rows [n_r, ...] (n_r differs per rank, may be 0) -> [sum n_r, ...] in rank order, on the caller's device."""
+_GATHER_BUFS = {}    # (device, dtype, world, nmax, row shape) -> ([world * nmax, ...] receive buffer, [nmax, ...] send buffer)
+_GATHER_INDEX = {}   # (device, counts, nmax) -> row indices of the live rows in the padded receive buffer (rank order)
+
+
+def shard_counts(scene_ptr, world):
+    """Agents per rank of shard_scene_batch's partition.  shard_scenes is a pure function of (scene_ptr, world), so EVERY rank derives
+    every rank's row count locally: gather_futures(..., counts=shard_counts(...)) needs no count exchange."""
+    ptr = np.asarray(scene_ptr, np.int64)
+    return [int(ptr[s1] - ptr[s0]) for s0, s1 in shard_scenes(ptr, world)]
+
+
+def gather_futures(pred_local, group=None, counts=None):
+    """All-gather of per-rank rows [n_r, ...] (n_r differs per rank, may be 0) -> [sum n_r, ...] in rank order, on the caller's device.
+
+    ONE collective: ``all_gather_into_tensor`` of the shard, padded to the largest one, into a preallocated [world * nmax, ...] buffer
+    (cached per shape; over xGMI every rank writes its rows to its 7 peers directly -- the result is what the reference's metric path wants
+    in one place, test.py:194,526; its only distributed code: core/utils.py:370-389).  ``counts`` = every rank's row count, known on every
+    rank whenever the partition is deterministic (shard_counts; equal shards of a weak-scaling run): no count exchange.  Without it the
+    counts travel first as one [world] int64 all-gather.  Equal shards come back as a view of the receive buffer (no copy); ragged ones are
+    compacted by one index_select with a cached index.  The returned tensor aliases the cache until the next call of the same shape."""
     world = dist.get_world_size(group)
     if world == 1:
         return pred_local
     cdev = _coll_device(pred_local, group)
-    n_local = torch.tensor([pred_local.shape[0]], dtype=torch.int64, device=cdev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c) for c in counts]
+    if counts is None:
+        mine = torch.tensor([pred_local.shape[0]], dtype=torch.int64, device=cdev)
+        allc = torch.empty(world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(allc, mine, group=group)
+        counts = allc.tolist()
+    counts = tuple(int(c) for c in counts)
+    if len(counts) != world or counts[dist.get_rank(group)] != pred_local.shape[0]:
+        raise ValueError(f'gather_futures: counts {counts} do not describe {world} ranks with {pred_local.shape[0]} rows on this one')
     nmax = max(max(counts), 1)
-    pad = torch.zeros((nmax,) + tuple(pred_local.shape[1:]), dtype=pred_local.dtype, device=cdev)
-    pad[: pred_local.shape[0]] = pred_local.to(cdev)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(pred_local.device)
+    row = tuple(pred_local.shape[1:])
+    key = (cdev, pred_local.dtype, world, nmax, row)
+    if key not in _GATHER_BUFS:
+        if len(_GATHER_BUFS) > 16:
+            _GATHER_BUFS.clear()
+        _GATHER_BUFS[key] = (torch.empty((world * nmax,) + row, dtype=pred_local.dtype, device=cdev),
+                             torch.zeros((nmax,) + row, dtype=pred_local.dtype, device=cdev))
+    recv, send = _GATHER_BUFS[key]
+    if pred_local.shape[0] == nmax and pred_local.device == cdev and pred_local.is_contiguous():
+        send = pred_local                                        # the shard itself is the send buffer
+    else:
+        send[: pred_local.shape[0]].copy_(pred_local)            # (rows past n_r keep their zeros / stale rows: they are never read)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    if all(c == nmax for c in counts):
+        out = recv
+    else:
+        ikey = (cdev, counts, nmax)
+        if ikey not in _GATHER_INDEX:
+            if len(_GATHER_INDEX) > 64:
+                _GATHER_INDEX.clear()
+            _GATHER_INDEX[ikey] = torch.cat([torch.arange(r * nmax, r * nmax + c, dtype=torch.int64) for r, c in enumerate(counts)]).to(cdev)
+        out = recv.index_select(0, _GATHER_INDEX[ikey])
+    return out if out.device == pred_local.device else out.to(pred_local.device)
 
 
 def infer_sharded(model, sb, rank, world, z=None, group=None, gather=True):
@@ -77,7 +117,7 @@ def infer_sharded(model, sb, rank, world, z=None, group=None, gather=True):
         sums = tuple(t.cpu() for t in sums)
     metrics = reduce_metrics(sums[0], sums[1], local.n_agents, group=group)
     if gather and multi:
-        pred = gather_futures(pred.permute(1, 0, 2, 3).contiguous(), group=group).permute(1, 0, 2, 3)
+        pred = gather_futures(pred.permute(1, 0, 2, 3).contiguous(), group=group, counts=shard_counts(sb.scene_ptr, world)).permute(1, 0, 2, 3)
     return pred, metrics
 
 

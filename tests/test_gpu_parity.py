@@ -538,17 +538,18 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         m.reset_async()
 
 
-@pytest.mark.parametrize('case', ['eth_N2', 'eth_N7', 'eth_N32', 'sdd_ragged', 'nba_B4', 'nba_B32', 'nba_B128', 'nba_long_B8'])
-def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
-    """The exploratory mode against the REFERENCE's own vectors (tests/golden/*.npz), at the same rtol 1e-4 + atol 1e-4 as the fp32 path:
-    every golden inference case pushed through the fused chain launch (forced: these batches are below the automatic threshold) with the
-    three-way bf16 split -- ETH N = 2 / 7 / 32, the four ragged SDD scenes in one batch, NBA B = 4 / 32 / 128, the long horizon."""
+GOLDEN_INFERENCE_CASES = ['eth_N2', 'eth_N7', 'eth_N32', 'sdd_ragged', 'nba_B4', 'nba_B32', 'nba_B128', 'nba_long_B8']
+
+
+def _golden_inference_case(golden, case, what):
+    """-> (model, feed(), z, check(out)) of one reference-golden inference case (tests/golden/*.npz: inputs, injected latents and the
+    REFERENCE's own inference() output): ETH N = 2 / 7 / 32, the four ragged SDD scenes in one batch, NBA B = 4 / 32 / 128, the long horizon."""
     from sttode_amd import scenes
     g = golden(case)
     if case.startswith('eth_N'):
         m = hip_model('eth', 8, 12)
         feed = lambda: m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
-        z, check = g['z'], lambda out: assert_close(out, g['out'], what=f'{case}: bf16x3 vs reference')
+        z, check = g['z'], lambda out: assert_close(out, g['out'], what=f'{case}: {what} vs reference')
     elif case == 'sdd_ragged':
         m = hip_model('eth', 8, 12)
         past = np.concatenate([g[f's{i}_obs'].transpose(0, 2, 1) for i in range(4)])
@@ -559,7 +560,7 @@ def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
 
         def check(out):
             for i in range(4):
-                assert_close(out[:, ptr[i]:ptr[i + 1]], g[f's{i}_out'], what=f'{case} scene {i}: bf16x3 vs reference')
+                assert_close(out[:, ptr[i]:ptr[i + 1]], g[f's{i}_out'], what=f'{case} scene {i}: {what} vs reference')
     else:
         Tp, Tf, N = (10, 40, 10) if case == 'nba_long_B8' else (5, 10, 11)
         m = hip_model('nba', Tp, Tf)
@@ -570,7 +571,16 @@ def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
             d, z, st = scenes.nba_batch(int(g['nba_seed']), B), scenes.latents(int(g['z_seed']), B * 11), int(g['stride'])
         data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
         feed = lambda: m.set_data_nba(data)
-        check = lambda out: assert_close(out[:, ::st], g['out'], what=f'{case}: bf16x3 vs reference')
+        check = lambda out: assert_close(out[:, ::st], g['out'], what=f'{case}: {what} vs reference')
+    return m, feed, z, check
+
+
+@pytest.mark.parametrize('case', GOLDEN_INFERENCE_CASES)
+def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
+    """The exploratory mode against the REFERENCE's own vectors (tests/golden/*.npz), at the same rtol 1e-4 + atol 1e-4 as the fp32 path:
+    every golden inference case pushed through the fused chain launch (forced: these batches are below the automatic threshold) with the
+    three-way bf16 split -- ETH N = 2 / 7 / 32, the four ragged SDD scenes in one batch, NBA B = 4 / 32 / 128, the long horizon."""
+    m, feed, z, check = _golden_inference_case(golden, case, 'bf16x3')
     try:
         m.native().set_chain(1)
         m.mfma_mode = 'bf16x3'
@@ -580,6 +590,82 @@ def test_exploratory_bf16x3_mode_vs_reference_golden(golden, case):
         m.mfma_mode = 'f32'
         m.native().set_chain(-1)
     check(out)
+
+
+@pytest.mark.parametrize('case', GOLDEN_INFERENCE_CASES)
+def test_headline_f32_chain_launch_vs_reference_golden(golden, case):
+    """The HEADLINE kernel (the fp32 chain launch that carries `value` in bench.py: traj_chain_kernel, model/STTODE.py:574-623 as one launch
+    per call) against the REFERENCE's own vectors at rtol 1e-4 + atol 1e-4: every golden inference case is forced through it (these batches
+    sit below the automatic threshold, where the per-scene and three-kernel forms would run) -- once as a serial call and once through the
+    pipelined product path (inference_async / wait: the form bench.py times), which must agree with the serial call to fp32 rounding."""
+    m, feed, z, check = _golden_inference_case(golden, case, 'f32 chain launch')
+    zt = torch.from_numpy(z)
+    try:
+        m.native().set_chain(1)
+        m.reset_async()
+        feed()
+        out = m.inference(None, z=zt).cpu().numpy()
+        hs = []
+        for _ in range(3):                                  # three calls in flight, as in the bench; every one must carry the same answer
+            feed()
+            hs.append(m.inference_async(z=zt))
+        outs = [m.wait(h).cpu().numpy() for h in hs]
+    finally:
+        m.native().set_chain(-1)
+        m.reset_async()
+    assert np.isfinite(out).all()
+    check(out)
+    for o in outs:
+        check(o)
+        assert_close(o, out, rtol=2e-5, atol=2e-5, what=f'{case}: pipelined vs serial chain launch')
+
+
+@pytest.mark.parametrize('case', ['ucy_256', 'sdd_256', 'nba_128', 'nba_long_64'])
+def test_headline_f32_chain_launch_vs_oracle_at_leg_sizes(case):
+    """The fp32 chain launch at the per-GPU sizes of bench.py's secondary legs (BASELINE configs 2-5: UCY-mixed 256 scenes, SDD 256 ragged
+    scenes, NBA B = 128 x 11, NBA long horizon at obs 10 / pred 40), DIRECTLY against the CPU oracle at rtol 1e-4 + atol 1e-4
+    (sampled scenes for the scene batches; the NBA groups are one attention group, so the oracle runs the whole batch -- the long-horizon
+    group is compared on a 64-scene attention group of the same shapes, which the oracle finishes in seconds), serial and pipelined."""
+    from sttode_amd import scenes
+    if case in ('ucy_256', 'sdd_256'):
+        m, ora = hip_model('eth', 8, 12), oracle_model('eth', 8, 12)
+        sb = scenes.make_scene_batch(range(0, 256), case[:3])
+        z = scenes.latents(77, sb.n_agents)
+        feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    else:
+        Tp, Tf, B, N = (5, 10, 128, 11) if case == 'nba_128' else (10, 40, 64, 10)
+        m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+        d = scenes.nba_batch(7000, B, N=N, obs_len=Tp, pred_len=Tf)
+        z = scenes.latents(78, B * N)
+        data = {'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])}
+        feed = lambda: m.set_data_nba(data)
+    zt = torch.from_numpy(z)
+    try:
+        m.native().set_chain(1)
+        m.reset_async()
+        feed()
+        out = m.inference(None, z=zt).cpu().numpy()
+        feed()
+        h = m.inference_async(z=zt)
+        outp = m.wait(h).cpu().numpy()
+    finally:
+        m.native().set_chain(-1)
+        m.reset_async()
+    assert np.isfinite(out).all() and np.isfinite(outp).all()
+    assert_close(outp, out, rtol=2e-5, atol=2e-5, what=f'{case}: pipelined vs serial chain launch')
+    if case in ('ucy_256', 'sdd_256'):
+        for s in range(0, sb.n_scenes, 19):
+            a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+            obs, pred = sb.scene(s)
+            ref = oracle_scene_inference(ora, obs, pred, z[a * 20:b * 20])
+            assert_close(out[:, a:b], ref, what=f'{case} scene {s}: f32 chain launch vs oracle')
+            assert_close(outp[:, a:b], ref, what=f'{case} scene {s}: pipelined f32 chain launch vs oracle')
+    else:
+        with torch.no_grad():
+            ora.set_data_nba(data)
+            ref = ora.inference(data, z=zt).numpy()
+        assert_close(out, ref, what=f'{case}: f32 chain launch vs oracle')
+        assert_close(outp, ref, what=f'{case}: pipelined f32 chain launch vs oracle')
 
 
 @pytest.mark.parametrize('case', ['eth_512', 'eth_61', 'sdd', 'nba_128', 'nba_long'])

@@ -32,7 +32,15 @@ def _worker(rank, world, port, q):
     a0 = int(sb.scene_ptr[s0])
     zl = z[a0 * 20:(a0 + local.n_agents) * 20]
     pred = torch.from_numpy(_local_predictions(local, zl))
-    full = parallel.gather_futures(pred)
+    full = parallel.gather_futures(pred, counts=parallel.shard_counts(sb.scene_ptr, world)).clone()   # ONE collective: every rank derives the counts
+    assert torch.equal(parallel.gather_futures(pred), full)                      # counts exchanged instead: the same rows
+    same = parallel.gather_futures(torch.full((3, 2), float(rank)), counts=[3] * world)   # equal shards: a view of the receive buffer
+    assert same.shape == (3 * world, 2) and all(float(same[3 * r, 0]) == r for r in range(world))
+    try:
+        parallel.gather_futures(pred, counts=[1] * world)
+        raise AssertionError('wrong counts were accepted')
+    except ValueError:
+        pass
     ade, fde = best_of_k_ade_fde(pred.numpy(), local.future)
     g = parallel.reduce_metrics(float(ade.sum()), float(fde.sum()), local.n_agents)
     if rank == 0:
