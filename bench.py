@@ -22,8 +22,8 @@ The JSON line carries
   configs      : secondary legs for BASELINE configs 2-5 at the per-GPU share each config implies (UCY-mixed 2048/8 = 256 scenes,
                  SDD 1024/4 = 256 scenes, NBA B=128 x 11 agents (test.py:616-622), NBA long horizon 4096/8 = 512 scenes x 10 agents,
                  obs 10 / pred 40), each with ms_per_step, trajectories/s, its dominant kernel's roofline and a short CPU sample;
-  sustained    : the headline workload as an 80-step run in the form a serving loop would use (every call's H2D, latents, launch and
-                 metrics on the call's own pipeline stream; model.next_async_stream) -- a second figure, never `value`;
+  sustained    : the headline workload, the same step, as an 80-step run (pipeline fill and drain weigh 1/4 of the 20-step run's)
+                 -- a second figure, never `value`;
   per_scene    : the reference's evaluation call pattern, ONE scene per call (set_data + inference + .cpu(), test.py:171-188): ms per scene;
   train        : training steps/s of the train.py loop, with its own CPU baseline.
 """
@@ -163,10 +163,7 @@ LEGS = {
 
 
 class Leg:
-    DEPTH = 4
-    ASYNC_METRICS = False
-    AHEAD = 0
-    OWN_STREAM = False
+    STREAMS = 2      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
         import torch
@@ -207,7 +204,7 @@ class Leg:
             v.copy_(t)
         self.host = views(self.host_buf)
         self.h2d_bytes = sum(t.numel() * t.element_size() for t in self.host)
-        self.depth = Leg.DEPTH                                    # calls in flight (= model.async_depth): device input slots
+        self.depth = 2 * Leg.STREAMS                              # calls in flight (= model.async_depth): device input / workspace slots
         self.model.async_depth = self.depth
         self.slot_bufs = [torch.empty(tot, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
         self.slots = [views(b) for b in self.slot_bufs]
@@ -227,16 +224,11 @@ class Leg:
             self.model.set_data_nba({'past_traj': slot[0], 'future_traj': slot[1]})
 
     def _finish(self, h):
-        import torch
+        # best-of-K on the call's own pipeline stream, behind the launch that carries its trajectory groups (stream order, no event).
+        # Nothing goes onto the caller's stream here; whoever needs the call's outputs or its slot waits for the event (settle()).
         self.last_pred = h['pred']
-        if Leg.ASYNC_METRICS or Leg.OWN_STREAM:
-            # best-of-K on the call's own pipeline stream (it starts the moment the call's launch drains; as a kernel on the caller's stream it
-            # queued ~0.5 ms for workgroup slots on a chip full of other calls' chains, with the next call's inputs behind it).  Nothing goes
-            # onto the caller's stream here; whoever needs the call's outputs or its slot waits for the event (settle()).
-            self.unsettled = h
-            return self.model.best_of_k_async(h, gt=h['gt'])   # per-agent (ade, fde) of the slot; summed ONCE, after the last step
-        pred = self.model.wait(h)                               # [K, n, Tf, 2] (a permuted view of the contiguous [n, K, Tf, 2] buffer)
-        return self.model.best_of_k(pred.permute(1, 0, 2, 3), gt=h['gt'])
+        self.unsettled = h
+        return self.model.best_of_k_async(h, gt=h['gt'])       # per-agent (ade, fde) of the slot; summed ONCE, after the last step
 
     def settle(self):
         """(an event wait on the caller's stream, no kernel) the latest finished call's launch and metrics are complete: its futures may be
@@ -251,41 +243,27 @@ class Leg:
         return torch.stack((af[0].sum(), af[1].sum(), self.n_dev))   # local sums; ONE all-reduce after the last step
 
     def step(self, serial=False):
+        """ONE step form for the headline and every leg.  Pipelined (default): everything of call k is enqueued on ITS pipeline stream, in
+        order -- H2D of the inputs, the latents, the launch (its per-agent roles + the trajectory groups of the call made STREAMS calls
+        earlier on that stream), then the metrics of that earlier call -- so there is no cross-stream event anywhere, and no stream carries
+        a chain of small kernels that every step has to wait for (round 3's default step kept H2D, latents and metrics on the caller's
+        stream: starved by the chain launches they take ~1 ms each there and became the critical path in long runs,
+        profiles/r04/cadence_default_80.txt)."""
         import torch
         if serial:
             self._load()
             pred = self.model.inference(None)
             self.last_pred = self.model.diverse_pred            # contiguous [n, K, Tf, 2]
             return self.model.best_of_k(pred.permute(1, 0, 2, 3))
-        if Leg.OWN_STREAM:
-            # everything of call k on ITS pipeline stream, in order: metrics of the stream's previous call (k-3), H2D of the inputs, the latents,
-            # the launch -- no cross-stream event anywhere (depth 3 = the three streams: a slot is only ever reused by its own stream)
-            out = self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
-            st = self.model.next_async_stream(self.n)
-            if st is None:
-                raise RuntimeError('--own-stream needs the one-stream fused form')
-            with torch.cuda.stream(st):
-                self._load()
-                h = self.model.inference_async()
-            h['gt'] = self.model._future
-            self.pending.append(h)
-            return out
-        if not Leg.ASYNC_METRICS:
+        st = self.model.next_async_stream(self.n)
+        if st is None:
+            raise RuntimeError('bench.py: the workload does not take the pipelined chain form')
+        with torch.cuda.stream(st):
             self._load()
             h = self.model.inference_async()                    # z is drawn on device exactly like Normal.rsample in the reference
-            h['gt'] = self.model._future
-            self.pending.append(h)
-            return self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth else None
-        # Order of a pipelined step k (depth 4, three pipeline streams in rotation): the call finished in step k-1 (k-4) is settled, so its
-        # input slot -- this step's -- may be overwritten; the metrics of call k-3 go onto ITS stream, which is also call k's, BEFORE
-        # call k's launch is enqueued there (behind it they would wait for call k to finish and hold call k+1's slot).
-        self.settle()
-        self._load()
-        out = self._finish(self.pending.pop(0)) if len(self.pending) >= self.depth - 1 else None
-        h = self.model.inference_async()
         h['gt'] = self.model._future
         self.pending.append(h)
-        return out
+        return self._finish(self.pending.pop(0)) if len(self.pending) > Leg.STREAMS else None
 
     def drain(self):
         out = None
@@ -315,16 +293,8 @@ class Leg:
         gc.collect()
         gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
         t0 = time.perf_counter()
-        ahead = []                                                # host-side flow control: at most Leg.AHEAD steps enqueued beyond the device
         for _ in range(steps):
-            if Leg.AHEAD > 0 and not serial:
-                if len(ahead) >= Leg.AHEAD:
-                    ahead.pop(0).synchronize()
-                ev = torch.cuda.Event()
             r = self.step(serial)
-            if Leg.AHEAD > 0 and not serial:
-                ev.record()
-                ahead.append(ev)
             if r is not None:
                 acc = r
                 if d2h or gather:
@@ -673,8 +643,6 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--time-every', type=int, default=4, help='bracket the kernels of every n-th step with HIP events (0 = never)')
     ap.add_argument('--serial', action='store_true', help='no cross-step pipelining (one inference() per step)')
-    ap.add_argument('--depth', type=int, default=4, help='calls in flight of the software pipeline (2..4): workspace / prediction slots; the launches rotate over three streams')
-    ap.add_argument('--col-parts', type=int, default=0, help='column parts pipelined over streams (0 = library default)')
     ap.add_argument('--legs', default='all', help="secondary legs: 'all', 'none' or a comma list of " + ','.join(k for k in LEGS if k != 'eth_512'))
     ap.add_argument('--leg-steps', type=int, default=40)
     ap.add_argument('--only-leg', default='', help='run ONE leg alone (profiling passes) and print a short line')
@@ -686,9 +654,6 @@ def main():
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
     ap.add_argument('--no-sustained', action='store_true', help='skip the 80-step own-stream run (key sustained)')
-    ap.add_argument('--own-stream', action='store_true', help='experiment: H2D, latents, launch and metrics of a call all on its pipeline stream (use with --depth 3)')
-    ap.add_argument('--ahead', type=int, default=0, help='host-side flow control: steps the host may enqueue beyond the device (0 = unbounded)')
-    ap.add_argument('--async-metrics', action='store_true', help='best-of-K on the call\'s own pipeline stream (model.best_of_k_async) instead of a kernel on the caller\'s stream; measured neutral')
     ap.add_argument('--no-per-scene', action='store_true', help='skip the one-scene-per-call latency loop (key per_scene)')
     ap.add_argument('--no-exploratory', action='store_true', help='skip the exploratory bf16x3 region (key exploratory_bf16x3)')
     ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
@@ -717,10 +682,8 @@ def main():
             dist.destroy_process_group()
         return 0
 
-    Leg.DEPTH = max(2, min(4, args.depth))
-    Leg.ASYNC_METRICS = args.async_metrics
-    Leg.AHEAD = max(0, args.ahead)
-    Leg.OWN_STREAM = args.own_stream
+    if os.environ.get('STTODE_LAGGED') in ('2', '3'):              # (experiments: the library reads the same variable)
+        Leg.STREAMS = int(os.environ['STTODE_LAGGED'])
     if args.only_leg:
         # one leg alone (profiling passes: `rocprofv3 --kernel-trace --stats -- python3 bench.py --only-leg sdd_1024 --serial` gives that
         # leg's serial per-launch durations without the headline's launches of the same kernel in the table)
@@ -737,8 +700,6 @@ def main():
             dist.destroy_process_group()
         return 0
     head = Leg('eth_512', rank, dev, size=args.scenes)
-    if args.col_parts:
-        head.model.native().set_col_parts(args.col_parts)
     r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial)
     roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every)
     if roof:
@@ -760,27 +721,21 @@ def main():
            'config': head.config(world), 'roofline': roof, 'kernels': kern,
            'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
                            'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
-           'kernels_note': 'HIP-event durations on the launch streams; launches of consecutive pipelined steps share the chip (three streams in '
-                           'rotation), so a launch takes longer than it would alone; the fused launch contains the per-agent roles'}
+           'step_form': f'pipelined, lagged launches over {Leg.STREAMS} streams: launch k = per-agent roles of call k (throughput form) + trajectory '
+                        f'groups of call k-{Leg.STREAMS}; every step completes inside the timed region (the drain enqueues the outstanding groups)',
+           'kernels_note': 'HIP-event durations on the launch streams; launches of consecutive pipelined steps share the chip, so a launch takes '
+                           'longer than it would alone; a launch contains the per-agent roles of one call and the trajectory groups of another '
+                           '(same shapes: its FLOP are one call\'s)'}
     if rank == 0:
         out['ade_fde_synthetic'] = [float(acc[0] / acc[2]), float(acc[1] / acc[2])]
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
     r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
     if not args.serial and not args.no_sustained and world == 1:   # (single-GPU figure; the multi-rank runs keep to the contract's regions)
-        # the same workload as a LONG run in the form a serving loop would use: every call's H2D, latents, launch and metrics on the call's own
-        # pipeline stream (model.next_async_stream), depth 3 -- 80 steps, so that filling and draining the pipeline weigh 1/4 of what they
-        # do in the 20-step contract run.  A second figure beside `value`, never `value` itself.
-        keep = (Leg.OWN_STREAM, head.depth, head.model.async_depth)
-        Leg.OWN_STREAM, head.depth, head.model.async_depth = True, 3, 3
-        head.model.reset_async()
-        try:
-            r3 = head.timed(80, 5, dist, 0)
-        finally:
-            Leg.OWN_STREAM, head.depth, head.model.async_depth = keep
-            head.model.reset_async()
-        out['sustained'] = {'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'steps': 80, 'warmup': 5,
-                            'form': 'H2D + latents + launch + best-of-K of a call all on its own pipeline stream, three streams, depth 3'}
+        # the same workload, the same step, as a LONG run: 80 steps, so that filling and draining the pipeline weigh 1/4 of what they do in
+        # the 20-step contract run.  A second figure beside `value`, never `value` itself.
+        r3 = head.timed(80, 5, dist, 0)
+        out['sustained'] = {'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'steps': 80, 'warmup': 5, 'form': 'the default step'}
     out['ms_per_step_incl_d2h'] = r2['ms_per_step']
 
     if not args.no_exploratory:

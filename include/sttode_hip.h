@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 /* Version of this header: the library returns it from sttode_abi_version(); a binding compares before its first call (round 1-2: 1). */
-#define STTODE_ABI_VERSION 4
+#define STTODE_ABI_VERSION 5
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
@@ -313,6 +313,8 @@ enum SttodeWeight {
     STT_W_B1_CONVP, STT_W_B1_CONVB, STT_W_B1_WIHP, STT_W_B1_WHHP, STT_W_B1_GBIAS, STT_W_B1_YWA, STT_W_B1_YB1, STT_W_B1_STREAM,
     STT_W_CHAIN_POOL, STT_W_CHAIN_PROG, STT_W_CHAIN_CONSTS, STT_W_G0_POOL, STT_W_G0_PROG, STT_W_G0_CONSTS,
     STT_W_CHAINB3_POOL, STT_W_CHAINB3_PROG,   /* exploratory bf16-split stream of the fused launch (packing.chain_stream_b3) */
+    STT_W_ROLE32_POOL, STT_W_ROLE32_PROG_SCENES, STT_W_ROLE32_PROG_NBA, STT_W_ROLE32_CONSTS_SCENES,
+    STT_W_ROLE32_CONSTS_NBA,                  /* throughput-form per-agent roles of the lagged launch (packing.role_stream, round 4) */
     STT_W_COUNT
 };
 
@@ -411,15 +413,32 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
 
-/* Pipelined forms: consecutive calls run on the pipeline's internal streams so that the grid tail of one call's big launch is filled by
- * the next call's (fused launches rotate over three streams; unfused: the per-agent stage on one stream beside the per-trajectory stage
- * of the PREVIOUS call on two others).  Up to four workspace/pred slots (slot in [0, 4)); workspace, pred and z of a slot must stay
- * untouched until sttode_wait(slot) has been enqueued on the consuming stream.  Results are bitwise identical to the serial forms. */
+/* Pipelined forms (STTODENet.inference as a stream of calls, model/STTODE.py:574-623; caller loop test.py:171-184): consecutive calls run
+ * on the pipeline's internal streams so that the grid tail of one call's big launch is filled by the next call's.
+ *   LAGGED form (round 4; default for every call whose per-trajectory stage takes the chain, reference integrator): calls rotate over
+ *   `streams` pipeline streams (sttode_set_lagged; default 2); the ONE launch a call enqueues carries ITS per-agent stage in throughput form
+ *   (128 agents per workgroup, csrc/role32.hpp) followed by the trajectory groups of the call made `streams` calls earlier on the same
+ *   stream -- whose per-agent tables the previous launch of that stream produced.  Nothing inside a launch depends on anything else in it
+ *   (no flags, no spinning).  A call's predictions are therefore produced by the launch of a LATER call -- or by sttode_wait(slot) /
+ *   sttode_async_best_of_k(slot), which enqueue the outstanding groups of that slot as a launch of their own if no later call has done so.
+ *   Slots: up to 8 (slot in [0, 8)); a loop that keeps 2 x streams calls in flight never waits on another stream.  Agrees with the serial
+ *   forms to fp32 rounding (different MFMA tiling and host-folded embedding in the per-agent stage), not bitwise.
+ *   sttode_set_lagged(m, 0): the round-3 forms (fused launches of one call each on three streams / separate per-agent launches), bitwise
+ *   the serial forms, slots in [0, 4).
+ * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream. */
+int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 (default, or env STTODE_LAGGED) or 3 */);
+/* Enqueue every outstanding trajectory-group launch of the lagged form (before buffers of pending calls are released or reused). */
+int sttode_async_flush(SttodeModel* m);
 int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
                                   float* workspace, float* pred, int slot, void* stream);
 int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                                int slot, void* stream);
 int sttode_wait(SttodeModel* m, int slot, void* stream);
+/* Health of the in-launch hand-off (round-3 fused launches and the one-launch scene form: a group whose producer never signalled gives up
+ * after ~1 s, poisons its predictions with NaN and sets the launch's time-out word).  Reads the time-out word of the LAST launch that used
+ * `workspace` (laid out for n agents / S scenes) after synchronising `stream`: returns 0 if it is clear, 3 (and sttode_last_error) if a
+ * group gave up -- the caller's predictions of that call are not valid.  Lagged launches have no hand-off and always pass. */
+int sttode_check(SttodeModel* m, const float* workspace, int n, int S, void* stream);
 
 #ifdef __cplusplus
 }

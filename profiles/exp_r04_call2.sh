@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 4, second GPU call: the lagged launch (throughput-form roles) -- GPU tests, then same-box A/B against the round-3 pipelined form.
+#   gpurun --timeout 1100 -- bash profiles/exp_r04_call2.sh
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r04b
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1 || { tail -30 $O/gputests.log; exit 1; }
+tail -2 $O/gputests.log
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline'] or {}; print(round(d['value']/1e6,2), round(d['ms_per_step'],3), round(r.get('frac',0),3), d.get('ade_fde_synthetic'))"; }
+legs() { python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(round(d['value']/1e6,2), ' '.join(f\"{k}={v['value']/1e6:.1f}M/{v['ms_per_step']:.3f}ms\" for k,v in d['configs'].items()), round(d.get('value_incl_d2h',0)/1e6,1))"; }
+B="timeout -k 10 200 python bench.py --legs none --no-cpu --no-train --no-exploratory --no-per-scene --no-sustained --no-serial-check --warmup 5"
+$B --steps 10 > /dev/null 2>$O/first.err || { tail -20 $O/first.err; exit 1; }
+for i in 1 2; do
+for st in 20 80 160; do
+echo "steps $st lagged 2 : $(STTODE_LAGGED=2 $B --steps $st 2>/dev/null | line)" | tee -a $O/ab_lagged.txt
+echo "steps $st lagged 3 : $(STTODE_LAGGED=3 $B --steps $st 2>/dev/null | line)" | tee -a $O/ab_lagged.txt
+echo "steps $st round-3  : $(STTODE_LAGGED=0 $B --steps $st 2>/dev/null | line)" | tee -a $O/ab_lagged.txt
+done; done
+L="timeout -k 10 300 python bench.py --no-cpu --no-train --steps 20 --warmup 5 --no-exploratory --no-per-scene --no-sustained --no-serial-check"
+for i in 1 2; do
+echo "legs lagged 2 : $(STTODE_LAGGED=2 $L 2>/dev/null | legs)" | tee -a $O/ab_lagged.txt
+echo "legs lagged 3 : $(STTODE_LAGGED=3 $L 2>/dev/null | legs)" | tee -a $O/ab_lagged.txt
+echo "legs round-3  : $(STTODE_LAGGED=0 $L 2>/dev/null | legs)" | tee -a $O/ab_lagged.txt
+done
+for sc in 128 256 1024 2048; do
+echo "scenes $sc lagged 2: $(STTODE_LAGGED=2 $B --steps 40 --scenes $sc 2>/dev/null | line)" | tee -a $O/ab_lagged.txt
+echo "scenes $sc round-3 : $(STTODE_LAGGED=0 $B --steps 40 --scenes $sc 2>/dev/null | line)" | tee -a $O/ab_lagged.txt
+done

@@ -11,7 +11,7 @@ _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 4   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
+ABI_VERSION = 5   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
@@ -92,6 +92,9 @@ SIGNATURES = {
     'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_wait': [_P, _I, _P],
+    'sttode_set_lagged': [_P, _I],
+    'sttode_async_flush': [_P],
+    'sttode_check': [_P, _P, _I, _I, _P],
 }
 
 # enum SttodeWeight / SttodeBuffer / SttodeStage of include/sttode_hip.h (order is ABI)
@@ -101,7 +104,8 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                 + [('blk0', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'x_WA', 'x_b1', 'y_WA', 'y_b1', 'stream')]
                 + [('blk1', k) for k in ('convP', 'convB', 'wihP', 'whhP', 'gbias', 'y_WA', 'y_b1', 'stream')]
                 + [('chain', k) for k in ('pool', 'prog', 'consts')] + [('gru0s', k) for k in ('pool', 'prog', 'consts')]
-                + [('chain_b3', k) for k in ('pool', 'prog')])
+                + [('chain_b3', k) for k in ('pool', 'prog')]
+                + [('role32', k) for k in ('pool', 'prog_scenes', 'prog_nba', 'consts_scenes', 'consts_nba')])
 TRUNK_PTRS = ('fc1_w', 'fc1_b', 'pos_w', 'pos_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b', 'inproj_w', 'inproj_b', 'out_w', 'out_b', 'info_w', 'info_b',
               'gate_w', 'gate_b', 'ln1_w', 'ln1_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'ln2_w', 'ln2_b', 'enc_in', 'last', 'pe', 'drop', 'posin', 'tp',
               'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode')   # enum SttodeTrunkPtr
@@ -157,6 +161,16 @@ class NativeModel:
         Results are bitwise the same in every mode."""
         if lib().sttode_set_fused(self.h, int(mode)) != 0:
             raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())
+
+    def set_lagged(self, streams):
+        """Pipelined calls in the LAGGED form (default 2 streams): a call's launch = its throughput-form per-agent roles + the trajectory
+        groups of the call made `streams` calls earlier; 0: the round-3 forms (bitwise the serial forms).  See include/sttode_hip.h."""
+        call('sttode_set_lagged', self.h, int(streams))
+
+    def check(self, workspace, n, S):
+        """Raise if a group of the last launch on `workspace` gave up waiting for its producer (in-launch hand-off forms only)."""
+        import torch
+        call('sttode_check', self.h, workspace, int(n), int(S), stream_ptr())
 
     def set_mfma_mode(self, mode):
         """EXPLORATORY: 1 = block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix cores; 0 = fp32."""

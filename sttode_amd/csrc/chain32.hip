@@ -65,6 +65,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define C32_RING (2 * C32_CMAX * C32_TILE)  // f32x4 in the double buffer (24 KiB)
 #define C32_SLOT 256                        // f32x4 per wave gather slot (4 KiB)
 
+struct Role32Args {   // throughput-form per-agent roles (role32.hpp)
+    const f32x4* pool; const int2* prog; int prog_len; const float* consts;   // packing.role_stream (the host picks the variant)
+    const float* enc_in; const int* last;                                     // [n][4 Tp] encoder inputs, [n] last-agent flag (scenes variant)
+    const float* g_in; const float* attn; int ld_attn;                        // NBA variant: g [n][64], attention output before out_proj; attn == nullptr: scenes
+    const float* xpad; int ldx;                                               // [n][ldx] normalised track, flattened (t, c), zero padded
+    float* pf; float* state0; float* A0x; float* A0y; float* A1y;             // [n][128], [n][96], [n][512] x 3
+    int n, Tp, kte, nwg;                                                      // agents, observed frames, k-tiles of x, role workgroups in the grid
+    float ode_time;
+};
+
 struct ChainArgs {
     const float* A0x; const float* A0y; const float* A1y;  // [nagents][512] per-agent layer-1 pre-activations (b1 included)
     const f32x4* pool;                                      // PK32 tile pool
@@ -80,7 +90,8 @@ struct ChainArgs {
     long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS / C32_DIAG_TRACE): per-workgroup stamps
     int trace_tag;   // diagnostic builds only: launch number
     int xcd_map;     // fused launch, roles in front: group blocks b, b + 8, b + 16, .. (dispatched to ONE XCD) take consecutive group ids
-    RoleArgs R;      // fused launch only (traj_chain_kernel<NY, true>)
+    RoleArgs R;      // fused launch only (traj_chain_kernel<NY, 1>)
+    Role32Args R32;  // lagged launch only (traj_chain_kernel<NY, 2>): throughput-form roles of ANOTHER call in front of this call's groups
 };
 
 // consts layout (floats): b2x[256] b3x[32] | b2y[256] b3y[32*NY] | gbias[4][96] convb[32] | b2m[256] b3m[32*NY]
@@ -611,6 +622,8 @@ __device__ __forceinline__ void gru32_steps(ST& st, const float* gb, const float
 
 }
 
+#include "role32.hpp"
+
 // makes a per-lane integer opaque to the optimiser: address arithmetic derived from it is redone where it is used instead of
 // being computed once at the top of the group and kept live (64-bit pointers held across phases were what spilled)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -650,7 +663,9 @@ __host__ __device__ __forceinline__ int xcd_group(int b, int G) {
     return x * q + (x < r ? x : r) + i;
 }
 
-template <int NY, bool FUSE, bool B3M>
+// FUSE: 0 = trajectory groups only; 1 = round-3 fused launch (latency-form roles of THIS call in front, tile flags); 2 = lagged launch
+// (round 4: throughput-form roles of a LATER call in front, no dependency inside the launch; either part may be empty)
+template <int NY, int FUSE, bool B3M>
 __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     typedef ChainStreamT<B3M ? C32_BUF_B3 : C32_CMAX * C32_TILE, B3M> Stream;   // B3M: exploratory bf16-split mode (block-0 MLPs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -671,15 +686,20 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     const int ngroups = (A.ncols + 127) >> 7;
 
     C32_TRACE_BEGIN();
-    if (FUSE && A.R.split && (int)blockIdx.x < 5 * A.R.ntiles) {   // (uniform) split per-agent roles, all in front of the groups
+    if (FUSE == 2 && (int)blockIdx.x < A.R32.nwg) {   // (uniform) a throughput-form role workgroup: 128 agents of the roles' call
+        role32_body(A.R32, blockIdx.x, smem);
+        C32_TRACE_END(1);
+        return;
+    }
+    if (FUSE == 1 && A.R.split && (int)blockIdx.x < 5 * A.R.ntiles) {   // (uniform) split per-agent roles, all in front of the groups
         split_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, blockIdx.x, smem);
         C32_TRACE_END(1);
         return;
     }
-    int fb = !FUSE ? (int)blockIdx.x : A.R.split ? (int)blockIdx.x - 5 * A.R.ntiles
+    int fb = FUSE == 0 ? (int)blockIdx.x : FUSE == 2 ? (int)blockIdx.x - A.R32.nwg : A.R.split ? (int)blockIdx.x - 5 * A.R.ntiles
                                                 : fused_block_of(blockIdx.x, A.R.ntiles, ngroups, A.K, A.R.lead);
     if (FUSE && A.xcd_map && fb >= 0) fb = xcd_group(fb, ngroups);   // (roles in front: fb was the group block's position in dispatch order)
-    if (FUSE && fb < 0) {   // (uniform) a per-agent role
+    if (FUSE == 1 && fb < 0) {   // (uniform) a per-agent role
         agent_role(A.R, (A.ncols + A.K - 1) / A.K, A.Tp, A.ldx, A.xpad, -1 - fb, smem);
         C32_TRACE_END(1);
         return;
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
     for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
     if (threadIdx.x == 0) sq[0] = FUSE ? fb : A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
-    if (FUSE) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
+    if (FUSE == 1) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
         const int g0 = fb;
         const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
         const int t_lo = (c_lo / A.K) >> 4, t_hi = (c_hi / A.K) >> 4;
@@ -700,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     __syncthreads();
     C32_TRACE_PHASE(3);   // (groups) flags seen
     int g = sq[0];
-    if (FUSE && g < 0) {   // (uniform) time-out: poison the group's predictions, never hang
+    if (FUSE == 1 && g < 0) {   // (uniform) time-out: poison the group's predictions, never hang
         for (int i = threadIdx.x; i < 128 * A.Tf2; i += blockDim.x) {
             const size_t o = (size_t)fb * 128 * A.Tf2 + i;
             if (o < (size_t)A.ncols * A.Tf2) A.pred[o] = __builtin_nanf("");
@@ -922,7 +942,9 @@ static int role_lds(int Tp) {   // agent_role's phases: embed (Tp*256 + 512 f32x
     return e > g ? e : g;
 }
 
-template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
+static int role32_lds(int prog_len) { return C32_RING * 16 + R32C::total * 4 + prog_len * 8 + 16; }
+
+template <int NY, int FUSE, bool B3M = false> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
     STT_SET_LDS_ONCE((traj_chain_kernel<NY, FUSE, B3M>), 96 * 1024);   // once per (instantiation, device)
     const int ngroups = (a.ncols + 127) / 128;
     // STTODE_CHAIN_RESERVE=r leaves r of the chip's 2-per-CU workgroup slots to concurrently running kernels (the per-agent stage
@@ -931,7 +953,8 @@ template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const Cha
     if (reserve < 0) { const char* e = getenv("STTODE_CHAIN_RESERVE"); reserve = e ? atoi(e) : 0; if (reserve < 0 || reserve > chain_cus()) reserve = 0; }
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
-    if (FUSE) grid = (a.R.split ? 5 : 1) * a.R.ntiles + ngroups;   // roles ahead of their consumers, one group per workgroup
+    if (FUSE == 1) grid = (a.R.split ? 5 : 1) * a.R.ntiles + ngroups;   // roles ahead of their consumers, one group per workgroup
+    else if (FUSE == 2) grid = a.R32.nwg + (a.ncols > 0 ? ngroups : 0);   // another call's throughput-form roles, then this call's groups
     else if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
@@ -941,10 +964,11 @@ template <int NY, bool FUSE, bool B3M = false> static int chain_launch(const Cha
     if (wgs_env < 0) { const char* e = getenv("STTODE_CHAIN_WGS"); wgs_env = e ? atoi(e) : 0; }
     const int wgs = wgs_env > 0 ? wgs_env : wgs_per_cu;
     int lds = chain_lds(NY, a.prog_len, B3M);
-    if (FUSE && lds < role_lds(a.Tp)) lds = role_lds(a.Tp);
+    if (FUSE == 1 && lds < role_lds(a.Tp)) lds = role_lds(a.Tp);
+    if (FUSE == 2 && a.R32.nwg > 0 && lds < role32_lds(a.R32.prog_len)) lds = role32_lds(a.R32.prog_len);
     if (wgs == 1 && lds < 84 * 1024) lds = 84 * 1024;
     STT_REQUIRE(lds <= 96 * 1024, "sttode_traj_chain: dynamic LDS beyond the 96 KiB the kernel is registered for");
-    if (FUSE) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)(a.R.split ? 5 : 1) * a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
+    if (FUSE == 1) STT_HIP(hipMemsetAsync(a.R.flags, 0, (((size_t)(a.R.split ? 5 : 1) * a.R.ntiles + 1) * 4 + 15) / 16 * 16, s));   // tile flags + time-out word
     hipLaunchKernelGGL((traj_chain_kernel<NY, FUSE, B3M>), dim3(grid), dim3(256), lds, s, a);
     STT_HIP(hipGetLastError());
     return 0;
@@ -1015,16 +1039,16 @@ static int traj_chain_impl(const float* A0x, const float* A0y, const float* A1y,
     if (b3) {
         a.persistent = 0;
         switch (NY) {
-            case 1: return chain_launch<1, false, true>(a, wgs_per_cu, s);
-            case 2: return chain_launch<2, false, true>(a, wgs_per_cu, s);
-            case 3: return chain_launch<3, false, true>(a, wgs_per_cu, s);
+            case 1: return chain_launch<1, 0, true>(a, wgs_per_cu, s);
+            case 2: return chain_launch<2, 0, true>(a, wgs_per_cu, s);
+            case 3: return chain_launch<3, 0, true>(a, wgs_per_cu, s);
             default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
         }
     }
     switch (NY) {
-        case 1: return chain_launch<1, false>(a, wgs_per_cu, s);
-        case 2: return chain_launch<2, false>(a, wgs_per_cu, s);
-        case 3: return chain_launch<3, false>(a, wgs_per_cu, s);
+        case 1: return chain_launch<1, 0>(a, wgs_per_cu, s);
+        case 2: return chain_launch<2, 0>(a, wgs_per_cu, s);
+        case 3: return chain_launch<3, 0>(a, wgs_per_cu, s);
         default: STT_REQUIRE(false, "sttode_traj_chain: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;
@@ -1090,10 +1114,71 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     const int NY = (2 * Tf + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
     switch (NY) {
-        case 1: return b3 ? chain_launch<1, true, true>(a, wgs_per_cu, s) : chain_launch<1, true>(a, wgs_per_cu, s);
-        case 2: return b3 ? chain_launch<2, true, true>(a, wgs_per_cu, s) : chain_launch<2, true>(a, wgs_per_cu, s);
-        case 3: return b3 ? chain_launch<3, true, true>(a, wgs_per_cu, s) : chain_launch<3, true>(a, wgs_per_cu, s);
+        case 1: return b3 ? chain_launch<1, 1, true>(a, wgs_per_cu, s) : chain_launch<1, 1>(a, wgs_per_cu, s);
+        case 2: return b3 ? chain_launch<2, 1, true>(a, wgs_per_cu, s) : chain_launch<2, 1>(a, wgs_per_cu, s);
+        case 3: return b3 ? chain_launch<3, 1, true>(a, wgs_per_cu, s) : chain_launch<3, 1>(a, wgs_per_cu, s);
         default: STT_REQUIRE(false, "stt_chain_fused: future length beyond the built instantiations (2*Tf <= 96)");
+    }
+    return 0;
+}
+
+// Internal (csrc/pipeline.hip): the LAGGED launch of the pipelined path (round 4) -- ONE grid = the throughput-form per-agent roles of one
+// call (role32.hpp: 128 agents per workgroup; rW / ws_r / off_r / n_r; skipped when ws_r == nullptr) followed by the trajectory groups of
+// ANOTHER, earlier call whose roles ran in an earlier launch of the same stream (ws_g / off_g / n_g / z / pred; skipped when ws_g ==
+// nullptr).  Nothing in the grid depends on anything else in it.  attn != nullptr (NBA: attention groups > 1): embed_qkv and mhgsa_attn of
+// the roles' call have run on `stream` before, the roles read g and the attention output from ws_r.  The reference's one Euler step only.
+bool stt_chain_lagged_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32; }
+int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
+                     float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
+                     void* stream) {
+    STT_REQUIRE(W && (ws_r || ws_g), "stt_chain_lagged: nothing to launch");
+    STT_REQUIRE(K > 0 && stt_chain_lagged_covers(Tp) && Tf >= 1, "stt_chain_lagged: shape outside the lagged launch");
+    ChainArgs a;
+    a.R = RoleArgs();
+    a.R32 = Role32Args();
+    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.persistent = 0; a.counter = nullptr;
+    a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.ncols = 0;
+    a.pool = (const f32x4*)W[b3 ? STT_W_CHAINB3_POOL : STT_W_CHAIN_POOL]; a.prog = (const int2*)W[b3 ? STT_W_CHAINB3_PROG : STT_W_CHAIN_PROG];
+    a.prog_len = prog_len; a.consts = W[STT_W_CHAIN_CONSTS];
+    a.A0x = a.A0y = a.A1y = nullptr; a.z = nullptr; a.xpad = nullptr; a.cur = a.orig = nullptr; a.pred = nullptr;
+    if (ws_g) {
+        STT_REQUIRE(off_g && z && pred && n_g > 0 && (long)n_g * K <= 0x7fffffffL, "stt_chain_lagged: bad group arguments");
+        STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "stt_chain_lagged: chunk program length does not match (Tp, Tf)");
+        a.A0x = ws_g + off_g[STT_B_A0X]; a.A0y = ws_g + off_g[STT_B_A0Y]; a.A1y = ws_g + off_g[STT_B_A1Y];
+        a.z = z; a.xpad = ws_g + off_g[STT_B_XPAD]; a.cur = ws_g + off_g[STT_B_CUR]; a.orig = ws_g + off_g[STT_B_ORIG]; a.pred = pred;
+        a.ncols = n_g * K;
+        static int xm = -1;
+        if (xm < 0) { const char* e = getenv("STTODE_XCD_MAP"); xm = e ? atoi(e) != 0 : 1; }
+        a.xcd_map = xm;
+    }
+    if (ws_r) {
+        STT_REQUIRE(off_r && n_r > 0, "stt_chain_lagged: bad role arguments");
+        STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_lagged: bad attention leading dimension");
+        Role32Args& r = a.R32;
+        r.pool = (const f32x4*)W[STT_W_ROLE32_POOL];
+        r.prog = (const int2*)W[attn ? STT_W_ROLE32_PROG_NBA : STT_W_ROLE32_PROG_SCENES];
+        r.consts = W[attn ? STT_W_ROLE32_CONSTS_NBA : STT_W_ROLE32_CONSTS_SCENES];
+        r.kte = (4 * Tp + 31) / 32;
+        const int e = attn ? 8 : 2 * r.kte + 8;   // == packing.role_prog_len
+        r.prog_len = attn ? 13 * Tp + (e + 2) / 3 + (128 + 288 + 2) / 3 : 13 * Tp + (e + 128 + 288 + 2) / 3;
+        r.enc_in = ws_r + off_r[STT_B_ENC_IN]; r.last = (const int*)(ws_r + off_r[STT_B_LAST]);
+        r.g_in = ws_r + off_r[STT_B_G]; r.attn = attn; r.ld_attn = ld_attn;
+        r.xpad = ws_r + off_r[STT_B_XPAD]; r.ldx = a.ldx;
+        r.pf = ws_r + off_r[STT_B_PF]; r.state0 = ws_r + off_r[STT_B_STATE0];
+        r.A0x = ws_r + off_r[STT_B_A0X]; r.A0y = ws_r + off_r[STT_B_A0Y]; r.A1y = ws_r + off_r[STT_B_A1Y];
+        r.n = n_r; r.Tp = Tp; r.nwg = (n_r + 127) / 128; r.ode_time = ode_time;
+    }
+#if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
+    a.dbg = g_chain_dbg;
+    a.trace_tag = g_trace_tag++;
+#endif
+    const int NY = (2 * Tf + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    switch (NY) {
+        case 1: return b3 ? chain_launch<1, 2, true>(a, 2, s) : chain_launch<1, 2>(a, 2, s);
+        case 2: return b3 ? chain_launch<2, 2, true>(a, 2, s) : chain_launch<2, 2>(a, 2, s);
+        case 3: return b3 ? chain_launch<3, 2, true>(a, 2, s) : chain_launch<3, 2>(a, 2, s);
+        default: STT_REQUIRE(false, "stt_chain_lagged: future length beyond the built instantiations (2*Tf <= 96)");
     }
     return 0;
 }

@@ -19,8 +19,11 @@
 #include <cstdlib>
 #define STT_MAX_PARTS 8
 #define STT_MAX_DEVICES 64
-#define STT_MAX_SLOTS 4   // workspace / prediction slots of the cross-call pipeline (sttode_inference_*_async)
+#define STT_MAX_SLOTS 8   // workspace / prediction slots of the cross-call pipeline (sttode_inference_*_async)
 struct TimRec { int stage; hipEvent_t e0, e1; };
+
+// LAGGED form: a call whose per-agent roles have been enqueued (in the launch it made) but whose trajectory groups have not yet
+struct LagPending { bool valid; float* ws; long off[STT_B_COUNT]; int n; const float* z; float* pred; hipStream_t s; int si; };
 
 struct SttodeModel {
     int Tp, Tf, TPX, NOY, K;
@@ -46,6 +49,10 @@ struct SttodeModel {
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB, sB2;
+    int lag_streams;                 // 0: lagged form off; 2 (default) / 3: pipeline streams the lagged calls rotate over
+    long lag_calls;
+    LagPending lag[STT_MAX_SLOTS];   // per slot
+    int lag_q[3][STT_MAX_SLOTS]; int lag_qn[3];   // per stream: slots with outstanding groups, oldest first
     hipStream_t sX[3];   // extra streams of the fused rotation (STTODE_FUSED_STREAMS = 4..6; experiments: they share the runtime's hardware queues)
     int fused_streams;
     int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate calls between sB and sB2
@@ -57,6 +64,11 @@ struct SttodeModel {
     std::vector<TimRec> recs;
     std::vector<hipEvent_t> pool;
 };
+
+bool stt_chain_lagged_covers(int Tp);
+int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
+                     float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
+                     void* stream);
 
 static std::mutex g_stream_mu;   // guards the creation of the process-wide streams (sA / sB / sB2 / side, per device)
 
@@ -87,7 +99,10 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
-    for (int p = 0; p < STT_MAX_SLOTS; ++p) m->slot_stream[p] = nullptr;
+    for (int p = 0; p < STT_MAX_SLOTS; ++p) { m->slot_stream[p] = nullptr; m->lag[p].valid = false; }
+    m->lag_streams = 2; m->lag_calls = 0;
+    for (int i = 0; i < 3; ++i) m->lag_qn[i] = 0;
+    if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0;
     m->scene_launch = 128;
     if (const char* e = getenv("STTODE_SCENE_LAUNCH")) m->scene_launch = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
@@ -214,6 +229,16 @@ extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
     m->fused_mode = mode ? 1 : 0;
     m->fe_in_role = mode == 2;
     m->role_lead = mode == 3 ? 160 : mode == 4 ? -2 : -1;
+    return 0;
+}
+
+static int lag_flush_all(SttodeModel* m);
+extern "C" int sttode_set_lagged(SttodeModel* m, int streams) {
+    STT_REQUIRE(m, "sttode_set_lagged: null model");
+    STT_REQUIRE(streams == 0 || streams == 2 || streams == 3, "sttode_set_lagged: streams must be 0 (off), 2 or 3");
+    if (int rc = lag_flush_all(m)) return rc;   // outstanding groups belong to the old rotation
+    m->lag_streams = streams;
+    m->lag_calls = 0;
     return 0;
 }
 
@@ -598,14 +623,92 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
 
+// ---- LAGGED form (round 4) ---------------------------------------------------------------------------------------------------------
+// Calls whose per-trajectory stage takes the chain (reference integrator) rotate over lag_streams pipeline streams.  The launch call k
+// enqueues on its stream = [throughput-form roles of call k | trajectory groups of the oldest call of that stream whose groups are still
+// outstanding] (csrc/role32.hpp, stt_chain_lagged): the groups read the tables an EARLIER launch of the same stream wrote, so stream order
+// is the only dependency and nothing inside a launch waits.  Why: as workgroups of the launch that consumes them (round 3) the roles had
+// to be latency forms, held 9-12 % of the chip's workgroup slots for 5 % of the FLOP, and bounded every small launch by role + group.
+static bool use_lagged(const SttodeModel* m, int n) {
+    const long ncols_all = (long)n * m->K;
+    const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
+    return m->lag_streams > 0 && m->fused_mode == 1 && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_chain_lagged_covers(m->Tp);
+}
+static hipStream_t lag_stream(const SttodeModel* m, int si) { return si == 0 ? m->sB : si == 1 ? m->sB2 : m->sA; }
+static void lag_unqueue(SttodeModel* m, int slot) {
+    const int si = m->lag[slot].si;
+    int w = 0;
+    for (int i = 0; i < m->lag_qn[si]; ++i)
+        if (m->lag_q[si][i] != slot) m->lag_q[si][w++] = m->lag_q[si][i];
+    m->lag_qn[si] = w;
+}
+// the outstanding groups of `slot` as a launch of their own (nobody made a later call on that stream, or the slot is wanted back)
+static int lag_flush(SttodeModel* m, int slot) {
+    LagPending& p = m->lag[slot];
+    if (!p.valid) return 0;
+    lag_unqueue(m, slot);
+    p.valid = false;
+    RUN(STT_STAGE_FUSED, p.s,
+        stt_chain_lagged(m->w, nullptr, nullptr, 0, nullptr, 0, 12.0f, p.ws, p.off, p.n, p.z, p.pred, m->K, m->Tp, m->Tf, m->prog_len, m->b3, p.s));
+    STT_HIP(hipEventRecord(m->evB_done[slot], p.s));
+    return 0;
+}
+static int lag_flush_all(SttodeModel* m) {
+    for (int p = 0; p < STT_MAX_SLOTS; ++p)
+        if (int rc = lag_flush(m, p)) return rc;
+    return 0;
+}
+static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
+                      float* pred, int slot, const long* off, hipStream_t s) {
+    const float* const* W = m->w;
+    const int si = (int)(m->lag_calls % m->lag_streams);
+    hipStream_t sf = lag_stream(m, si);
+    ++m->lag_calls;
+    STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));              // inputs and z of this call (a wait for itself when the caller works on sf)
+    STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));       // the slot's previous user has drained (same stream in a 2 x streams rotation)
+    if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
+    const float* attn = nullptr;
+    if (!scene_ptr && B > 1) {   // attention groups > 1: embedding + attention stay launches in front (the attention reads every agent of the group)
+        float* qkv = ws + off[STT_B_QKV];
+        RUN(STT_STAGE_EMBED, sf,
+            sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
+                             W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],
+                             (const int*)(ws + off[STT_B_LAST]), ws + off[STT_B_G], qkv, n, m->Tp, sf));
+        const long st_seq = (long)N * 192;   // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
+        RUN(STT_STAGE_ATTN, sf,
+            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, ws + off[STT_B_ATTN], nullptr, nullptr, B, B, N, st_seq, 192, st_seq, 192, st_seq, 192,
+                              (long)N * 64, 64, 1.0f, 0.35355339059327373f, sf));
+        attn = ws + off[STT_B_ATTN];
+    }
+    const int gs = m->lag_qn[si] > 0 ? m->lag_q[si][0] : -1;     // the oldest call of this stream whose groups are outstanding
+    LagPending* g = gs >= 0 ? &m->lag[gs] : nullptr;
+    RUN(STT_STAGE_FUSED, sf,
+        stt_chain_lagged(W, ws, off, n, attn, 64, 12.0f, g ? g->ws : nullptr, g ? g->off : nullptr, g ? g->n : 0, g ? g->z : nullptr,
+                         g ? g->pred : nullptr, m->K, m->Tp, m->Tf, m->prog_len, m->b3, sf));
+    if (g) {
+        lag_unqueue(m, gs);
+        g->valid = false;
+        STT_HIP(hipEventRecord(m->evB_done[gs], sf));
+    }
+    LagPending& p = m->lag[slot];
+    p.valid = true; p.ws = ws; p.n = n; p.z = z; p.pred = pred; p.s = sf; p.si = si;
+    memcpy(p.off, off, sizeof(p.off));
+    m->lag_q[si][m->lag_qn[si]++] = slot;
+    m->slot_stream[slot] = sf;
+    return 0;
+}
+
 // pipelined form: stage A on sA, stage B on sB, two workspace slots; the caller later waits with sttode_wait(slot)
 static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
                      float* pred, int slot, hipStream_t s) {
-    STT_REQUIRE(slot >= 0 && slot < STT_MAX_SLOTS, "sttode_inference_*_async: slot must be in [0, 4)");
+    STT_REQUIRE(slot >= 0 && slot < STT_MAX_SLOTS, "sttode_inference_*_async: slot must be in [0, 8)");
     arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    if (int rc = lag_flush(m, slot)) return rc;                  // the slot is wanted back: its outstanding groups (if any) go first
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
+    if (use_lagged(m, n)) return run_lagged(m, past, scene_ptr, n, S, B, N, z, ws, pred, slot, off, s);
+    STT_REQUIRE(slot < 4, "sttode_inference_*_async: the round-3 forms take slots in [0, 4)");
     if (use_fused(m, n)) {
         // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
         // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)
@@ -674,6 +777,7 @@ extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pre
                                       float* ade, float* fde) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_best_of_k: bad model / slot");
     STT_REQUIRE(m->slot_stream[slot] != nullptr, "sttode_async_best_of_k: no asynchronous call has used this slot");
+    if (int rc = lag_flush(m, slot)) return rc;   // (lagged form) nobody has enqueued this call's groups yet: they go first
     if (int rc = sttode_best_of_k(pred, gt, n, K, Tf, scale, ade, fde, m->slot_stream[slot])) return rc;
     STT_HIP(hipEventRecord(m->evB_done[slot], m->slot_stream[slot]));
     return 0;
@@ -685,6 +789,7 @@ extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pre
 extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
     STT_REQUIRE(m && stream && n > 0, "sttode_async_next_stream: bad arguments");
     *stream = nullptr;
+    if (use_lagged(m, n)) { *stream = lag_stream(m, (int)(m->lag_calls % m->lag_streams)); return 0; }
     if (!use_fused(m, n)) return 0;
     const int si = (int)(m->acalls % m->fused_streams);
     *stream = si == 0 ? m->sB : si == 1 ? m->sB2 : si == 2 ? m->sA : m->sX[si - 3];
@@ -694,6 +799,29 @@ extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");
+    if (int rc = lag_flush(m, slot)) return rc;   // (lagged form) no later call carried this call's groups: they are enqueued now
     STT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->evB_done[slot], 0));
+    return 0;
+}
+
+// every outstanding trajectory-group launch of the lagged form is enqueued (before buffers of pending calls are released or reused)
+extern "C" int sttode_async_flush(SttodeModel* m) {
+    STT_REQUIRE(m, "sttode_async_flush: null model");
+    return lag_flush_all(m);
+}
+
+// time-out word of the in-launch hand-off forms (chain32.hip FUSE == 1: word [tiles] of STT_B_FLAGS; split roles and scene_lat.hip keep theirs
+// at the same index): see include/sttode_hip.h
+extern "C" int sttode_check(SttodeModel* m, const float* workspace, int n, int S, void* stream) {
+    STT_REQUIRE(m && workspace && n > 0 && S >= 0, "sttode_check: bad arguments");
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    unsigned word = 0;
+    STT_HIP(hipMemcpyAsync(&word, workspace + off[STT_B_FLAGS] + (n + 15) / 16, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    STT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (word != 0) {
+        stt_set_error("sttode_check: a trajectory group gave up waiting for its per-agent role (time-out word set): the predictions of that call are not valid");
+        return 3;
+    }
     return 0;
 }

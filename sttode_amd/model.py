@@ -252,7 +252,8 @@ class STTODENet(nn.Module):
                     'post': packing.pack_posterior(sd),
                     'chain': packing.chain_stream(sd, a.past_length, a.future_length),
                     'chain_b3': packing.chain_stream_b3(sd, a.past_length, a.future_length),
-                    'gru0s': packing.gru32_stream(sd, 0, a.past_length)}
+                    'gru0s': packing.gru32_stream(sd, 0, a.past_length),
+                    'role32': packing.role_stream(sd, a.past_length)}
             self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
                                 for k, v in d.items()} for g, d in host.items()}
             self._packed_key = key
@@ -265,6 +266,8 @@ class STTODENet(nn.Module):
         """Drop the native pipeline handle (its events; the pipeline's streams are process-wide), the packed weights and the cached
         workspaces; all are rebuilt on the next call."""
         if self.device.type == 'cuda':
+            if self._native is not None:
+                capi.call('sttode_async_flush', self._native.h)
             torch.cuda.synchronize(self.device)
         self._native, self._packed, self._packed_key = None, None, None
         self._wscache, self._async_bufs = {}, {}
@@ -693,11 +696,14 @@ class STTODENet(nn.Module):
 
     @torch.no_grad()
     def inference_async(self, z=None):
-        """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  The per-agent stage
-        runs on an internal stream beside the per-trajectory kernels of the previous calls; ``async_depth`` (default 4) slots rotate,
-        so at most that many calls may be in flight: call ``wait(handle)`` (which returns the [K, n, Tf, 2] view) before the
-        ``async_depth``-th next call.
-        Inputs set by set_data / set_scene_batch / set_data_nba must stay unmodified until then.  Bitwise identical to inference()."""
+        """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  ``async_depth`` (default 4, at most 8)
+        workspace / prediction slots rotate, so at most that many calls may be in flight: call ``wait(handle)`` (which returns the
+        [K, n, Tf, 2] view) before the ``async_depth``-th next call.  Inputs set by set_data / set_scene_batch / set_data_nba must stay
+        unmodified until then.
+        Batches whose per-trajectory stage takes the chain run in the LAGGED form (include/sttode_hip.h, csrc/role32.hpp): the launch a call
+        enqueues carries its per-agent stage and the trajectory groups of the call made two calls earlier, so a call's predictions are
+        produced when a later call -- or ``wait`` / ``best_of_k_async`` -- enqueues them.  Agrees with inference() to fp32 rounding
+        (``native().set_lagged(0)``: the round-3 forms, bitwise inference())."""
         self._require_gpu()
         a = self.args
         if self._mode is None:
@@ -711,11 +717,11 @@ class STTODENet(nn.Module):
         if tuple(z.shape) != (n * K, a.zdim):
             raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
         S = self._S if self._mode == 'scenes' else 0
-        slot = self._async_calls % max(2, min(4, int(self.async_depth)))
+        slot = self._async_calls % max(2, min(8, int(self.async_depth)))
         self._async_calls += 1
         key = (n, S, slot)
         if key not in self._async_bufs:
-            if len(self._async_bufs) > 8:
+            if len(self._async_bufs) > 16:
                 raise capi.SttodeError('too many distinct batch shapes in flight for the async pipeline; call reset_async()')
             _, tot = nat.layout(n, S)
             self._async_bufs[key] = (torch.empty(tot, dtype=torch.float32, device=self.device),
@@ -767,6 +773,8 @@ class STTODENet(nn.Module):
         return mb[0], mb[1]
 
     def reset_async(self):
+        if self._native is not None:
+            capi.call('sttode_async_flush', self._native.h)      # outstanding groups of lagged calls read the buffers dropped below
         torch.cuda.synchronize(self.device)
         self._async_bufs = {}
         self._async_metrics = {}

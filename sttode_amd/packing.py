@@ -395,6 +395,118 @@ def gru32_stream(sd, block, Tp):
             'consts': np.ascontiguousarray(consts), 'prog_len': len(prog)}
 
 
+# constants of the throughput-form per-agent roles (csrc/role32.hpp R32C): float offsets into role_stream()['consts_*']
+R32_CONSTS = dict(bc=0, wlast=64, bi=128, bg=192, ln1w=256, ln1b=320, l1b=384, l2b=1408, ln2w=1472, ln2b=1536, gbias=1600, convb=1984,
+                  b1x=2016, b1y=2528, b11=3040, total=3552)
+
+
+def role_fold(sd, Tp):
+    """The affine foldings of role_stream, float64: dict with Wc [64, 32 kte], bc, wlast [64] and, per variant v in (scenes, nba),
+    Ki_v / Kg_v [64, 64], bi_v / bg_v [64]."""
+    f64 = lambda k: np.asarray(sd[k], np.float64)
+    pe_ = 'past_encoder.'
+    att = pe_ + 'ODE_Encoder.odeblock.odefunc.layers.0.self_attn.'
+    W1, b1 = f64(pe_ + 'input_fc.weight'), f64(pe_ + 'input_fc.bias')
+    Wpos, bpos, pe = f64(pe_ + 'pos_encoder.fc.weight'), f64(pe_ + 'pos_encoder.fc.bias'), f64(pe_ + 'pos_encoder.pe')
+    W2, b2 = f64(pe_ + 'input_fc2.weight'), f64(pe_ + 'input_fc2.bias')
+    W3, b3 = f64(pe_ + 'input_fc3.weight'), f64(pe_ + 'input_fc3.bias')
+    W3a = W3[:, :64]
+    kte = (4 * Tp + 31) // 32
+    Wc = np.zeros((64, 32 * kte))
+    acc = b2.copy()
+    for t in range(Tp):
+        W2t = W2[:, 64 * t:64 * t + 64]
+        Wc[:, 4 * t:4 * t + 4] = W3a @ W2t @ Wpos[:, :64] @ W1
+        acc = acc + W2t @ (Wpos[:, :64] @ b1 + Wpos[:, 64:] @ pe[t] + bpos)
+    Win, bin_ = f64(att + 'temporal_attention_before.in_proj_weight'), f64(att + 'temporal_attention_before.in_proj_bias')
+    Wo, bo = f64(att + 'temporal_attention_before.out_proj.weight'), f64(att + 'temporal_attention_before.out_proj.bias')
+    Wi, bi = f64(att + 'temporal_info.weight'), f64(att + 'temporal_info.bias')
+    Wg, bg = f64(att + 'temporal_gate.weight'), f64(att + 'temporal_gate.bias')
+    WoWv, boc = Wo @ Win[128:192], Wo @ bin_[128:192] + bo
+    return {'kte': kte, 'Wc': Wc, 'bc': W3a @ acc + b3, 'wlast': W3[:, 66],
+            'Ki_scenes': Wi @ WoWv, 'Kg_scenes': Wg @ WoWv, 'bi_scenes': Wi @ boc + bi, 'bg_scenes': Wg @ boc + bg,
+            'Ki_nba': Wi @ Wo, 'Kg_nba': Wg @ Wo, 'bi_nba': Wi @ bo + bi, 'bg_nba': Wg @ bo + bg}
+
+
+def role_stream(sd, Tp):
+    """Weight stream of the THROUGHPUT form of the per-agent stage (csrc/role32.hpp, round 4): 128 agents per workgroup on the 32 MFMA columns
+    of each wave, every weight streamed as PK32 tiles exactly like the trajectory chain's.  Consumption order of one workgroup:
+      block-0 conv + GRU (the tiles and per-step program of gru32_stream, Tp steps)  ->  E  ->  FFN  ->  the three layer-1 tables.
+    Two foldings on top of pack_trunk's (role_fold: float64 on the host, rounded once; the function is unchanged -- everything between the
+    encoder's inputs and the gate nonlinearity is affine in eval mode: the positional dropout is the identity, model/STTODE.py:176,214-236):
+      * E, scenes (attention length 1):  g = Wc x + bc (+ [last agent] wlast),  x = the agent's Tp x 4 encoder inputs,
+            Wc[:, 4t:4t+4] = W3a W2_t Wpos_x W1,   bc = W3a (sum_t W2_t (Wpos_x b1 + Wpos_pe pe_t + bpos) + b2) + b3,   wlast = W3[:, 66];
+        softmax over ONE key is 1, so the attention output is out_proj(v(g)):  info = (Wi Wo Wv) g + (Wi (Wo bv + bo) + bi), gate likewise.
+      * E, attention groups > 1 (NBA): g and the attention output arrive from the launches in front;  info = (Wi Wo) attn + (Wi bo + bi).
+    E tiles: [g: row tile j x k-tile (scenes only)] then per row tile j: info k0 k1, gate k0 k1.  FFN: per 32-row hidden tile: linear1 k0 k1,
+    linear2 row tiles 0 1.  Tables: decoder_x, decoder_y of block 0 (k = [pf | state0]: 7 k-tiles), decoder_y of block 1 (k = pf: 4), per
+    32-row tile of the 512 pre-activations its k-tiles.
+    Returns pool [tiles, 1024]; prog_scenes / prog_nba int32 [chunks, 2] ((first tile, tiles <= 3): one workgroup's order, chunks are runs of
+    consecutive pool tiles); consts_scenes / consts_nba float32 [R32_CONSTS['total']]; kte = k-tiles of x (ceil(4 Tp / 32))."""
+    f64 = lambda k: np.asarray(sd[k], np.float64)
+    att = 'past_encoder.ODE_Encoder.odeblock.odefunc.layers.0.'
+    F = role_fold(sd, Tp)
+    kte = F['kte']
+    gs = gru32_stream(sd, 0, Tp)                                # block-0 conv + GRU: its tiles lead the pool, its program leads both programs
+    tiles = list(gs['pool'])
+    gru_prog = [tuple(int(v) for v in e) for e in gs['prog']]
+
+    def chunks(first, count):                                   # a run of consecutive pool tiles cut into chunks of <= 3
+        return [(first + o, min(3, count - o)) for o in range(0, count, 3)]
+
+    def e_tiles(v):
+        Pi, Pg = pk32_tiles(F['Ki_' + v]), pk32_tiles(F['Kg_' + v])   # [2, 2, 1024]
+        ts = []
+        if v == 'scenes':
+            P = pk32_tiles(F['Wc'])                              # [2, kte, 1024]
+            ts += [P[j, kt] for j in range(2) for kt in range(kte)]
+        for j in range(2):
+            ts += [Pi[j, 0], Pi[j, 1], Pg[j, 0], Pg[j, 1]]
+        return ts
+
+    P1, P2 = pk32_tiles(f64(att + 'linear1.weight')), pk32_tiles(f64(att + 'linear2.weight'))   # [32, 2, 1024], [2, 32, 1024]
+    rest = []
+    for ht in range(32):
+        rest += [P1[ht, 0], P1[ht, 1], P2[0, ht], P2[1, ht]]
+    for blk, nm, with_state in ((0, 'x', True), (0, 'y', True), (1, 'y', False)):
+        Wl = f64(f'decoder.decompose.{blk}.decoder_{nm}.layers.0.weight')
+        P = pk32_tiles(np.concatenate([Wl[:, :128], Wl[:, 160:256]], axis=1) if with_state else Wl[:, :128])   # [16, 7 | 4, 1024]
+        rest += [P[rt, kt] for rt in range(16) for kt in range(P.shape[1])]
+    es, en = e_tiles('scenes'), e_tiles('nba')
+    base_s = len(tiles)                                         # pool: [GRU | E_scenes | FFN + tables | E_nba]
+    tiles += es + rest
+    base_n = len(tiles)
+    tiles += en
+    progs = {'scenes': gru_prog + chunks(base_s, len(es) + len(rest)),
+             'nba': gru_prog + chunks(base_n, len(en)) + chunks(base_s + len(es), len(rest))}
+    out = {'kte': kte, 'pool': np.ascontiguousarray(np.stack([np.asarray(t, np.float32) for t in tiles]))}
+    C = R32_CONSTS
+    for v in ('scenes', 'nba'):
+        c = np.zeros(C['total'], np.float64)
+        c[C['bc']:C['bc'] + 64], c[C['wlast']:C['wlast'] + 64] = F['bc'], F['wlast']
+        c[C['bi']:C['bi'] + 64], c[C['bg']:C['bg'] + 64] = F['bi_' + v], F['bg_' + v]
+        c[C['ln1w']:C['ln1w'] + 64], c[C['ln1b']:C['ln1b'] + 64] = f64(att + 'norm1.weight'), f64(att + 'norm1.bias')
+        c[C['l1b']:C['l1b'] + 1024], c[C['l2b']:C['l2b'] + 64] = f64(att + 'linear1.bias'), f64(att + 'linear2.bias')
+        c[C['ln2w']:C['ln2w'] + 64], c[C['ln2b']:C['ln2b'] + 64] = f64(att + 'norm2.weight'), f64(att + 'norm2.bias')
+        c[C['gbias']:C['gbias'] + 416] = gs['consts']
+        for nm, blk, key in (('x', 0, 'b1x'), ('y', 0, 'b1y'), ('y', 1, 'b11')):
+            c[C[key]:C[key] + 512] = f64(f'decoder.decompose.{blk}.decoder_{nm}.layers.0.bias')
+        out['consts_' + v] = np.ascontiguousarray(c.astype(np.float32))
+        out['prog_' + v] = np.ascontiguousarray(np.asarray(progs[v], np.int32))
+        out['prog_len_' + v] = len(progs[v])
+        assert len(progs[v]) == role_prog_len(Tp, v == 'nba')
+    return out
+
+
+def role_prog_len(Tp, nba):
+    """Chunks of one workgroup's program (csrc/role32.hpp checks it): GRU 13 Tp | E | FFN 128 tiles | tables 288 tiles."""
+    kte = (4 * Tp + 31) // 32
+    e = 8 if nba else 2 * kte + 8
+    if nba:
+        return 13 * Tp + (e + 2) // 3 + (128 + 288 + 2) // 3
+    return 13 * Tp + (e + 128 + 288 + 2) // 3
+
+
 def pack_posterior(sd):
     """FutureEncoder head (model/STTODE.py:258-261,297-299): out_mlp 256->128 relu, qz_layer 128->2*zdim."""
     g = lambda k: np.asarray(sd['future_encoder.' + k], np.float32)

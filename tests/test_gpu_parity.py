@@ -517,8 +517,10 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
                 assert torch.equal(out, ref[v][0]), f'{case} variant {v} rep {rep}: fused launch != separate launches'
                 for k in inter:
                     assert torch.equal(inter[k], ref[v][1][k]), f'{case} variant {v} rep {rep}: {k} differs'
-        # three calls in flight on the pipeline's streams, workspace slots reused every third call
+        # three calls in flight on the pipeline's streams, workspace slots reused every third call (the round-3 pipelined form: one call
+        # per fused launch; the default lagged form has its own tests below)
         m.native().set_fused(2)
+        m.native().set_lagged(0)
         m.reset_async()
         handles, outs, order = [], [], [0, 1, 2, 3, 2, 0, 3, 1, 1, 0]
         for v in order:
@@ -536,6 +538,7 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         m.native().set_fused(1)
         m.native().set_chain(-1)
         m.reset_async()
+        m.native().set_lagged(2)
 
 
 GOLDEN_INFERENCE_CASES = ['eth_N2', 'eth_N7', 'eth_N32', 'sdd_ragged', 'nba_B4', 'nba_B32', 'nba_B128', 'nba_long_B8']
@@ -964,8 +967,11 @@ def test_one_launch_scene_form_gives_up_instead_of_hanging():
     assert torch.equal(m.inference(None, z=z), good)
 
 
-def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_stream():
-    """best_of_k_async: the metrics of a pipelined call enqueued on the call's own pipeline stream (behind its launch, in stream order) are
+@pytest.mark.parametrize('lagged', [0, 2, 3])
+def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_stream(lagged):
+    """(lagged = 0: the round-3 pipelined form, bitwise the serial calls; 2 / 3: the default lagged form -- the metrics of a call whose
+    trajectory groups nobody has enqueued yet trigger that launch themselves -- fp32 rounding of the serial calls.)
+    best_of_k_async: the metrics of a pipelined call enqueued on the call's own pipeline stream (behind its launch, in stream order) are
     the bits of best_of_k on the waited predictions; the slot's completion event covers them, so a slot reused four calls later never sees
     its metric buffers or its ground truth overwritten early (ten calls through four slots, three batches of one shape in rotation)."""
     from sttode_amd import scenes
@@ -982,6 +988,7 @@ def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_s
         out = m.inference(None, z=z)
         a, f = m.best_of_k(out.permute(1, 0, 2, 3), gt=fut)
         ref.append((a.clone(), f.clone()))
+    m.native().set_lagged(lagged)
     m.reset_async()
     pend, got = [], []
     for i in range(10):
@@ -1003,14 +1010,21 @@ def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_s
     torch.cuda.synchronize()
     assert len(got) == 10
     for i, (vv, a, f) in enumerate(got):
-        assert torch.equal(a, ref[vv][0]) and torch.equal(f, ref[vv][1]), f'call {i} (batch {vv}): metrics on the call\'s stream differ'
+        if lagged == 0:
+            assert torch.equal(a, ref[vv][0]) and torch.equal(f, ref[vv][1]), f'call {i} (batch {vv}): metrics on the call\'s stream differ'
+        else:
+            assert_close(a.cpu().numpy(), ref[vv][0].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i} (batch {vv}): ADE')
+            assert_close(f.cpu().numpy(), ref[vv][1].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i} (batch {vv}): FDE')
     with pytest.raises(ValueError):
         m.best_of_k_async(h, gt=np.zeros((3, 12, 2), np.float32))
     m.reset_async()
+    m.native().set_lagged(2)
 
 
-def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial():
-    """next_async_stream: the H2D copy of a call's inputs, its latents and the call itself all enqueued on the pipeline stream the call
+@pytest.mark.parametrize('lagged', [0, 2, 3])
+def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial(lagged):
+    """(lagged = 0: the round-3 pipelined form, three streams, bitwise; 2 / 3: the default lagged form on that many streams, fp32 rounding.)
+    next_async_stream: the H2D copy of a call's inputs, its latents and the call itself all enqueued on the pipeline stream the call
     will run on (no cross-stream event anywhere), metrics on that stream too -- nine calls over the three streams, depth 3 -- give the
     predictions and best-of-K values of the serial calls, bit for bit, with latents from the same generator sequence."""
     from sttode_amd import scenes
@@ -1030,8 +1044,9 @@ def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial():
             out = m.inference(None)
             a, f = m.best_of_k(out.permute(1, 0, 2, 3))
             ref.append((out.clone(), a.clone(), f.clone()))
+        m.native().set_lagged(lagged)
         m.reset_async()
-        m.async_depth = 3
+        m.async_depth = 3 if lagged == 0 else 2 * lagged
         torch.manual_seed(21)
         pend, got = [], []
         for i in range(9):
@@ -1053,12 +1068,154 @@ def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial():
         # slots are reused every third call: only the last three calls' buffers still hold their own results
         for i in (6, 7, 8):
             h, (a, f) = got[i]
-            assert torch.equal(h['pred'].permute(1, 0, 2, 3), ref[i][0]), f'call {i}: predictions differ'
-            assert torch.equal(a, ref[i][1]) and torch.equal(f, ref[i][2]), f'call {i}: metrics differ'
+            if lagged == 0:
+                assert torch.equal(h['pred'].permute(1, 0, 2, 3), ref[i][0]), f'call {i}: predictions differ'
+                assert torch.equal(a, ref[i][1]) and torch.equal(f, ref[i][2]), f'call {i}: metrics differ'
+            else:
+                assert_close(h['pred'].permute(1, 0, 2, 3).cpu().numpy(), ref[i][0].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i}: predictions')
+                assert_close(a.cpu().numpy(), ref[i][1].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i}: ADE')
     finally:
         m.async_depth = old_depth
         m.native().set_chain(-1)
         m.reset_async()
+        m.native().set_lagged(2)
+
+
+@pytest.mark.parametrize('case', ['eth_61', 'eth_512', 'eth_long', 'sdd_96', 'nba_128', 'nba_long'])
+def test_lagged_launch_vs_serial_forms_and_oracle(case):
+    """Round 4, the default pipelined form: a call's launch = its per-agent stage in THROUGHPUT form (csrc/role32.hpp: 128 agents per
+    workgroup on 32-column MFMA tiles, host-folded embedding; PastEncoder.forward model/STTODE.py:214-236, block 0 of Decoder.forward
+    :320-347) + the trajectory groups of the call made `streams` calls earlier.  Against the serial form (latency-form roles, 16-column
+    tiles, unfolded embedding) on the same inputs: predictions AND the per-agent intermediates the roles write (pf, state0, the three
+    layer-1 tables) to fp32 rounding; against the CPU oracle at rtol 1e-4 + atol 1e-4.  Calls with DIFFERENT inputs share the rotation
+    (slots reused, 2 and 3 streams); the launch order is exercised three ways: later calls carry the groups, wait() right after the call
+    (the groups become a launch of their own), metrics first.  The same call gives the same bits every time."""
+    from sttode_amd import scenes
+    variants = []
+    if not case.startswith('nba'):
+        Tp, Tf = (10, 40) if case == 'eth_long' else (8, 12)
+        m, ora = hip_model('eth', Tp, Tf), oracle_model('eth', Tp, Tf)
+        if case == 'sdd_96':
+            sb = scenes.make_scene_batch(range(0, 96), 'sdd')
+        else:
+            nsc = {'eth_61': 61, 'eth_512': 512, 'eth_long': 40}[case]
+            sb = scenes.make_scene_batch(range(2000, 2000 + nsc), 'eth', obs_len=Tp, pred_len=Tf)
+        n, S = sb.n_agents, sb.n_scenes
+        for v in range(3):
+            past = (sb.past * (1.0 + 0.03 * v) + 0.1 * v).astype(np.float32)
+            variants.append(((torch.from_numpy(past).to(m.device), torch.from_numpy(sb.future).to(m.device),
+                              torch.from_numpy(sb.scene_ptr).to(m.device)), torch.from_numpy(scenes.latents(300 + v, n)).to(m.device)))
+        feed = lambda inp: m.set_scene_batch(*inp)
+    else:
+        Tp, Tf, B, N = (5, 10, 128, 11) if case == 'nba_128' else (10, 40, 24, 10)
+        m, ora = hip_model('nba', Tp, Tf), oracle_model('nba', Tp, Tf)
+        n, S = B * N, 0
+        for v in range(3):
+            d = scenes.nba_batch(60 + v, B, N=N, obs_len=Tp, pred_len=Tf)
+            variants.append(({'past_traj': torch.from_numpy(d['past_traj']).to(m.device), 'future_traj': torch.from_numpy(d['future_traj']).to(m.device)},
+                             torch.from_numpy(scenes.latents(300 + v, n)).to(m.device)))
+        feed = lambda inp: m.set_data_nba(inp)
+    names = (('pf', 128), ('state0', 96), ('A0x', 512), ('A0y', 512), ('A1y', 512))
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        ref = []
+        for inp, z in variants:                              # serial form: one launch with latency-form roles
+            feed(inp)
+            out = m.inference(None, z=z).clone()
+            buf, off = m._workspace(n, S)
+            ref.append((out, {k: m._view(buf, off, k, n, w).clone() for k, w in names}))
+        first = {}
+        for streams in (2, 3):
+            nat.set_lagged(streams)
+            m.reset_async()
+            m.async_depth = 2 * streams
+            order = [0, 1, 2, 2, 0, 1, 1, 0, 2, 0, 1]
+            pend, outs = [], []
+            for i, v in enumerate(order):
+                inp, z = variants[v]
+                feed(inp)
+                h = m.inference_async(z=z)
+                pend.append((v, h))
+                if i == 3:                                   # wait right behind the call: nobody else has enqueued its groups
+                    vv, hh = pend.pop()
+                    outs.append((vv, hh, m.wait(hh).clone()))
+                elif len(pend) > streams:                    # steady state: the groups came with a later call's launch
+                    vv, hh = pend.pop(0)
+                    if i % 2:
+                        m.best_of_k_async(hh)
+                    outs.append((vv, hh, m.wait(hh).clone()))
+            while pend:
+                vv, hh = pend.pop(0)
+                outs.append((vv, hh, m.wait(hh).clone()))
+            torch.cuda.synchronize()
+            assert len(outs) == len(order)
+            for vv, hh, o in outs:
+                assert torch.isfinite(o).all()
+                assert_close(o.cpu().numpy(), ref[vv][0].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'{case} {streams} streams variant {vv}: lagged vs serial form')
+                if vv in first:
+                    assert torch.equal(o, first[vv]), f'{case} {streams} streams variant {vv}: the lagged form is not deterministic'
+                first.setdefault(vv, o)
+            # the per-agent intermediates of the last call of every slot still in its workspace
+            seen = set()
+            for vv, hh, o in reversed(outs):
+                if hh['slot'] in seen:
+                    continue
+                seen.add(hh['slot'])
+                buf = m._async_bufs[(n, S, hh['slot'])][0]
+                off, _ = nat.layout(n, S)
+                for k, w in names:
+                    got = m._view(buf, off, k, n, w).cpu().numpy()
+                    want = ref[vv][1][k].cpu().numpy()
+                    # pf's second half is the x12-amplified FFN output: two correct fp32 evaluations differ by a few 1e-5 there
+                    assert_close(got, want, rtol=5e-5, atol=5e-5, what=f'{case} {streams} streams variant {vv}: {k}')
+        # the oracle, directly
+        inp, z = variants[0]
+        got = first[0].cpu().numpy()
+        if not case.startswith('nba'):
+            zn = z.cpu().numpy()
+            for s in range(0, S, max(1, S // 6)):
+                a, b = int(sb.scene_ptr[s]), int(sb.scene_ptr[s + 1])
+                obs = np.ascontiguousarray(inp[0][a:b].cpu().numpy().transpose(0, 2, 1))
+                pred = np.ascontiguousarray(inp[1][a:b].cpu().numpy().transpose(0, 2, 1))
+                assert_close(got[:, a:b], oracle_scene_inference(ora, obs, pred, zn[a * 20:b * 20]), what=f'{case} scene {s}: lagged form vs oracle')
+        else:
+            data = {k: v.cpu() for k, v in inp.items()}
+            with torch.no_grad():
+                ora.set_data_nba(data)
+                want = ora.inference(data, z=z.cpu()).numpy()
+            assert_close(got, want, what=f'{case}: lagged form vs oracle')
+    finally:
+        nat.set_chain(-1)
+        m.reset_async()
+        nat.set_lagged(2)
+        m.async_depth = 4
+
+
+def test_check_reports_a_given_up_hand_off():
+    """sttode_check: the host-visible error path of the in-launch hand-off forms (round-3 fused launch): after a launch in which a group
+    gave up waiting for its producer (fault injection) the check fails loudly; after a healthy launch it passes."""
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(4000, 4061), 'eth')
+    z = torch.from_numpy(scenes.latents(9, sb.n_agents)).to(m.device)
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        m.inference(None, z=z)
+        buf, _ = m._workspace(sb.n_agents, sb.n_scenes)
+        nat.check(buf, sb.n_agents, sb.n_scenes)
+        capi.call('sttode_debug_drop_role_flag', nat.h, 3)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        m.inference(None, z=z)
+        with pytest.raises(capi.SttodeError):
+            nat.check(buf, sb.n_agents, sb.n_scenes)
+    finally:
+        capi.call('sttode_debug_drop_role_flag', nat.h, -1)
+        nat.set_chain(-1)
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    m.inference(None, z=z)
 
 
 def test_async_latents_follow_the_same_generator_sequence_as_serial_calls():
