@@ -163,6 +163,7 @@ LEGS = {
 
 
 class Leg:
+    FUSED_METRICS = os.environ.get('STTODE_FUSED_METRICS', '1') != '0'
     STREAMS = 2      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -211,6 +212,7 @@ class Leg:
         self.n_dev = torch.tensor(float(self.n), dtype=torch.float32, device=dev)
         self.calls = 0
         self.pending = []
+        self.d2h_bufs = None
         self.model.packed()
 
     def _load(self):
@@ -226,9 +228,14 @@ class Leg:
     def _finish(self, h):
         # best-of-K on the call's own pipeline stream, behind the launch that carries its trajectory groups (stream order, no event).
         # Nothing goes onto the caller's stream here; whoever needs the call's outputs or its slot waits for the event (settle()).
+        import torch
         self.last_pred = h['pred']
         self.unsettled = h
-        return self.model.best_of_k_async(h, gt=h['gt'])       # per-agent (ade, fde) of the slot; summed ONCE, after the last step
+        out = self.model.best_of_k_async(h, gt=h['gt'])        # per-agent (ade, fde) of the slot; summed ONCE, after the last step
+        if self.d2h_bufs is not None:                           # D2H of the call's futures on ITS stream, behind its groups and metrics
+            with torch.cuda.stream(h['stream']):
+                self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
+        return out
 
     def settle(self):
         """(an event wait on the caller's stream, no kernel) the latest finished call's launch and metrics are complete: its futures may be
@@ -260,7 +267,9 @@ class Leg:
             raise RuntimeError('bench.py: the workload does not take the pipelined chain form')
         with torch.cuda.stream(st):
             self._load()
-            h = self.model.inference_async()                    # z is drawn on device exactly like Normal.rsample in the reference
+            # latents z ~ N(0, I) like Normal.rsample in the reference, drawn by the call's own launch; best-of-K ADE / FDE against the
+            # batch's futures computed by the call's trajectory groups (STTODE_FUSED_METRICS=0: a best_of_k kernel on the call's stream)
+            h = self.model.inference_async(metrics_gt=self.model._future if Leg.FUSED_METRICS else None)
         h['gt'] = self.model._future
         self.pending.append(h)
         return self._finish(self.pending.pop(0)) if len(self.pending) > Leg.STREAMS else None
@@ -277,29 +286,32 @@ class Leg:
         gather: additionally all-gather every step's futures [n_r, K, Tf, 2] over the ranks (parallel.gather_futures: RCCL over xGMI),
         which is what the reference's metric path needs when the futures are wanted on one rank (test.py:194,526)."""
         import torch
-        from sttode_amd import parallel
+        from sttode_amd import capi, parallel
         dev = self.dev
-        hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H target
+        hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H targets
+        self.d2h_bufs = [hostbuf, torch.empty_like(hostbuf).pin_memory()] if d2h and not serial else None   # (one per pipeline stream)
         acc = None
+        import gc
+        gc.collect()                                              # before the warm-up: a collector run between warm-up and region would idle the GPU
+        gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
+        clk = torch.zeros(4, dtype=torch.int64, device=dev)
         for _ in range(warmup):
             self.step(serial)
         self.drain()
+        capi.call('sttode_clock_probe', clk, capi.stream_ptr())   # shader clock the region starts with (20 us, ahead of the synchronize)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         self.model.native().timing(time_every)
-        import gc
-        gc.collect()
-        gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
         t0 = time.perf_counter()
         for _ in range(steps):
             r = self.step(serial)
             if r is not None:
                 acc = r
-                if d2h or gather:
+                if gather or (d2h and serial):
                     self.settle()                                 # the futures about to be copied are complete
-                if d2h:
+                if d2h and serial:
                     hostbuf.copy_(self.last_pred, non_blocking=True)
                 if gather:
                     self.gathered = parallel.gather_futures(self.last_pred)
@@ -307,12 +319,13 @@ class Leg:
         r = self.drain()                                          # every one of the K steps completes inside the timed region
         if r is not None:
             acc = r
-            if d2h or gather:
+            if gather or (d2h and serial):
                 self.settle()
-            if d2h:
+            if d2h and serial:
                 hostbuf.copy_(self.last_pred, non_blocking=True)
             if gather:
                 self.gathered = parallel.gather_futures(self.last_pred)
+        self.d2h_bufs = None
         acc = self.sums(acc)                                      # the last step's per-agent best-of-K values -> (sum ADE, sum FDE, agents)
         if dist is not None:
             dist.all_reduce(acc)                                  # metrics of the last step over all ranks
@@ -322,6 +335,9 @@ class Leg:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gc.enable()
+        capi.call('sttode_clock_probe', clk[2:], capi.stream_ptr())   # ... and the clock it ends with (outside the region)
+        c = clk.tolist()
+        clock = [c[0] / (10.0 * c[1]) if c[1] else None, c[2] / (10.0 * c[3]) if c[3] else None]
         stage_ms = self.model.native().read_timing()
         self.busy_ms = dict(getattr(self.model.native(), 'busy_ms', {}))
         self.model.native().timing(0)
@@ -333,7 +349,7 @@ class Leg:
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             dt, total = float(tmax[0]), float(tt[1])
         return {'dt': dt, 'total_traj': total, 'value': total * steps / dt, 'ms_per_step': 1e3 * dt / steps, 'stage_ms': stage_ms,
-                'metrics': acc, 'host_ms_per_step': 1e3 * t_host / steps}
+                'metrics': acc, 'host_ms_per_step': 1e3 * t_host / steps, 'clock_ghz': clock}
 
     def roofline(self, stage_ms, value_per_gpu, time_every):
         """Dominant kernel's rate.  Launches of consecutive pipelined steps run CONCURRENTLY (two streams, one workgroup per CU each), so
@@ -700,6 +716,13 @@ def main():
             dist.destroy_process_group()
         return 0
     head = Leg('eth_512', rank, dev, size=args.scenes)
+    r3 = None
+    if not args.serial and not args.no_sustained:
+        # The same workload and the same step as a LONG run, 80 steps -- FIRST: after an idle gap the shader clock needs 25-40 ms of load to
+        # climb from ~2.1 to ~2.4 GHz (profiles/r04/clock_ramp.txt; `clock_ghz` = [start, end] of every region), so a 46-ms contract region
+        # that starts cold runs its first half 5-12 % below the clock the device sustains.  This region brings the clock up and shows the
+        # sustained rate; the contract region (W warm-up + K timed steps, unchanged) follows it directly.
+        r3 = head.timed(80, 5, dist, 0)
     r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial)
     roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every)
     if roof:
@@ -717,7 +740,7 @@ def main():
     out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': r['ms_per_step'], 'host_enqueue_ms_per_step': r['host_ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'clock_ghz': r['clock_ghz'],
            'config': head.config(world), 'roofline': roof, 'kernels': kern,
            'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
                            'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
@@ -731,11 +754,9 @@ def main():
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
     r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
-    if not args.serial and not args.no_sustained and world == 1:   # (single-GPU figure; the multi-rank runs keep to the contract's regions)
-        # the same workload, the same step, as a LONG run: 80 steps, so that filling and draining the pipeline weigh 1/4 of what they do in
-        # the 20-step contract run.  A second figure beside `value`, never `value` itself.
-        r3 = head.timed(80, 5, dist, 0)
-        out['sustained'] = {'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'steps': 80, 'warmup': 5, 'form': 'the default step'}
+    if r3 is not None:
+        out['sustained'] = {'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'steps': 80, 'warmup': 5, 'clock_ghz': r3['clock_ghz'],
+                            'form': 'the default step; measured BEFORE the contract region (see clock_ghz)'}
     out['ms_per_step_incl_d2h'] = r2['ms_per_step']
 
     if not args.no_exploratory:
@@ -773,6 +794,8 @@ def main():
         leg = Leg(name, rank, dev)
         # two timed regions, the faster one reported (both kept in `ms_per_step_runs`): a leg's region is only 20-80 ms long, and one
         # host pause (first use of an allocation size, a collector run of another library) moves it by tens of percent
+        if not args.serial:
+            leg.timed(3 * args.leg_steps, 5, dist, 0)             # (untimed: brings the shader clock up after the idle gap of building the leg)
         runs = [leg.timed(args.leg_steps, 5, dist, 1 if args.serial else 2, serial=args.serial) for _ in range(2)]
         lr = min(runs, key=lambda r: r['ms_per_step'])
         lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2)
@@ -783,7 +806,7 @@ def main():
                 lroof['mean_launch_s_serial'] = ms * 1e-3 / cnt
                 lroof['frac_serial_equivalent'] = lroof['flop_per_launch'] / lroof['mean_launch_s_serial'] / PEAK_F32_MFMA
         legs[name] = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'],
-                      'host_enqueue_ms_per_step': lr['host_ms_per_step'], 'ms_per_step_runs': [r['ms_per_step'] for r in runs],
+                      'host_enqueue_ms_per_step': lr['host_ms_per_step'], 'ms_per_step_runs': [r['ms_per_step'] for r in runs], 'clock_ghz': lr['clock_ghz'],
                       'steps': args.leg_steps, 'config': leg.config(world), 'roofline': lroof,
                       'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}
         leg.model.release_native()                                # packed weights / workspaces back to the allocator

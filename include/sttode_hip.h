@@ -427,6 +427,23 @@ int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const 
  *   the serial forms, slots in [0, 4).
  * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream. */
 int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 (default, or env STTODE_LAGGED) or 3 */);
+/* Latents on device (lagged form; replaces the torch.randn_like of Normal.rsample, model/STTODE.py:89-93,609-616, for that call): returns 1
+ * -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged form; that call then treats its `z`
+ * argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples (Philox4x32-10, 64-bit key, counter = the
+ * float4's index; two Box-Muller pairs per block) before its trajectory groups read it.  Returns 0, nothing armed, for every other form
+ * (the caller then supplies z).  NOTE: the one entry point that does not return a status. */
+int sttode_async_device_latents(SttodeModel* m, int n, unsigned long long key);
+/* Fused metrics (lagged form; replaces a sttode_best_of_k launch per call): returns 1 -- and arms it -- if the next
+ * sttode_inference_*_async call of n agents will take the lagged form: that call's trajectory groups then also compute its min-over-K
+ * ADE / FDE (compute_ADE / compute_FDE, utils/metrics.py:7-26; the values of sttode_best_of_k on the same predictions, bit for bit)
+ * against gt [n][Tf][2] into ade / fde [n], valid once sttode_wait(slot) has passed.  Returns 0, nothing armed, otherwise.  Like
+ * sttode_async_device_latents this is a query, not a status. */
+int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt, float* ade, float* fde, float scale);
+/* Measurement aid: the shader clock at this moment.  out[0] = shader cycles, out[1] = ticks of the constant 100 MHz clock over ~20 us on
+ * one lane (device memory, two int64): GHz = out[0] / (10 out[1]). */
+int sttode_clock_probe(long long* out, void* stream);
+/* Enqueue the outstanding trajectory-group launch of the call in `slot` now (no-op when a later call has carried it already). */
+int sttode_async_enqueue(SttodeModel* m, int slot);
 /* Enqueue every outstanding trajectory-group launch of the lagged form (before buffers of pending calls are released or reused). */
 int sttode_async_flush(SttodeModel* m);
 int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,

@@ -59,8 +59,9 @@ print(f'{n} records, {len(np.unique(tag))} launches, {len(np.unique(cu))} distin
 for g in np.unique(tag):
     m = tag == g
     ro, gr = m & (kind == 1), m & (kind == 0)
+    gd = (t1 - t0)[gr] if gr.any() else np.zeros(1)
     print(f'launch {g:3d}: start {t0[m].min():9.1f} end {t1[m].max():9.1f} span {t1[m].max() - t0[m].min():8.1f} | roles {ro.sum():5d} median {np.median((t1 - t0)[ro]) if ro.any() else 0:7.1f} us '
-          f'| groups {gr.sum():5d} median {np.median((t1 - t0)[gr]):7.1f} p10 {np.percentile((t1 - t0)[gr], 10):7.1f} p90 {np.percentile((t1 - t0)[gr], 90):7.1f}')
+          f'| groups / workers {gr.sum():5d} median {np.median(gd):7.1f} p10 {np.percentile(gd, 10):7.1f} p90 {np.percentile(gd, 90):7.1f}')
 tags = np.unique(tag)
 lo, hi = t0[tag == tags[len(tags) // 4]].min(), t0[tag == tags[-len(tags) // 4]].min()       # steady-state window
 ev = np.concatenate([np.stack([t0, np.ones(n)], 1), np.stack([t1, -np.ones(n)], 1)]); ev = ev[np.argsort(ev[:, 0])]
@@ -72,7 +73,7 @@ for k, nm in ((1, 'roles'), (0, 'groups')):
     m = (kind == k) & (t0 >= lo) & (t1 < hi)
     print(f'  {nm}: {m.sum()} blocks, slot-time {((t1 - t0)[m]).sum() / (hi - lo):.1f} slots on average, median duration {np.median((t1 - t0)[m]):.1f} us')
 ro = kind == 1
-if ro.any():
+if ro.any() and os.environ.get('ROLE_PHASES'):
     ph = (r[ro][:, 8:11] * 0.01 - base)
     seg = np.stack([ph[:, 0] - t0[ro], ph[:, 1] - ph[:, 0], ph[:, 2] - ph[:, 1], t1[ro] - ph[:, 2]], 1)
     print('  role phases (median us): embed %.1f | post-attention %.1f | block-0 GRU %.1f | pre-activation tables + publish %.1f' % tuple(np.median(seg, 0)))

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 4, fourth GPU call: workers with static first tickets; latents drawn by the roles (no torch.randn kernel per call).
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r04d
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "lagged or headline or own_pipeline or async or latents" > $O/gputests.log 2>&1 || { tail -30 $O/gputests.log; exit 1; }
+tail -2 $O/gputests.log
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline'] or {}; print(round(d['value']/1e6,2), round(d['ms_per_step'],3), round(r.get('frac',0),3), 'incl d2h', round(d['value_incl_d2h']/1e6,2))"; }
+legs() { python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(round(d['value']/1e6,2), ' '.join(f\"{k}={v['value']/1e6:.1f}M/{v['ms_per_step']:.3f}ms\" for k,v in d['configs'].items()), round(d.get('value_incl_d2h',0)/1e6,1))"; }
+B="timeout -k 10 200 python bench.py --legs none --no-cpu --no-train --no-exploratory --no-per-scene --no-sustained --no-serial-check --warmup 5"
+$B --steps 10 > /dev/null 2>$O/first.err || { tail -20 $O/first.err; exit 1; }
+for i in 1 2; do
+for st in 20 80 160; do
+echo "steps $st workers + device latents : $($B --steps $st 2>/dev/null | line)" | tee -a $O/ab.txt
+echo "steps $st workers + torch.randn    : $(STTODE_DEVICE_LATENTS=0 $B --steps $st 2>/dev/null | line)" | tee -a $O/ab.txt
+echo "steps $st one-per-group + device z : $(STTODE_LAG_WORKERS=0 $B --steps $st 2>/dev/null | line)" | tee -a $O/ab.txt
+done; done
+L="timeout -k 10 300 python bench.py --no-cpu --no-train --steps 20 --warmup 5 --no-exploratory --no-per-scene --no-sustained --no-serial-check"
+for i in 1 2; do
+echo "legs workers + device latents : $($L 2>/dev/null | legs)" | tee -a $O/ab.txt
+echo "legs workers + torch.randn    : $(STTODE_DEVICE_LATENTS=0 $L 2>/dev/null | legs)" | tee -a $O/ab.txt
+echo "legs one-per-group + device z : $(STTODE_LAG_WORKERS=0 $L 2>/dev/null | legs)" | tee -a $O/ab.txt
+done
+for sc in 128 256 1024; do
+echo "scenes $sc workers + device latents : $($B --steps 40 --scenes $sc 2>/dev/null | line)" | tee -a $O/ab.txt
+echo "scenes $sc one-per-group + device z : $(STTODE_LAG_WORKERS=0 $B --steps 40 --scenes $sc 2>/dev/null | line)" | tee -a $O/ab.txt
+done

@@ -73,6 +73,13 @@ struct Role32Args {   // throughput-form per-agent roles (role32.hpp)
     float* pf; float* state0; float* A0x; float* A0y; float* A1y;             // [n][128], [n][96], [n][512] x 3
     int n, Tp, kte, nwg;                                                      // agents, observed frames, k-tiles of x, role workgroups in the grid
     float ode_time;
+    int* counter;   // work queue of THIS call's trajectory groups (a later launch of the same stream): zeroed by role workgroup 0
+    float* zgen; unsigned zkey0, zkey1; int K;   // zgen != nullptr: the roles draw this call's latents z [n K][32] ~ N(0, I) themselves (role32.hpp latents32)
+    // past != nullptr (scene batches): the roles run STTODENet.set_data for their own 128 agents first (role32.hpp frontend32) -- no front-end
+    // launch.  past / scene_ptr may be device memory or pinned host memory (the reads then ARE the H2D transfer of the call's inputs).
+    const float* past; const int* scene_ptr; int S; float* scene_orig; int* agent_scene;
+    float* enc_in_w; float* xpad_w; float* cur_w; float* orig_w; int* last_w;
+    float* m_ade; float* m_fde;   // fused metrics of this call (ChainArgs::m_*): set to +inf here, atomicMin'ed by its groups two launches later
 };
 
 struct ChainArgs {
@@ -87,6 +94,11 @@ struct ChainArgs {
     int* counter;                                           // work queue (zeroed before the launch)
     int ncols, K, Tp, Tf2;
     int persistent;  // 1: workgroups pull groups from the work queue until it is empty; 0: one group per workgroup (grid = groups)
+    // fused metrics (lagged launch, optional): min-over-K ADE / FDE of the predictions against gt [nagents][Tf][2] (utils/metrics.py:7-26) by
+    // the groups themselves -- each column's two values in best_of_k_kernel's summation order, then atomicMin on the float bits (>= 0)
+    // into ade / fde [nagents], which the roles of the same call set to +inf two launches earlier
+    const float* m_gt; float* m_ade; float* m_fde; float m_scale;
+    int nworkers;    // lagged launch with workers: worker w starts with group w, further groups are tickets nworkers + counter++
     long long* dbg;  // diagnostic builds only (C32_DIAG_STAMPS / C32_DIAG_TRACE): per-workgroup stamps
     int trace_tag;   // diagnostic builds only: launch number
     int xcd_map;     // fused launch, roles in front: group blocks b, b + 8, b + 16, .. (dispatched to ONE XCD) take consecutive group ids
@@ -706,7 +718,10 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
     }
     for (int i = threadIdx.x; i < CO::total; i += blockDim.x) cst[i] = A.consts[i];
     for (int i = threadIdx.x; i < A.prog_len; i += blockDim.x) lprog[i] = A.prog[i];
-    if (threadIdx.x == 0) sq[0] = FUSE ? fb : A.persistent ? atomicAdd(A.counter, 1) : (int)blockIdx.x;
+    // A.persistent (FUSE 0 / 2): the workgroup is a WORKER that pulls groups from the call's work queue until it is empty.  Lagged launch:
+    // worker w starts with group w and draws tickets only for its further groups, and not at all when every group has a worker --
+    // same-address atomics of a whole grid starting together serialise at ~1 us each (measured: 213 workers, +0.2 ms per launch)
+    if (threadIdx.x == 0) sq[0] = FUSE == 2 ? fb : (FUSE == 0 && A.persistent) ? atomicAdd(A.counter, 1) : FUSE ? fb : (int)blockIdx.x;
     if (FUSE == 1) {   // this group's per-agent tables come from role workgroups of THIS launch: wait for their tiles (one wave polls)
         const int g0 = fb;
         const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
@@ -755,7 +770,9 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         // the NEXT group is requested now (one ticket of look-ahead: the last MLP prefetches its first gather); every wave reads
         // it after the many barriers of this group
         __syncthreads();  // every wave has read sq[1] of the previous hand-over before it is overwritten
-        if (threadIdx.x == 0) sq[1] = (!FUSE && A.persistent) ? atomicAdd(A.counter, 1) : ngroups;
+        if (threadIdx.x == 0)
+            sq[1] = (FUSE == 2 && A.persistent && ngroups > A.nworkers) ? A.nworkers + atomicAdd(A.counter, 1)
+                    : (FUSE == 0 && A.persistent) ? atomicAdd(A.counter, 1) : ngroups;
 
         f32x16 acc2[8];
         f32x16 d;
@@ -835,31 +852,70 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
             f32x16 yo[NY];
             if (B3M) mlp_l3_b3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
             else mlp_l3<NY>(st, acc2, cst + CO::b2m, cst + CO::b3m, yo, h);
-            if (live) {
+            {
                 agent = opaque(agent);
                 const float cx = A.cur[2 * agent], cy = A.cur[2 * agent + 1];
                 const float ox = A.orig[2 * agent], oy = A.orig[2 * agent + 1];
+                const bool vec = (A.Tf2 & 3) == 0;
+                const float* yrow = A.pred + (size_t)opaque(colc) * A.Tf2;     // y_hat0 parked by this lane (dead lanes: a live column's, unused)
                 float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
+                const float* grow = FUSE == 2 && A.m_gt ? A.m_gt + (size_t)agent * A.Tf2 : nullptr;
+                float dd[NY][4][2];                                           // fused metrics: this lane's displacement norms (steps t0, t0 + 1)
 #pragma unroll
                 for (int o = 0; o < NY; ++o)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const int row0 = 32 * o + 8 * a + 4 * h;
-                        float* p = prow + row0;
-                        if (row0 + 3 < A.Tf2 && (A.Tf2 & 3) == 0) {
-                            const f32x4 y0 = ld4(p);
-                            f32x4 v;
-                            v[0] = ((y0[0] + yo[o][4 * a + 0]) + cx) + ox;
-                            v[1] = ((y0[1] + yo[o][4 * a + 1]) + cy) + oy;
-                            v[2] = ((y0[2] + yo[o][4 * a + 2]) + cx) + ox;
-                            v[3] = ((y0[3] + yo[o][4 * a + 3]) + cy) + oy;
-                            st4(p, v);
-                        } else {
+                        const bool whole = vec && row0 + 3 < A.Tf2;
+                        f32x4 y0 = splat4(0.f);
+                        if (whole) y0 = ld4(yrow + row0);
+                        else {
 #pragma unroll
                             for (int b = 0; b < 4; ++b)
-                                if (row0 + b < A.Tf2) p[b] = ((p[b] + yo[o][4 * a + b]) + ((b & 1) ? cy : cx)) + ((b & 1) ? oy : ox);
+                                if (row0 + b < A.Tf2) y0[b] = yrow[row0 + b];
+                        }
+                        f32x4 v;
+                        v[0] = ((y0[0] + yo[o][4 * a + 0]) + cx) + ox;
+                        v[1] = ((y0[1] + yo[o][4 * a + 1]) + cy) + oy;
+                        v[2] = ((y0[2] + yo[o][4 * a + 2]) + cx) + ox;
+                        v[3] = ((y0[3] + yo[o][4 * a + 3]) + cy) + oy;
+                        if (live) {
+                            if (whole) st4(prow + row0, v);
+                            else {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b)
+                                    if (row0 + b < A.Tf2) prow[row0 + b] = v[b];
+                            }
+                        }
+                        dd[o][a][0] = dd[o][a][1] = 0.f;
+                        if (FUSE == 2 && grow) {   // (uniform)
+                            if (row0 < A.Tf2) { const float2 g = *reinterpret_cast<const float2*>(grow + row0); dd[o][a][0] = bok_dist(v[0], v[1], g.x, g.y, A.m_scale); }
+                            if (row0 + 2 < A.Tf2) { const float2 g = *reinterpret_cast<const float2*>(grow + row0 + 2); dd[o][a][1] = bok_dist(v[2], v[3], g.x, g.y, A.m_scale); }
                         }
                     }
+                if (FUSE == 2 && grow) {   // (uniform) sum over t in order t = 0, 1, ..: lane (c, h = 0) holds steps 4a, 4a + 1 of tile row group a, lane (c, 1) steps 4a + 2, 4a + 3
+                    const int Tf = A.Tf2 >> 1;
+                    float acc = 0.f, fdl = -1.f;
+#pragma unroll
+                    for (int o = 0; o < NY; ++o)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int t0 = (32 * o + 8 * a + 4 * h) >> 1;
+                            float mine = acc;
+                            if (h == 0) { if (t0 < Tf) mine += dd[o][a][0]; if (t0 + 1 < Tf) mine += dd[o][a][1]; }
+                            float mine1 = __shfl(mine, c, 64);
+                            if (h == 1) { if (t0 < Tf) mine1 += dd[o][a][0]; if (t0 + 1 < Tf) mine1 += dd[o][a][1]; }
+                            acc = __shfl(mine1, c + 32, 64);
+                            if (t0 == Tf - 1) fdl = dd[o][a][0];
+                            if (t0 + 1 == Tf - 1) fdl = dd[o][a][1];
+                        }
+                    fdl = fmaxf(fdl, __shfl_xor(fdl, 32, 64));
+                    const float adev = acc / (float)Tf;
+                    if (live && h == 0) {
+                        atomicMin(reinterpret_cast<unsigned*>(A.m_ade) + agent, __float_as_uint(adev));
+                        atomicMin(reinterpret_cast<unsigned*>(A.m_fde) + agent, __float_as_uint(fdl));
+                    }
+                }
             }
         }
         C32_STAMP(4);
@@ -944,7 +1000,7 @@ static int role_lds(int Tp) {   // agent_role's phases: embed (Tp*256 + 512 f32x
 
 static int role32_lds(int prog_len) { return C32_RING * 16 + R32C::total * 4 + prog_len * 8 + 16; }
 
-template <int NY, int FUSE, bool B3M = false> static int chain_launch(const ChainArgs& a, int wgs_per_cu, hipStream_t s) {
+template <int NY, int FUSE, bool B3M = false> static int chain_launch(ChainArgs a, int wgs_per_cu, hipStream_t s) {
     STT_SET_LDS_ONCE((traj_chain_kernel<NY, FUSE, B3M>), 96 * 1024);   // once per (instantiation, device)
     const int ngroups = (a.ncols + 127) / 128;
     // STTODE_CHAIN_RESERVE=r leaves r of the chip's 2-per-CU workgroup slots to concurrently running kernels (the per-agent stage
@@ -954,7 +1010,14 @@ template <int NY, int FUSE, bool B3M = false> static int chain_launch(const Chai
     int grid = 2 * chain_cus() - reserve;
     if (grid > ngroups || !a.persistent) grid = ngroups;
     if (FUSE == 1) grid = (a.R.split ? 5 : 1) * a.R.ntiles + ngroups;   // roles ahead of their consumers, one group per workgroup
-    else if (FUSE == 2) grid = a.R32.nwg + (a.ncols > 0 ? ngroups : 0);   // another call's throughput-form roles, then this call's groups
+    else if (FUSE == 2) {   // another call's throughput-form roles, then this call's groups: one workgroup each, or (persistent) workers
+        int workers = ngroups;
+        const int cap = a.persistent > 1 ? a.persistent : 2 * chain_cus();   // workers: the chip's workgroup slots (or STTODE_LAG_WORKERS=count)
+        if (a.persistent && workers > cap) workers = cap;
+        grid = a.R32.nwg + (a.ncols > 0 ? workers : 0);
+        a.nworkers = workers;
+        if (workers < ngroups) a.xcd_map = 0;   // (the XCD-aware order is a permutation of one-workgroup-per-group grids)
+    }
     else if (a.persistent) STT_HIP(hipMemsetAsync(a.counter, 0, sizeof(int), s));   // the work queue of the persistent form
     // wgs_per_cu == 1: ask for more than half of the CU's LDS so that only ONE chain workgroup is resident per CU.  A lone workgroup
     // keeps the matrix pipe about as busy as two do (469 vs 2 x 397 us per group), and the other half of the register file plus ~76 KiB
@@ -1021,7 +1084,7 @@ static int traj_chain_impl(const float* A0x, const float* A0y, const float* A1y,
     a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
     a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
     a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
-    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0;
+    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.nworkers = 0; a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
     a.R = RoleArgs();   // unused by the unfused instantiation
     {
         static int pers = -1;   // default 0: one group per workgroup (slots free up continuously, so kernels of other streams -- the next
@@ -1087,7 +1150,8 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     a.prog_len = prog_len;
     a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.cur = ws + off[STT_B_CUR];
     a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
-    a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0;
+    a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.nworkers = 0;
+    a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
 #if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
     a.dbg = g_chain_dbg;
     a.trace_tag = g_trace_tag++;
@@ -1130,23 +1194,39 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
 bool stt_chain_lagged_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32; }
 int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
                      float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
-                     void* stream) {
+                     float* zgen, unsigned long long zkey, const float* past, const int* scene_ptr, int S,
+                     float* r_ade, float* r_fde, const float* g_gt, float* g_ade, float* g_fde, float g_scale, int lag_workers_ok, void* stream) {
     STT_REQUIRE(W && (ws_r || ws_g), "stt_chain_lagged: nothing to launch");
     STT_REQUIRE(K > 0 && stt_chain_lagged_covers(Tp) && Tf >= 1, "stt_chain_lagged: shape outside the lagged launch");
     ChainArgs a;
     a.R = RoleArgs();
     a.R32 = Role32Args();
-    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.persistent = 0; a.counter = nullptr;
+    a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.persistent = 0; a.counter = nullptr; a.nworkers = 0;
     a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.ncols = 0;
     a.pool = (const f32x4*)W[b3 ? STT_W_CHAINB3_POOL : STT_W_CHAIN_POOL]; a.prog = (const int2*)W[b3 ? STT_W_CHAINB3_PROG : STT_W_CHAIN_PROG];
     a.prog_len = prog_len; a.consts = W[STT_W_CHAIN_CONSTS];
     a.A0x = a.A0y = a.A1y = nullptr; a.z = nullptr; a.xpad = nullptr; a.cur = a.orig = nullptr; a.pred = nullptr;
+    a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
+    if (ws_g && g_gt) {
+        STT_REQUIRE(g_ade && g_fde, "stt_chain_lagged: fused metrics need ade and fde");
+        a.m_gt = g_gt; a.m_ade = g_ade; a.m_fde = g_fde; a.m_scale = g_scale;
+    }
     if (ws_g) {
         STT_REQUIRE(off_g && z && pred && n_g > 0 && (long)n_g * K <= 0x7fffffffL, "stt_chain_lagged: bad group arguments");
         STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "stt_chain_lagged: chunk program length does not match (Tp, Tf)");
         a.A0x = ws_g + off_g[STT_B_A0X]; a.A0y = ws_g + off_g[STT_B_A0Y]; a.A1y = ws_g + off_g[STT_B_A1Y];
         a.z = z; a.xpad = ws_g + off_g[STT_B_XPAD]; a.cur = ws_g + off_g[STT_B_CUR]; a.orig = ws_g + off_g[STT_B_ORIG]; a.pred = pred;
         a.ncols = n_g * K;
+        // Workers (default): the launch holds at most the chip's 2-per-CU workgroup slots, and its workgroups pull groups from the call's
+        // work queue.  One workgroup per group (STTODE_LAG_WORKERS=0) deals the groups to the 8 XCDs statically (block % 8), the next launch
+        // on another queue starts only when this grid is fully dispatched, and the XCDs do not run at one speed: the block trace shows six
+        // XCDs idle for 250-700 us at the end of every launch while the slowest still has blocks to place (profiles/r04/trace_lagged_static.txt)
+        static int workers = -1;
+        if (workers < 0) { const char* e = getenv("STTODE_LAG_WORKERS"); workers = e ? atoi(e) : 1; if (workers < 0) workers = 1; }
+        // (calls with launches in front of the roles -- the NBA branch's front-end, embedding and attention -- keep one workgroup per group:
+        // workers hold every slot until their queue is empty and those kernels would wait for the launch's end; measured -8 % there)
+        a.persistent = lag_workers_ok ? workers : 0;
+        a.counter = (int*)(ws_g + off_g[STT_B_QUEUE]);       // zeroed by the roles of this call (an earlier launch of this stream)
         static int xm = -1;
         if (xm < 0) { const char* e = getenv("STTODE_XCD_MAP"); xm = e ? atoi(e) != 0 : 1; }
         a.xcd_map = xm;
@@ -1167,6 +1247,14 @@ int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int 
         r.pf = ws_r + off_r[STT_B_PF]; r.state0 = ws_r + off_r[STT_B_STATE0];
         r.A0x = ws_r + off_r[STT_B_A0X]; r.A0y = ws_r + off_r[STT_B_A0Y]; r.A1y = ws_r + off_r[STT_B_A1Y];
         r.n = n_r; r.Tp = Tp; r.nwg = (n_r + 127) / 128; r.ode_time = ode_time;
+        r.counter = (int*)(ws_r + off_r[STT_B_QUEUE]);
+        r.zgen = zgen; r.zkey0 = (unsigned)zkey; r.zkey1 = (unsigned)(zkey >> 32); r.K = K;
+        STT_REQUIRE(!past || (scene_ptr && S > 0 && !attn), "stt_chain_lagged: the in-role front-end needs scene_ptr, S > 0 and attention length 1");
+        r.past = past; r.scene_ptr = scene_ptr; r.S = S;
+        r.scene_orig = ws_r + off_r[STT_B_SCENE_ORIG]; r.agent_scene = (int*)(ws_r + off_r[STT_B_AGENT_SCENE]);
+        r.enc_in_w = ws_r + off_r[STT_B_ENC_IN]; r.xpad_w = ws_r + off_r[STT_B_XPAD]; r.cur_w = ws_r + off_r[STT_B_CUR];
+        r.orig_w = ws_r + off_r[STT_B_ORIG]; r.last_w = (int*)(ws_r + off_r[STT_B_LAST]);
+        r.m_ade = r_ade; r.m_fde = r_fde;
     }
 #if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
     a.dbg = g_chain_dbg;

@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256) void best_of_k_kernel(const float* __restrict_
         // stage all K*Tf distances in LDS (coalesced global reads), then lanes reduce whole samples
         for (int i = lane; i < tot; i += 64) {
             const float2 v = p[i], r = g[i % Tf];
-            const float dx = (v.x - r.x) * scale, dy = (v.y - r.y) * scale;
-            sd[w][i] = sqrtf(dx * dx + dy * dy);
+            sd[w][i] = bok_dist(v.x, v.y, r.x, r.y, scale);
         }
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < K; k += 64) {
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256) void best_of_k_kernel(const float* __restrict_
             float sum = 0.f, dl = 0.f;
             for (int t = 0; t < Tf; ++t) {
                 const float2 v = p[k * Tf + t], r = g[t];
-                const float dx = (v.x - r.x) * scale, dy = (v.y - r.y) * scale;
-                dl = sqrtf(dx * dx + dy * dy);
+                dl = bok_dist(v.x, v.y, r.x, r.y, scale);
                 sum += dl;
             }
             best_a = fminf(best_a, sum / (float)Tf);
@@ -205,6 +203,25 @@ extern "C" int sttode_best_of_k(const float* pred, const float* gt, int n, int K
     STT_REQUIRE(pred && gt && ade && fde, "sttode_best_of_k: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && Tf > 0, "sttode_best_of_k: n, K, Tf must be positive");
     hipLaunchKernelGGL(best_of_k_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, gt, n, K, Tf, scale, ade, fde);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Shader clock right now: one lane counts shader cycles (s_memtime) over ~20 us of the constant 100 MHz clock (s_memrealtime).  bench.py
+// reads it on both sides of a timed region: after an idle gap the clock needs ~25-40 ms of load to climb from ~2.1 to 2.4 GHz
+// (profiles/r04/clock_ramp.txt), which a 20-step region feels and an 80-step one hardly does.
+__global__ void clock_probe_kernel(long long* out) {
+    if (threadIdx.x == 0) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+        long long t1 = t0;
+        while (t1 - t0 < 2000) { __builtin_amdgcn_s_sleep(8); t1 = __builtin_amdgcn_s_memrealtime(); }
+        out[0] = __builtin_amdgcn_s_memtime() - c0;
+        out[1] = t1 - t0;
+    }
+}
+extern "C" int sttode_clock_probe(long long* out, void* stream) {
+    STT_REQUIRE(out, "sttode_clock_probe: null pointer");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
     STT_HIP(hipGetLastError());
     return 0;
 }

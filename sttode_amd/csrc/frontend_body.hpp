@@ -65,3 +65,10 @@ __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict
     if (orig) { fe_store<SC1>(orig + 2 * a, ox); fe_store<SC1>(orig + 2 * a + 1, oy); }
     if (last_flag) last_flag[a] = last;
 }
+
+// One displacement norm of compute_ADE / compute_FDE (utils/metrics.py:7-26), with the contraction spelled out so that every kernel that
+// evaluates it (best_of_k_kernel, the trajectory groups' fused metrics) produces the same bits from the same inputs.
+__device__ __forceinline__ float bok_dist(float px, float py, float gx, float gy, float scale) {
+    const float dx = (px - gx) * scale, dy = (py - gy) * scale;
+    return sqrtf(__fmaf_rn(dx, dx, dy * dy));
+}

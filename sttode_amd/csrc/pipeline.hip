@@ -23,7 +23,9 @@
 struct TimRec { int stage; hipEvent_t e0, e1; };
 
 // LAGGED form: a call whose per-agent roles have been enqueued (in the launch it made) but whose trajectory groups have not yet
-struct LagPending { bool valid; float* ws; long off[STT_B_COUNT]; int n; const float* z; float* pred; hipStream_t s; int si; };
+struct LagPending { bool valid; float* ws; long off[STT_B_COUNT]; int n; const float* z; float* pred; hipStream_t s; int si;
+                    const float* gt; float* ade; float* fde; float scale;
+                    int one_launch; };   // the call was ONE launch (scene batch, front-end in the roles): its groups may run as workers   // gt != nullptr: fused metrics of this call
 
 struct SttodeModel {
     int Tp, Tf, TPX, NOY, K;
@@ -49,6 +51,8 @@ struct SttodeModel {
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB, sB2;
+    bool met_armed; const float* met_gt; float* met_ade; float* met_fde; float met_scale;   // fused metrics of the next lagged call
+    bool zgen_armed; unsigned long long zgen_key;   // the next lagged call draws its own latents with this Philox key (sttode_async_device_latents)
     int lag_streams;                 // 0: lagged form off; 2 (default) / 3: pipeline streams the lagged calls rotate over
     long lag_calls;
     LagPending lag[STT_MAX_SLOTS];   // per slot
@@ -68,7 +72,8 @@ struct SttodeModel {
 bool stt_chain_lagged_covers(int Tp);
 int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
                      float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
-                     void* stream);
+                     float* zgen, unsigned long long zkey, const float* past, const int* scene_ptr, int S,
+                     float* r_ade, float* r_fde, const float* g_gt, float* g_ade, float* g_fde, float g_scale, int lag_workers_ok, void* stream);
 
 static std::mutex g_stream_mu;   // guards the creation of the process-wide streams (sA / sB / sB2 / side, per device)
 
@@ -100,7 +105,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { m->slot_stream[p] = nullptr; m->lag[p].valid = false; }
-    m->lag_streams = 2; m->lag_calls = 0;
+    m->lag_streams = 2; m->lag_calls = 0; m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
     for (int i = 0; i < 3; ++i) m->lag_qn[i] = 0;
     if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0;
     m->scene_launch = 128;
@@ -649,7 +654,8 @@ static int lag_flush(SttodeModel* m, int slot) {
     lag_unqueue(m, slot);
     p.valid = false;
     RUN(STT_STAGE_FUSED, p.s,
-        stt_chain_lagged(m->w, nullptr, nullptr, 0, nullptr, 0, 12.0f, p.ws, p.off, p.n, p.z, p.pred, m->K, m->Tp, m->Tf, m->prog_len, m->b3, p.s));
+        stt_chain_lagged(m->w, nullptr, nullptr, 0, nullptr, 0, 12.0f, p.ws, p.off, p.n, p.z, p.pred, m->K, m->Tp, m->Tf, m->prog_len, m->b3,
+                         nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, p.gt, p.ade, p.fde, p.scale, p.one_launch, p.s));
     STT_HIP(hipEventRecord(m->evB_done[slot], p.s));
     return 0;
 }
@@ -666,7 +672,11 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     ++m->lag_calls;
     STT_HIP(hipStreamWaitEvent(sf, m->ev_call, 0));              // inputs and z of this call (a wait for itself when the caller works on sf)
     STT_HIP(hipStreamWaitEvent(sf, m->evB_done[slot], 0));       // the slot's previous user has drained (same stream in a 2 x streams rotation)
-    if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
+    // scene batches: set_data runs inside the roles (role32.hpp frontend32): the call is ONE launch (STTODE_LAG_FE=0: front-end launches)
+    static const bool fe_in = !(getenv("STTODE_LAG_FE") && atoi(getenv("STTODE_LAG_FE")) == 0);
+    const bool fe_role = fe_in && scene_ptr != nullptr;
+    if (!fe_role)
+        if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
     const float* attn = nullptr;
     if (!scene_ptr && B > 1) {   // attention groups > 1: embedding + attention stay launches in front (the attention reads every agent of the group)
         float* qkv = ws + off[STT_B_QKV];
@@ -682,9 +692,15 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     }
     const int gs = m->lag_qn[si] > 0 ? m->lag_q[si][0] : -1;     // the oldest call of this stream whose groups are outstanding
     LagPending* g = gs >= 0 ? &m->lag[gs] : nullptr;
+    float* zgen = m->zgen_armed ? const_cast<float*>(z) : nullptr;   // armed: `z` is this call's latent BUFFER, filled by its roles
+    m->zgen_armed = false;
+    const bool met = m->met_armed;                                   // armed: this call's groups will compute its best-of-K metrics
+    m->met_armed = false;
     RUN(STT_STAGE_FUSED, sf,
         stt_chain_lagged(W, ws, off, n, attn, 64, 12.0f, g ? g->ws : nullptr, g ? g->off : nullptr, g ? g->n : 0, g ? g->z : nullptr,
-                         g ? g->pred : nullptr, m->K, m->Tp, m->Tf, m->prog_len, m->b3, sf));
+                         g ? g->pred : nullptr, m->K, m->Tp, m->Tf, m->prog_len, m->b3, zgen, m->zgen_key, fe_role ? past : nullptr,
+                         fe_role ? scene_ptr : nullptr, fe_role ? S : 0, met ? m->met_ade : nullptr, met ? m->met_fde : nullptr,
+                         g ? g->gt : nullptr, g ? g->ade : nullptr, g ? g->fde : nullptr, g ? g->scale : 1.0f, fe_role && (!g || g->one_launch), sf));
     if (g) {
         lag_unqueue(m, gs);
         g->valid = false;
@@ -692,6 +708,8 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     }
     LagPending& p = m->lag[slot];
     p.valid = true; p.ws = ws; p.n = n; p.z = z; p.pred = pred; p.s = sf; p.si = si;
+    p.one_launch = fe_role;
+    p.gt = met ? m->met_gt : nullptr; p.ade = met ? m->met_ade : nullptr; p.fde = met ? m->met_fde : nullptr; p.scale = met ? m->met_scale : 1.0f;
     memcpy(p.off, off, sizeof(p.off));
     m->lag_q[si][m->lag_qn[si]++] = slot;
     m->slot_stream[slot] = sf;
@@ -706,6 +724,8 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = lag_flush(m, slot)) return rc;                  // the slot is wanted back: its outstanding groups (if any) go first
+    if (m->met_armed && !use_lagged(m, n)) { m->met_armed = false; STT_REQUIRE(false, "sttode_inference_*_async: fused metrics were armed for a call of another form"); }
+    if (m->zgen_armed && !use_lagged(m, n)) { m->zgen_armed = false; STT_REQUIRE(false, "sttode_inference_*_async: device latents were armed for a call of another form"); }
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
     if (use_lagged(m, n)) return run_lagged(m, past, scene_ptr, n, S, B, N, z, ws, pred, slot, off, s);
     STT_REQUIRE(slot < 4, "sttode_inference_*_async: the round-3 forms take slots in [0, 4)");
@@ -796,12 +816,38 @@ extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
     return 0;
 }
 
+// Latents on device (lagged form): returns 1 -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged
+// form: that call then treats its `z` argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples
+// (Philox4x32-10 keyed by `key`, csrc/role32.hpp latents32) before its trajectory groups read it; returns 0 (nothing armed) otherwise.
+extern "C" int sttode_async_device_latents(SttodeModel* m, int n, unsigned long long key) {
+    if (!m || n <= 0 || !use_lagged(m, n)) return 0;
+    m->zgen_armed = true;
+    m->zgen_key = key;
+    return 1;
+}
+
+// Fused metrics (lagged form): returns 1 -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged form:
+// that call's trajectory groups then also compute its best-of-K ADE / FDE (utils/metrics.py:7-26, the values of sttode_best_of_k bit for
+// bit) against gt [n][Tf][2] into ade / fde [n] -- no metrics kernel; valid once sttode_wait(slot) has passed.  0: nothing armed.
+extern "C" int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt, float* ade, float* fde, float scale) {
+    if (!m || n <= 0 || !gt || !ade || !fde || !use_lagged(m, n)) return 0;
+    m->met_armed = true;
+    m->met_gt = gt; m->met_ade = ade; m->met_fde = fde; m->met_scale = scale;
+    return 1;
+}
+
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");
     if (int rc = lag_flush(m, slot)) return rc;   // (lagged form) no later call carried this call's groups: they are enqueued now
     STT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->evB_done[slot], 0));
     return 0;
+}
+
+// the outstanding trajectory-group launch of ONE slot's call is enqueued now (no-op if a later call carried it already)
+extern "C" int sttode_async_enqueue(SttodeModel* m, int slot) {
+    STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_enqueue: bad model / slot");
+    return lag_flush(m, slot);
 }
 
 // every outstanding trajectory-group launch of the lagged form is enqueued (before buffers of pending calls are released or reused)

@@ -88,6 +88,73 @@ __device__ __forceinline__ void table32(FD& fd, const float* bias, float* out, c
     }
 }
 
+// Latents of the role's call drawn by the launch itself: z [n K][32] ~ N(0, I), the prior samples of Decoder.forward (model/STTODE.py:609-616;
+// Normal.rsample :89-93 is torch.randn_like there).  Philox4x32-10 (Salmon et al., SC'11; the counter-based generator torch and cuRAND use),
+// key = 64 bits the host draws from torch's generator per call, counter = index of the float4 in z; two Box-Muller pairs per block.  As a
+// separate torch.randn kernel the draw waited ~0.7-1 ms per call for workgroup slots on a chip the chain launches keep full and held the
+// CU halves it got all that time (profiles/r04/cadence_*.txt); here it is ~10 k VALU instructions per role lane, issued beside the other
+// wave's MFMAs.  Workgroup wg writes the rows of its own 128 agents; the trajectory groups read them two launches later.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (unsigned)p1; c[2] = n2; c[3] = (unsigned)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void latents32(float* z, unsigned k0, unsigned k1, int wg, int n, int K) {
+    const int a0 = wg * 128, na = n - a0 < 128 ? n - a0 : 128;
+    const long first4 = (long)a0 * K * 8;                       // float4 index of the first row of this workgroup's agents (32 floats per row)
+    const int count4 = na * K * 8;
+    for (int i = threadIdx.x; i < count4; i += blockDim.x) {
+        const unsigned long long g4 = (unsigned long long)(first4 + i);
+        unsigned c[4] = {(unsigned)g4, (unsigned)(g4 >> 32), 0u, 0u};
+        philox4x32_10(c, k0, k1);
+        f32x4 v;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float u1 = (float)(c[2 * p] >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;      // (0, 1): (x >> 8) 2^-24 + 2^-25
+            const float u2 = (float)(c[2 * p + 1] >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
+            const float rad = sqrtf(-2.0f * __logf(u1));
+            float sn, cs;
+            __sincosf(6.283185307179586f * u2, &sn, &cs);
+            v[2 * p] = rad * cs; v[2 * p + 1] = rad * sn;
+        }
+        st4(z + (first4 + i) * 4, v);
+    }
+}
+
+// STTODENet.set_data for the workgroup's 128 agents (model/STTODE.py:397-461), one thread per agent: the agent's scene by binary search in
+// the CSR, the scene origin = mean of the scene's last observed positions summed in agent order (as scene_orig_kernel does: identical bits),
+// then the normalised track, velocities, cur_location and the last-agent flag (agent_inputs_core, frontend_body.hpp) into the workspace
+// rows the other phases of this workgroup and -- two launches later -- the trajectory groups read.
+__device__ __forceinline__ void frontend32(const Role32Args& R, int wg) {
+    const int a = wg * 128 + (int)threadIdx.x;
+    if (threadIdx.x < 128 && a < R.n) {
+        float2 trk[16];                               // the agent's own track does not depend on its scene: requested first
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < R.Tp) trk[t] = reinterpret_cast<const float2*>(R.past + (size_t)a * R.Tp * 2)[t];
+        int lo = 0, hi = R.S - 1;                     // largest s with scene_ptr[s] <= a
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (R.scene_ptr[mid] <= a) lo = mid; else hi = mid - 1;
+        }
+        const int a0 = R.scene_ptr[lo], a1 = R.scene_ptr[lo + 1];
+        float sx = 0.f, sy = 0.f;
+        for (int aa = a0; aa < a1; ++aa) {
+            sx += R.past[((size_t)aa * R.Tp + (R.Tp - 1)) * 2 + 0];
+            sy += R.past[((size_t)aa * R.Tp + (R.Tp - 1)) * 2 + 1];
+        }
+        const float inv = (float)(a1 - a0);
+        const float ox = sx / inv, oy = sy / inv;
+        if (a == a0) { R.scene_orig[2 * lo] = ox; R.scene_orig[2 * lo + 1] = oy; }
+        R.agent_scene[a] = lo;
+        agent_inputs_core<false, 16>(a, R.past, R.Tp, R.ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, R.xpad_w, R.enc_in_w, R.cur_w, R.orig_w, R.last_w, trk);
+    }
+}
+
 // The whole per-agent stage of 128 agents: workgroup `wg` of R.nwg, 4 waves x 32 columns.  smem: ring (24 KiB) | consts | program.
 __device__ __forceinline__ void role32_body(const Role32Args& R, int wg, char* smem) {
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
@@ -95,6 +162,18 @@ __device__ __forceinline__ void role32_body(const Role32Args& R, int wg, char* s
     int2* lprog = reinterpret_cast<int2*>(cst + R32C::total);
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wg == 0 && threadIdx.x == 0) *R.counter = 0;   // the work queue of this call's trajectory groups (read by a LATER launch of this stream)
+    if (R.m_ade && threadIdx.x < 128 && wg * 128 + (int)threadIdx.x < R.n) {   // fused metrics of this call: the minimum starts at +inf
+        R.m_ade[wg * 128 + threadIdx.x] = INFINITY;
+        R.m_fde[wg * 128 + threadIdx.x] = INFINITY;
+    }
+    if (R.past) frontend32(R, wg);                                   // (uniform) scene batches: set_data for this workgroup's agents
+    if (R.zgen) latents32(R.zgen, R.zkey0, R.zkey1, wg, R.n, R.K);   // (uniform)
+    if (R.past) {   // the rows written above are read by other threads of this workgroup below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     for (int i = threadIdx.x; i < R32C::total; i += blockDim.x) cst[i] = R.consts[i];
     for (int i = threadIdx.x; i < R.prog_len; i += blockDim.x) lprog[i] = R.prog[i];
     __syncthreads();

@@ -125,6 +125,11 @@ _DATA_PTR = torch.Tensor.data_ptr
 _VERSION = operator.attrgetter('_version')
 
 
+def lib_device_latents(handle, n, key):
+    """capi: arm device-side latents for the next async call if it takes the lagged form (1) -- see include/sttode_hip.h."""
+    return capi.lib().sttode_async_device_latents(handle, int(n), int(key))
+
+
 def _on(t, device):
     device = torch.device(device)
     return t.device.type == device.type and (device.index is None or t.device.index == device.index)
@@ -190,7 +195,9 @@ class STTODENet(nn.Module):
         # EXPLORATORY, opt-in: 'bf16x3' runs the two block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix
         # cores (fp32-class accuracy, fp32 accumulate; csrc/chain32.hip B3M); 'f32' (default) = fp32 MFMA everywhere.  env STTODE_BF16X3=1
         self.mfma_mode = 'bf16x3' if os.environ.get('STTODE_BF16X3', '0') not in ('', '0') else 'f32'
-        self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 4)
+        self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 8)
+        # inference_async(z=None) in the lagged form: latents drawn by the call's own launch (csrc/role32.hpp); env STTODE_DEVICE_LATENTS=0: torch.randn
+        self.device_latents = os.environ.get('STTODE_DEVICE_LATENTS', '1') != '0'
         self._async_bufs = {}
         self._async_metrics = {}
         self._ext_streams = {}
@@ -695,7 +702,7 @@ class STTODENet(nn.Module):
         return pred.permute(1, 0, 2, 3)
 
     @torch.no_grad()
-    def inference_async(self, z=None):
+    def inference_async(self, z=None, metrics_gt=None, metrics_scale=1.0):
         """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  ``async_depth`` (default 4, at most 8)
         workspace / prediction slots rotate, so at most that many calls may be in flight: call ``wait(handle)`` (which returns the
         [K, n, Tf, 2] view) before the ``async_depth``-th next call.  Inputs set by set_data / set_scene_batch / set_data_nba must stay
@@ -703,19 +710,16 @@ class STTODENet(nn.Module):
         Batches whose per-trajectory stage takes the chain run in the LAGGED form (include/sttode_hip.h, csrc/role32.hpp): the launch a call
         enqueues carries its per-agent stage and the trajectory groups of the call made two calls earlier, so a call's predictions are
         produced when a later call -- or ``wait`` / ``best_of_k_async`` -- enqueues them.  Agrees with inference() to fp32 rounding
-        (``native().set_lagged(0)``: the round-3 forms, bitwise inference())."""
+        (``native().set_lagged(0)``: the round-3 forms, bitwise inference()).
+        ``metrics_gt`` [n, Tf, 2] (contiguous float32 device tensor, e.g. the futures set with the batch): in the lagged form the call's own
+        trajectory groups also compute its min-over-K ADE / FDE (utils/metrics.py:7-26) -- ``best_of_k_async(handle)`` then returns them
+        without launching a kernel (the values of best_of_k on the same predictions, bit for bit)."""
         self._require_gpu()
         a = self.args
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference_async()')
         nat = self.native()
         K, n = a.sample_k, self._past.shape[0]
-        if z is None:
-            z = torch.randn(n * K, a.zdim, device=self.device)
-        elif not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
-            z = _f32(z, self.device)
-        if tuple(z.shape) != (n * K, a.zdim):
-            raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
         S = self._S if self._mode == 'scenes' else 0
         slot = self._async_calls % max(2, min(8, int(self.async_depth)))
         self._async_calls += 1
@@ -725,19 +729,41 @@ class STTODENet(nn.Module):
                 raise capi.SttodeError('too many distinct batch shapes in flight for the async pipeline; call reset_async()')
             _, tot = nat.layout(n, S)
             self._async_bufs[key] = (torch.empty(tot, dtype=torch.float32, device=self.device),
-                                     torch.empty(n, K, a.future_length, 2, dtype=torch.float32, device=self.device))
-        buf, pred = self._async_bufs[key]
+                                     torch.empty(n, K, a.future_length, 2, dtype=torch.float32, device=self.device),
+                                     torch.empty(n * K, a.zdim, dtype=torch.float32, device=self.device))
+        if z is None:
+            # Latents like Normal.rsample (model/STTODE.py:89-93,609-616).  Lagged form: the call's own launch draws them (Philox4x32-10 on
+            # device, csrc/role32.hpp) into the slot's latent buffer, keyed by 64 bits taken from torch's generator here -- reproducible
+            # under torch.manual_seed, not the sequence torch.randn would give (device_latents = False: torch.randn on the caller's stream).
+            # Every other form: torch.randn.
+            if self.device_latents and lib_device_latents(nat.h, n, int(torch.empty((), dtype=torch.int64).random_()) & 0x7fffffffffffffff):
+                z = self._async_bufs[key][2]
+            else:
+                z = torch.randn(n * K, a.zdim, device=self.device)
+        elif not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
+            z = _f32(z, self.device)
+        if tuple(z.shape) != (n * K, a.zdim):
+            raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
+        buf, pred = self._async_bufs[key][:2]
         st = capi.stream_ptr()
-        if self._mode == 'scenes':
-            capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, st)
-        else:
-            capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, st)
+        pstream = self.next_async_stream(n)                     # the pipeline stream this call's launches (and its metrics) run on, or None
         mb = self._async_metrics.get(key)
         if mb is None:                                           # per-slot best-of-K outputs (best_of_k_async): no allocation per call
             t = torch.empty(2, n, dtype=torch.float32, device=self.device)
             mb = self._async_metrics[key] = (t[0], t[1])
-        return {'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None)), 'metrics': mb,
-                'gt_default': self._future}
+        fused = None
+        if metrics_gt is not None:
+            if not (isinstance(metrics_gt, torch.Tensor) and metrics_gt.is_cuda and metrics_gt.dtype == torch.float32 and metrics_gt.is_contiguous()
+                    and tuple(metrics_gt.shape) == (n, a.future_length, 2)):
+                raise ValueError(f'metrics_gt must be a contiguous float32 device tensor [{n}, {a.future_length}, 2]')
+            if capi.lib().sttode_async_fused_metrics(nat.h, n, metrics_gt.data_ptr(), mb[0].data_ptr(), mb[1].data_ptr(), float(metrics_scale)):
+                fused = (metrics_gt, float(metrics_scale))
+        if self._mode == 'scenes':
+            capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, st)
+        else:
+            capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, st)
+        return {'fused_metrics': fused, 'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None)), 'metrics': mb,
+                'gt_default': self._future, 'stream': pstream}
 
     def wait(self, handle):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
@@ -762,7 +788,12 @@ class STTODENet(nn.Module):
         """Min-over-K ADE / FDE per agent of an inference_async() call, enqueued on the pipeline stream the call runs on (they start the
         moment the call's launch drains; nothing goes onto the caller's stream).  Returns (ade [n], fde [n]): views of the slot's metric
         buffers, valid after ``wait(handle)`` and until the slot's next call.  ``gt`` [n, Tf, 2] must have been written before the
-        inference_async() call (default: the futures set with the batch)."""
+        inference_async() call (default: the futures set with the batch).  Further work on the call's results -- a D2H copy of its
+        futures -- may follow on ``handle['stream']`` (stream order: no event; ``wait(handle)`` still covers the metrics only)."""
+        fm = handle.get('fused_metrics')
+        if fm is not None and (gt is None or gt.data_ptr() == fm[0].data_ptr()) and float(scale) == fm[1]:
+            capi.call('sttode_async_enqueue', self.native().h, handle['slot'])   # the call's groups compute them: make sure they are enqueued
+            return handle['metrics']
         gt = handle.get('gt_default') if gt is None else gt
         if not (isinstance(gt, torch.Tensor) and gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous()):
             raise ValueError('best_of_k_async needs a contiguous float32 device tensor gt [n, Tf, 2] that was written before the call')

@@ -46,6 +46,8 @@ def test_ctypes_table_matches_header():
                 assert decl.startswith('float '), (name, decl)
             elif ct is ctypes.c_long:
                 assert decl.startswith('long '), (name, decl)
+            elif ct is ctypes.c_ulonglong:
+                assert decl.startswith('unsigned long long '), (name, decl)
             else:
                 assert '*' in decl, (name, decl)
 
@@ -78,14 +80,14 @@ def test_every_entry_point_rejects_null_arguments():
     from sttode_amd import capi
     L = capi.lib()
     skip = {'sttode_abi_version', 'sttode_last_error', 'sttode_model_destroy', 'sttode_timing_enable', 'sttode_chain_prog_len',
-            'sttode_set_latency_tiles'}
+            'sttode_set_latency_tiles', 'sttode_async_device_latents', 'sttode_async_fused_metrics'}   # (the last two are queries: 0 = not armed, also for a NULL model)
     checked = 0
     for name, argtypes in capi.SIGNATURES.items():
         if name in skip:
             continue
         args = []
         for t in argtypes:
-            if t in (ctypes.c_int, ctypes.c_long):
+            if t in (ctypes.c_int, ctypes.c_long, ctypes.c_ulonglong):
                 args.append(0)
             elif t is ctypes.c_float:
                 args.append(0.0)
@@ -97,6 +99,7 @@ def test_every_entry_point_rejects_null_arguments():
         assert name.replace('_async', '') in msg or 'sttode_' in msg, (name, msg)
         checked += 1
     assert checked >= 40
+    assert L.sttode_async_device_latents(None, 0, 0) == 0 and L.sttode_async_fused_metrics(None, 0, None, None, None, 1.0) == 0
 
 
 def test_pk16_layout_and_mlp_stream_roundtrip():

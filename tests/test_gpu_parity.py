@@ -1047,6 +1047,7 @@ def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial(lagg
         m.native().set_lagged(lagged)
         m.reset_async()
         m.async_depth = 3 if lagged == 0 else 2 * lagged
+        m.device_latents = False                                  # the serial calls' torch.randn sequence (device latents: their own test)
         torch.manual_seed(21)
         pend, got = [], []
         for i in range(9):
@@ -1076,6 +1077,7 @@ def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial(lagg
                 assert_close(a.cpu().numpy(), ref[i][1].cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i}: ADE')
     finally:
         m.async_depth = old_depth
+        m.device_latents = True
         m.native().set_chain(-1)
         m.reset_async()
         m.native().set_lagged(2)
@@ -1116,6 +1118,7 @@ def test_lagged_launch_vs_serial_forms_and_oracle(case):
                              torch.from_numpy(scenes.latents(300 + v, n)).to(m.device)))
         feed = lambda inp: m.set_data_nba(inp)
     names = (('pf', 128), ('state0', 96), ('A0x', 512), ('A0y', 512), ('A1y', 512))
+    fe_names = (('xpad', 16 * (1 if 2 * Tp <= 16 else 2)), ('enc_in', 4 * Tp), ('cur', 2), ('orig', 2))   # set_data's outputs (scene batches: written by the roles)
     nat = m.native()
     try:
         nat.set_chain(1)
@@ -1124,7 +1127,10 @@ def test_lagged_launch_vs_serial_forms_and_oracle(case):
             feed(inp)
             out = m.inference(None, z=z).clone()
             buf, off = m._workspace(n, S)
-            ref.append((out, {k: m._view(buf, off, k, n, w).clone() for k, w in names}))
+            inter = {k: m._view(buf, off, k, n, w).clone() for k, w in names + fe_names}
+            if S:
+                inter['scene_orig'] = m._view(buf, off, 'scene_orig', S, 2).clone()
+            ref.append((out, inter))
         first = {}
         for streams in (2, 3):
             nat.set_lagged(streams)
@@ -1169,6 +1175,9 @@ def test_lagged_launch_vs_serial_forms_and_oracle(case):
                     want = ref[vv][1][k].cpu().numpy()
                     # pf's second half is the x12-amplified FFN output: two correct fp32 evaluations differ by a few 1e-5 there
                     assert_close(got, want, rtol=5e-5, atol=5e-5, what=f'{case} {streams} streams variant {vv}: {k}')
+                for k, w in fe_names + ((('scene_orig', 2),) if S else ()):   # same arithmetic in the same order as the front-end kernels: same bits
+                    got = m._view(buf, off, k, S if k == 'scene_orig' else n, w)
+                    assert torch.equal(got, ref[vv][1][k]), f'{case} {streams} streams variant {vv}: front-end output {k} differs'
         # the oracle, directly
         inp, z = variants[0]
         got = first[0].cpu().numpy()
@@ -1190,6 +1199,143 @@ def test_lagged_launch_vs_serial_forms_and_oracle(case):
         m.reset_async()
         nat.set_lagged(2)
         m.async_depth = 4
+
+
+@pytest.mark.parametrize('case', ['eth_61', 'eth_odd_Tf', 'nba', 'nba_long'])
+def test_fused_metrics_of_the_lagged_form_are_bitwise_best_of_k(case):
+    """inference_async(metrics_gt=...) in the lagged form: the call's trajectory groups compute its min-over-K ADE / FDE themselves
+    (compute_ADE / compute_FDE, utils/metrics.py:7-26): per column the displacement norms summed in best_of_k_kernel's order, then an
+    atomic minimum on the float bits per agent.  Against best_of_k on the call's own predictions: the same bits (agents that straddle two
+    128-trajectory groups and two waves included), for Tf = 12, an odd Tf (2 Tf not a multiple of 4: the element-wise epilogue), the NBA
+    shapes and the long horizon; with a scale factor; slots reused with different batches; against the NumPy oracle of the metric."""
+    from oracle.metrics_ref import best_of_k_ade_fde
+    from sttode_amd import scenes
+    batches = []
+    if case.startswith('eth'):
+        Tp, Tf = (8, 11) if case == 'eth_odd_Tf' else (8, 12)
+        m = hip_model('eth', Tp, Tf)
+        for v in range(3):
+            sb = scenes.make_scene_batch(range(8300 + 70 * v, 8361 + 70 * v), 'eth', obs_len=Tp, pred_len=Tf)
+            batches.append(('scenes', (torch.from_numpy(sb.past).to(m.device), torch.from_numpy(sb.future).to(m.device), torch.from_numpy(sb.scene_ptr).to(m.device))))
+    else:
+        Tp, Tf, B, N = (5, 10, 64, 11) if case == 'nba' else (10, 40, 16, 10)
+        m = hip_model('nba', Tp, Tf)
+        for v in range(3):
+            d = scenes.nba_batch(80 + v, B, N=N, obs_len=Tp, pred_len=Tf)
+            batches.append(('nba', {'past_traj': torch.from_numpy(d['past_traj']).to(m.device), 'future_traj': torch.from_numpy(d['future_traj']).to(m.device)}))
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        m.reset_async()
+        pend, got = [], []
+        for i in range(9):
+            kind, inp = batches[(2 * i + i // 4) % 3]
+            if kind == 'scenes':
+                m.set_scene_batch(*inp)
+            else:
+                m.set_data_nba(inp)
+            scale = 1.0 if i % 3 else 2.5
+            h = m.inference_async(metrics_gt=m._future, metrics_scale=scale)
+            assert h['fused_metrics'] is not None
+            pend.append((h, m._future, scale))
+            if len(pend) > 2:
+                hh, fut, sc = pend.pop(0)
+                a, f = m.best_of_k_async(hh, scale=sc)            # no kernel: the groups' own values
+                pred = m.wait(hh)
+                got.append((a.clone(), f.clone(), pred.clone(), fut, sc))
+        while pend:
+            hh, fut, sc = pend.pop(0)
+            a, f = m.best_of_k_async(hh, scale=sc)
+            pred = m.wait(hh)
+            got.append((a.clone(), f.clone(), pred.clone(), fut, sc))
+        torch.cuda.synchronize()
+        assert len(got) == 9
+        for i, (a, f, pred, fut, sc) in enumerate(got):
+            ra, rf = m.best_of_k(pred.permute(1, 0, 2, 3), gt=fut, scale=sc)
+            assert torch.isfinite(a).all() and torch.isfinite(f).all()
+            assert torch.equal(a, ra) and torch.equal(f, rf), f'{case} call {i}: fused metrics differ from best_of_k on the same predictions'
+            oa, of = best_of_k_ade_fde(pred.permute(1, 0, 2, 3).cpu().numpy() * sc, fut.cpu().numpy() * sc)
+            assert_close(a.cpu().numpy(), oa, rtol=1e-5, atol=1e-5, what=f'{case} call {i}: ADE vs the NumPy oracle')
+            assert_close(f.cpu().numpy(), of, rtol=1e-5, atol=1e-5, what=f'{case} call {i}: FDE vs the NumPy oracle')
+    finally:
+        nat.set_chain(-1)
+        m.reset_async()
+
+
+def _philox_normals(key, first4, count4):
+
+    """NumPy restatement of csrc/role32.hpp latents32: Philox4x32-10 (key = 64 bits, counter = float4 index) + two Box-Muller pairs per
+    block -> float32 [count4 * 4]."""
+    g4 = np.arange(first4, first4 + count4, dtype=np.uint64)
+    c = [(g4 & np.uint64(0xffffffff)).astype(np.uint64), (g4 >> np.uint64(32)).astype(np.uint64), np.zeros(count4, np.uint64), np.zeros(count4, np.uint64)]
+    k0, k1 = np.uint64(key & 0xffffffff), np.uint64((key >> 32) & 0xffffffff)
+    M = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        n0, n2 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M
+        c = [n0, p1 & M, n2, p0 & M]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    out = np.empty((count4, 4), np.float32)
+    for p in range(2):
+        u1 = (c[2 * p] >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24) + np.float32(2.0 ** -25)
+        u2 = (c[2 * p + 1] >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24) + np.float32(2.0 ** -25)
+        rad = np.sqrt(np.float32(-2.0) * np.log(u1.astype(np.float64))).astype(np.float32)
+        ang = np.float32(6.283185307179586) * u2
+        out[:, 2 * p], out[:, 2 * p + 1] = rad * np.cos(ang.astype(np.float64)), rad * np.sin(ang.astype(np.float64))
+    return out.reshape(-1)
+
+
+def test_device_latents_of_the_lagged_form():
+    """inference_async(z=None) in the lagged form: the call's own launch draws z ~ N(0, I) (Philox4x32-10 keyed from torch's generator,
+    csrc/role32.hpp latents32; Normal.rsample, model/STTODE.py:89-93,609-616).  The latents are (a) the values of the NumPy restatement of
+    the generator for the key torch's generator hands out, (b) standard normal by their moments, different from call to call, the same
+    under the same torch seed; (c) exactly what the trajectory groups consumed: the serial form fed the SAME latents gives the call's
+    predictions; (d) switched off (device_latents = False) the call draws torch.randn like the serial form."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(8100, 8161), 'eth')
+    n = sb.n_agents
+    feed = lambda: m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        m.reset_async()
+        runs = []
+        for rep in range(2):
+            torch.manual_seed(5)
+            key = int(torch.empty((), dtype=torch.int64).random_()) & 0x7fffffffffffffff      # what inference_async will draw first
+            torch.manual_seed(5)
+            hs = []
+            for _ in range(3):
+                feed()
+                hs.append(m.inference_async())
+            outs = [(m.wait(h).clone(), h['z'].clone()) for h in hs]
+            runs.append((key, outs))
+        torch.cuda.synchronize()
+        key, outs = runs[0]
+        z0 = outs[0][1].cpu().numpy()
+        assert z0.shape == (n * 20, 32)
+        want = _philox_normals(key, 0, n * 20 * 8).reshape(n * 20, 32)
+        assert_close(z0, want, rtol=1e-4, atol=1e-4, what='device latents vs the NumPy restatement of the generator')
+        allz = np.concatenate([o[1].cpu().numpy().reshape(-1) for o in outs]).astype(np.float64)
+        assert abs(allz.mean()) < 5e-3 and abs(allz.std() - 1.0) < 5e-3 and abs((allz ** 4).mean() - 3.0) < 0.05 and np.abs(allz).max() < 7.0
+        assert not torch.equal(outs[0][1], outs[1][1]) and not torch.equal(outs[1][1], outs[2][1])
+        for i in range(3):
+            assert torch.equal(runs[0][1][i][1], runs[1][1][i][1]) and torch.equal(runs[0][1][i][0], runs[1][1][i][0]), 'same torch seed, different latents'
+            feed()
+            ser = m.inference(None, z=outs[i][1])
+            assert_close(outs[i][0].cpu().numpy(), ser.cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'call {i}: groups consumed other latents than the call reports')
+        m.device_latents = False
+        torch.manual_seed(9)
+        feed()
+        h = m.inference_async()
+        m.wait(h)
+        torch.manual_seed(9)
+        assert torch.equal(h['z'], torch.randn(n * 20, 32, device=m.device))
+    finally:
+        m.device_latents = True
+        nat.set_chain(-1)
+        m.reset_async()
 
 
 def test_check_reports_a_given_up_hand_off():
