@@ -338,6 +338,9 @@ enum SttodeStage {
  * round-robin at creation: a later model's own streams could land on the caller's queue and serialise the pipeline). */
 int sttode_model_create(SttodeModel** out, const void* const* weights, int count, int Tp, int Tf, int K, int n_chunks0,
                         int n_chunks1);
+/* Hand over (or replace) one entry of the weight table after creation.  The two entries of the exploratory bf16-split stream
+ * (STT_W_CHAINB3_*) may be NULL at creation and arrive here before sttode_set_mfma_mode(m, 1). */
+int sttode_model_set_weight(SttodeModel* m, int index, const void* ptr);
 int sttode_model_destroy(SttodeModel* m);
 int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*[STT_B_COUNT]*/, long* total_floats);
 /* number of column parts (1..8) the per-trajectory kernels are pipelined over on separate streams (default 1,
@@ -416,7 +419,7 @@ int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const 
 /* Pipelined forms (STTODENet.inference as a stream of calls, model/STTODE.py:574-623; caller loop test.py:171-184): consecutive calls run
  * on the pipeline's internal streams so that the grid tail of one call's big launch is filled by the next call's.
  *   LAGGED form (round 4; default for every call whose per-trajectory stage takes the chain, reference integrator): calls rotate over
- *   `streams` pipeline streams (sttode_set_lagged; default 2); the ONE launch a call enqueues carries ITS per-agent stage in throughput form
+ *   `streams` pipeline streams (sttode_set_lagged; default 3); the ONE launch a call enqueues carries ITS per-agent stage in throughput form
  *   (128 agents per workgroup, csrc/role32.hpp) followed by the trajectory groups of the call made `streams` calls earlier on the same
  *   stream -- whose per-agent tables the previous launch of that stream produced.  Nothing inside a launch depends on anything else in it
  *   (no flags, no spinning).  A call's predictions are therefore produced by the launch of a LATER call -- or by sttode_wait(slot) /
@@ -426,7 +429,7 @@ int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const 
  *   sttode_set_lagged(m, 0): the round-3 forms (fused launches of one call each on three streams / separate per-agent launches), bitwise
  *   the serial forms, slots in [0, 4).
  * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream. */
-int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 (default, or env STTODE_LAGGED) or 3 */);
+int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 or 3 (default, or env STTODE_LAGGED) */);
 /* Latents on device (lagged form; replaces the torch.randn_like of Normal.rsample, model/STTODE.py:89-93,609-616, for that call): returns 1
  * -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged form; that call then treats its `z`
  * argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples (Philox4x32-10, 64-bit key, counter = the

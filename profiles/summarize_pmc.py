@@ -62,7 +62,10 @@ def main(src, dst):
             continue
         base = name.split('<')[0].split('[')[0]
         st = STAGE_OF.get(base)
-        if base == 'traj_chain_kernel' and 'true' in name:        # traj_chain_kernel<NY, true>: the fused launch (per-agent roles + groups)
+        targs = [t.strip() for t in name.split('<', 1)[1].rstrip('>').split(',')] if '<' in name else []
+        if base == 'traj_chain_kernel' and len(targs) > 1 and targs[1] in ('1', '2', 'true'):   # FUSE != 0: roles + groups in one launch
+            if targs[1] != '2' and 'agents+trajectory_chain[fused launch]' in traffic:
+                continue                                          # (the lagged launch of the pipelined path is the one bench.py times)
             st = 'agents+trajectory_chain[fused launch]'
         if st == 'gru_cols':
             st = 'gru_cols[block1,trajectories]' if 'trajectories' in name else 'gru_cols[block0,agents]'

@@ -73,6 +73,7 @@ SIGNATURES = {
     # native pipeline (csrc/pipeline.hip)
     'sttode_model_create': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _I, _I, _I, _I, _I, _I],
     'sttode_model_destroy': [_P],
+    'sttode_model_set_weight': [_P, _I, _P],
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
@@ -124,7 +125,7 @@ class NativeModel:
 
     def __init__(self, packed, Tp, Tf, K):
         self.packed = packed  # keeps the device tensors alive
-        tbl = (ctypes.c_void_p * len(WEIGHT_ORDER))(*[packed[g][k].data_ptr() for g, k in WEIGHT_ORDER])
+        tbl = (ctypes.c_void_p * len(WEIGHT_ORDER))(*[(packed[g][k].data_ptr() if g in packed else None) for g, k in WEIGHT_ORDER])
         h = ctypes.c_void_p()
         rc = lib().sttode_model_create(ctypes.byref(h), tbl, len(WEIGHT_ORDER), Tp, Tf, K, int(packed['blk0']['n_chunks']),
                                        int(packed['blk1']['n_chunks']))
@@ -167,7 +168,7 @@ class NativeModel:
             raise SttodeError('sttode_set_fused failed: ' + lib().sttode_last_error().decode())
 
     def set_lagged(self, streams):
-        """Pipelined calls in the LAGGED form (default 2 streams): a call's launch = its throughput-form per-agent roles + the trajectory
+        """Pipelined calls in the LAGGED form (default 3 streams): a call's launch = its throughput-form per-agent roles + the trajectory
         groups of the call made `streams` calls earlier; 0: the round-3 forms (bitwise the serial forms).  See include/sttode_hip.h."""
         call('sttode_set_lagged', self.h, int(streams))
 
@@ -175,6 +176,13 @@ class NativeModel:
         """Raise if a group of the last launch on `workspace` gave up waiting for its producer (in-launch hand-off forms only)."""
         import torch
         call('sttode_check', self.h, workspace, int(n), int(S), stream_ptr())
+
+    def set_weights(self, group, tensors):
+        """Hand a weight group that was not there at creation (the opt-in bf16-split stream) to the native model."""
+        self.packed[group] = tensors
+        for i, (g, k) in enumerate(WEIGHT_ORDER):
+            if g == group:
+                call('sttode_model_set_weight', self.h, i, tensors[k])
 
     def set_mfma_mode(self, mode):
         """EXPLORATORY: 1 = block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix cores; 0 = fp32."""

@@ -236,15 +236,18 @@ extern "C" int sttode_clock_probe(long long* out, void* stream) {
 struct StageSlot { float* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
 static StageSlot g_stage[STT_ATTR_DEVICES][4];
 static int g_stage_k[STT_ATTR_DEVICES];
-static std::mutex g_stage_mu;
+static std::mutex g_stage_mu[STT_ATTR_DEVICES];   // one per device: staging threads of different devices do not serialise on each other
 
 extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream) {
     STT_REQUIRE(pre && dev, "sttode_stage_scene: null pointer");
     STT_REQUIRE(N > 0 && Tp > 0 && Tf >= 0 && (fut || Tf == 0), "sttode_stage_scene: bad N/Tp/Tf");
+    // the ring of the device that OWNS `dev` (a model on a non-current device must not be staged on the current device's ring and stream)
     int d = 0;
-    STT_HIP(hipGetDevice(&d));
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, dev) == hipSuccess) d = pa.device;
+    else { (void)hipGetLastError(); STT_HIP(hipGetDevice(&d)); }
     STT_REQUIRE(d >= 0 && d < STT_ATTR_DEVICES, "sttode_stage_scene: device index beyond the staging table");
-    std::lock_guard<std::mutex> lock(g_stage_mu);
+    std::lock_guard<std::mutex> lock(g_stage_mu[d]);
     StageSlot& s = g_stage[d][g_stage_k[d] = (g_stage_k[d] + 1) & 3];
     const size_t need = (size_t)N * (Tp + Tf) * 2;
     if (s.ev) STT_HIP(hipEventSynchronize(s.ev));   // the copy that last read this slot is done
@@ -252,8 +255,10 @@ extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int
     if (s.cap < need) {
         if (s.host) STT_HIP(hipHostFree(s.host));
         s.host = nullptr;
-        s.cap = need < 4096 ? 4096 : 2 * need;
-        STT_HIP(hipHostMalloc((void**)&s.host, s.cap * sizeof(float), hipHostMallocDefault));
+        s.cap = 0;                                   // (a failed allocation below must not leave a capacity behind a null pointer)
+        const size_t want = need < 4096 ? 4096 : 2 * need;
+        STT_HIP(hipHostMalloc((void**)&s.host, want * sizeof(float), hipHostMallocDefault));
+        s.cap = want;
     }
     float* h = s.host;
     for (int a = 0; a < N; ++a)

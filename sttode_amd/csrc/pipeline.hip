@@ -53,7 +53,7 @@ struct SttodeModel {
     hipStream_t sA, sB, sB2;
     bool met_armed; const float* met_gt; float* met_ade; float* met_fde; float met_scale;   // fused metrics of the next lagged call
     bool zgen_armed; unsigned long long zgen_key;   // the next lagged call draws its own latents with this Philox key (sttode_async_device_latents)
-    int lag_streams;                 // 0: lagged form off; 2 (default) / 3: pipeline streams the lagged calls rotate over
+    int lag_streams;                 // 0: lagged form off; 2 / 3 (default): pipeline streams the lagged calls rotate over
     long lag_calls;
     LagPending lag[STT_MAX_SLOTS];   // per slot
     int lag_q[3][STT_MAX_SLOTS]; int lag_qn[3];   // per stream: slots with outstanding groups, oldest first
@@ -84,7 +84,8 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     STT_REQUIRE(out && weights, "sttode_model_create: null pointer");
     STT_REQUIRE(count == STT_W_COUNT, "sttode_model_create: weight table must have STT_W_COUNT entries");
     STT_REQUIRE(Tp >= 2 && 2 * Tp <= 32 && Tf >= 1 && K >= 1, "sttode_model_create: bad Tp/Tf/K");
-    for (int i = 0; i < count; ++i) STT_REQUIRE(weights[i] != nullptr, "sttode_model_create: null weight pointer");
+    for (int i = 0; i < count; ++i)   // (the exploratory bf16-split stream may arrive later: sttode_model_set_weight)
+        STT_REQUIRE(weights[i] != nullptr || i == STT_W_CHAINB3_POOL || i == STT_W_CHAINB3_PROG, "sttode_model_create: null weight pointer");
     SttodeModel* m = new SttodeModel();
     m->Tp = Tp; m->Tf = Tf; m->K = K;
     m->TPX = (2 * Tp <= 16) ? 1 : 2;
@@ -101,11 +102,11 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->ode_method = 0; m->ode_steps = 1;
     if (const char* e = getenv("STTODE_CHAIN")) m->chain_mode = atoi(e) > 0 ? 1 : atoi(e) == 0 ? 0 : -1;
     m->fused_mode = 1;
-    m->b3 = getenv("STTODE_BF16X3") && atoi(getenv("STTODE_BF16X3")) != 0;
+    m->b3 = 0;   // (STTODE_BF16X3=1 is honoured by the Python layer, which packs the bf16-split stream before switching the mode on)
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { m->slot_stream[p] = nullptr; m->lag[p].valid = false; }
-    m->lag_streams = 2; m->lag_calls = 0; m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
+    m->lag_streams = 3; m->lag_calls = 0;   // 3 streams: the small legs gain 3-9 % over 2, 512 scenes tie (profiles/r04/streams_2_vs_3.txt) m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
     for (int i = 0; i < 3; ++i) m->lag_qn[i] = 0;
     if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0;
     m->scene_launch = 128;
@@ -172,6 +173,13 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
         return 2;
     }
     *out = m;
+    return 0;
+}
+
+// hand over (or replace) one entry of the packed-weight table after creation: the opt-in bf16-split stream is packed on first use
+extern "C" int sttode_model_set_weight(SttodeModel* m, int index, const void* ptr) {
+    STT_REQUIRE(m && ptr && index >= 0 && index < STT_W_COUNT, "sttode_model_set_weight: bad arguments");
+    m->w[index] = (const float*)ptr;
     return 0;
 }
 
@@ -263,6 +271,8 @@ extern "C" int sttode_set_scene_launch(SttodeModel* m, int max_tiles) {
 extern "C" int sttode_set_mfma_mode(SttodeModel* m, int mode) {
     STT_REQUIRE(m, "sttode_set_mfma_mode: null model");
     STT_REQUIRE(mode == 0 || mode == 1, "sttode_set_mfma_mode: mode must be 0 (fp32) or 1 (three-way bf16 split, exploratory)");
+    STT_REQUIRE(mode == 0 || (m->w[STT_W_CHAINB3_POOL] && m->w[STT_W_CHAINB3_PROG]),
+                "sttode_set_mfma_mode: the bf16-split weight stream has not been handed over (sttode_model_set_weight)");
     m->b3 = mode;
     return 0;
 }

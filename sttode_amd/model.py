@@ -195,7 +195,7 @@ class STTODENet(nn.Module):
         # EXPLORATORY, opt-in: 'bf16x3' runs the two block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix
         # cores (fp32-class accuracy, fp32 accumulate; csrc/chain32.hip B3M); 'f32' (default) = fp32 MFMA everywhere.  env STTODE_BF16X3=1
         self.mfma_mode = 'bf16x3' if os.environ.get('STTODE_BF16X3', '0') not in ('', '0') else 'f32'
-        self.async_depth = 4     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 8)
+        self.async_depth = 6     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 8; 2 x pipeline streams)
         # inference_async(z=None) in the lagged form: latents drawn by the call's own launch (csrc/role32.hpp); env STTODE_DEVICE_LATENTS=0: torch.randn
         self.device_latents = os.environ.get('STTODE_DEVICE_LATENTS', '1') != '0'
         self._async_bufs = {}
@@ -258,7 +258,6 @@ class STTODENet(nn.Module):
                     'future': packing.pack_trunk(sd, 'future_encoder.', a.future_length),
                     'post': packing.pack_posterior(sd),
                     'chain': packing.chain_stream(sd, a.past_length, a.future_length),
-                    'chain_b3': packing.chain_stream_b3(sd, a.past_length, a.future_length),
                     'gru0s': packing.gru32_stream(sd, 0, a.past_length),
                     'role32': packing.role_stream(sd, a.past_length)}
             self._packed = {g: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
@@ -288,6 +287,12 @@ class STTODENet(nn.Module):
         if self._native is not None and getattr(self._native, '_mfma', None) != self.mfma_mode:
             if self.mfma_mode not in ('f32', 'bf16x3'):
                 raise ValueError("mfma_mode must be 'f32' or 'bf16x3'")
+            if self.mfma_mode == 'bf16x3' and 'chain_b3' not in self._packed:
+                # the opt-in mode's weight stream (1.5x the fp32 stream, ~20 k small NumPy ops) is packed on FIRST use, not with every weight set
+                sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+                b3 = packing.chain_stream_b3(sd, self.args.past_length, self.args.future_length)
+                self._native.set_weights('chain_b3', {k: (torch.from_numpy(np.ascontiguousarray(v)).to(self.device) if isinstance(v, np.ndarray) else v)
+                                                      for k, v in b3.items()})
             self._native.set_mfma_mode(1 if self.mfma_mode == 'bf16x3' else 0)
             self._native._mfma = self.mfma_mode
         return self._native
@@ -703,12 +708,12 @@ class STTODENet(nn.Module):
 
     @torch.no_grad()
     def inference_async(self, z=None, metrics_gt=None, metrics_scale=1.0):
-        """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  ``async_depth`` (default 4, at most 8)
+        """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  ``async_depth`` (default 6, at most 8)
         workspace / prediction slots rotate, so at most that many calls may be in flight: call ``wait(handle)`` (which returns the
         [K, n, Tf, 2] view) before the ``async_depth``-th next call.  Inputs set by set_data / set_scene_batch / set_data_nba must stay
         unmodified until then.
         Batches whose per-trajectory stage takes the chain run in the LAGGED form (include/sttode_hip.h, csrc/role32.hpp): the launch a call
-        enqueues carries its per-agent stage and the trajectory groups of the call made two calls earlier, so a call's predictions are
+        enqueues carries its per-agent stage and the trajectory groups of the call made three calls earlier (same pipeline stream), so a call's predictions are
         produced when a later call -- or ``wait`` / ``best_of_k_async`` -- enqueues them.  Agrees with inference() to fp32 rounding
         (``native().set_lagged(0)``: the round-3 forms, bitwise inference()).
         ``metrics_gt`` [n, Tf, 2] (contiguous float32 device tensor, e.g. the futures set with the batch): in the lagged form the call's own

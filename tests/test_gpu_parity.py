@@ -538,7 +538,7 @@ def test_fused_launch_is_bitwise_the_separate_per_agent_launches(case):
         m.native().set_fused(1)
         m.native().set_chain(-1)
         m.reset_async()
-        m.native().set_lagged(2)
+        m.native().set_lagged(3)
 
 
 GOLDEN_INFERENCE_CASES = ['eth_N2', 'eth_N7', 'eth_N32', 'sdd_ragged', 'nba_B4', 'nba_B32', 'nba_B128', 'nba_long_B8']
@@ -1018,7 +1018,7 @@ def test_async_best_of_k_on_the_calls_stream_matches_the_kernel_on_the_callers_s
     with pytest.raises(ValueError):
         m.best_of_k_async(h, gt=np.zeros((3, 12, 2), np.float32))
     m.reset_async()
-    m.native().set_lagged(2)
+    m.native().set_lagged(3)
 
 
 @pytest.mark.parametrize('lagged', [0, 2, 3])
@@ -1080,7 +1080,7 @@ def test_pipelined_calls_prepared_on_their_own_pipeline_stream_match_serial(lagg
         m.device_latents = True
         m.native().set_chain(-1)
         m.reset_async()
-        m.native().set_lagged(2)
+        m.native().set_lagged(3)
 
 
 @pytest.mark.parametrize('case', ['eth_61', 'eth_512', 'eth_long', 'sdd_96', 'nba_128', 'nba_long'])
@@ -1197,8 +1197,8 @@ def test_lagged_launch_vs_serial_forms_and_oracle(case):
     finally:
         nat.set_chain(-1)
         m.reset_async()
-        nat.set_lagged(2)
-        m.async_depth = 4
+        nat.set_lagged(3)
+        m.async_depth = 6
 
 
 @pytest.mark.parametrize('case', ['eth_61', 'eth_odd_Tf', 'nba', 'nba_long'])
