@@ -351,11 +351,14 @@ class Leg:
         return {'dt': dt, 'total_traj': total, 'value': total * steps / dt, 'ms_per_step': 1e3 * dt / steps, 'stage_ms': stage_ms,
                 'metrics': acc, 'host_ms_per_step': 1e3 * t_host / steps, 'clock_ghz': clock}
 
-    def roofline(self, stage_ms, value_per_gpu, time_every):
-        """Dominant kernel's rate.  Launches of consecutive pipelined steps run CONCURRENTLY (two streams, one workgroup per CU each), so
-        the rate is  (algorithmic FLOP per launch x launches) / busy time,  busy time = length of the union of the launches' [start, end]
-        HIP-event intervals; FLOP / mean launch duration would count the shared time once per launch in flight.  The raw mean launch
-        duration (what rocprofv3 --stats averages) and the mean number of launches in flight are reported next to it."""
+    def roofline(self, stage_ms, value_per_gpu, time_every, calls=None):
+        """Dominant kernel's rate.  Launches of consecutive pipelined steps run CONCURRENTLY (three streams), so the rate is
+        (algorithmic FLOP of the region's calls) / busy time,  busy time = length of the union of the launches' [start, end] HIP-event
+        intervals; FLOP / mean launch duration would count the shared time once per launch in flight.  The raw mean launch duration (what
+        rocprofv3 --stats averages) and the mean number of launches in flight are reported next to it.
+        Lagged launches: a launch carries the per-agent roles of one call and the trajectory groups of another, and a region of `calls`
+        steps makes calls + STREAMS launches (its first STREAMS launches carry roles only, its last STREAMS groups only): the FLOP are
+        counted per CALL -- every call's roles and groups run exactly once inside the region -- not per launch."""
         kern, dom = {}, None
         for t, (ms, cnt) in stage_ms.items():
             mean_s = ms * 1e-3 / cnt
@@ -364,6 +367,10 @@ class Leg:
             fl = kernel_flops(t, self.n, self.m, self.F)
             if fl is None:
                 continue
+            if calls is not None and t == 'agents+trajectory_chain[fused launch]' and cnt > calls:
+                kern[t]['launches_sampled'] = cnt
+                kern[t]['calls'] = calls
+                fl = fl * calls / cnt                               # mean FLOP per launch of this region
             kern[t]['tflops'] = fl * cnt / busy_s / 1e12
             if dom is None or ms > dom[1]:
                 dom = (t, ms, fl, mean_s, cnt, busy_s)
@@ -708,7 +715,7 @@ def main():
             return 2
         leg = Leg(args.only_leg, rank, dev, size=args.scenes if args.only_leg == 'eth_512' else None)
         lr = leg.timed(args.leg_steps, 5, dist, 1, serial=args.serial)
-        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 1)
+        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 1, calls=None if args.serial else args.leg_steps)
         if rank == 0:
             print(json.dumps({'leg': args.only_leg, 'serial': bool(args.serial), 'value': lr['value'], 'ms_per_step': lr['ms_per_step'], 'steps': args.leg_steps,
                               'config': leg.config(world), 'roofline': lroof, 'kernels_mean_us': {k: round(v['mean_us'], 1) for k, v in lkern.items()}}))
@@ -717,7 +724,7 @@ def main():
         return 0
     head = Leg('eth_512', rank, dev, size=args.scenes)
     r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial)
-    roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every)
+    roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every, calls=None if args.serial else args.steps)
     if roof:
         roof['path_frac_survey_flops_superseded'] = r['value'] / world * F_TRAJ_SURVEY / PEAK_F32_MFMA
     if roof and not args.serial and not args.no_serial_check:
@@ -795,7 +802,7 @@ def main():
             leg.timed(3 * args.leg_steps, 5, dist, 0)             # (untimed: brings the shader clock up after the idle gap of building the leg)
         runs = [leg.timed(args.leg_steps, 5, dist, 1 if args.serial else 2, serial=args.serial) for _ in range(2)]
         lr = min(runs, key=lambda r: r['ms_per_step'])
-        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2)
+        lroof, lkern = leg.roofline(lr['stage_ms'], lr['value'] / world, 2, calls=None if args.serial else args.leg_steps)
         if lroof and not args.serial and not args.no_serial_check:
             rs = leg.timed(8, 2, dist, 1, serial=True)
             ms, cnt = rs['stage_ms'].get(lroof['kernel'], (0.0, 0))

@@ -28,6 +28,7 @@
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
 #include <cstdlib>
+#include <cstddef>
 
 // C32_DIAG_TRACE (diagnostic build, profiles/exp_r03_trace.py): every workgroup appends one record {launch tag, block, kind, start, end (100 MHz
 // s_memrealtime), HW_ID, XCC_ID} to the debug buffer -- who ran where and when, across overlapping launches
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
 
     C32_TRACE_BEGIN();
     if (FUSE == 2 && (int)blockIdx.x < A.R32.nwg) {   // (uniform) a throughput-form role workgroup: 128 agents of the roles' call
-        role32_body(A.R32, blockIdx.x, smem);
+        role32_body(*(KRole32Args*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, R32)),
+                    blockIdx.x, smem);
         C32_TRACE_END(1);
         return;
     }

@@ -39,7 +39,9 @@ __device__ __forceinline__ void agent_inputs_core(int a, const float* __restrict
     }
 #pragma unroll
     for (int t = 0; t < (TMAX > 0 ? TMAX : T); ++t) {
-        if (TMAX > 0 && t >= T) break;
+        // (a guard, not a break: with a break the loop is not fully unrolled, wb[] is indexed dynamically and lives in SCRATCH --
+        // 128 B per lane of every wave of whatever launch contains this code)
+        if (TMAX > 0 && t >= T) continue;
         const float wx = TMAX > 0 ? wb[t].x : p[2 * t], wy = TMAX > 0 ? wb[t].y : p[2 * t + 1];
         const float nx = wx - ox, ny = wy - oy;
         float vx, vy;

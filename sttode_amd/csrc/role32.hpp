@@ -24,6 +24,10 @@ struct R32C {   // == packing.R32_CONSTS
 };
 
 // (struct Role32Args: chain32.hip, beside ChainArgs)
+// The role reads its arguments straight from the kernel-argument segment (constant address space: scalar loads where they are needed).
+// Taken from the by-value ChainArgs parameter instead, hipcc loads 64 bytes of them at the top of the kernel -- in front of the branch
+// that separates roles from groups -- and, with every VGPR taken by the groups' code, parks them in SCRATCH: 128 B per lane of every wave.
+typedef const __attribute__((address_space(4))) Role32Args KRole32Args;
 
 // The stream as a flat sequence of tiles: next() hands out the tiles of the program in order and steps over chunk boundaries (prefetch of the
 // following chunk, barrier) wherever they fall -- a layer need not be a whole number of chunks.  Uniform control flow: every wave of the
@@ -129,13 +133,9 @@ __device__ __forceinline__ void latents32(float* z, unsigned k0, unsigned k1, in
 // the CSR, the scene origin = mean of the scene's last observed positions summed in agent order (as scene_orig_kernel does: identical bits),
 // then the normalised track, velocities, cur_location and the last-agent flag (agent_inputs_core, frontend_body.hpp) into the workspace
 // rows the other phases of this workgroup and -- two launches later -- the trajectory groups read.
-__device__ __forceinline__ void frontend32(const Role32Args& R, int wg) {
+__device__ __forceinline__ void frontend32(KRole32Args& R, int wg) {
     const int a = wg * 128 + (int)threadIdx.x;
     if (threadIdx.x < 128 && a < R.n) {
-        float2 trk[16];                               // the agent's own track does not depend on its scene: requested first
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (t < R.Tp) trk[t] = reinterpret_cast<const float2*>(R.past + (size_t)a * R.Tp * 2)[t];
         int lo = 0, hi = R.S - 1;                     // largest s with scene_ptr[s] <= a
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -151,12 +151,14 @@ __device__ __forceinline__ void frontend32(const Role32Args& R, int wg) {
         const float ox = sx / inv, oy = sy / inv;
         if (a == a0) { R.scene_orig[2 * lo] = ox; R.scene_orig[2 * lo + 1] = oy; }
         R.agent_scene[a] = lo;
-        agent_inputs_core<false, 16>(a, R.past, R.Tp, R.ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, R.xpad_w, R.enc_in_w, R.cur_w, R.orig_w, R.last_w, trk);
+        // (no preloaded track handed over by pointer: an array whose address is taken lives in scratch -- 128 B per lane of EVERY wave of the
+        // launch for a value 128 lanes use once)
+        agent_inputs_core<false, 16>(a, R.past, R.Tp, R.ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, R.xpad_w, R.enc_in_w, R.cur_w, R.orig_w, R.last_w);
     }
 }
 
 // The whole per-agent stage of 128 agents: workgroup `wg` of R.nwg, 4 waves x 32 columns.  smem: ring (24 KiB) | consts | program.
-__device__ __forceinline__ void role32_body(const Role32Args& R, int wg, char* smem) {
+__device__ __forceinline__ void role32_body(KRole32Args& R, int wg, char* smem) {
     f32x4* ring = reinterpret_cast<f32x4*>(smem);
     float* cst = reinterpret_cast<float*>(ring + C32_RING);
     int2* lprog = reinterpret_cast<int2*>(cst + R32C::total);
