@@ -171,6 +171,7 @@ class NativeModel:
         """Pipelined calls in the LAGGED form (default 3 streams): a call's launch = its throughput-form per-agent roles + the trajectory
         groups of the call made `streams` calls earlier; 0: the round-3 forms (bitwise the serial forms).  See include/sttode_hip.h."""
         call('sttode_set_lagged', self.h, int(streams))
+        self._lagged = int(streams)
 
     def check(self, workspace, n, S):
         """Raise if a group of the last launch on `workspace` gave up waiting for its producer (in-launch hand-off forms only)."""

@@ -14,6 +14,7 @@
 //               writes past_feature = cat(ftraj_input, ode_out).
 #include "chain.hpp"
 #include "latency_bodies.hpp"
+#include "frontend_body.hpp"
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
 
@@ -94,6 +95,21 @@ __global__ __launch_bounds__(256) void embed_qkv_lat_kernel(EmbedW w, const floa
                                                             float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen) {
     extern __shared__ __attribute__((aligned(16))) char smem_e[];
     embed_lat_body(w, enc_in, last_flag, g, qkv, n, Tlen, blockIdx.x, reinterpret_cast<f32x4*>(smem_e));
+}
+
+// The NBA branch's set_data_nba (model/STTODE.py:463-486: no normalisation, velocities, last-slot flag) for the workgroup's 16 agents, then
+// the embedding: one launch instead of two in front of the attention (lagged pipelined calls, pipeline.hip).  The front-end's rows are
+// written by 16 lanes and read by the whole workgroup: workgroup-scope release / barrier / acquire.
+struct NbaFe { const float* past; int N, TPX; float* xpad; float* enc_in; float* cur; float* orig; int* last; };
+__global__ __launch_bounds__(256) void embed_qkv_fe_kernel(EmbedW w, NbaFe f, float* __restrict__ g, float* __restrict__ qkv, int n, int Tlen) {
+    extern __shared__ __attribute__((aligned(16))) char smem_e[];
+    const int a = blockIdx.x * 16 + (int)threadIdx.x;
+    if (threadIdx.x < 16 && a < n)
+        agent_inputs_core<false, 16>(a, f.past, Tlen, f.TPX, 1, 0.f, 0.f, a % f.N == f.N - 1, nullptr, f.xpad, f.enc_in, f.cur, f.orig, f.last);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    embed_lat_body(w, f.enc_in, f.last, g, qkv, n, Tlen, blockIdx.x, reinterpret_cast<f32x4*>(smem_e));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -244,6 +260,64 @@ __global__ __launch_bounds__(256) void post_attn_rhs_kernel(PostW w, const float
         st4(kout + (size_t)col * 64 + 16 * wv + 4 * q, xo);
     }
 }
+// One STAGE of a multi-step / Runge-Kutta integration with attention groups > 1 as ONE launch (round 4; the op-level form ran in-projection,
+// attention, right-hand side and up to four copy / axpy launches per stage: ~30 launches per RK4 step): k_new = f(state) with the attention
+// output of `state` given, then the NEXT state  out = base + cA kA + cB kB + cC kC + cN k_new  (the stage's Butcher row, or the step's
+// update when it is the last stage; null pointers are skipped), then -- the accumulator layout of `out` is the B operand of the
+// in-projection -- qkv(out) for the attention of the next stage, and past_feature = cat(g, relu(out)) behind the last stage of the last
+// step (ode_demo.py:231, model/STTODE.py:233-235).  Per stage: this launch + the attention.  Every workgroup reads and writes only its own
+// 16 agents' rows, so `out` may alias `state` or `base`.
+struct OdeStage {
+    const float* state; const float* attn; int ld_attn;
+    const float* base; const float* kA; const float* kB; const float* kC; float cA, cB, cC, cN;
+    float* kout; float* out; const f32x4* inP; const float* inb; float* qkv; const float* g; float* pf;
+};
+__global__ __launch_bounds__(256) void post_attn_stage_kernel(PostW w, OdeStage o, int n) {
+    __shared__ f32x4 sX[4][4][64];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 16 + c;
+    const int colc = col < n ? col : n - 1;
+    f32x4 a[4], yy[4], x[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        yy[T] = ld4(o.state + (size_t)colc * 64 + 16 * T + 4 * q);
+        a[T] = ld4(o.attn + (size_t)colc * o.ld_attn + 16 * T + 4 * q);
+    }
+    ode_rhs(w, sX, a, yy, x, lane, q, wv);       // every wave leaves with the full k_new in x[4]
+    f32x4 t[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const size_t e = (size_t)colc * 64 + 16 * T + 4 * q;
+        f32x4 v = ld4(o.base + e);
+        if (o.kA) { const f32x4 k = ld4(o.kA + e); for (int r = 0; r < 4; ++r) v[r] = fmaf(o.cA, k[r], v[r]); }
+        if (o.kB) { const f32x4 k = ld4(o.kB + e); for (int r = 0; r < 4; ++r) v[r] = fmaf(o.cB, k[r], v[r]); }
+        if (o.kC) { const f32x4 k = ld4(o.kC + e); for (int r = 0; r < 4; ++r) v[r] = fmaf(o.cC, k[r], v[r]); }
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(o.cN, x[T][r], v[r]);
+        t[T] = v;
+    }
+    __syncthreads();                             // (every lane has read its base / state rows before `out` may overwrite them)
+    if (col < n) {
+        const f32x4 ko = wv == 0 ? x[0] : wv == 1 ? x[1] : wv == 2 ? x[2] : x[3];
+        const f32x4 to = wv == 0 ? t[0] : wv == 1 ? t[1] : wv == 2 ? t[2] : t[3];
+        if (o.kout) st4(o.kout + (size_t)col * 64 + 16 * wv + 4 * q, ko);
+        st4(o.out + (size_t)col * 64 + 16 * wv + 4 * q, to);
+        if (o.pf) {
+            st4(o.pf + (size_t)col * 128 + 16 * wv + 4 * q, ld4(o.g + (size_t)col * 64 + 16 * wv + 4 * q));
+            st4(o.pf + (size_t)col * 128 + 64 + 16 * wv + 4 * q, relu4(to));
+        }
+    }
+    if (o.qkv) {                                 // in-projection of the next state: wave w computes row tiles w, w + 4, w + 8 of q | k | v
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int it = wv + 4 * i;
+            f32x4 acc = ld4(o.inb + 16 * it + 4 * q);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc = mfma_k16(acc, o.inP[(it * 4 + T) * 64 + lane], t[T]);
+            if (col < n) st4(o.qkv + (size_t)col * 192 + 16 * it + 4 * q, acc);
+        }
+    }
+}
 // past_feature = cat(ftraj_input, relu(ODE state at t = ode_time)) (ode_demo.py:231, model/STTODE.py:233-235)
 __global__ void ode_state_to_pf_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ pf, int n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,6 +375,26 @@ extern "C" int sttode_embed_qkv(const float* fc1P, const float* fc1b, const floa
     return 0;
 }
 
+// Internal (pipeline.hip): sttode_frontend_nba + sttode_embed_qkv as ONE launch (W = the model's weight table); false: shape not covered
+bool stt_embed_qkv_fe_covers(int n, int Tlen) {
+    return (n + 15) / 16 <= stt_enc_lat_tiles() && ((size_t)Tlen * 256 + 512) * 16 <= 64 * 1024 && Tlen <= 16;
+}
+int stt_embed_qkv_fe(const float* const* W, const float* past, int n, int N, int Tlen, int TPX, float* xpad, float* enc_in, float* cur,
+                     float* orig, int* last, float* g, float* qkv, void* stream) {
+    STT_REQUIRE(W && past && xpad && enc_in && cur && orig && last && g && qkv, "stt_embed_qkv_fe: null pointer");
+    STT_REQUIRE(n > 0 && N > 0 && n % N == 0 && stt_embed_qkv_fe_covers(n, Tlen), "stt_embed_qkv_fe: shape outside the fused form");
+    EmbedW w;
+    w.fc1P = W[STT_W_FC1P]; w.fc1b = W[STT_W_FC1B]; w.posP = (const f32x4*)W[STT_W_POSP]; w.peb = W[STT_W_PEB];
+    w.fc2P = (const f32x4*)W[STT_W_FC2P]; w.fc2b = W[STT_W_FC2B]; w.fc3P = (const f32x4*)W[STT_W_FC3P]; w.fc3b = W[STT_W_FC3B];
+    w.fc3last = W[STT_W_FC3LAST]; w.inP = (const f32x4*)W[STT_W_INP]; w.inb = W[STT_W_INB];
+    NbaFe f;
+    f.past = past; f.N = N; f.TPX = TPX; f.xpad = xpad; f.enc_in = enc_in; f.cur = cur; f.orig = orig; f.last = last;
+    const size_t lat_lds = ((size_t)Tlen * 256 + 512) * 16;
+    hipLaunchKernelGGL(embed_qkv_fe_kernel, dim3((n + 15) / 16), dim3(256), lat_lds, (hipStream_t)stream, w, f, g, qkv, n, Tlen);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out, float* rowsum, float* wout, int rows,
                                  int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b,
                                  long os_seq, long os_b, float rscale, float cscale, void* stream) {
@@ -350,6 +444,23 @@ extern "C" int sttode_post_attn_rhs(const float* outP, const float* outb, const 
     w.gateb = gateb; w.ln1w = ln1w; w.ln1b = ln1b; w.l1P = (const f32x4*)l1P; w.l1b = l1b; w.l2P = (const f32x4*)l2P; w.l2b = l2b;
     w.ln2w = ln2w; w.ln2b = ln2b;
     hipLaunchKernelGGL(post_attn_rhs_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, y, attn, ld_attn, kout, n);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+// Internal (pipeline.hip): one fused stage, see post_attn_stage_kernel.  W = the model's weight table.
+int stt_post_attn_stage(const float* const* W, const float* state, const float* attn, int ld_attn, const float* base, const float* kA, float cA,
+                        const float* kB, float cB, const float* kC, float cC, float cN, float* kout, float* out, float* qkv, const float* g,
+                        float* pf, int n, void* stream) {
+    STT_REQUIRE(W && state && attn && base && out && n > 0 && ld_attn >= 64 && ld_attn % 4 == 0 && (!pf || g), "stt_post_attn_stage: bad arguments");
+    PostW w;
+    w.outP = (const f32x4*)W[STT_W_OUTP]; w.outb = W[STT_W_OUTB]; w.infoP = (const f32x4*)W[STT_W_INFOP]; w.infob = W[STT_W_INFOB];
+    w.gateP = (const f32x4*)W[STT_W_GATEP]; w.gateb = W[STT_W_GATEB]; w.ln1w = W[STT_W_LN1W]; w.ln1b = W[STT_W_LN1B];
+    w.l1P = (const f32x4*)W[STT_W_L1P]; w.l1b = W[STT_W_L1B]; w.l2P = (const f32x4*)W[STT_W_L2P]; w.l2b = W[STT_W_L2B];
+    w.ln2w = W[STT_W_LN2W]; w.ln2b = W[STT_W_LN2B];
+    OdeStage o;
+    o.state = state; o.attn = attn; o.ld_attn = ld_attn; o.base = base; o.kA = kA; o.kB = kB; o.kC = kC; o.cA = cA; o.cB = cB; o.cC = cC; o.cN = cN;
+    o.kout = kout; o.out = out; o.inP = (const f32x4*)W[STT_W_INP]; o.inb = W[STT_W_INB]; o.qkv = qkv; o.g = g; o.pf = pf;
+    hipLaunchKernelGGL(post_attn_stage_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, o, n);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -75,6 +75,14 @@ int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int 
                      float* zgen, unsigned long long zkey, const float* past, const int* scene_ptr, int S,
                      float* r_ade, float* r_fde, const float* g_gt, float* g_ade, float* g_fde, float g_scale, int lag_workers_ok, void* stream);
 
+bool stt_embed_qkv_fe_covers(int n, int Tlen);
+int stt_embed_qkv_fe(const float* const* W, const float* past, int n, int N, int Tlen, int TPX, float* xpad, float* enc_in, float* cur,
+                     float* orig, int* last, float* g, float* qkv, void* stream);
+
+int stt_post_attn_stage(const float* const* W, const float* state, const float* attn, int ld_attn, const float* base, const float* kA, float cA,
+                        const float* kB, float cB, const float* kC, float cC, float cN, float* kout, float* out, float* qkv, const float* g,
+                        float* pf, int n, void* stream);
+
 static std::mutex g_stream_mu;   // guards the creation of the process-wide streams (sA / sB / sB2 / side, per device)
 
 static inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // 256-byte alignment in floats
@@ -448,47 +456,48 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     }
     if ((m->ode_method != 0 || m->ode_steps != 1) && attn_len > 1) {
         // Multi-step Euler / RK4 with an attention group > 1: every stage is a pass over the whole group.  y' = f(y), f = the encoder layer
-        // with the attention of state y (TransformerEncoder_ode, ode_demo.py:25-72), integrated over [0, 12] on a uniform grid exactly as
-        // hypertransformer.ode_integrate does at op level (same stage algebra and axpy order).  Launch-bound by construction.
+        // with the attention of state y (TransformerEncoder_ode, ode_demo.py:25-72), integrated over [0, 12] on a uniform grid with the stage
+        // algebra of hypertransformer.ode_integrate (the op-level form; the Butcher rows are summed old stages first here: fp32 rounding apart).
         float* ob = ws + off[STT_B_ODE];
         const size_t nf = (size_t)n * 64;
-        float *y = ob, *k1 = ob + nf, *k2 = ob + 2 * nf, *k3 = ob + 3 * nf, *k4 = ob + 4 * nf, *t = ob + 5 * nf;
+        float *y = ob, *k1 = ob + nf, *k2 = ob + 2 * nf, *k3 = ob + 3 * nf, *t = ob + 5 * nf;
         const long st_seq = (long)attn_slots * 192;
-        auto F = [&](const float* state, float* kout) -> int {
-            RUN(STT_STAGE_EMBED, s, sttode_linear_cols(state, 64, 64, nullptr, 0, 0, W[STT_W_INP], W[STT_W_INB], qkv, 192, n, 192, 0, s));
+        // Round 4: every stage = ONE fused launch (right-hand side at the stage's state -> next state by the stage's Butcher row ->
+        // its in-projection; the last stage of the last step writes past_feature) + the attention of the next state: 2 launches per stage,
+        // 8 per RK4 step (the op-level sequence of round 3: ~30).  y0 = g; qkv / attn of y0 are the launches above.
+        auto attention = [&]() -> int {
             RUN(STT_STAGE_ATTN, s,
                 sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, attn, nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
                                   st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
-            RUN(STT_STAGE_POST, s,
-                sttode_post_attn_rhs(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
-                                     W[STT_W_LN1B], W[STT_W_L1P], W[STT_W_L1B], W[STT_W_L2P], W[STT_W_L2B], W[STT_W_LN2W], W[STT_W_LN2B], state,
-                                     attn, 64, kout, n, s));
             return 0;
         };
-        auto copy = [&](float* dst, const float* src) -> int { STT_HIP(hipMemcpyAsync(dst, src, nf * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0; };
-        auto axpy = [&](float* yv, double a, const float* x) -> int {
-            return sttode_train_ewise(1, yv, x, nullptr, nullptr, nullptr, (long)nf, 0, (float)a, s);
+        // stage(state, base, kA cA, kB cB, kC cC, cN, kout, out, last): `last` = the integration ends here (no next attention, pf written)
+        auto stage = [&](const float* state, const float* base, const float* kA, double cA, const float* kB, double cB, const float* kC, double cC,
+                         double cN, float* kout, float* out, bool last) -> int {
+            RUN(STT_STAGE_POST, s,
+                stt_post_attn_stage(W, state, attn, 64, base, kA, (float)cA, kB, (float)cB, kC, (float)cC, (float)cN, kout, out, last ? nullptr : qkv,
+                                    g, last ? pf : nullptr, n, s));
+            return last ? 0 : attention();
         };
 #define ODE_DO(call) do { if (int _rc = (call)) return _rc; } while (0)
-        ODE_DO(copy(y, g));
         const double h = 12.0 / (double)m->ode_steps;
         for (int st = 0; st < m->ode_steps; ++st) {
-            ODE_DO(F(y, k1));
-            if (m->ode_method == 0) { ODE_DO(axpy(y, h, k1)); continue; }
+            const bool fin = st + 1 == m->ode_steps;
+            const float* y0 = st == 0 ? g : y;                   // (the first step reads g itself: no copy)
+            if (m->ode_method == 0) { ODE_DO(stage(y0, y0, nullptr, 0, nullptr, 0, nullptr, 0, h, nullptr, y, fin)); continue; }
             if (m->ode_method == 1) {   // torchdiffeq's fixed-grid rk4 = the 3/8 rule (rk4_alt_step_func)
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 3, k1)); ODE_DO(F(t, k2));
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k2)); ODE_DO(axpy(t, -h / 3, k1)); ODE_DO(F(t, k3));
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k1)); ODE_DO(axpy(t, -h, k2)); ODE_DO(axpy(t, h, k3)); ODE_DO(F(t, k4));
-                ODE_DO(axpy(y, h / 8, k1)); ODE_DO(axpy(y, 3 * h / 8, k2)); ODE_DO(axpy(y, 3 * h / 8, k3)); ODE_DO(axpy(y, h / 8, k4));
+                ODE_DO(stage(y0, y0, nullptr, 0, nullptr, 0, nullptr, 0, h / 3, k1, t, false));
+                ODE_DO(stage(t, y0, k1, -h / 3, nullptr, 0, nullptr, 0, h, k2, t, false));
+                ODE_DO(stage(t, y0, k1, h, k2, -h, nullptr, 0, h, k3, t, false));
+                ODE_DO(stage(t, y0, k1, h / 8, k2, 3 * h / 8, k3, 3 * h / 8, h / 8, nullptr, y, fin));
             } else {                    // classical RK4
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 2, k1)); ODE_DO(F(t, k2));
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h / 2, k2)); ODE_DO(F(t, k3));
-                ODE_DO(copy(t, y)); ODE_DO(axpy(t, h, k3)); ODE_DO(F(t, k4));
-                ODE_DO(axpy(y, h / 6, k1)); ODE_DO(axpy(y, h / 3, k2)); ODE_DO(axpy(y, h / 3, k3)); ODE_DO(axpy(y, h / 6, k4));
+                ODE_DO(stage(y0, y0, nullptr, 0, nullptr, 0, nullptr, 0, h / 2, k1, t, false));
+                ODE_DO(stage(t, y0, nullptr, 0, nullptr, 0, nullptr, 0, h / 2, k2, t, false));
+                ODE_DO(stage(t, y0, nullptr, 0, nullptr, 0, nullptr, 0, h, k3, t, false));
+                ODE_DO(stage(t, y0, k1, h / 6, k2, h / 3, k3, h / 3, h / 6, nullptr, y, fin));
             }
         }
 #undef ODE_DO
-        RUN(STT_STAGE_POST, s, sttode_ode_state_to_pf(g, y, pf, n, s));
     } else if (m->ode_method != 0 || m->ode_steps != 1) {
         RUN(STT_STAGE_POST, s,
             sttode_post_attn_ode(W[STT_W_OUTP], W[STT_W_OUTB], W[STT_W_INFOP], W[STT_W_INFOB], W[STT_W_GATEP], W[STT_W_GATEB], W[STT_W_LN1W],
@@ -685,11 +694,18 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     // scene batches: set_data runs inside the roles (role32.hpp frontend32): the call is ONE launch (STTODE_LAG_FE=0: front-end launches)
     static const bool fe_in = !(getenv("STTODE_LAG_FE") && atoi(getenv("STTODE_LAG_FE")) == 0);
     const bool fe_role = fe_in && scene_ptr != nullptr;
-    if (!fe_role)
+    // NBA, attention groups > 1: set_data_nba rides in the embedding's launch (one launch fewer in front of the roles)
+    const bool fe_embed = fe_in && !scene_ptr && B > 1 && stt_embed_qkv_fe_covers(n, m->Tp);
+    if (!fe_role && !fe_embed)
         if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
     const float* attn = nullptr;
     if (!scene_ptr && B > 1) {   // attention groups > 1: embedding + attention stay launches in front (the attention reads every agent of the group)
         float* qkv = ws + off[STT_B_QKV];
+        if (fe_embed) {
+            RUN(STT_STAGE_EMBED, sf,
+                stt_embed_qkv_fe(W, past, n, N, m->Tp, m->TPX, ws + off[STT_B_XPAD], ws + off[STT_B_ENC_IN], ws + off[STT_B_CUR], ws + off[STT_B_ORIG],
+                                 (int*)(ws + off[STT_B_LAST]), ws + off[STT_B_G], qkv, sf));
+        } else
         RUN(STT_STAGE_EMBED, sf,
             sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
                              W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],

@@ -148,6 +148,185 @@ __global__ __launch_bounds__(256) void tlinear_kernel(TLin a, int ksplit) {
     tlinear_body<RT, CT, U>(a, ksplit, blockIdx.x, blockIdx.y, part);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// tgemm (round 4): the three products of nn.Linear's training step at BATCH sizes (more than 2048 columns: NBA batches, scene batches)
+//     forward          Y [c][i]  = act(sum_j X[c / xdiv][j] W[i][j] + b[i])         (train.py:83 -> model/STTODE.py:553-568)
+//     input gradient   dX[c][k]  = mask(sum_n dY[c][n] W[n][k] (+ dX[c][k]))
+//     weight gradient  dW[n][k] += sum_c dY[c][n] X[c / xdiv][k],   db[n] += sum_c dY[c][n]
+// as ONE LDS-tiled kernel  C[m][n] (+)= sum_k A(m, k) B(n, k).  The generic kernels above read every MFMA operand straight from global
+// memory with per-lane 16-byte (or, for the transposed operands, four strided 4-byte) loads and no look-ahead: 0.35-0.39 of the fp32 MFMA
+// peak, bound by operand-load latency (profiles/r03).  Here a workgroup owns a 64 x 64 tile of C; per 32-deep k tile all 256 threads
+// fetch the two 64 x 32 operand panels with coalesced 16-byte loads -- along k where k is the contiguous index, along the row index and
+// transposed on the way into LDS where it is not -- one k tile AHEAD of the MFMAs (registers -> the other LDS buffer), and every wave
+// computes a 32 x 32 block with v_mfma_f32_32x32x2_f32 from 16-byte LDS reads (rows padded to 36 words: conflict-free).
+// MFMA step 4g + r consumes the k pair (8g + r, 8g + 4 + r): both operands are read as f32x4 at k = 8g + 4h + (0..3) by lane half h.
+// ---------------------------------------------------------------------------------------------------
+struct TG {
+    const float* A; const float* B; float* C;
+    long lda, ldb, ldc;
+    int M, N, Kt;            // C is M x N, the reduction runs over Kt
+    int adiv, bkdiv;         // row of A = m / adiv (A not transposed: tlinear's broadcast rows); reduction index of B = k / bkdiv (twgrad's X rows)
+    int ones_row;            // twgrad: B(n == ones_row, .) = 1 -- the bias gradient rides as one more column of dW; -1: none
+    int avec, bvec, cvec;    // operand / result rows 16-byte aligned
+    const float* bias; const float* mask; long ldm; int act, accumulate;   // mode 0 (tlinear) epilogue
+    float* db; float* scratch; int S, kchunk, mode;                        // mode 1 (twgrad): split s = blockIdx.z reduces k in [s kchunk, (s + 1) kchunk)
+};
+
+typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+
+// one 64 x 32 operand panel: 2 x f32x4 per thread.  T = false: memory is [row][k] (k contiguous): thread -> (row, 4 k); T = true: memory is
+// [k][row] (row contiguous): thread -> (k, 4 rows), transposed when stored to LDS.
+template <bool T>
+static __device__ __forceinline__ void tg_fetch(f32x4 (&v)[2], const float* __restrict__ src, long ld, int row0, int rows, int rdiv, int k0, int kend,
+                                                int kdiv, int ones_row, bool vec) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = (int)threadIdx.x + 256 * p;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (!T) {
+            const int row = row0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+            if (row < rows && k < kend) {
+                const float* q = src + (long)(row / rdiv) * ld + k;
+                if (vec && k + 3 < kend) x = ld4(q);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) x[e] = q[e];
+                }
+            }
+        } else {
+            const int k = k0 + (idx >> 4), row = row0 + (idx & 15) * 4;
+            if (k < kend && row < rows + (ones_row >= 0 ? 1 : 0)) {
+                const float* q = src + (long)(k / kdiv) * ld + row;
+                if (vec && row + 3 < rows) x = ld4(q);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < rows) x[e] = q[e];
+                        else if (row + e == ones_row) x[e] = 1.0f;
+                }
+            }
+        }
+        v[p] = x;
+    }
+}
+// LDS panel of one operand (2304 floats).  T = false: [64 rows][36] (k contiguous, rows padded to 36 words: 16-byte stores and 16-byte
+// fragment reads, conflict-free).  T = true: [32 k][68] (rows contiguous: the transposed source's 16-byte pieces are stored as they are;
+// the fragment is read as four 4-byte words, lanes on consecutive rows -- transposing on the way IN, four scalar stores at a stride of
+// 36 words, is an 8-way bank conflict: measured 36 us per weight gradient against 34.5 us for the generic kernel).
+#define TG_PANEL 2304
+template <bool T>
+static __device__ __forceinline__ void tg_store(const f32x4 (&v)[2], float* S) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = (int)threadIdx.x + 256 * p;
+        if (!T) *reinterpret_cast<f32x4*>(S + (idx >> 3) * 36 + (idx & 7) * 4) = v[p];
+        else *reinterpret_cast<f32x4*>(S + (idx >> 4) * 68 + (idx & 15) * 4) = v[p];
+    }
+}
+// the fragment of MFMA steps 4q .. 4q + 3 for row `row` (0..63) of the panel: k = 8q + 4h + (0..3)
+template <bool T>
+static __device__ __forceinline__ f32x4 tg_frag(const float* S, int row, int q, int h) {
+    if (!T) return *reinterpret_cast<const f32x4*>(S + row * 36 + 8 * q + 4 * h);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = S[(8 * q + 4 * h + e) * 68 + row];
+    return r;
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
+    __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TG_PANEL];
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int kbeg = g.mode == 1 ? blockIdx.z * g.kchunk : 0;
+    const int kend = g.mode == 1 ? (kbeg + g.kchunk < g.Kt ? kbeg + g.kchunk : g.Kt) : g.Kt;
+    const int mt = wave & 1, nt = wave >> 1;
+    tg_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 va[2], vb[2];
+    tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, kbeg, kend, 1, -1, g.avec);
+    tg_fetch<BT>(vb, g.B, g.ldb, n0, g.N - (g.ones_row >= 0 ? 1 : 0), 1, kbeg, kend, g.bkdiv, g.ones_row, g.bvec);
+    tg_store<AT>(va, As[0]);
+    tg_store<BT>(vb, Bs[0]);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        const bool more = k0 + 32 < kend;
+        if (more) {   // the next k tile travels while this one is multiplied
+            tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, k0 + 32, kend, 1, -1, g.avec);
+            tg_fetch<BT>(vb, g.B, g.ldb, n0, g.N - (g.ones_row >= 0 ? 1 : 0), 1, k0 + 32, kend, g.bkdiv, g.ones_row, g.bvec);
+        }
+        const float* Sa = As[buf];
+        const float* Sb = Bs[buf];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = tg_frag<BT>(Sb, nt * 32 + c, q, h);   // MFMA rows = n
+            const f32x4 b = tg_frag<AT>(Sa, mt * 32 + c, q, h);   // MFMA columns = m
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+        }
+        if (more) {
+            tg_store<AT>(va, As[buf ^ 1]);
+            tg_store<BT>(vb, Bs[buf ^ 1]);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // lane (c, h): m = m0 + 32 mt + c; register 4a + b <-> n = n0 + 32 nt + 8a + 4h + b
+    const int m = m0 + mt * 32 + c;
+    if (g.mode == 1 && g.S > 1) {
+        // split reduction: the partial tile goes to scratch [split][M][N]; twgrad_reduce_kernel adds the splits in order (deterministic).
+        // (Combining inside the launch -- last workgroup of a tile, ticket counter -- was built and measured: the agent-scope release every
+        // workgroup needs before its ticket writes the whole L2 back on this part, 183 us per weight gradient against 36 us + 10 us.)
+        if (m >= g.M) return;
+        float* part = g.scratch + ((long)blockIdx.z * g.M + m) * g.N;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int n = n0 + nt * 32 + 8 * a + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) part[n + e] = acc[4 * a + e];
+        }
+        return;
+    }
+    if (m >= g.M) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = n0 + nt * 32 + 8 * a + 4 * h;
+        if (n >= g.N) continue;
+        f32x4 v = {acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
+        if (g.mode == 0) {
+            float* yp = g.C + (long)m * g.ldc + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= g.N) continue;
+                float x = v[e];
+                if (g.bias) x += g.bias[n + e];
+                if (g.accumulate) x += yp[e];
+                x = act_apply(x, g.act);
+                if (g.mask && !(g.mask[(long)m * g.ldm + n + e] > 0.f)) x = 0.f;
+                v[e] = x;
+            }
+            if (g.cvec && n + 3 < g.N) st4(yp, v);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) yp[e] = v[e];
+        } else {
+            const int K = g.N - 1;   // the last column of C is the bias gradient
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= g.N) continue;
+                if (n + e < K) g.C[(long)m * g.ldc + n + e] += v[e];        // (S == 1; the split case returned above)
+                else if (g.db) g.db[m] += v[e];
+            }
+        }
+    }
+}
+
 #ifndef TLIN_MEDIUM_BELOW
 #define TLIN_MEDIUM_BELOW 4096   // throughput-mode wave count below which the 32 x 32 tiling is used instead
 #endif
@@ -166,6 +345,20 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
     a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
+    static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);   // STTODE_TGEMM=0: the generic kernels (A/B)
+    if (tg_on && cols > 2048) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
+        TG g;
+        g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+        g.M = cols; g.N = I; g.Kt = J; g.adiv = xdiv; g.bkdiv = 1; g.ones_row = -1;
+        g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
+        g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
+        g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
+        dim3 grid((cols + 63) / 64, (I + 63) / 64);
+        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((tgemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     if (cols <= 1024) {
         // latency mode: one 16 x 16 block per WG, reduction split over up to 4 waves (128 indices per round trip and wave)
         const int ksplit = J > 256 ? 4 : (J > 128 ? 2 : 1);
@@ -285,6 +478,31 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.cols = cols; a.N = N; a.K = K; a.xdiv = xdiv;
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
+    static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
+    if (tg_on && cols > 2048 && scratch) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
+        const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
+        int S = (480 + tiles - 1) / tiles;
+        if (S > 64) S = 64;
+        if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
+        if ((long)per * S > scratch_floats) S = (int)(scratch_floats / per);
+        if (S >= 1) {
+            TG g;
+            g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
+            g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
+            g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
+            g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
+            g.db = db; g.scratch = scratch; g.S = S; g.mode = 1;
+            g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
+            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, S);
+            hipLaunchKernelGGL((tgemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            if (S > 1) {
+                a.S = S;
+                hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+            }
+            STT_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     int S = chunks <= 64 ? 1 : (chunks + 31) / 32;    // >= 512 columns per split; up to 1024 columns one workgroup per tile (no reduce launch)
     if (S > 64) S = 64;
     if (!scratch || per * S > scratch_floats) S = scratch && scratch_floats >= 2 * per ? (int)(scratch_floats / per) : 1;

@@ -1837,8 +1837,11 @@ def test_tlinear_and_twgrad_vs_torch():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     scratch = torch.empty(1 << 20, device=dev)
     st = capi.stream_ptr()
+    # (more than 2048 columns: the LDS-tiled kernel of round 4 -- ragged tiles in every dimension, k not a multiple of 32, unaligned rows,
+    # broadcast rows, outputs narrower than a tile, the NBA step's shapes)
     for cols, J, I, xdiv, act in ((37, 67, 64, 1, 0), (7, 4, 64, 1, 0), (640, 256, 512, 20, 1), (33, 512, 24, 1, 0), (5000, 96, 288, 1, 3),
-                                  (19, 1024, 64, 1, 2)):
+                                  (19, 1024, 64, 1, 2), (7392, 256, 512, 21, 1), (7392, 512, 256, 1, 1), (7040, 256, 20, 1, 0), (1100, 67, 70, 1, 2),
+                                  (36960, 32, 288, 1, 0), (2049, 131, 33, 3, 3), (3001, 67, 70, 1, 2)):
         rows = (cols + xdiv - 1) // xdiv
         Xw = rng.standard_normal((rows, J + 5)).astype(np.float32)          # strided view: ld = J + 5 (unaligned unless J+5 % 4 == 0)
         W = (rng.standard_normal((I, J)) / np.sqrt(J)).astype(np.float32)
