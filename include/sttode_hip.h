@@ -427,7 +427,7 @@ int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const 
  *   Slots: up to 8 (slot in [0, 8)); a loop that keeps 2 x streams calls in flight never waits on another stream.  Agrees with the serial
  *   forms to fp32 rounding (different MFMA tiling and host-folded embedding in the per-agent stage), not bitwise.
  *   sttode_set_lagged(m, 0): the round-3 forms (fused launches of one call each on three streams / separate per-agent launches), bitwise
- *   the serial forms, slots in [0, 4).
+ *   the serial forms.  Calls below the chain threshold or with a non-default integrator always take those forms.
  * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream. */
 int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 or 3 (default, or env STTODE_LAGGED) */);
 /* Latents on device (lagged form; replaces the torch.randn_like of Normal.rsample, model/STTODE.py:89-93,609-616, for that call): returns 1

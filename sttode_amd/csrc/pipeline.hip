@@ -754,7 +754,6 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     if (m->zgen_armed && !use_lagged(m, n)) { m->zgen_armed = false; STT_REQUIRE(false, "sttode_inference_*_async: device latents were armed for a call of another form"); }
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
     if (use_lagged(m, n)) return run_lagged(m, past, scene_ptr, n, S, B, N, z, ws, pred, slot, off, s);
-    STT_REQUIRE(slot < 4, "sttode_inference_*_async: the round-3 forms take slots in [0, 4)");
     if (use_fused(m, n)) {
         // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
         // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)

@@ -49,10 +49,8 @@ __device__ __forceinline__ void role_frontend(const RoleArgs& R, int nag, int Tp
     if (threadIdx.x < 16) {
         const int a = tile * 16 + (int)threadIdx.x;
         if (a < nag) {
-            float2 trk[16];                           // the agent's own track does not depend on its scene: requested first, it travels
-#pragma unroll                                        // while the scene search and the origin sum make their dependent round trips
-            for (int t = 0; t < 16; ++t)
-                if (t < Tp) trk[t] = reinterpret_cast<const float2*>(R.past + (size_t)a * Tp * 2)[t];
+            // (the track is NOT preloaded into a local array handed over by pointer: such an array lives in scratch, and hipcc then waits for
+            // every one of its 16 loads in turn before the store -- 16 serial memory round trips at the head of every one-scene call)
             int lo = 0, hi = R.S - 1;                 // the agent's scene: largest s with scene_ptr[s] <= a
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
@@ -71,7 +69,7 @@ __device__ __forceinline__ void role_frontend(const RoleArgs& R, int nag, int Tp
                 R.agent_scene[a] = lo;
             }
             agent_inputs_core<true, 16>(a, R.past, Tp, ldx / 16, 1, ox, oy, a == a1 - 1, nullptr, traj ? R.xpad_w : nullptr, enc ? R.enc_in_w : nullptr,
-                                    traj ? R.cur_w : nullptr, traj ? R.orig_w : nullptr, enc ? R.last_w : nullptr, trk);
+                                    traj ? R.cur_w : nullptr, traj ? R.orig_w : nullptr, enc ? R.last_w : nullptr);
         }
     }
 }

@@ -234,68 +234,81 @@ static __device__ __forceinline__ f32x4 tg_frag(const float* S, int row, int q, 
     return r;
 }
 
-template <bool AT, bool BT>
+// NB: 64-wide blocks of n per workgroup (1: a 64 x 64 tile of C; 2: 64 x 128 -- twice the MFMAs per fetched byte and per barrier; used
+// where the wider tile still fills the chip)
+template <bool AT, bool BT, int NB>
 __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
     __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TG_PANEL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NB][TG_PANEL];
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * (64 * NB);
     const int kbeg = g.mode == 1 ? blockIdx.z * g.kchunk : 0;
     const int kend = g.mode == 1 ? (kbeg + g.kchunk < g.Kt ? kbeg + g.kchunk : g.Kt) : g.Kt;
     const int mt = wave & 1, nt = wave >> 1;
-    tg_f32x16 acc;
+    tg_f32x16 accs[NB];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    f32x4 va[2], vb[2];
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[j][e] = 0.f;
+    f32x4 va[2], vb[NB][2];
+    const int brows = g.N - (g.ones_row >= 0 ? 1 : 0);
     tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, kbeg, kend, 1, -1, g.avec);
-    tg_fetch<BT>(vb, g.B, g.ldb, n0, g.N - (g.ones_row >= 0 ? 1 : 0), 1, kbeg, kend, g.bkdiv, g.ones_row, g.bvec);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) tg_fetch<BT>(vb[j], g.B, g.ldb, n0 + 64 * j, brows, 1, kbeg, kend, g.bkdiv, g.ones_row, g.bvec);
     tg_store<AT>(va, As[0]);
-    tg_store<BT>(vb, Bs[0]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) tg_store<BT>(vb[j], Bs[0][j]);
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         const bool more = k0 + 32 < kend;
         if (more) {   // the next k tile travels while this one is multiplied
             tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, k0 + 32, kend, 1, -1, g.avec);
-            tg_fetch<BT>(vb, g.B, g.ldb, n0, g.N - (g.ones_row >= 0 ? 1 : 0), 1, k0 + 32, kend, g.bkdiv, g.ones_row, g.bvec);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) tg_fetch<BT>(vb[j], g.B, g.ldb, n0 + 64 * j, brows, 1, k0 + 32, kend, g.bkdiv, g.ones_row, g.bvec);
         }
         const float* Sa = As[buf];
-        const float* Sb = Bs[buf];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 a = tg_frag<BT>(Sb, nt * 32 + c, q, h);   // MFMA rows = n
-            const f32x4 b = tg_frag<AT>(Sa, mt * 32 + c, q, h);   // MFMA columns = m
+            const f32x4 b = tg_frag<AT>(Sa, mt * 32 + c, q, h);                 // MFMA columns = m
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 a = tg_frag<BT>(Bs[buf][j], nt * 32 + c, q, h);     // MFMA rows = n
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accs[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], accs[j], 0, 0, 0);
+            }
         }
         if (more) {
             tg_store<AT>(va, As[buf ^ 1]);
-            tg_store<BT>(vb, Bs[buf ^ 1]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) tg_store<BT>(vb[j], Bs[buf ^ 1][j]);
         }
         __syncthreads();
         buf ^= 1;
     }
     // lane (c, h): m = m0 + 32 mt + c; register 4a + b <-> n = n0 + 32 nt + 8a + 4h + b
     const int m = m0 + mt * 32 + c;
+    if (m >= g.M) return;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+    const tg_f32x16& acc = accs[j];
     if (g.mode == 1 && g.S > 1) {
         // split reduction: the partial tile goes to scratch [split][M][N]; twgrad_reduce_kernel adds the splits in order (deterministic).
         // (Combining inside the launch -- last workgroup of a tile, ticket counter -- was built and measured: the agent-scope release every
         // workgroup needs before its ticket writes the whole L2 back on this part, 183 us per weight gradient against 36 us + 10 us.)
-        if (m >= g.M) return;
         float* part = g.scratch + ((long)blockIdx.z * g.M + m) * g.N;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int n = n0 + nt * 32 + 8 * a + 4 * h;
+            const int n = n0 + 64 * j + nt * 32 + 8 * a + 4 * h;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (n + e < g.N) part[n + e] = acc[4 * a + e];
         }
-        return;
+        continue;
     }
-    if (m >= g.M) return;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int n = n0 + nt * 32 + 8 * a + 4 * h;
+        const int n = n0 + 64 * j + nt * 32 + 8 * a + 4 * h;
         if (n >= g.N) continue;
         f32x4 v = {acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
         if (g.mode == 0) {
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
             }
         }
     }
+    }   // j
 }
 
 #ifndef TLIN_MEDIUM_BELOW
@@ -353,9 +367,17 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
         g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
         g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
-        dim3 grid((cols + 63) / 64, (I + 63) / 64);
-        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL((tgemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        // 64 x 128 tiles (NB = 2) measured SLOWER at the NBA step's shapes (36-38 us against 19-25 us per product: 55 KB of LDS leave two
+        // workgroups per CU to hide the panel loads instead of four): kept as an instantiation, not used
+        const bool wide = false;
+        dim3 grid((cols + 63) / 64, wide ? (I + 127) / 128 : (I + 63) / 64);
+        if (trans) {
+            if (wide) hipLaunchKernelGGL((tgemm_kernel<false, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((tgemm_kernel<false, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        } else {
+            if (wide) hipLaunchKernelGGL((tgemm_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((tgemm_kernel<false, false, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        }
         STT_HIP(hipGetLastError());
         return 0;
     }
@@ -480,7 +502,8 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     const long per = (long)N * (K + 1);
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
     if (tg_on && cols > 2048 && scratch) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
-        const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
+        const bool wide = false;                                   // (see sttode_tlinear)
+        const int tiles = ((N + 63) / 64) * (wide ? (K + 1 + 127) / 128 : (K + 1 + 63) / 64);
         int S = (480 + tiles - 1) / tiles;
         if (S > 64) S = 64;
         if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
@@ -493,8 +516,9 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
             g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
             g.db = db; g.scratch = scratch; g.S = S; g.mode = 1;
             g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
-            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, S);
-            hipLaunchKernelGGL((tgemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            dim3 grid((N + 63) / 64, wide ? (K + 1 + 127) / 128 : (K + 1 + 63) / 64, S);
+            if (wide) hipLaunchKernelGGL((tgemm_kernel<true, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((tgemm_kernel<true, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
             if (S > 1) {
                 a.S = S;
                 hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);

@@ -726,8 +726,7 @@ class STTODENet(nn.Module):
         nat = self.native()
         K, n = a.sample_k, self._past.shape[0]
         S = self._S if self._mode == 'scenes' else 0
-        # (the round-3 pipelined forms, native().set_lagged(0), take at most 4 slots)
-        slot = self._async_calls % max(2, min(8 if getattr(nat, '_lagged', 3) else 4, int(self.async_depth)))
+        slot = self._async_calls % max(2, min(8, int(self.async_depth)))
         self._async_calls += 1
         key = (n, S, slot)
         if key not in self._async_bufs:
