@@ -164,6 +164,7 @@ LEGS = {
 
 class Leg:
     FUSED_METRICS = os.environ.get('STTODE_FUSED_METRICS', '1') != '0'
+    D2H_OWN_STREAM = os.environ.get('STTODE_BENCH_D2H', 'own') == 'own'   # (experiment switch: 'copy' = a dedicated copy stream)
     STREAMS = 3      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -232,9 +233,14 @@ class Leg:
         self.last_pred = h['pred']
         self.unsettled = h
         out = self.model.best_of_k_async(h, gt=h['gt'])        # per-agent (ade, fde) of the slot; summed ONCE, after the last step
-        if self.d2h_bufs is not None:                           # D2H of the call's futures on ITS stream, behind its groups and metrics
-            with torch.cuda.stream(h['stream']):
-                self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
+        if self.d2h_bufs is not None:
+            if Leg.D2H_OWN_STREAM:                              # D2H of the call's futures on ITS stream, behind its groups and metrics
+                with torch.cuda.stream(h['stream']):
+                    self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
+            else:                                               # ... or on a copy stream of its own that waits for the call's event
+                with torch.cuda.stream(self.copy_stream):
+                    self.model.wait(h)
+                    self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
         return out
 
     def settle(self):
@@ -289,7 +295,9 @@ class Leg:
         from sttode_amd import capi, parallel
         dev = self.dev
         hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H targets
-        self.d2h_bufs = [hostbuf, torch.empty_like(hostbuf).pin_memory()] if d2h and not serial else None   # (one per pipeline stream)
+        self.d2h_bufs = [hostbuf] + [torch.empty_like(hostbuf).pin_memory() for _ in range(Leg.STREAMS - 1)] if d2h and not serial else None   # (one per pipeline stream)
+        if d2h and not serial and not hasattr(self, 'copy_stream'):
+            self.copy_stream = torch.cuda.Stream()
         acc = None
         import gc
         gc.collect()                                              # before the warm-up: a collector run between warm-up and region would idle the GPU
@@ -731,6 +739,8 @@ def main():
         # the same kernel with ONE launch in flight (a few serial steps, every launch bracketed): the plain per-launch formula
         # flop_per_launch / mean launch duration, the figure `rocprofv3 --kernel-trace --stats` of `bench.py --serial` reproduces
         rs = head.timed(8, 2, dist, 1, serial=True)
+        # the serial form's in-launch hand-off must not have given up anywhere (its time-out word as a status; the pipelined form has none)
+        head.model.native().check(head.model._workspace(head.n, head.sb.n_scenes)[0], head.n, head.sb.n_scenes)
         ms, cnt = rs['stage_ms'].get(roof['kernel'], (0.0, 0))
         if cnt:
             roof['mean_launch_s_serial'] = ms * 1e-3 / cnt

@@ -653,8 +653,9 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 // pipeline a role has finished by the time its consumers are dispatched (nobody spins), and a single serial launch starts its
 // trajectory groups at once instead of behind ALL roles (the per-agent stage then costs its matrix work, not a prologue).  Sort key:
 // role t -> max(0, g_first(t) - lead), group g -> g, roles first on ties; every role a group needs has g_first <= g, hence a smaller
-// block index: with in-order dispatch every producer is resident or finished before its consumer starts (no deadlock; the bounded
-// spin of wait_tiles is the backstop).  Returns the group index, or -1 - tile for a role.  Scalar code: ~10 binary-search steps.
+// block index: workgroups are dispatched in index order PER XCD (each XCD takes block % 8), and a role never waits, so within ONE launch
+// every producer finishes whatever its consumers do (no deadlock; the bounded spin of wait_tiles is the backstop).  Several such launches
+// in flight on different queues have no such guarantee across XCDs: the pipelined path uses the lagged form (FUSE = 2), which has no hand-off.  Returns the group index, or -1 - tile for a role.  Scalar code: ~10 binary-search steps.
 __host__ __device__ __forceinline__ int fused_block_of(long b, long T, long G, long K, long lead) {
     auto roles_upto = [&](long x) { const long c = (8 * (x + lead + 1) + K - 1) / K; return c < T ? c : T; };   // #roles with key <= x
     long lo = -1, hi = G - 1;                       // largest g with position g + roles_upto(g) <= b
@@ -1174,7 +1175,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
         if (xm < 0) { const char* e = getenv("STTODE_XCD_MAP"); xm = e ? atoi(e) != 0 : 1; }
         a.xcd_map = xm && lead < 0;
     }
-    r.split = lead == -2;   // -2: roles first, each tile's role split into E | G | three table workgroups (default); -1: one workgroup per tile
+    r.split = lead == -2;   // -2: roles first, each tile's role split into E | G | three table workgroups (opt-in, sttode_set_fused mode 4); -1 (default): one workgroup per tile
     r.gflags = r.flags + r.ntiles + 1; r.pflags = r.gflags + r.ntiles;
     r.drop_tile = drop_tile;
     const int NY = (2 * Tf + 31) / 32;

@@ -1,5 +1,6 @@
-// The per-agent ROLE shared by the fused launches (chain32.hip: roles + trajectory groups; scene_lat.hip: roles + 16-column tiles of a
-// single scene) and the tile-flag hand-off between workgroups of ONE launch.
+// The per-agent ROLE (latency form) shared by the launches with an in-launch hand-off (chain32.hip FUSE = 1: the SERIAL call's roles +
+// trajectory groups; scene_lat.hip: roles + 16-column tiles of a single scene) and the tile-flag hand-off between workgroups of ONE launch.
+// Pipelined calls use the throughput form of role32.hpp (round 4), which has no hand-off.
 #pragma once
 #include "latency_bodies.hpp"
 #include "frontend_body.hpp"
@@ -13,7 +14,7 @@
 // per-agent stage -- encoder (embed_lat_body -> post_attn_body), block-0 conv + GRU (gru_lat4_body) and the three layer-1 pre-activation
 // tables (preact_rows) -- and publish ONE flag per tile; the trajectory groups behind them in the grid wait for the flags of the tiles
 // their agents live in.  Why: as separate launches on their own stream these kernels were starved by the running chain (its queue keeps
-// every freed workgroup slot until its grid is fully dispatched: 1.85 ms for a 0.1 ms stage, profiles/r03/timeline_default.txt), which
+// every freed workgroup slot until its grid is fully dispatched: 1.85 ms for a 0.1 ms stage: measured at the start of round 3, the capture was not kept), which
 // forced ONE chain workgroup per CU in the pipelined path; inside the launch nothing needs a chain-free CU.
 struct RoleArgs {
     EmbedW ew; PostW pw;

@@ -250,6 +250,10 @@ class STTODENet(nn.Module):
         """Fragment-ordered device copies of the weights; re-packed whenever a parameter changes."""
         key = self._weights_key()
         if self._packed is None or key != self._packed_key:
+            if getattr(self, '_native', None) is not None:
+                # calls in flight (lagged form: groups still outstanding) read the old packed weights and the workspaces dropped below
+                capi.call('sttode_async_flush', self._native.h)
+                torch.cuda.synchronize(self.device)
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
             a = self.args
             host = {'past': packing.pack_trunk(sd, 'past_encoder.', a.past_length),
@@ -778,7 +782,10 @@ class STTODENet(nn.Module):
     def next_async_stream(self, n):
         """torch stream (an ExternalStream over the pipeline's own) the next inference_async() call of ``n`` agents will run on, or None
         when that call will not take the one-stream fused form.  Work enqueued there before the call -- the H2D copy of its inputs, the
-        latents -- is ordered in front of it without any cross-stream event:  ``with torch.cuda.stream(s): load(); h = m.inference_async()``."""
+        latents -- is ordered in front of it without any cross-stream event:  ``with torch.cuda.stream(s): load(); h = m.inference_async()``.
+        Buffers the caller owns per call: the inputs (past, scene_ptr) are read by the call's own launch, the ground truth of fused
+        metrics by the launch of the call made <pipeline streams> calls later -- keep one set per slot (``async_depth`` of them) and reuse a
+        set only for the call that reuses its slot."""
         import ctypes
         out = ctypes.c_void_p(0)
         capi.call('sttode_async_next_stream', self.native().h, int(n), ctypes.addressof(out))

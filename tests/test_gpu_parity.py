@@ -1338,6 +1338,55 @@ def test_device_latents_of_the_lagged_form():
         m.reset_async()
 
 
+def test_lagged_form_with_mixed_batch_shapes_and_small_calls_in_between():
+    """Robustness of the lagged rotation: consecutive pipelined calls of DIFFERENT shapes (two chain-sized scene batches with different
+    agent counts: a call's trajectory groups ride in the launch of another shape's call) with calls BELOW the chain threshold in between
+    (they take the round-3 unfused form on the same pipeline streams), a weight change in the middle (re-packed weights, new native
+    model: outstanding groups are flushed first), all against serial calls."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    big = [scenes.make_scene_batch(range(9000, 9060), 'eth'), scenes.make_scene_batch(range(9100, 9175), 'eth')]   # ~20 k and ~26 k trajectories
+    small = scenes.make_scene_batch(range(9200, 9212), 'eth')
+    batches = [big[0], big[1], small, big[1], big[0], big[0], small, big[1]]
+    zs = [torch.from_numpy(scenes.latents(500 + i, b.n_agents)).to(m.device) for i, b in enumerate(batches)]
+
+    def serial_all():
+        outs = []
+        for b, z in zip(batches, zs):
+            m.set_scene_batch(b.past, b.future, b.scene_ptr)
+            outs.append(m.inference(None, z=z).clone())
+        return outs
+    try:
+        ref = serial_all()
+        m.reset_async()
+        hs, outs = [], []
+        for b, z in zip(batches, zs):
+            m.set_scene_batch(b.past, b.future, b.scene_ptr)
+            hs.append(m.inference_async(z=z))
+            if len(hs) > 4:                                   # (at most async_depth = 6 calls may be in flight: a slot's buffers are reused)
+                outs.append(m.wait(hs.pop(0)).clone())
+        outs += [m.wait(h).clone() for h in hs]
+        torch.cuda.synchronize()
+        for i, (o, r) in enumerate(zip(outs, ref)):
+            assert_close(o.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol=2e-5, what=f'mixed shapes, call {i}')
+        # weight change with calls in flight: the next packed() builds a new native model
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.set_scene_batch(big[0].past, big[0].future, big[0].scene_ptr)
+        h_old = m.inference_async(z=zs[0])
+        with torch.no_grad():
+            m.decoder.decompose[1].decoder_y.layers[2].bias.add_(0.25)
+        m.set_scene_batch(big[0].past, big[0].future, big[0].scene_ptr)
+        h_new = m.inference_async(z=zs[0])
+        o_new = m.wait(h_new).clone()
+        m.set_scene_batch(big[0].past, big[0].future, big[0].scene_ptr)
+        s_new = m.inference(None, z=zs[0])
+        assert_close(o_new.cpu().numpy(), s_new.cpu().numpy(), rtol=2e-5, atol=2e-5, what='call after a weight change')
+        assert float((o_new - ref[0]).abs().max()) > 0.1      # the new bias really is in the result
+    finally:
+        m.load_state_dict(sd, strict=True) if 'sd' in dir() else None
+        m.reset_async()
+
+
 def test_check_reports_a_given_up_hand_off():
     """sttode_check: the host-visible error path of the in-launch hand-off forms (round-3 fused launch): after a launch in which a group
     gave up waiting for its producer (fault injection) the check fails loudly; after a healthy launch it passes."""
