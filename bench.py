@@ -375,13 +375,14 @@ class Leg:
             fl = kernel_flops(t, self.n, self.m, self.F)
             if fl is None:
                 continue
+            fl_call = fl
             if calls is not None and t == 'agents+trajectory_chain[fused launch]' and cnt > calls:
                 kern[t]['launches_sampled'] = cnt
                 kern[t]['calls'] = calls
                 fl = fl * calls / cnt                               # mean FLOP per launch of this region
             kern[t]['tflops'] = fl * cnt / busy_s / 1e12
             if dom is None or ms > dom[1]:
-                dom = (t, ms, fl, mean_s, cnt, busy_s)
+                dom = (t, ms, fl, mean_s, cnt, busy_s, fl_call)
         roof = None
         if dom:
             traffic = None
@@ -391,7 +392,7 @@ class Leg:
             ach = dom[2] * dom[4] / dom[5]
             roof = {'kernel': dom[0], 'bound': 'mfma', 'achieved': ach / 1e12, 'peak': PEAK_F32_MFMA / 1e12,
                     'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA, 'traffic': traffic,
-                    'flop_per_launch': dom[2], 'launches': dom[4], 'busy_time_s': dom[5], 'mean_launch_s': dom[3],
+                    'flop_per_launch': dom[2], 'flop_per_call': dom[6], 'launches': dom[4], 'busy_time_s': dom[5], 'mean_launch_s': dom[3],
                     'launches_in_flight': dom[3] * dom[4] / dom[5],
                     'achieved_definition': 'flop_per_launch * launches / busy_time_s (union of the launch intervals); with launches_in_flight = 1 '
                                            'this is flop_per_launch / mean_launch_s',
@@ -744,7 +745,7 @@ def main():
         ms, cnt = rs['stage_ms'].get(roof['kernel'], (0.0, 0))
         if cnt:
             roof['mean_launch_s_serial'] = ms * 1e-3 / cnt
-            roof['frac_serial_equivalent'] = roof['flop_per_launch'] / roof['mean_launch_s_serial'] / PEAK_F32_MFMA
+            roof['frac_serial_equivalent'] = roof['flop_per_call'] / roof['mean_launch_s_serial'] / PEAK_F32_MFMA   # (a serial launch = one call)
             roof['ms_per_step_serial'] = rs['ms_per_step']
     acc = r['metrics']
     out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
@@ -818,7 +819,7 @@ def main():
             ms, cnt = rs['stage_ms'].get(lroof['kernel'], (0.0, 0))
             if cnt:
                 lroof['mean_launch_s_serial'] = ms * 1e-3 / cnt
-                lroof['frac_serial_equivalent'] = lroof['flop_per_launch'] / lroof['mean_launch_s_serial'] / PEAK_F32_MFMA
+                lroof['frac_serial_equivalent'] = lroof['flop_per_call'] / lroof['mean_launch_s_serial'] / PEAK_F32_MFMA
         legs[name] = {'value': lr['value'], 'unit': 'trajectories/s', 'ms_per_step': lr['ms_per_step'],
                       'host_enqueue_ms_per_step': lr['host_ms_per_step'], 'ms_per_step_runs': [r['ms_per_step'] for r in runs], 'clock_ghz': lr['clock_ghz'],
                       'steps': args.leg_steps, 'config': leg.config(world), 'roofline': lroof,
