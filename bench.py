@@ -780,7 +780,7 @@ def main():
         head.model.mfma_mode = 'bf16x3'
         rx = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial)
         out['exploratory_bf16x3'] = {
-            'value': rx['value'], 'unit': 'trajectories/s', 'ms_per_step': rx['ms_per_step'],
+            'value': rx['value'], 'unit': 'trajectories/s', 'ms_per_step': rx['ms_per_step'], 'clock_ghz': rx['clock_ghz'],
             'dtype': 'bf16x3: operands of the decoder MLPs and GRU split three ways into bf16 (x = hi + mid + lo, six products per k block on '
                      'v_mfma_f32_32x32x16_bf16), fp32 accumulate, everything else f32',
             'speedup_vs_f32_headline': rx['value'] / r['value'],
