@@ -164,7 +164,10 @@ LEGS = {
 
 class Leg:
     FUSED_METRICS = os.environ.get('STTODE_FUSED_METRICS', '1') != '0'
-    D2H_OWN_STREAM = os.environ.get('STTODE_BENCH_D2H', 'own') == 'own'   # (experiment switch: 'copy' = a dedicated copy stream)
+    # futures to the host (value_incl_d2h): 'own' = a D2H copy on the call's own stream (default: 63 M traj/s); experiment switches: 'copy' = a
+    # D2H copy on a dedicated stream (55 M), 'zero' = the launch writes them straight to pinned host memory (inference_async(pred_host=True):
+    # no copy, but the epilogue's 32-byte pieces at a 96-byte stride make poor PCIe writes: 36-45 M; profiles/r04/d2h_placement_ab.txt)
+    D2H = os.environ.get('STTODE_BENCH_D2H', 'own')
     STREAMS = 3      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -233,8 +236,8 @@ class Leg:
         self.last_pred = h['pred']
         self.unsettled = h
         out = self.model.best_of_k_async(h, gt=h['gt'])        # per-agent (ade, fde) of the slot; summed ONCE, after the last step
-        if self.d2h_bufs is not None:
-            if Leg.D2H_OWN_STREAM:                              # D2H of the call's futures on ITS stream, behind its groups and metrics
+        if self.d2h_bufs is not None and Leg.D2H != 'zero':
+            if Leg.D2H == 'own':                                # D2H of the call's futures on ITS stream, behind its groups and metrics
                 with torch.cuda.stream(h['stream']):
                     self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
             else:                                               # ... or on a copy stream of its own that waits for the call's event
@@ -275,7 +278,8 @@ class Leg:
             self._load()
             # latents z ~ N(0, I) like Normal.rsample in the reference, drawn by the call's own launch; best-of-K ADE / FDE against the
             # batch's futures computed by the call's trajectory groups (STTODE_FUSED_METRICS=0: a best_of_k kernel on the call's stream)
-            h = self.model.inference_async(metrics_gt=self.model._future if Leg.FUSED_METRICS else None)
+            h = self.model.inference_async(metrics_gt=self.model._future if Leg.FUSED_METRICS else None,
+                                           pred_host=self.d2h_bufs is not None and Leg.D2H == 'zero')
         h['gt'] = self.model._future
         self.pending.append(h)
         return self._finish(self.pending.pop(0)) if len(self.pending) > Leg.STREAMS else None

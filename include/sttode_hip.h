@@ -454,6 +454,12 @@ int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* 
 int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                                int slot, void* stream);
 int sttode_wait(SttodeModel* m, int slot, void* stream);
+/* Zero-copy futures (lagged form): the trajectory groups of a lagged call only WRITE `pred` (block 0's y_hat0 waits in the workspace), so
+ * `pred` may be pinned host memory addressed by its host pointer: the futures reach the host with the launch itself, no D2H copy
+ * (test.py:186-188 moves every prediction to NumPy).  sttode_async_is_lagged: 1 if the next async call of n agents takes that form (a
+ * query, not a status); sttode_wait_host: the HOST waits for the call of `slot` (its outstanding groups are enqueued first). */
+int sttode_async_is_lagged(SttodeModel* m, int n);
+int sttode_wait_host(SttodeModel* m, int slot);
 /* Health of the in-launch hand-off (round-3 fused launches and the one-launch scene form: a group whose producer never signalled gives up
  * after ~1 s, poisons its predictions with NaN and sets the launch's time-out word).  Reads the time-out word of the LAST launch that used
  * `workspace` (laid out for n agents / S scenes) after synchronising `stream`: returns 0 if it is clear, 3 (and sttode_last_error) if a

@@ -93,6 +93,8 @@ SIGNATURES = {
     'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
     'sttode_wait': [_P, _I, _P],
+    'sttode_async_is_lagged': [_P, _I],
+    'sttode_wait_host': [_P, _I],
     'sttode_set_lagged': [_P, _I],
     'sttode_async_flush': [_P],
     'sttode_clock_probe': [_P, _P],

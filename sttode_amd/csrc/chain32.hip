@@ -91,7 +91,8 @@ struct ChainArgs {
     const float* z;                                         // [ncols][32]
     const float* xpad; int ldx;                             // [nagents][ldx] normalised past, flattened (t,c), zero padded
     const float* cur; const float* orig;                    // [nagents][2]
-    float* pred;                                            // [ncols][Tf2]
+    float* pred;                                            // [ncols][Tf2]; WRITE-ONLY for the kernel when `park` is another buffer (may then be pinned host memory)
+    float* park;                                            // [ncols][Tf2] where block 0's y_hat0 waits for the epilogue (== pred: the round-2/3 layout)
     int* counter;                                           // work queue (zeroed before the launch)
     int ncols, K, Tp, Tf2;
     int persistent;  // 1: workgroups pull groups from the work queue until it is empty; 0: one group per workgroup (grid = groups)
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                 mlp_l3<NY>(st, acc2, cst + CO::b2y, cst + CO::b3y, yo, h);
             }
             if (live) {
-                float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
+                float* prow = A.park + (size_t)opaque(col) * A.Tf2;
 #pragma unroll
                 for (int o = 0; o < NY; ++o)
 #pragma unroll
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
                 const float cx = A.cur[2 * agent], cy = A.cur[2 * agent + 1];
                 const float ox = A.orig[2 * agent], oy = A.orig[2 * agent + 1];
                 const bool vec = (A.Tf2 & 3) == 0;
-                const float* yrow = A.pred + (size_t)opaque(colc) * A.Tf2;     // y_hat0 parked by this lane (dead lanes: a live column's, unused)
+                const float* yrow = A.park + (size_t)opaque(colc) * A.Tf2;     // y_hat0 parked by this lane (dead lanes: a live column's, unused)
                 float* prow = A.pred + (size_t)opaque(col) * A.Tf2;
                 const float* grow = FUSE == 2 && A.m_gt ? A.m_gt + (size_t)agent * A.Tf2 : nullptr;
                 float dd[NY][4][2];                                           // fused metrics: this lane's displacement norms (steps t0, t0 + 1)
@@ -1085,7 +1086,7 @@ static int traj_chain_impl(const float* A0x, const float* A0y, const float* A1y,
     STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "sttode_traj_chain: chunk program length does not match (Tp, Tf)");
     ChainArgs a;
     a.A0x = A0x; a.A0y = A0y; a.A1y = A1y; a.pool = (const f32x4*)pool; a.prog = (const int2*)prog; a.prog_len = prog_len;
-    a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.counter = counter;
+    a.consts = consts; a.z = z; a.xpad = xpad; a.ldx = ldx; a.cur = cur; a.orig = orig; a.pred = pred; a.park = pred; a.counter = counter;
     a.ncols = ncols; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf;
     a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.nworkers = 0; a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
     a.R = RoleArgs();   // unused by the unfused instantiation
@@ -1152,7 +1153,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     a.pool = (const f32x4*)W[b3 ? STT_W_CHAINB3_POOL : STT_W_CHAIN_POOL]; a.prog = (const int2*)W[b3 ? STT_W_CHAINB3_PROG : STT_W_CHAIN_PROG];
     a.prog_len = prog_len;
     a.consts = W[STT_W_CHAIN_CONSTS]; a.z = z; a.xpad = ws + off[STT_B_XPAD]; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.cur = ws + off[STT_B_CUR];
-    a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
+    a.orig = ws + off[STT_B_ORIG]; a.pred = pred; a.park = pred; a.counter = (int*)(ws + off[STT_B_QUEUE]);
     a.ncols = n * K; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.persistent = 0; a.dbg = nullptr; a.trace_tag = 0; a.xcd_map = 0; a.nworkers = 0;
     a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
 #if defined(C32_DIAG_STAMPS) || defined(C32_DIAG_TRACE)
@@ -1208,7 +1209,7 @@ int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int 
     a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.ldx = 2 * Tp <= 16 ? 16 : 32; a.ncols = 0;
     a.pool = (const f32x4*)W[b3 ? STT_W_CHAINB3_POOL : STT_W_CHAIN_POOL]; a.prog = (const int2*)W[b3 ? STT_W_CHAINB3_PROG : STT_W_CHAIN_PROG];
     a.prog_len = prog_len; a.consts = W[STT_W_CHAIN_CONSTS];
-    a.A0x = a.A0y = a.A1y = nullptr; a.z = nullptr; a.xpad = nullptr; a.cur = a.orig = nullptr; a.pred = nullptr;
+    a.A0x = a.A0y = a.A1y = nullptr; a.z = nullptr; a.xpad = nullptr; a.cur = a.orig = nullptr; a.pred = nullptr; a.park = nullptr;
     a.m_gt = nullptr; a.m_ade = a.m_fde = nullptr; a.m_scale = 1.0f;
     if (ws_g && g_gt) {
         STT_REQUIRE(g_ade && g_fde, "stt_chain_lagged: fused metrics need ade and fde");
@@ -1219,6 +1220,7 @@ int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int 
         STT_REQUIRE(prog_len == sttode_chain_prog_len(Tp, Tf), "stt_chain_lagged: chunk program length does not match (Tp, Tf)");
         a.A0x = ws_g + off_g[STT_B_A0X]; a.A0y = ws_g + off_g[STT_B_A0Y]; a.A1y = ws_g + off_g[STT_B_A1Y];
         a.z = z; a.xpad = ws_g + off_g[STT_B_XPAD]; a.cur = ws_g + off_g[STT_B_CUR]; a.orig = ws_g + off_g[STT_B_ORIG]; a.pred = pred;
+        a.park = ws_g + off_g[STT_B_YBUF];   // (m x 16 NOY floats >= m x 2 Tf): the kernel never reads `pred`, which may be pinned host memory
         a.ncols = n_g * K;
         // Workers (default): the launch holds at most the chip's 2-per-CU workgroup slots, and its workgroups pull groups from the call's
         // work queue.  One workgroup per group (STTODE_LAG_WORKERS=0) deals the groups to the 8 XCDs statically (block % 8), the next launch

@@ -861,6 +861,19 @@ extern "C" int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt
     return 1;
 }
 
+// 1 if the next sttode_inference_*_async call of n agents will take the lagged form (whose trajectory groups never READ the prediction
+// buffer: it may then be pinned host memory -- the futures arrive on the host with the launch, no D2H copy), else 0
+extern "C" int sttode_async_is_lagged(SttodeModel* m, int n) { return m && n > 0 && use_lagged(m, n) ? 1 : 0; }
+
+// the HOST waits until the async call that used `slot` has produced its predictions (outstanding groups are enqueued first): for
+// predictions written straight to pinned host memory
+extern "C" int sttode_wait_host(SttodeModel* m, int slot) {
+    STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait_host: bad arguments");
+    if (int rc = lag_flush(m, slot)) return rc;
+    STT_HIP(hipEventSynchronize(m->evB_done[slot]));
+    return 0;
+}
+
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");

@@ -711,7 +711,7 @@ class STTODENet(nn.Module):
         return pred.permute(1, 0, 2, 3)
 
     @torch.no_grad()
-    def inference_async(self, z=None, metrics_gt=None, metrics_scale=1.0):
+    def inference_async(self, z=None, metrics_gt=None, metrics_scale=1.0, pred_host=False):
         """Pipelined inference (build-defined): enqueue this batch and return a handle immediately.  ``async_depth`` (default 6, at most 8)
         workspace / prediction slots rotate, so at most that many calls may be in flight: call ``wait(handle)`` (which returns the
         [K, n, Tf, 2] view) before the ``async_depth``-th next call.  Inputs set by set_data / set_scene_batch / set_data_nba must stay
@@ -722,7 +722,10 @@ class STTODENet(nn.Module):
         (``native().set_lagged(0)``: the round-3 forms, bitwise inference()).
         ``metrics_gt`` [n, Tf, 2] (contiguous float32 device tensor, e.g. the futures set with the batch): in the lagged form the call's own
         trajectory groups also compute its min-over-K ADE / FDE (utils/metrics.py:7-26) -- ``best_of_k_async(handle)`` then returns them
-        without launching a kernel (the values of best_of_k on the same predictions, bit for bit)."""
+        without launching a kernel (the values of best_of_k on the same predictions, bit for bit).
+        ``pred_host=True`` (lagged form only; raises otherwise): the call's futures are written by the launch STRAIGHT to pinned host
+        memory (``handle['pred']`` is then a pinned CPU tensor [n, K, Tf, 2]; ``wait_host(handle)`` makes the host wait for it) -- what
+        test.py:186-188 does with a .cpu() per call, without a D2H copy."""
         self._require_gpu()
         a = self.args
         if self._mode is None:
@@ -754,6 +757,13 @@ class STTODENet(nn.Module):
         if tuple(z.shape) != (n * K, a.zdim):
             raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
         buf, pred = self._async_bufs[key][:2]
+        if pred_host:
+            if not capi.lib().sttode_async_is_lagged(nat.h, n):
+                raise capi.SttodeError('pred_host=True needs the lagged pipelined form (a chain-sized batch, reference integrator)')
+            hk = ('host',) + key
+            if hk not in self._async_bufs:
+                self._async_bufs[hk] = torch.empty(n, K, a.future_length, 2, dtype=torch.float32).pin_memory()
+            pred = self._async_bufs[hk]
         st = capi.stream_ptr()
         pstream = self.next_async_stream(n)                     # the pipeline stream this call's launches (and its metrics) run on, or None
         mb = self._async_metrics.get(key)
@@ -777,6 +787,12 @@ class STTODENet(nn.Module):
     def wait(self, handle):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
         capi.call('sttode_wait', self.native().h, handle['slot'], capi.stream_ptr())
+        return handle['pred'].permute(1, 0, 2, 3)
+
+    def wait_host(self, handle):
+        """The HOST waits for an inference_async() result (for ``pred_host=True`` calls: the pinned tensor may be read afterwards);
+        returns predictions [K, n, Tf, 2]."""
+        capi.call('sttode_wait_host', self.native().h, handle['slot'])
         return handle['pred'].permute(1, 0, 2, 3)
 
     def next_async_stream(self, n):

@@ -1387,6 +1387,52 @@ def test_lagged_form_with_mixed_batch_shapes_and_small_calls_in_between():
         m.reset_async()
 
 
+def test_zero_copy_futures_of_the_lagged_form():
+    """inference_async(pred_host=True): the trajectory groups of a lagged call write the futures straight to PINNED HOST memory (the kernel
+    only writes `pred`: block 0's y_hat0 waits in the workspace), what test.py:186-188 does with a .cpu() per call -- the same bits as the
+    device-buffer call, fused metrics included, slots reused; refused for calls that do not take the lagged form."""
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(8600, 8661), 'eth')
+    z = torch.from_numpy(scenes.latents(77, sb.n_agents)).to(m.device)
+    fut = torch.from_numpy(sb.future).to(m.device)
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        m.reset_async()
+        outs = {}
+        for host in (False, True):
+            hs = []
+            for _ in range(7):                                    # more calls than slots
+                m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+                h = m.inference_async(z=z, metrics_gt=m._future, pred_host=host)
+                hs.append(h)
+                if len(hs) > 3:
+                    hh = hs.pop(0)
+                    a, f = m.best_of_k_async(hh)
+                    p = m.wait_host(hh) if host else m.wait(hh)
+                    torch.cuda.synchronize()
+                    outs.setdefault(host, []).append((torch.as_tensor(p).cpu().clone(), a.clone(), f.clone()))
+            for hh in hs:
+                a, f = m.best_of_k_async(hh)
+                p = m.wait_host(hh) if host else m.wait(hh)
+                torch.cuda.synchronize()
+                outs[host].append((torch.as_tensor(p).cpu().clone(), a.clone(), f.clone()))
+            assert (hs[-1]['pred'].is_pinned() and not hs[-1]['pred'].is_cuda) == host
+        assert len(outs[True]) == len(outs[False]) == 7
+        for (ph, ah, fh), (pd, ad, fd) in zip(outs[True], outs[False]):
+            assert torch.isfinite(ph).all()
+            assert torch.equal(ph, pd) and torch.equal(ah, ad) and torch.equal(fh, fd), 'futures written to pinned host memory differ from the device-buffer call'
+        small = scenes.make_scene_batch(range(8700, 8704), 'eth')
+        nat.set_chain(-1)
+        m.set_scene_batch(small.past, small.future, small.scene_ptr)
+        with pytest.raises(capi.SttodeError):
+            m.inference_async(pred_host=True)
+    finally:
+        nat.set_chain(-1)
+        m.reset_async()
+
+
 def test_check_reports_a_given_up_hand_off():
     """sttode_check: the host-visible error path of the in-launch hand-off forms (round-3 fused launch): after a launch in which a group
     gave up waiting for its producer (fault injection) the check fails loudly; after a healthy launch it passes."""
