@@ -134,6 +134,11 @@ __device__ __forceinline__ float exp_neg_acos(float x) {
     const float ac = x < 0.f ? 3.14159265358979f - a : a;  // acos(x)
     return __builtin_amdgcn_exp2f(-1.4426950408889634f * ac);
 }
+// Round 4: a workgroup takes 64 rows, and its four waves split every 128-column tile four ways (wave w: columns 32 w .. 32 w + 31 of the
+// tile); the four partial (sum, weighted values) of a row are added through LDS in wave order (deterministic).  One row per lane over ALL
+// columns (round 1-3) made a launch as long as one lane's serial loop -- 512 columns x ~35 VALU instructions = 30 us for a 512-long group
+// whatever the chip had free (the grid is rows / 256 x slots x heads workgroups: 160 for config 5's 512 x 10 group); the multi-stage
+// integrator runs one such launch per stage.
 __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict__ R, const float* __restrict__ C,
                                                          const float* __restrict__ V, float* __restrict__ out,
                                                          float* __restrict__ rowsum,  // optional [Nb][8][rows]
@@ -141,8 +146,10 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
                                                          long vs_seq, long vs_b, long os_seq, long os_b, float rscale, float cscale) {
     __shared__ __attribute__((aligned(16))) float sC[ATT_TJ][8];
     __shared__ __attribute__((aligned(16))) float sV[ATT_TJ][8];
+    __shared__ float sP[3][64][9];                                   // partials of waves 1..3: l, acc[8]
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int rl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + rl;
     const int ic = i < rows ? i : rows - 1;
     float r[8];
     {
@@ -179,9 +186,10 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
         }
         __syncthreads();
         const int jn = min(ATT_TJ, cols - j0);
+        const int ja = 32 * w, jb = min(ja + 32, jn);
 #pragma unroll 8
-        for (int jj = 0; jj < jn; ++jj) {
-            // all lanes read the same column (LDS broadcast): two b128 reads for c_j, two for v_j
+        for (int jj = ja; jj < jb; ++jj) {
+            // all lanes of a wave read the same column (LDS broadcast): two b128 reads for c_j, two for v_j
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[jj][0]), c1 = *reinterpret_cast<const f32x4*>(&sC[jj][4]);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sV[jj][0]), v1 = *reinterpret_cast<const f32x4*>(&sV[jj][4]);
             float dot = r[0] * c0[0];
@@ -194,7 +202,19 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
             acc[4] = fmaf(p, v1[0], acc[4]); acc[5] = fmaf(p, v1[1], acc[5]); acc[6] = fmaf(p, v1[2], acc[6]); acc[7] = fmaf(p, v1[3], acc[7]);
         }
     }
-    if (i < rows) {
+    if (w > 0) {
+        sP[w - 1][rl][0] = l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) sP[w - 1][rl][1 + d] = acc[d];
+    }
+    __syncthreads();
+    if (w == 0 && i < rows) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                // wave order 0 + 1 + 2 + 3
+            l += sP[k][rl][0];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[d] += sP[k][rl][1 + d];
+        }
         float* o = out + i * os_seq + b * os_b + 8 * h;
         const float inv = 1.0f / l;
 #pragma unroll
@@ -402,7 +422,7 @@ extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V,
     STT_REQUIRE(rows > 0 && cols > 0 && Nb > 0 && Nb * 8 <= 65535, "sttode_mhgsa_attn: bad rows/cols/Nb (Nb*8 must fit gridDim.y)");
     STT_REQUIRE(!wout || rowsum, "sttode_mhgsa_attn: weights output needs the rowsum workspace");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 255) / 256, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
+    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 63) / 64, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
                        rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale);
     STT_HIP(hipGetLastError());
     if (wout) {
