@@ -55,3 +55,20 @@ int stt_enc_lat_tiles();   // crossover of the encoder's latency form (decoder.h
             if (_dev >= 0 && _dev < STT_ATTR_DEVICES) _done[_dev] = true;                                       \
         }                                                                                                       \
     } while (0)
+
+// The two halves of a LAGGED launch (chain32.hip stt_chain_lagged; pipeline.hip run_lagged / lag_flush): the call whose per-agent roles ride
+// in the launch and the (earlier) call whose trajectory groups do.  ws == nullptr: that half is absent.
+struct LagRoles {
+    float* ws; const long* off; int n;                       // workspace, its layout, agents
+    const float* attn; int ld_attn; float ode_time;          // attention output of the launches in front (NBA: attention groups > 1) or nullptr
+    float* zgen; unsigned long long zkey;                    // the roles draw the call's latents into zgen (nullptr: the caller supplied z)
+    const float* past; const int* scene_ptr; int S;          // scene batches: set_data inside the roles (nullptr: a front-end launch ran)
+    float* ade; float* fde;                                  // fused metrics of this call start at +inf here (nullptr: none)
+};
+struct LagGroups {
+    float* ws; const long* off; int n; const float* z; float* pred;
+    const float* gt; float* ade; float* fde; float scale;    // fused metrics (gt == nullptr: none)
+    int workers;                                             // the groups may run as workers on the call's work queue
+};
+int stt_chain_lagged(const float* const* W, const LagRoles& r, const LagGroups& g, int K, int Tp, int Tf, int prog_len, int b3, void* stream);
+bool stt_chain_lagged_covers(int Tp);

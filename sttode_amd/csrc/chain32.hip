@@ -1196,10 +1196,12 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
 // nullptr).  Nothing in the grid depends on anything else in it.  attn != nullptr (NBA: attention groups > 1): embed_qkv and mhgsa_attn of
 // the roles' call have run on `stream` before, the roles read g and the attention output from ws_r.  The reference's one Euler step only.
 bool stt_chain_lagged_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32; }
-int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
-                     float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
-                     float* zgen, unsigned long long zkey, const float* past, const int* scene_ptr, int S,
-                     float* r_ade, float* r_fde, const float* g_gt, float* g_ade, float* g_fde, float g_scale, int lag_workers_ok, void* stream) {
+int stt_chain_lagged(const float* const* W, const LagRoles& lr, const LagGroups& lg, int K, int Tp, int Tf, int prog_len, int b3, void* stream) {
+    float* ws_r = lr.ws; const long* off_r = lr.off; const int n_r = lr.n; const float* attn = lr.attn; const int ld_attn = lr.ld_attn;
+    const float ode_time = lr.ode_time; float* zgen = lr.zgen; const unsigned long long zkey = lr.zkey; const float* past = lr.past;
+    const int* scene_ptr = lr.scene_ptr; const int S = lr.S; float* r_ade = lr.ade; float* r_fde = lr.fde;
+    float* ws_g = lg.ws; const long* off_g = lg.off; const int n_g = lg.n; const float* z = lg.z; float* pred = lg.pred;
+    const float* g_gt = lg.gt; float* g_ade = lg.ade; float* g_fde = lg.fde; const float g_scale = lg.scale; const int lag_workers_ok = lg.workers;
     STT_REQUIRE(W && (ws_r || ws_g), "stt_chain_lagged: nothing to launch");
     STT_REQUIRE(K > 0 && stt_chain_lagged_covers(Tp) && Tf >= 1, "stt_chain_lagged: shape outside the lagged launch");
     ChainArgs a;

@@ -69,12 +69,6 @@ struct SttodeModel {
     std::vector<hipEvent_t> pool;
 };
 
-bool stt_chain_lagged_covers(int Tp);
-int stt_chain_lagged(const float* const* W, float* ws_r, const long* off_r, int n_r, const float* attn, int ld_attn, float ode_time,
-                     float* ws_g, const long* off_g, int n_g, const float* z, float* pred, int K, int Tp, int Tf, int prog_len, int b3,
-                     float* zgen, unsigned long long zkey, const float* past, const int* scene_ptr, int S,
-                     float* r_ade, float* r_fde, const float* g_gt, float* g_ade, float* g_fde, float g_scale, int lag_workers_ok, void* stream);
-
 bool stt_embed_qkv_fe_covers(int n, int Tlen);
 int stt_embed_qkv_fe(const float* const* W, const float* past, int n, int N, int Tlen, int TPX, float* xpad, float* enc_in, float* cur,
                      float* orig, int* last, float* g, float* qkv, void* stream);
@@ -672,9 +666,9 @@ static int lag_flush(SttodeModel* m, int slot) {
     if (!p.valid) return 0;
     lag_unqueue(m, slot);
     p.valid = false;
-    RUN(STT_STAGE_FUSED, p.s,
-        stt_chain_lagged(m->w, nullptr, nullptr, 0, nullptr, 0, 12.0f, p.ws, p.off, p.n, p.z, p.pred, m->K, m->Tp, m->Tf, m->prog_len, m->b3,
-                         nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, p.gt, p.ade, p.fde, p.scale, p.one_launch, p.s));
+    LagRoles none = {};
+    LagGroups lg = {p.ws, p.off, p.n, p.z, p.pred, p.gt, p.ade, p.fde, p.scale, p.one_launch};
+    RUN(STT_STAGE_FUSED, p.s, stt_chain_lagged(m->w, none, lg, m->K, m->Tp, m->Tf, m->prog_len, m->b3, p.s));
     STT_HIP(hipEventRecord(m->evB_done[slot], p.s));
     return 0;
 }
@@ -722,11 +716,11 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     m->zgen_armed = false;
     const bool met = m->met_armed;                                   // armed: this call's groups will compute its best-of-K metrics
     m->met_armed = false;
-    RUN(STT_STAGE_FUSED, sf,
-        stt_chain_lagged(W, ws, off, n, attn, 64, 12.0f, g ? g->ws : nullptr, g ? g->off : nullptr, g ? g->n : 0, g ? g->z : nullptr,
-                         g ? g->pred : nullptr, m->K, m->Tp, m->Tf, m->prog_len, m->b3, zgen, m->zgen_key, fe_role ? past : nullptr,
-                         fe_role ? scene_ptr : nullptr, fe_role ? S : 0, met ? m->met_ade : nullptr, met ? m->met_fde : nullptr,
-                         g ? g->gt : nullptr, g ? g->ade : nullptr, g ? g->fde : nullptr, g ? g->scale : 1.0f, fe_role && (!g || g->one_launch), sf));
+    LagRoles lr = {ws, off, n, attn, 64, 12.0f, zgen, m->zgen_key, fe_role ? past : nullptr, fe_role ? scene_ptr : nullptr, fe_role ? S : 0,
+                   met ? m->met_ade : nullptr, met ? m->met_fde : nullptr};
+    LagGroups lg = {};
+    if (g) lg = LagGroups{g->ws, g->off, g->n, g->z, g->pred, g->gt, g->ade, g->fde, g->scale, fe_role && g->one_launch};
+    RUN(STT_STAGE_FUSED, sf, stt_chain_lagged(W, lr, lg, m->K, m->Tp, m->Tf, m->prog_len, m->b3, sf));
     if (g) {
         lag_unqueue(m, gs);
         g->valid = false;

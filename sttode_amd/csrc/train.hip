@@ -367,17 +367,11 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
         g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
         g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
-        // 64 x 128 tiles (NB = 2) measured SLOWER at the NBA step's shapes (36-38 us against 19-25 us per product: 55 KB of LDS leave two
-        // workgroups per CU to hide the panel loads instead of four): kept as an instantiation, not used
-        const bool wide = false;
-        dim3 grid((cols + 63) / 64, wide ? (I + 127) / 128 : (I + 63) / 64);
-        if (trans) {
-            if (wide) hipLaunchKernelGGL((tgemm_kernel<false, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            else hipLaunchKernelGGL((tgemm_kernel<false, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
-        } else {
-            if (wide) hipLaunchKernelGGL((tgemm_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            else hipLaunchKernelGGL((tgemm_kernel<false, false, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
-        }
+        // (NB = 2, 64 x 128 tiles, measured SLOWER at the NBA step's shapes -- 36-38 us against 19-25 us per product: 55 KB of LDS leave two
+        // workgroups per CU to hide the panel loads instead of four -- and is not instantiated)
+        dim3 grid((cols + 63) / 64, (I + 63) / 64);
+        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((tgemm_kernel<false, false, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
         STT_HIP(hipGetLastError());
         return 0;
     }
@@ -502,8 +496,7 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     const long per = (long)N * (K + 1);
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
     if (tg_on && cols > 2048 && scratch) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
-        const bool wide = false;                                   // (see sttode_tlinear)
-        const int tiles = ((N + 63) / 64) * (wide ? (K + 1 + 127) / 128 : (K + 1 + 63) / 64);
+        const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
         int S = (480 + tiles - 1) / tiles;
         if (S > 64) S = 64;
         if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
@@ -516,9 +509,8 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
             g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
             g.db = db; g.scratch = scratch; g.S = S; g.mode = 1;
             g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
-            dim3 grid((N + 63) / 64, wide ? (K + 1 + 127) / 128 : (K + 1 + 63) / 64, S);
-            if (wide) hipLaunchKernelGGL((tgemm_kernel<true, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            else hipLaunchKernelGGL((tgemm_kernel<true, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, S);
+            hipLaunchKernelGGL((tgemm_kernel<true, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
             if (S > 1) {
                 a.S = S;
                 hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
