@@ -29,20 +29,30 @@ struct R32C {   // == packing.R32_CONSTS
 // that separates roles from groups -- and, with every VGPR taken by the groups' code, parks them in SCRATCH: 128 B per lane of every wave.
 typedef const __attribute__((address_space(4))) Role32Args KRole32Args;
 
-// The stream as a flat sequence of tiles: next() hands out the tiles of the program in order and steps over chunk boundaries (prefetch of the
-// following chunk, barrier) wherever they fall -- a layer need not be a whole number of chunks.  Uniform control flow: every wave of the
-// workgroup asks for the same tiles in the same order.
+// The stream as a flat sequence of tiles: mma() multiplies the next tile of the program into an accumulator and steps over chunk boundaries
+// (prefetch of the following chunk, barrier) wherever they fall -- a layer need not be a whole number of chunks.  Fragment look-ahead as in
+// the trajectory chain (tile_mma2): the fragments of the next tile OF THE SAME CHUNK are requested halfway through the current tile's
+// MFMAs; the first tile of a chunk is read before the chunk's DMA pieces are issued.  (Without it a role alone on its SIMD ran at 71 % of
+// its MFMA time, and beside a trajectory group it outlasted the group: 0.8-1.0 ms against 0.73 -- the long pole of every small launch.)
+// Uniform control flow: every wave of the workgroup asks for the same tiles in the same order.
 template <class ST> struct TileFeed {
-    ST& st; int t, cnt;
-    __device__ __forceinline__ explicit TileFeed(ST& s) : st(s), t(0), cnt(0) {}
+    ST& st; int t, cnt; bool pre;
+    Frag cur, nxt;
+    __device__ __forceinline__ explicit TileFeed(ST& s) : st(s), t(0), cnt(0), pre(false) {}
     __device__ __forceinline__ void open() {        // the current chunk has landed and passed its barrier; begin() was not yet called for it
         cnt = __builtin_amdgcn_readfirstlane(st.lprog[st.p].y);
         t = 0;
+        ldfrag(cur, st.cur());                      // first tile of the chunk: its read latency overlaps the DMA issue below
         st.begin();
+        pre = false;
     }
-    __device__ __forceinline__ const f32x4* next() {
+    __device__ __forceinline__ void mma(f32x16& acc, const f32x16& B) {
         if (t == cnt) { st.end(); open(); }
-        return st.cur() + (t++) * C32_TILE;
+        else if (pre) cur = nxt;                    // (16 register moves per 16 MFMAs; the arrays must not be indexed by a run-time value)
+        const f32x4* tn = t + 1 < cnt ? st.cur() + (t + 1) * C32_TILE : nullptr;
+        tile_mma2(acc, cur, B, nxt, tn);
+        pre = tn != nullptr;
+        ++t;
     }
     __device__ __forceinline__ void close() { st.end(); }   // drains the last prefetch (nobody reads it) before the workgroup leaves
 };
@@ -87,7 +97,7 @@ __device__ __forceinline__ void table32(FD& fd, const float* bias, float* out, c
     for (int rt = 0; rt < 16; ++rt) {
         f32x16 acc = ldrows(bias + 32 * rt, h);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) tile_mma(acc, fd.next(), B[kt]);
+        for (int kt = 0; kt < KT; ++kt) fd.mma(acc, B[kt]);
         if (live) strows(out + (size_t)col * 512 + 32 * rt, acc, h);
     }
 }
@@ -227,8 +237,8 @@ __device__ __forceinline__ void role32_body(KRole32Args& R, int wg, char* smem) 
             const f32x16 b = ldrows(cst + R32C::bc + 32 * j, h), wl = ldrows(cst + R32C::wlast + 32 * j, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[j][r] = fmaf(wl[r], lastf, b[r]);
-            tile_mma(G[j], fd.next(), X[0]);
-            if (R.kte > 1) tile_mma(G[j], fd.next(), X[1]);
+            fd.mma(G[j], X[0]);
+            if (R.kte > 1) fd.mma(G[j], X[1]);
         }
         S[0] = G[0]; S[1] = G[1];
     } else {
@@ -242,11 +252,11 @@ __device__ __forceinline__ void role32_body(KRole32Args& R, int wg, char* smem) 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         f32x16 vi = ldrows(cst + R32C::bi + 32 * j, h);
-        tile_mma(vi, fd.next(), S[0]);
-        tile_mma(vi, fd.next(), S[1]);
+        fd.mma(vi, S[0]);
+        fd.mma(vi, S[1]);
         f32x16 vg = ldrows(cst + R32C::bg + 32 * j, h);
-        tile_mma(vg, fd.next(), S[0]);
-        tile_mma(vg, fd.next(), S[1]);
+        fd.mma(vg, S[0]);
+        fd.mma(vg, S[1]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) XR[j][r] = G[j][r] + tanhf(vi[r]) * sigmoidf_(vg[r]);
     }
@@ -257,11 +267,11 @@ __device__ __forceinline__ void role32_body(KRole32Args& R, int wg, char* smem) 
 #pragma unroll 1
         for (int ht = 0; ht < 32; ++ht) {
             f32x16 hid = ldrows(cst + R32C::l1b + 32 * ht, h);
-            tile_mma(hid, fd.next(), XR[0]);
-            tile_mma(hid, fd.next(), XR[1]);
+            fd.mma(hid, XR[0]);
+            fd.mma(hid, XR[1]);
             hid = relu16(hid);
-            tile_mma(FF[0], fd.next(), hid);
-            tile_mma(FF[1], fd.next(), hid);
+            fd.mma(FF[0], hid);
+            fd.mma(FF[1], hid);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
