@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 /* Version of this header: the library returns it from sttode_abi_version(); a binding compares before its first call (round 1-2: 1). */
-#define STTODE_ABI_VERSION 5
+#define STTODE_ABI_VERSION 6
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
@@ -192,6 +192,14 @@ int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv,
 int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, long ldw, const float* mask, long ldm, float* dX, long lddx,
                        int Kdx, int accumulate, const float* X, long ldx, int xdiv, float* dW, long ldgw, float* db, int cols, int N,
                        int K, float* scratch, long scratch_floats, void* stream);
+/* Batch sizes (cols > 2048) split a weight gradient's reduction over the columns; the partial sums are added into dW / db by a reduction
+ * launch.  sttode_twgrad_defer(1, buf, floats): from now on the partial sums are bump-allocated from buf (device memory nothing else
+ * writes) and the reductions run as ONE launch per 16 gradients -- or earlier: buf full, a destination that is already pending, another
+ * stream.  sttode_twgrad_defer(0, NULL, 0): run what is pending (on the stream of the gradients that queued it), back to a reduction per
+ * gradient; sttode_twgrad_defer(-1, NULL, 0): forget what is pending (error paths).  sttode_twgrad_flush(): run what is pending, keep the
+ * mode.  Process-wide host-side state; a training step brackets its backward pass with defer(1) / defer(0) (sttode_amd/training.py). */
+int sttode_twgrad_defer(int on, float* buf, long floats);
+int sttode_twgrad_flush(void);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
 /* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */

@@ -11,7 +11,7 @@ _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 5   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
+ABI_VERSION = 6   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
@@ -44,6 +44,8 @@ SIGNATURES = {
     # training step (csrc/train.hip)
     'sttode_tlinear': [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
+    'sttode_twgrad_defer': [_I, _P, _L],
+    'sttode_twgrad_flush': [],
     'sttode_tlinear_bwd': [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
     'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],

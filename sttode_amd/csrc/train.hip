@@ -9,6 +9,7 @@
 // plus the element-wise forward/backward pieces (GRU cell, conv1d k=3, LayerNorm, gate, Euler+relu,
 // geodesic attention backward, reparameterisation + KL, squared-error / best-of-K losses).
 #include "api_util.hpp"
+#include <mutex>
 #include "chain.hpp"
 
 // ---------------------------------------------------------------------------------------------------
@@ -18,6 +19,7 @@ struct TLin {
     const float* X; const float* W; const float* bias; const float* mask; float* Y;
     long ldx, ldw, ldy, ldm;
     int cols, J, I, trans, act, accumulate, xdiv, xvec, wvec, yvec;
+    int evec;   // I % 4 == 0 and Y, bias, mask 16-byte aligned: the epilogue runs on 16-byte pieces
 };
 
 static __device__ __forceinline__ f32x4 ld_guard4(const float* row, int j, int J, bool rowok, bool vec) {
@@ -114,6 +116,41 @@ static __device__ __forceinline__ void tlinear_body(const TLin& a, int ksplit, i
                     for (int t = 0; t < CT; ++t) acc[i][t] += part[(wave / ksplit) * (ksplit - 1) + k - 1][i * CT + t][lane];
     }
     if (!active || ksub != 0) return;
+    if (a.evec) {
+        // every operand of the epilogue in 16-byte pieces, all requested before the first is used (element by element, each load under its
+        // own bounds check is followed by its own wait: 4-12 dependent L2 round trips in a kernel that lasts 5-9 us at scene sizes)
+        f32x4 bv[RT], yv[RT][CT], mv[RT][CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int o = (it0 + i) * 16 + 4 * q, oc = o < a.I ? o : 0;   // (I % 4 == 0: a piece is inside or outside as a whole)
+            if (a.bias) bv[i] = ld4(a.bias + oc);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const long cc = colok[t] ? col[t] : 0;
+                if (a.accumulate) yv[i][t] = ld4(a.Y + cc * a.ldy + oc);
+                if (a.mask) mv[i][t] = ld4(a.mask + cc * a.ldm + oc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int o = (it0 + i) * 16 + 4 * q;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                f32x4 v = acc[i][t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r];
+                    if (a.bias) x += bv[i][r];
+                    if (a.accumulate) x += yv[i][t][r];
+                    x = act_apply(x, a.act);
+                    if (a.mask && !(mv[i][t][r] > 0.f)) x = 0.f;
+                    v[r] = x;
+                }
+                if (colok[t] && o < a.I) st4(a.Y + (long)col[t] * a.ldy + o, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         if (!colok[t]) continue;
@@ -168,6 +205,8 @@ struct TG {
     int adiv, bkdiv;         // row of A = m / adiv (A not transposed: tlinear's broadcast rows); reduction index of B = k / bkdiv (twgrad's X rows)
     int ones_row;            // twgrad: B(n == ones_row, .) = 1 -- the bias gradient rides as one more column of dW; -1: none
     int avec, bvec, cvec;    // operand / result rows 16-byte aligned
+    int evec;                // mode 0: N % 4 == 0 and C, bias, mask 16-byte aligned -- the epilogue runs on 16-byte pieces
+    int fast;                // operands fit tg_fetch_fast (tg_fast below)
     const float* bias; const float* mask; long ldm; int act, accumulate;   // mode 0 (tlinear) epilogue
     float* db; float* scratch; int S, kchunk, mode;                        // mode 1 (twgrad): split s = blockIdx.z reduces k in [s kchunk, (s + 1) kchunk)
 };
@@ -234,81 +273,184 @@ static __device__ __forceinline__ f32x4 tg_frag(const float* S, int row, int q, 
     return r;
 }
 
-// NB: 64-wide blocks of n per workgroup (1: a 64 x 64 tile of C; 2: 64 x 128 -- twice the MFMAs per fetched byte and per barrier; used
-// where the wider tile still fills the chip)
-template <bool AT, bool BT, int NB>
-__global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
-    __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
-    __shared__ __attribute__((aligned(16))) float Bs[2][NB][TG_PANEL];
+// Branch-free form of tg_fetch for the shapes the training step is made of (g.fast: 16-byte aligned operands, no broadcast rows, the
+// contiguous index a multiple of 4): addresses are clamped into the operand instead of tested, pieces beyond [.., kend) are zeroed by a
+// select.  Without branches the compiler counts outstanding loads exactly, and a tile can be requested TWO tiles ahead: a 64 x 64 tile
+// needs 16 KB per 32-deep step for 262 kFLOP -- at the MFMA rate that is 38 GB/s per CU, 9.6 TB/s chip-wide out of L2 -- and with one
+// tile in flight per workgroup the step lasted one loaded L2 round trip instead (measured 30 us for a product with 12 us of MFMA).
+template <bool T>
+static __device__ __forceinline__ void tg_fetch_fast(f32x4 (&v)[2], const float* __restrict__ src, long ld, int row0, int rows, int k0, int kend) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = (int)threadIdx.x + 256 * p;
+        if (!T) {
+            const int row = row0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+            v[p] = ld4(src + (long)(row < rows ? row : rows - 1) * ld + (k < kend ? k : kend - 4));
+        } else {
+            const int k = k0 + (idx >> 4), row = row0 + (idx & 15) * 4;
+            v[p] = ld4(src + (long)(k < kend ? k : kend - 1) * ld + (row + 3 < rows ? row : rows - 4));
+        }
+    }
+}
+// ... and what the bounds tests would have done, applied when the tile goes to LDS (not at the request: the selects would wait for the data)
+template <bool T>
+static __device__ __forceinline__ void tg_store_fast(f32x4 (&v)[2], float* S, int row0, int k0, int kend, int ones_row) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = (int)threadIdx.x + 256 * p;
+        f32x4 x = v[p];
+        if (!T) {
+            if (!(k0 + (idx & 7) * 4 < kend)) x = splat4(0.f);
+            *reinterpret_cast<f32x4*>(S + (idx >> 3) * 36 + (idx & 7) * 4) = x;
+        } else {
+            const int row = row0 + (idx & 15) * 4;
+            if (ones_row >= 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (row + e == ones_row) x[e] = 1.0f;
+            }
+            if (!(k0 + (idx >> 4) < kend)) x = splat4(0.f);
+            *reinterpret_cast<f32x4*>(S + (idx >> 4) * 68 + (idx & 15) * 4) = x;
+        }
+    }
+}
+
+template <bool AT, bool BT>
+static __device__ __forceinline__ void tg_mma_tile(tg_f32x16& acc, const float* Sa, const float* Sb, int mt, int nt, int c, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = tg_frag<AT>(Sa, mt * 32 + c, q, h);     // MFMA columns = m
+        const f32x4 a = tg_frag<BT>(Sb, nt * 32 + c, q, h);     // MFMA rows = n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+    }
+}
+
+// one 64 x 64 tile of C (tile indices bx, by; bz: the split of the reduction in mode 1) by the calling workgroup
+template <bool AT, bool BT>
+static __device__ __forceinline__ void tgemm_body(const TG& g, int bx, int by, int bz, float (*As)[TG_PANEL], float (*Bs)[TG_PANEL]) {
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * (64 * NB);
-    const int kbeg = g.mode == 1 ? blockIdx.z * g.kchunk : 0;
+    const int m0 = bx * 64, n0 = by * 64;
+    const int kbeg = g.mode == 1 ? bz * g.kchunk : 0;
     const int kend = g.mode == 1 ? (kbeg + g.kchunk < g.Kt ? kbeg + g.kchunk : g.Kt) : g.Kt;
     const int mt = wave & 1, nt = wave >> 1;
-    tg_f32x16 accs[NB];
+    tg_f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accs[j][e] = 0.f;
-    f32x4 va[2], vb[NB][2];
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 va[2], vb[2];
     const int brows = g.N - (g.ones_row >= 0 ? 1 : 0);
+    if (g.fast && kbeg < kend) {
+        // two tiles ahead: register set 0 / 1 holds tile t / t + 1 on its way to LDS buffer 0 / 1 (requests beyond the last tile read one
+        // clamped piece and give zeros); lds_barrier(): the workgroup barrier WITHOUT the vmcnt(0) of __syncthreads(), which would drain
+        // the requests of the tile after next at every step
+        f32x4 ua[2], ub[2];
+        const int P = (kend - kbeg + 31) / 32;
+        tg_fetch_fast<AT>(va, g.A, g.lda, m0, g.M, kbeg, kend);
+        tg_fetch_fast<BT>(vb, g.B, g.ldb, n0, brows, kbeg, kend);
+        tg_fetch_fast<AT>(ua, g.A, g.lda, m0, g.M, kbeg + 32, kend);
+        tg_fetch_fast<BT>(ub, g.B, g.ldb, n0, brows, kbeg + 32, kend);
+        __builtin_amdgcn_sched_barrier(0);
+        tg_store_fast<AT>(va, As[0], m0, kbeg, kend, -1);
+        tg_store_fast<BT>(vb, Bs[0], n0, kbeg, kend, g.ones_row);
+        lds_barrier();
+        int t = 0;
+        for (; t + 2 <= P; t += 2) {
+            const int k1 = kbeg + 32 * (t + 1);
+            tg_fetch_fast<AT>(va, g.A, g.lda, m0, g.M, k1 + 32, kend);
+            tg_fetch_fast<BT>(vb, g.B, g.ldb, n0, brows, k1 + 32, kend);
+            __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the requests to their first use, behind the MFMAs)
+            tg_mma_tile<AT, BT>(acc, As[0], Bs[0], mt, nt, c, h);
+            __builtin_amdgcn_sched_barrier(0);
+            tg_store_fast<AT>(ua, As[1], m0, k1, kend, -1);
+            tg_store_fast<BT>(ub, Bs[1], n0, k1, kend, g.ones_row);
+            lds_barrier();
+            tg_fetch_fast<AT>(ua, g.A, g.lda, m0, g.M, k1 + 64, kend);
+            tg_fetch_fast<BT>(ub, g.B, g.ldb, n0, brows, k1 + 64, kend);
+            __builtin_amdgcn_sched_barrier(0);
+            tg_mma_tile<AT, BT>(acc, As[1], Bs[1], mt, nt, c, h);
+            __builtin_amdgcn_sched_barrier(0);
+            tg_store_fast<AT>(va, As[0], m0, k1 + 32, kend, -1);
+            tg_store_fast<BT>(vb, Bs[0], n0, k1 + 32, kend, g.ones_row);
+            lds_barrier();
+        }
+        if (t < P) tg_mma_tile<AT, BT>(acc, As[0], Bs[0], mt, nt, c, h);
+    } else {
     tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, kbeg, kend, 1, -1, g.avec);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) tg_fetch<BT>(vb[j], g.B, g.ldb, n0 + 64 * j, brows, 1, kbeg, kend, g.bkdiv, g.ones_row, g.bvec);
+    tg_fetch<BT>(vb, g.B, g.ldb, n0, brows, 1, kbeg, kend, g.bkdiv, g.ones_row, g.bvec);
     tg_store<AT>(va, As[0]);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) tg_store<BT>(vb[j], Bs[0][j]);
+    tg_store<BT>(vb, Bs[0]);
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         const bool more = k0 + 32 < kend;
         if (more) {   // the next k tile travels while this one is multiplied
             tg_fetch<AT>(va, g.A, g.lda, m0, g.M, g.adiv, k0 + 32, kend, 1, -1, g.avec);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tg_fetch<BT>(vb[j], g.B, g.ldb, n0 + 64 * j, brows, 1, k0 + 32, kend, g.bkdiv, g.ones_row, g.bvec);
+            tg_fetch<BT>(vb, g.B, g.ldb, n0, brows, 1, k0 + 32, kend, g.bkdiv, g.ones_row, g.bvec);
         }
-        const float* Sa = As[buf];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 b = tg_frag<AT>(Sa, mt * 32 + c, q, h);                 // MFMA columns = m
+            const f32x4 b = tg_frag<AT>(As[buf], mt * 32 + c, q, h);     // MFMA columns = m
+            const f32x4 a = tg_frag<BT>(Bs[buf], nt * 32 + c, q, h);     // MFMA rows = n
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const f32x4 a = tg_frag<BT>(Bs[buf][j], nt * 32 + c, q, h);     // MFMA rows = n
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accs[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], accs[j], 0, 0, 0);
-            }
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
         }
         if (more) {
             tg_store<AT>(va, As[buf ^ 1]);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tg_store<BT>(vb[j], Bs[buf ^ 1][j]);
+            tg_store<BT>(vb, Bs[buf ^ 1]);
         }
         __syncthreads();
         buf ^= 1;
     }
+    }
     // lane (c, h): m = m0 + 32 mt + c; register 4a + b <-> n = n0 + 32 nt + 8a + 4h + b
     const int m = m0 + mt * 32 + c;
     if (m >= g.M) return;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-    const tg_f32x16& acc = accs[j];
     if (g.mode == 1 && g.S > 1) {
-        // split reduction: the partial tile goes to scratch [split][M][N]; twgrad_reduce_kernel adds the splits in order (deterministic).
+        // split reduction: the partial tile goes to scratch [split][M][N]; the splits are added in order by a reduction launch (deterministic).
         // (Combining inside the launch -- last workgroup of a tile, ticket counter -- was built and measured: the agent-scope release every
         // workgroup needs before its ticket writes the whole L2 back on this part, 183 us per weight gradient against 36 us + 10 us.)
-        float* part = g.scratch + ((long)blockIdx.z * g.M + m) * g.N;
+        float* part = g.scratch + ((long)bz * g.M + m) * g.N;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int n = n0 + 64 * j + nt * 32 + 8 * a + 4 * h;
+            const int n = n0 + nt * 32 + 8 * a + 4 * h;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (n + e < g.N) part[n + e] = acc[4 * a + e];
         }
-        continue;
+        return;
+    }
+    if (g.mode == 0 && g.evec) {
+        // every operand of the epilogue in 16-byte pieces, all requested before the first is used (element by element under its bounds
+        // check each load is followed by its own wait: 16-48 dependent L2 round trips per lane, 5-10 us of a 25-us product)
+        f32x4 bv[4], yv[4], mv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int n = n0 + nt * 32 + 8 * a + 4 * h;
+            const int nc = n < g.N ? n : 0;                   // (N % 4 == 0: a piece is inside or outside as a whole)
+            if (g.bias) bv[a] = ld4(g.bias + nc);
+            if (g.accumulate) yv[a] = ld4(g.C + (long)m * g.ldc + nc);
+            if (g.mask) mv[a] = ld4(g.mask + (long)m * g.ldm + nc);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int n = n0 + nt * 32 + 8 * a + 4 * h;
+            f32x4 v = {acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                if (g.bias) x += bv[a][e];
+                if (g.accumulate) x += yv[a][e];
+                x = act_apply(x, g.act);
+                if (g.mask && !(mv[a][e] > 0.f)) x = 0.f;
+                v[e] = x;
+            }
+            if (n < g.N) st4(g.C + (long)m * g.ldc + n, v);
+        }
+        return;
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int n = n0 + 64 * j + nt * 32 + 8 * a + 4 * h;
+        const int n = n0 + nt * 32 + 8 * a + 4 * h;
         if (n >= g.N) continue;
         f32x4 v = {acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
         if (g.mode == 0) {
@@ -338,7 +480,45 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
             }
         }
     }
-    }   // j
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
+    __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TG_PANEL];
+    tgemm_body<AT, BT>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// One launch for a layer's backward at batch sizes: blocks [0, nw) are the tiles x splits of the weight gradient dW = dY^T [X | 1],
+// the remaining blocks the tiles of the input gradient dX = dY W -- two products that share nothing but dY and have the chip to themselves
+// for 25-30 us each when launched one after the other (profiles/r04/train_shapes_before.txt: 0.31 of peak for the pair + its reduction).
+__global__ __launch_bounds__(256) void tgemm_bwd_kernel(TG gw, int gxw, int gyw, int nw, TG gx, int gxx) {
+    __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TG_PANEL];
+    int id = blockIdx.x;
+    if (id < nw) tgemm_body<true, true>(gw, id % gxw, (id / gxw) % gyw, id / (gxw * gyw), As, Bs);
+    else {
+        id -= nw;
+        tgemm_body<false, true>(gx, id % gxx, id / gxx, 0, As, Bs);
+    }
+}
+
+// Deferred reductions of split weight gradients: up to TG_RED_MAX of them are added into their dW / db by ONE launch (twenty 10-us launches
+// per NBA-size step otherwise).  Item i owns blocks [blk0[i], blk0[i + 1]).
+#define TG_RED_MAX 16
+struct TGRedItem { const float* part; float* dW; float* db; long ldw; long per; int K1, S, blk0; };
+struct TGRed { TGRedItem it[TG_RED_MAX]; int n; };
+__global__ __launch_bounds__(256) void tgemm_reduce_kernel(TGRed r) {
+    int i = 0;
+    while (i + 1 < r.n && (int)blockIdx.x >= r.it[i + 1].blk0) ++i;
+    const TGRedItem& t = r.it[i];
+    const long e = (long)(blockIdx.x - t.blk0) * 256 + threadIdx.x;
+    if (e >= t.per) return;
+    const int n = (int)(e / t.K1), k = (int)(e % t.K1);
+    float tot = 0.f;
+    for (int s = 0; s < t.S; ++s) tot += t.part[(long)s * t.per + e];
+    if (k < t.K1 - 1) t.dW[(long)n * t.ldw + k] += tot;
+    else if (t.db) t.db[n] += tot;
 }
 
 #ifndef TLIN_MEDIUM_BELOW
@@ -346,6 +526,18 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
 #endif
 
 static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
+// tg_fetch_fast: aligned operands without broadcast rows; the contiguous index of each operand (k, or the row index of a transposed one)
+// a multiple of 4 and at least 4; every split of the reduction a multiple of 4 long
+static inline int tg_fast(const TG& g, bool AT, bool BT) {
+    const int brows = g.N - (g.ones_row >= 0 ? 1 : 0);
+    if (!g.avec || !g.bvec || g.adiv != 1 || g.bkdiv != 1 || g.Kt < 4) return 0;
+    if (AT ? (g.M % 4 != 0 || g.M < 4) : g.Kt % 4 != 0) return 0;
+    if (BT ? (brows % 4 != 0 || brows < 4) : g.Kt % 4 != 0) return 0;
+    return 1;
+}
+static inline int tg_evec(const TG& g) {
+    return g.N % 4 == 0 && aligned16(g.C, g.ldc) && (!g.bias || aligned16(g.bias, 4)) && (!g.mask || aligned16(g.mask, g.ldm));
+}
 
 extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
                               const float* mask, long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate,
@@ -359,6 +551,7 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
     a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
+    a.evec = I % 4 == 0 && a.yvec && (!bias || aligned16(bias, 4)) && (!mask || aligned16(mask, ldm));
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);   // STTODE_TGEMM=0: the generic kernels (A/B)
     if (tg_on && cols > 2048) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
         TG g;
@@ -367,11 +560,12 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
         g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
         g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
+        g.evec = tg_evec(g); g.fast = tg_fast(g, false, trans != 0);
         // (NB = 2, 64 x 128 tiles, measured SLOWER at the NBA step's shapes -- 36-38 us against 19-25 us per product: 55 KB of LDS leave two
         // workgroups per CU to hide the panel loads instead of four -- and is not instantiated)
         dim3 grid((cols + 63) / 64, (I + 63) / 64);
-        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL((tgemm_kernel<false, false, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((tgemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
         STT_HIP(hipGetLastError());
         return 0;
     }
@@ -484,6 +678,80 @@ __global__ void twgrad_reduce_kernel(TWg a) {
     else if (a.db) a.db[n] += tot;
 }
 
+// ---- split weight gradients of the LDS-tiled kernel: where the partial sums go and when they are added up --------------------------------
+// Default: each weight gradient is followed by its own reduction launch (partial sums in the call's scratch).  Between
+// sttode_twgrad_defer(1, buf, floats) and sttode_twgrad_defer(0, ..) (the training engine brackets a backward pass with them) the partial
+// sums are bump-allocated from `buf` instead -- a buffer nothing else writes -- and the reductions run as ONE launch per TG_RED_MAX
+// gradients, or earlier: buf full, a destination that is already pending, another stream.  Host-side state only; inside a hipGraph capture
+// the flush is captured like any other launch.
+static std::mutex g_red_mu;
+static struct { TGRed r; int blocks; long used; float* buf; long cap; void* stream; bool defer; } g_red = {{}, 0, 0, nullptr, 0, nullptr, false};
+
+static void tg_red_flush_locked() {
+    if (g_red.r.n > 0) hipLaunchKernelGGL(tgemm_reduce_kernel, dim3((unsigned)g_red.blocks), dim3(256), 0, (hipStream_t)g_red.stream, g_red.r);
+    g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0;
+}
+
+// fills g for dW (+)= dY^T [X | 1] with the reduction over the columns split S ways (about want_blocks workgroups); false: no room for partial sums
+static bool tg_wgrad_fill(TG& g, const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,
+                          int K, float* scratch, long scratch_floats, int want_blocks, void* stream) {
+    const long per = (long)N * (K + 1);
+    const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
+    int S = (want_blocks + tiles - 1) / tiles;
+    if (S > 64) S = 64;
+    if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
+    if (S < 1) S = 1;
+    if (g_red.r.n > 0 && (g_red.stream != stream || !g_red.defer)) tg_red_flush_locked();
+    const bool defer = g_red.defer && g_red.buf && g_red.cap >= 2 * per;
+    if (defer && g_red.r.n > 0) {
+        bool again = g_red.r.n == TG_RED_MAX || (S > 1 && g_red.used + per * S > g_red.cap);
+        for (int i = 0; i < g_red.r.n && !again; ++i) {   // one launch adds every pending gradient: none of them may share a destination
+            const TGRedItem& t = g_red.r.it[i];
+            const float* lo = t.dW; const float* hi = t.dW + (t.per / t.K1) * t.ldw;
+            again = (dW < hi && lo < dW + (long)N * ldw) || (db && db == t.db);
+        }
+        if (again) tg_red_flush_locked();   // (also in front of an unsplit gradient to a pending destination: it adds into dW itself)
+    }
+    float* part = defer ? g_red.buf + g_red.used : scratch;
+    const long room = defer ? g_red.cap - g_red.used : scratch_floats;
+    if (S > 1 && (!part || per * S > room)) S = part ? (int)(room / per) : 1;
+    if (S < 1) return false;
+    g_red.stream = stream;
+    g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
+    g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
+    g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
+    g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
+    g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true);
+    g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
+    return true;
+}
+// after the launch that wrote g's partial sums: queue (or run) their reduction
+static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db) {
+    if (g.S <= 1) return;
+    const long per = (long)g.M * g.N;
+    TGRedItem& t = g_red.r.it[g_red.r.n++];
+    t.part = g.scratch; t.dW = dW; t.db = db; t.ldw = ldw; t.per = per; t.K1 = g.N; t.S = g.S; t.blk0 = g_red.blocks;
+    g_red.blocks += (int)((per + 255) / 256);
+    const bool in_buf = g_red.buf && g.scratch >= g_red.buf && g.scratch < g_red.buf + g_red.cap;
+    if (in_buf) g_red.used += per * g.S;
+    if (!g_red.defer || !in_buf) tg_red_flush_locked();
+}
+extern "C" int sttode_twgrad_defer(int on, float* buf, long floats) {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    if (on < 0) { g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0; }      // error paths: forget what is pending
+    tg_red_flush_locked();
+    g_red.defer = on > 0 && buf && floats > 0;
+    g_red.buf = g_red.defer ? buf : nullptr; g_red.cap = g_red.defer ? floats : 0;
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_twgrad_flush(void) {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    tg_red_flush_locked();
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db,
                              int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dY && X && dW, "sttode_twgrad: null pointer");
@@ -495,26 +763,13 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
-    if (tg_on && cols > 2048 && scratch) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
-        const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
-        int S = (480 + tiles - 1) / tiles;
-        if (S > 64) S = 64;
-        if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
-        if ((long)per * S > scratch_floats) S = (int)(scratch_floats / per);
-        if (S >= 1) {
-            TG g;
-            g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
-            g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
-            g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
-            g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
-            g.db = db; g.scratch = scratch; g.S = S; g.mode = 1;
-            g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
-            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, S);
-            hipLaunchKernelGGL((tgemm_kernel<true, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            if (S > 1) {
-                a.S = S;
-                hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-            }
+    if (tg_on && cols > 2048) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        TG g;
+        if (tg_wgrad_fill(g, dY, ldy, X, ldx, xdiv, dW, ldw, db, cols, N, K, scratch, scratch_floats, 480, stream)) {
+            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, g.S);
+            hipLaunchKernelGGL((tgemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            tg_wgrad_done(g, dW, ldw, db);
             STT_HIP(hipGetLastError());
             return 0;
         }
@@ -539,6 +794,28 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
                                   float* db, int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dY && W && dX && X && dW, "sttode_tlinear_bwd: null pointer");
     STT_REQUIRE(cols > 0 && N > 0 && K > 0 && Kdx > 0 && Kdx <= K && xdiv > 0, "sttode_tlinear_bwd: bad sizes");
+    static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
+    static const bool fuse_on = !(getenv("STTODE_TGEMM_BWD") && atoi(getenv("STTODE_TGEMM_BWD")) == 0);   // =0: the two products as two launches (A/B)
+    if (tg_on && fuse_on && cols > 2048 && xdiv == 1) {   // batch sizes: both products of the layer's backward in ONE launch
+        STT_REQUIRE(ldy >= N && ldx >= K && ldgw >= K && ldw >= K && lddx >= Kdx, "sttode_tlinear_bwd: leading dimension smaller than the row length");
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        TG gx;
+        gx.A = dY; gx.lda = ldy; gx.B = W; gx.ldb = ldw; gx.C = dX; gx.ldc = lddx;
+        gx.M = cols; gx.N = Kdx; gx.Kt = N; gx.adiv = 1; gx.bkdiv = 1; gx.ones_row = -1;
+        gx.avec = aligned16(dY, ldy); gx.bvec = aligned16(W, ldw); gx.cvec = aligned16(dX, lddx);
+        gx.bias = nullptr; gx.mask = mask; gx.ldm = ldm; gx.act = 0; gx.accumulate = accumulate;
+        gx.db = nullptr; gx.scratch = nullptr; gx.S = 1; gx.kchunk = 0; gx.mode = 0;
+        gx.evec = tg_evec(gx); gx.fast = tg_fast(gx, false, true);
+        const int gxx = (cols + 63) / 64, nx = gxx * ((Kdx + 63) / 64);
+        TG gw;
+        if (tg_wgrad_fill(gw, dY, ldy, X, ldx, 1, dW, ldgw, db, cols, N, K, scratch, scratch_floats, nx < 680 ? 1000 - nx : 320, stream)) {
+            const int gxw = (N + 63) / 64, gyw = (K + 1 + 63) / 64, nw = gxw * gyw * gw.S;
+            hipLaunchKernelGGL(tgemm_bwd_kernel, dim3(nw + nx), dim3(256), 0, (hipStream_t)stream, gw, gxw, gyw, nw, gx, gxx);
+            tg_wgrad_done(gw, dW, ldgw, db);
+            STT_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (cols > 1024 || xdiv != 1) {
         if (int rc = sttode_tlinear(dY, ldy, 1, W, ldw, 1, nullptr, mask, ldm, dX, lddx, cols, N, Kdx, 0, accumulate, stream)) return rc;
         return sttode_twgrad(dY, ldy, X, ldx, xdiv, dW, ldgw, db, cols, N, K, scratch, scratch_floats, stream);
@@ -549,6 +826,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     a.ldx = ldy; a.ldw = ldw; a.ldy = lddx; a.ldm = ldm;
     a.cols = cols; a.J = N; a.I = Kdx; a.trans = 1; a.act = 0; a.accumulate = accumulate; a.xdiv = 1;
     a.xvec = aligned16(dY, ldy); a.wvec = aligned16(W, ldw); a.yvec = aligned16(dX, lddx);
+    a.evec = Kdx % 4 == 0 && a.yvec && (!mask || aligned16(mask, ldm));
     const int ksplit = N > 256 ? 4 : (N > 128 ? 2 : 1);
     const int blocks_per_wg = 4 / ksplit;
     const int gxA = (cols + 15) / 16, gyA = ((Kdx + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg;

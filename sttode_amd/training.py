@@ -22,6 +22,9 @@ ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
 
+_SCRATCH_BATCH = 32 << 20     # floats (128 MB): split sums of one backward pass at batch sizes (more than 2048 GEMM columns)
+
+
 def _ld(t):
     assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
     return t.stride(0)
@@ -34,6 +37,7 @@ class Engine:
         self.net = net
         self.dev = net.device
         self.scratch = self.main_scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.dev)
+        self.red_scratch = None     # split sums of a backward pass's deferred weight-gradient reductions (batch sizes; allocated on first use)
         self.param_grads = True     # False: skip the weight-gradient GEMMs (stage-2 sampler training keeps this net frozen)
         # The step is written as segments (forward_segments / backward_segments); optionally the future trunk's segments run on a side
         # stream with its own split-k scratch (_use_streams: off by default).
@@ -379,6 +383,8 @@ class Engine:
         n, Tp, Tf, zd = net._past.shape[0], a.past_length, a.future_length, a.zdim
         mode = 0 if net._mode == 'scenes' else 1
         K1 = 21
+        if n * K1 * Tp > 2048 and self.red_scratch is None:         # batch sizes: room for a backward pass's deferred split sums
+            self.red_scratch = torch.empty(_SCRATCH_BATCH, dtype=torch.float32, device=self.dev)
         V = self.V = {}
 
         def f_front():
@@ -453,6 +459,8 @@ class Engine:
 
         def b_dec():
             self._grad_views()
+            if self.red_scratch is not None:                            # batch sizes: the split weight gradients' reductions as one launch per 16
+                capi.call('sttode_twgrad_defer', 1, self.red_scratch, self.red_scratch.numel())
             W['dpf'] = dpf = self.zeros(n, 128)
             dz = self.new(n * K1, zd)
             self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, dz)
@@ -473,7 +481,7 @@ class Engine:
             dpf = W['dpf']
             self.ew(EW_AXPY, dpf, self.hold(W['dhcat'][:, :128].contiguous()), f0=1.0)
             self.trunk_bwd(T['tp'], dpf)
-
+            capi.call('sttode_twgrad_defer', 0, None, 0)                # the pending reductions run here, behind the last gradient
             self.tape = None
 
         return [(-1, (), b_dec), (1, (), b_future), (-1, (), b_past)]
@@ -483,7 +491,11 @@ class Engine:
         if T is not None and step_id is not None and T.get('step_id') != step_id:
             raise SttodeError('training backward: this loss belongs to an earlier forward(); only the most recent forward() of a model '
                               'can be differentiated (its tape was overwritten by the newer forward())')
-        self.run_segments(self.backward_segments())
+        try:
+            self.run_segments(self.backward_segments())
+        except BaseException:
+            capi.call('sttode_twgrad_defer', -1, None, 0)
+            raise
         if gout is not None:
             self.Gflat.mul_(gout)
         return {k: self.G[k] for k in self.touched}
@@ -582,8 +594,12 @@ class _GraphedStep:
         self.graph_obj = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_obj):
             eng.run_segments(segs)
-            eng.run_segments(eng.backward_segments())
-        self.keep = (eng._hold, eng.V, eng.G)                          # static buffers of the graph
+            try:
+                eng.run_segments(eng.backward_segments())
+            except BaseException:
+                capi.call('sttode_twgrad_defer', -1, None, 0)
+                raise
+        self.keep = (eng._hold, eng.V, eng.G, eng.main_scratch, eng.red_scratch)        # static buffers of the graph
         eng._hold = []
         self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
 
@@ -636,6 +652,9 @@ def _names_params(eng, net):
     return names, params, token
 
 
+_GRAPH_MAX_AGENTS = int(os.environ.get('STTODE_TRAIN_GRAPH_MAX', '512'))
+
+
 def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
     """STTODENet.forward() with autograd support (see module docstring).  Returns the reference's 5-tuple.
     ``net.train_graphs`` (default True): after one eager step per shape the whole step is captured into a hipGraph."""
@@ -660,8 +679,9 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
            ptr_token, params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
            float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
-    # launch-bound regime only (one scene, <= ~100 agents): at NBA batch sizes the kernels dominate and replay is no faster
-    if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= 100:
+    # a step is ~170 launches of 5-30 us each and the host needs ~15 us to enqueue one: replay wins as long as the launches are short
+    # (one scene: launch-bound; an NBA batch of 32 x 11 agents: 3.5 ms eager for 2.5 ms of kernels)
+    if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= _GRAPH_MAX_AGENTS:
         if key in net._graphs or key in net._graph_seen:
             inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,
                           eps_q=eps_q, eps20=eps20, drop_past=drop_past, drop_future=drop_future)

@@ -1967,6 +1967,57 @@ def test_tlinear_and_twgrad_vs_torch():
         assert_close(gb.cpu().numpy(), refb, rtol=1e-5, atol=tol, what=f'twgrad db {cols}')
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('defer', [False, True])
+def test_layer_backward_at_batch_sizes_one_launch_and_deferred_reductions(defer):
+    """sttode_tlinear_bwd above 2048 columns: dX tiles and dW tiles x splits in ONE launch (aligned operands: the branch-free panel loads,
+    two tiles ahead; N = 10: the generic loads), the split sums added by a reduction per gradient or -- between sttode_twgrad_defer(1, buf)
+    and sttode_twgrad_defer(0) -- by one launch for all of them, including a second gradient into a destination that is already pending
+    (forces an early flush) and a buffer too small for everything (forces another)."""
+    from sttode_amd import capi
+    dev = _gpu()
+    rng = np.random.default_rng(77)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    scratch = torch.empty(1 << 20, device=dev)
+    st = capi.stream_ptr()
+    shapes = [(7392, 512, 256, 256), (4100, 20, 256, 256), (36960, 288, 32, 32), (2500, 64, 100, 64), (3000, 10, 256, 256), (2100, 256, 512, 512),
+              (7392, 512, 256, 256)]
+    cases = []
+    for i, (cols, N, K, Kdx) in enumerate(shapes):
+        dY = rng.standard_normal((cols, N)).astype(np.float32)
+        X = rng.standard_normal((cols, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(N)).astype(np.float32)
+        mask = rng.standard_normal((cols, Kdx)).astype(np.float32)
+        gW0, gb0 = rng.standard_normal((N, K)).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+        cases.append(dict(cols=cols, N=N, K=K, Kdx=Kdx, dY=dY, X=X, W=W, mask=mask, gW0=gW0, gb0=gb0, d=(t(dY), t(X), t(W), t(mask)),
+                          gW=t(gW0), gb=t(gb0), dX=torch.full((cols, Kdx), 3.0, device=dev)))
+    cases[6]['gW'], cases[6]['gb'] = cases[0]['gW'], cases[0]['gb']          # the same destination twice (a shared weight)
+    buf = torch.empty(3 << 20, device=dev)                                    # room for about two of the large gradients' split sums
+    if defer:
+        capi.call('sttode_twgrad_defer', 1, buf, buf.numel())
+    try:
+        for c in cases:
+            dY, X, W, mask = c['d']
+            capi.call('sttode_tlinear_bwd', dY, c['N'], W, c['K'], mask, c['Kdx'], c['dX'], c['Kdx'], c['Kdx'], 0, X, c['K'], 1, c['gW'], c['K'],
+                      c['gb'], c['cols'], c['N'], c['K'], scratch, scratch.numel(), st)
+    finally:
+        capi.call('sttode_twgrad_defer', 0, None, 0)
+    torch.cuda.synchronize()
+    for i, c in enumerate(cases):
+        ref = (c['dY'].astype(np.float64) @ c['W'].astype(np.float64)[:, :c['Kdx']]) * (c['mask'] > 0)
+        assert_close(c['dX'].cpu().numpy(), ref, rtol=1e-5, atol=2e-5, what=f"layer backward dX {c['cols']}x{c['N']}->{c['Kdx']}")
+        if i == 6:
+            continue
+        refW = c['dY'].astype(np.float64).T @ c['X'].astype(np.float64) + c['gW0']
+        refb = c['dY'].astype(np.float64).sum(0) + c['gb0']
+        if i == 0:                                                            # ... which received both gradients
+            refW += cases[6]['dY'].astype(np.float64).T @ cases[6]['X'].astype(np.float64)
+            refb += cases[6]['dY'].astype(np.float64).sum(0)
+        tol = 1e-5 * max(1.0, np.sqrt(c['cols']))
+        assert_close(c['gW'].cpu().numpy(), refW, rtol=1e-5, atol=tol, what=f"layer backward dW {c['cols']}x{c['N']}x{c['K']}")
+        assert_close(c['gb'].cpu().numpy(), refb, rtol=1e-5, atol=tol, what=f"layer backward db {c['cols']}x{c['N']}")
+
+
 def _hip_grads(tag, dataset, Tp, Tf, g, drop=None, train_mode=False):
     m = hip_model(dataset, Tp, Tf)
     m.zero_grad()
@@ -2399,6 +2450,15 @@ def test_training_step_nba_shapes_vs_oracle(B, N, Tp, Tf):
     g32 = {k: (p.grad.clone() if p.grad is not None else None) for k, p in o32.named_parameters()}
     o32.zero_grad()
     _grad_yardstick(grads, {k: p.grad for k, p in o.named_parameters()}, g32, f'training step nba B={B} N={N} Tp={Tp} Tf={Tf}')
+    # the same step again, twice: the second is the eager step's twin, the third the captured + replayed hipGraph (NBA batches replay too)
+    for _ in range(2):
+        m.zero_grad()
+        m.set_data_nba(data)
+        out2 = m.forward(*[torch.from_numpy(e) for e in eps])
+        out2[0].backward()
+        np.testing.assert_allclose([float(out2[0].detach())] + list(out2[1:]), [float(out[0].detach())] + list(out[1:]), rtol=1e-6)
+        _compare_grads({k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in m.named_parameters()}, grads, rtol=1e-6)
+    assert any(k[0] == 'nba' for k in m._graphs), 'the NBA-size step was not captured'
 
 
 def test_pmath_autograd_functions_vs_reference_golden(golden):
