@@ -207,6 +207,7 @@ struct TG {
     int avec, bvec, cvec;    // operand / result rows 16-byte aligned
     int evec;                // mode 0: N % 4 == 0 and C, bias, mask 16-byte aligned -- the epilogue runs on 16-byte pieces
     int fast;                // operands fit tg_fetch_fast (tg_fast below)
+    long long* dbg;          // diagnostic (sttode_tgemm_debug_buffer): [workgroup][4] stamps of the 100 MHz clock -- start, first tile in LDS, reduction done, end
     const float* bias; const float* mask; long ldm; int act, accumulate;   // mode 0 (tlinear) epilogue
     float* db; float* scratch; int S, kchunk, mode;                        // mode 1 (twgrad): split s = blockIdx.z reduces k in [s kchunk, (s + 1) kchunk)
 };
@@ -326,6 +327,7 @@ static __device__ __forceinline__ void tg_mma_tile(tg_f32x16& acc, const float* 
     }
 }
 
+static __device__ __forceinline__ void tg_epilogue(const TG& g, const tg_f32x16& acc, int m0, int n0, int mt, int nt, int c, int h, int bz);
 // one 64 x 64 tile of C (tile indices bx, by; bz: the split of the reduction in mode 1) by the calling workgroup
 template <bool AT, bool BT>
 static __device__ __forceinline__ void tgemm_body(const TG& g, int bx, int by, int bz, float (*As)[TG_PANEL], float (*Bs)[TG_PANEL]) {
@@ -339,6 +341,8 @@ static __device__ __forceinline__ void tgemm_body(const TG& g, int bx, int by, i
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     f32x4 va[2], vb[2];
     const int brows = g.N - (g.ones_row >= 0 ? 1 : 0);
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (g.dbg && threadIdx.x == 0) g.dbg[4 * wg] = __builtin_amdgcn_s_memrealtime();
     if (g.fast && kbeg < kend) {
         // two tiles ahead: register set 0 / 1 holds tile t / t + 1 on its way to LDS buffer 0 / 1 (requests beyond the last tile read one
         // clamped piece and give zeros); lds_barrier(): the workgroup barrier WITHOUT the vmcnt(0) of __syncthreads(), which would drain
@@ -353,6 +357,7 @@ static __device__ __forceinline__ void tgemm_body(const TG& g, int bx, int by, i
         tg_store_fast<AT>(va, As[0], m0, kbeg, kend, -1);
         tg_store_fast<BT>(vb, Bs[0], n0, kbeg, kend, g.ones_row);
         lds_barrier();
+        if (g.dbg && threadIdx.x == 0) g.dbg[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
         int t = 0;
         for (; t + 2 <= P; t += 2) {
             const int k1 = kbeg + 32 * (t + 1);
@@ -402,6 +407,14 @@ static __device__ __forceinline__ void tgemm_body(const TG& g, int bx, int by, i
         buf ^= 1;
     }
     }
+    if (g.dbg && threadIdx.x == 0) g.dbg[4 * wg + 2] = __builtin_amdgcn_s_memrealtime();
+    tg_epilogue(g, acc, m0, n0, mt, nt, c, h, bz);
+    if (g.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) g.dbg[4 * wg + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+static __device__ __forceinline__ void tg_epilogue(const TG& g, const tg_f32x16& acc, int m0, int n0, int mt, int nt, int c, int h, int bz) {
     // lane (c, h): m = m0 + 32 mt + c; register 4a + b <-> n = n0 + 32 nt + 8a + 4h + b
     const int m = m0 + mt * 32 + c;
     if (m >= g.M) return;
@@ -535,6 +548,8 @@ static inline int tg_fast(const TG& g, bool AT, bool BT) {
     if (BT ? (brows % 4 != 0 || brows < 4) : g.Kt % 4 != 0) return 0;
     return 1;
 }
+static long long* g_tg_dbg = nullptr;
+extern "C" int sttode_tgemm_debug_buffer(void* p) { g_tg_dbg = (long long*)p; return 0; }   // diagnostic: >= grid * 4 int64 (NULL: off); stand-alone launches only
 static inline int tg_evec(const TG& g) {
     return g.N % 4 == 0 && aligned16(g.C, g.ldc) && (!g.bias || aligned16(g.bias, 4)) && (!g.mask || aligned16(g.mask, g.ldm));
 }
@@ -560,7 +575,7 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
         g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
         g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
-        g.evec = tg_evec(g); g.fast = tg_fast(g, false, trans != 0);
+        g.evec = tg_evec(g); g.fast = tg_fast(g, false, trans != 0); g.dbg = g_tg_dbg;
         // (NB = 2, 64 x 128 tiles, measured SLOWER at the NBA step's shapes -- 36-38 us against 19-25 us per product: 55 KB of LDS leave two
         // workgroups per CU to hide the panel loads instead of four -- and is not instantiated)
         dim3 grid((cols + 63) / 64, (I + 63) / 64);
@@ -721,7 +736,7 @@ static bool tg_wgrad_fill(TG& g, const float* dY, long ldy, const float* X, long
     g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
     g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
     g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
-    g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true);
+    g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true); g.dbg = nullptr;
     g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
     return true;
 }
@@ -805,7 +820,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
         gx.avec = aligned16(dY, ldy); gx.bvec = aligned16(W, ldw); gx.cvec = aligned16(dX, lddx);
         gx.bias = nullptr; gx.mask = mask; gx.ldm = ldm; gx.act = 0; gx.accumulate = accumulate;
         gx.db = nullptr; gx.scratch = nullptr; gx.S = 1; gx.kchunk = 0; gx.mode = 0;
-        gx.evec = tg_evec(gx); gx.fast = tg_fast(gx, false, true);
+        gx.evec = tg_evec(gx); gx.fast = tg_fast(gx, false, true); gx.dbg = nullptr;
         const int gxx = (cols + 63) / 64, nx = gxx * ((Kdx + 63) / 64);
         TG gw;
         if (tg_wgrad_fill(gw, dY, ldy, X, ldx, 1, dW, ldgw, db, cols, N, K, scratch, scratch_floats, nx < 680 ? 1000 - nx : 320, stream)) {
