@@ -7,13 +7,19 @@ from helpers import make_args
 from sttode_amd import STTODENet, scenes, capi
 from sttode_amd.weights import make_weights, to_torch_state_dict
 dev = torch.device('cuda')
-Tp, Tf = 5, 10
-m = STTODENet(make_args('nba', Tp, Tf), dev); m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=Tp, future_length=Tf))); m.train()
+ETH = len(sys.argv) > 1 and sys.argv[1] == 'eth'          # `eth`: ONE scene of 10 pedestrians per step (train.py:72-95) instead of the NBA batch
+Tp, Tf = (8, 12) if ETH else (5, 10)
+m = STTODENet(make_args('eth' if ETH else 'nba', Tp, Tf), dev); m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=Tp, future_length=Tf))); m.train()
 m.train_graphs = False
-d = scenes.nba_batch(1, 32)
-data = {k: (torch.from_numpy(v) if hasattr(v, 'shape') else v) for k, v in d.items()}
-def step():
-    m.set_data_nba(data); tot = m.forward()[0]; tot.backward()
+if ETH:
+    ob, pr = scenes.eth_scene(1, n_min=10, n_max=10)
+    def step():
+        m.set_data(None, torch.from_numpy(ob), torch.from_numpy(pr), None, None); tot = m.forward()[0]; tot.backward()
+else:
+    d = scenes.nba_batch(1, 32)
+    data = {k: (torch.from_numpy(v) if hasattr(v, 'shape') else v) for k, v in d.items()}
+    def step():
+        m.set_data_nba(data); tot = m.forward()[0]; tot.backward()
 for _ in range(2): step()
 rec = []
 orig = capi.call
@@ -44,5 +50,5 @@ for (name, s), (cnt, a, fl) in groups.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'{len(rec)} native calls per step, {tot:.0f} us when each runs alone back to back')
-for t, name, s, cnt, us, fr in rows[:45]:
+for t, name, s, cnt, us, fr in rows[:(80 if ETH else 45)]:
     print(f'{name[7:]:22s} {s:46s} x{cnt:3d} {us:7.1f} us  sum {t:7.0f}' + (f'  {fr:.2f} of peak' if fr else ''))
