@@ -36,6 +36,45 @@ def hip_model(dataset='eth', Tp=8, Tf=12, seed=1234):
     return _MODELS[key]
 
 
+@pytest.mark.gpu
+def test_serial_inference_sees_a_weight_change_made_between_two_calls():
+    """inference() compares the parameter versions AFTER enqueueing its launch (the host is the critical path of the one-scene loop) and
+    launches again when they changed: the call after an in-place update, a load_state_dict and an optimizer-style step must each return
+    the NEW weights' predictions -- bitwise those of a model built on them -- for the one-launch scene form and for a scene batch."""
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    m = STTODENet(make_args('eth', 8, 12), dev).eval()
+    m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+    obs, pred = scenes.eth_scene(777, n_min=5, n_max=5)
+    sb = scenes.make_scene_batch(list(range(900, 940)), 'eth')
+    z1 = torch.from_numpy(scenes.latents(3, 5)).to(dev)
+    zb = torch.from_numpy(scenes.latents(4, sb.n_agents)).to(dev)
+
+    def both(mod):
+        mod.set_data(None, torch.from_numpy(obs), torch.from_numpy(pred))
+        a = mod.inference(None, z=z1).clone()
+        mod.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        return a, mod.inference(None, z=zb).clone()
+
+    def fresh():
+        f = STTODENet(make_args('eth', 8, 12), dev).eval()
+        f.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()}, strict=True)
+        return both(f)
+    base = both(m)
+    with torch.no_grad():                                              # in place, as an optimizer step does
+        m.decoder.decompose[1].decoder_y.layers[0].weight.mul_(1.25)
+        m.past_encoder.input_fc.bias.add_(0.05)
+    got, want = both(m), fresh()
+    assert not torch.equal(got[0], base[0]) and not torch.equal(got[1], base[1])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    m.load_state_dict(to_torch_state_dict(make_weights(99)), strict=True)
+    got, want = both(m), fresh()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    again = both(m)                                                    # unchanged weights: one launch, the same bits
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+
+
 def test_library_loaded_and_fails_loudly_on_cpu():
     from sttode_amd import STTODENet, capi
     _gpu()
