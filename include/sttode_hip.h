@@ -200,6 +200,11 @@ int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, long ldw, cons
  * mode.  Process-wide host-side state; a training step brackets its backward pass with defer(1) / defer(0) (sttode_amd/training.py). */
 int sttode_twgrad_defer(int on, float* buf, long floats);
 int sttode_twgrad_flush(void);
+/* Grouped launches: between sttode_tgemm_group(1) and sttode_tgemm_group(0) the batch-size products (cols > 2048) of sttode_tlinear,
+ * sttode_twgrad and sttode_tlinear_bwd are queued and leave as ONE launch (at most 4 products per launch; a fifth starts the next).  The
+ * caller promises that the products of a group do not depend on each other and do not write the same output; calls below the batch
+ * size launch at once as usual.  sttode_tgemm_group(-1): forget what is queued (error paths).  Process-wide host-side state. */
+int sttode_tgemm_group(int on);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
 /* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */

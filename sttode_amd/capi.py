@@ -46,6 +46,7 @@ SIGNATURES = {
     'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
     'sttode_twgrad_defer': [_I, _P, _L],
     'sttode_twgrad_flush': [],
+    'sttode_tgemm_group': [_I],
     'sttode_tlinear_bwd': [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
     'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],

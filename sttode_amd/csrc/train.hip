@@ -516,6 +516,35 @@ __global__ __launch_bounds__(256) void tgemm_bwd_kernel(TG gw, int gxw, int gyw,
     }
 }
 
+// Several independent products in ONE launch (sttode_tgemm_group): a 2-GFLOP product is one round of ~930 workgroups on 1024 slots and
+// pays ~7 us of start skew, first tile and store burst around 16 us of MFMA (profiles/r04/tgemm_workgroup_trace.txt); with the decoder's
+// decoder_x / decoder_y layers (same input, separate weights) or a layer's dX / dW side by side, a later product's workgroups start as an
+// earlier one's finish.  Problem p owns blocks [blk0[p], blk0[p + 1]); kind: 0 forward, 1 input gradient, 2 weight gradient.
+#define TG_MULTI_MAX 4
+struct TGMulti { TG g[TG_MULTI_MAX]; int blk0[TG_MULTI_MAX + 1]; int gx[TG_MULTI_MAX], gy[TG_MULTI_MAX], kind[TG_MULTI_MAX]; int n; };
+__global__ __launch_bounds__(256) void tgemm_multi_kernel(TGMulti M) {
+    __shared__ __attribute__((aligned(16))) float As[2][TG_PANEL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TG_PANEL];
+    int p = 0;
+    while (p + 1 < M.n && (int)blockIdx.x >= M.blk0[p + 1]) ++p;
+    p = __builtin_amdgcn_readfirstlane(p);
+    // the problem's descriptor out of the kernel-argument segment (uniform index: scalar loads; indexing the by-value struct would park
+    // all four descriptors in registers first)
+    TG g;
+    {
+        const __attribute__((address_space(4))) int* src = (const __attribute__((address_space(4))) int*)(
+            (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TGMulti, g) + (size_t)p * sizeof(TG));
+        int* dst = reinterpret_cast<int*>(&g);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(TG) / 4; ++i) dst[i] = src[i];
+    }
+    const int id = (int)blockIdx.x - M.blk0[p], gx = M.gx[p], gy = M.gy[p], kind = M.kind[p];
+    const int bx = id % gx, by = (id / gx) % gy, bz = id / (gx * gy);
+    if (kind == 0) tgemm_body<false, false>(g, bx, by, bz, As, Bs);
+    else if (kind == 1) tgemm_body<false, true>(g, bx, by, bz, As, Bs);
+    else tgemm_body<true, true>(g, bx, by, bz, As, Bs);
+}
+
 // Deferred reductions of split weight gradients: up to TG_RED_MAX of them are added into their dW / db by ONE launch (twenty 10-us launches
 // per NBA-size step otherwise).  Item i owns blocks [blk0[i], blk0[i + 1]).
 #define TG_RED_MAX 16
@@ -554,6 +583,140 @@ static inline int tg_evec(const TG& g) {
     return g.N % 4 == 0 && aligned16(g.C, g.ldc) && (!g.bias || aligned16(g.bias, 4)) && (!g.mask || aligned16(g.mask, g.ldm));
 }
 
+// ---- split weight gradients of the LDS-tiled kernel: where the partial sums go and when they are added up --------------------------------
+// Default: each weight gradient is followed by its own reduction launch (partial sums in the call's scratch).  Between
+// sttode_twgrad_defer(1, buf, floats) and sttode_twgrad_defer(0, ..) (the training engine brackets a backward pass with them) the partial
+// sums are bump-allocated from `buf` instead -- a buffer nothing else writes -- and the reductions run as ONE launch per TG_RED_MAX
+// gradients, or earlier: buf full, a destination that is already pending, another stream.  Host-side state only; inside a hipGraph capture
+// the flush is captured like any other launch.
+static std::mutex g_red_mu;
+static struct { TGRed r; int blocks; long used; float* buf; long cap; void* stream; bool defer; } g_red = {{}, 0, 0, nullptr, 0, nullptr, false};
+
+static void tg_red_flush_locked() {
+    if (g_red.r.n > 0) hipLaunchKernelGGL(tgemm_reduce_kernel, dim3((unsigned)g_red.blocks), dim3(256), 0, (hipStream_t)g_red.stream, g_red.r);
+    g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0;
+}
+
+// ---- grouped launches (sttode_tgemm_group): batch-size products queued between group(1) and group(0) leave as ONE tgemm_multi_kernel launch ----
+static struct {
+    TGMulti M; int gz[TG_MULTI_MAX];
+    struct { float* dW; long ldw; float* db; } post[TG_MULTI_MAX];   // weight gradients: their split sums are queued for reduction AFTER the launch
+    void* stream; bool on;
+} g_grp = {};
+static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db);
+static void tg_group_launch_locked() {
+    TGMulti& M = g_grp.M;
+    if (M.n == 0) return;
+    hipLaunchKernelGGL(tgemm_multi_kernel, dim3((unsigned)M.blk0[M.n]), dim3(256), 0, (hipStream_t)g_grp.stream, M);
+    const int n = M.n;
+    M.n = 0;
+    for (int i = 0; i < n; ++i)
+        if (M.kind[i] == 2) tg_wgrad_done(M.g[i], g_grp.post[i].dW, g_grp.post[i].ldw, g_grp.post[i].db);
+}
+// queue (group mode) or launch one product; kind: 0 forward, 1 input gradient, 2 weight gradient (its split sums: dW, ldw, db)
+static void tg_submit(const TG& g, int kind, int gx, int gy, int gz, void* stream, float* dW = nullptr, long ldw = 0, float* db = nullptr) {
+    if (g_grp.on) {
+        TGMulti& M = g_grp.M;
+        if (M.n == TG_MULTI_MAX || (M.n > 0 && g_grp.stream != stream)) tg_group_launch_locked();
+        const int i = M.n++;
+        if (i == 0) M.blk0[0] = 0;
+        M.g[i] = g; M.g[i].dbg = nullptr; M.kind[i] = kind; M.gx[i] = gx; M.gy[i] = gy; g_grp.gz[i] = gz;
+        M.blk0[i + 1] = M.blk0[i] + gx * gy * gz;
+        g_grp.post[i].dW = dW; g_grp.post[i].ldw = ldw; g_grp.post[i].db = db;
+        g_grp.stream = stream;
+        return;
+    }
+    const dim3 grid(gx, gy, gz);
+    if (kind == 0) hipLaunchKernelGGL((tgemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (kind == 1) hipLaunchKernelGGL((tgemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else {
+        hipLaunchKernelGGL((tgemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        tg_wgrad_done(g, dW, ldw, db);
+    }
+}
+extern "C" int sttode_tgemm_group(int on) {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    if (on < 0) g_grp.M.n = 0;            // error paths: forget what is queued
+    tg_group_launch_locked();
+    g_grp.on = on > 0;
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// fills g for dW (+)= dY^T [X | 1] with the reduction over the columns split S ways (about want_blocks workgroups); false: no room for partial sums
+static bool tg_wgrad_fill(TG& g, const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,
+                          int K, float* scratch, long scratch_floats, int want_blocks, void* stream) {
+    const long per = (long)N * (K + 1);
+    const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
+    int S = (want_blocks + tiles - 1) / tiles;
+    if (S > 64) S = 64;
+    if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
+    if (S < 1) S = 1;
+    if (g_red.r.n > 0 && (g_red.stream != stream || !g_red.defer)) { tg_group_launch_locked(); tg_red_flush_locked(); }
+    const bool defer = g_red.defer && g_red.buf && g_red.cap >= 2 * per;
+    if (defer && g_red.r.n > 0) {
+        bool again = g_red.r.n == TG_RED_MAX || (S > 1 && g_red.used + per * S > g_red.cap);
+        for (int i = 0; i < g_red.r.n && !again; ++i) {   // one launch adds every pending gradient: none of them may share a destination
+            const TGRedItem& t = g_red.r.it[i];
+            const float* lo = t.dW; const float* hi = t.dW + (t.per / t.K1) * t.ldw;
+            again = (dW < hi && lo < dW + (long)N * ldw) || (db && db == t.db);
+        }
+        if (again) { tg_group_launch_locked(); tg_red_flush_locked(); }   // (also in front of an unsplit gradient to a pending destination: it adds into dW itself)
+    }
+    if (defer && g_grp.M.n > 0) {         // queued, not yet launched gradients of the open group count as pending destinations too
+        bool again = S > 1 && g_red.used + per * S > g_red.cap;
+        for (int i = 0; i < g_grp.M.n && !again; ++i)
+            if (g_grp.M.kind[i] == 2) {
+                const float* lo = g_grp.post[i].dW; const float* hi = lo + (long)g_grp.M.g[i].M * g_grp.post[i].ldw;
+                again = (dW < hi && lo < dW + (long)N * ldw) || (db && db == g_grp.post[i].db);
+            }
+        if (again) { tg_group_launch_locked(); tg_red_flush_locked(); }
+    }
+    if (!defer && g_grp.M.n > 0) {        // without a buffer of its own every split gradient uses the call's scratch: one per launch
+        for (int i = 0; i < g_grp.M.n; ++i)
+            if (g_grp.M.kind[i] == 2) { tg_group_launch_locked(); break; }
+    }
+    float* part = defer ? g_red.buf + g_red.used : scratch;
+    const long room = defer ? g_red.cap - g_red.used : scratch_floats;
+    if (S > 1 && (!part || per * S > room)) S = part ? (int)(room / per) : 1;
+    if (S < 1) return false;
+    g_red.stream = stream;
+    g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
+    g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
+    g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
+    g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
+    g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true); g.dbg = nullptr;
+    if (defer && S > 1) g_red.used += per * S;     // reserved now: a second gradient of the same group must not get the same piece
+    g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
+    return true;
+}
+// after the launch that wrote g's partial sums: queue (or run) their reduction
+static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db) {
+    if (g.S <= 1) return;
+    const long per = (long)g.M * g.N;
+    if (g_red.r.n == TG_RED_MAX) tg_red_flush_locked();
+    TGRedItem& t = g_red.r.it[g_red.r.n++];
+    t.part = g.scratch; t.dW = dW; t.db = db; t.ldw = ldw; t.per = per; t.K1 = g.N; t.S = g.S; t.blk0 = g_red.blocks;
+    g_red.blocks += (int)((per + 255) / 256);
+    const bool in_buf = g_red.buf && g.scratch >= g_red.buf && g.scratch < g_red.buf + g_red.cap;
+    if (!g_red.defer || !in_buf) tg_red_flush_locked();
+}
+extern "C" int sttode_twgrad_defer(int on, float* buf, long floats) {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    if (on < 0) { g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0; }      // error paths: forget what is pending
+    tg_red_flush_locked();
+    g_red.defer = on > 0 && buf && floats > 0;
+    g_red.buf = g_red.defer ? buf : nullptr; g_red.cap = g_red.defer ? floats : 0;
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_twgrad_flush(void) {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    tg_red_flush_locked();
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
                               const float* mask, long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate,
                               void* stream) {
@@ -578,9 +741,8 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         g.evec = tg_evec(g); g.fast = tg_fast(g, false, trans != 0); g.dbg = g_tg_dbg;
         // (NB = 2, 64 x 128 tiles, measured SLOWER at the NBA step's shapes -- 36-38 us against 19-25 us per product: 55 KB of LDS leave two
         // workgroups per CU to hide the panel loads instead of four -- and is not instantiated)
-        dim3 grid((cols + 63) / 64, (I + 63) / 64);
-        if (trans) hipLaunchKernelGGL((tgemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL((tgemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        tg_submit(g, trans ? 1 : 0, (cols + 63) / 64, (I + 63) / 64, 1, stream);
         STT_HIP(hipGetLastError());
         return 0;
     }
@@ -693,80 +855,6 @@ __global__ void twgrad_reduce_kernel(TWg a) {
     else if (a.db) a.db[n] += tot;
 }
 
-// ---- split weight gradients of the LDS-tiled kernel: where the partial sums go and when they are added up --------------------------------
-// Default: each weight gradient is followed by its own reduction launch (partial sums in the call's scratch).  Between
-// sttode_twgrad_defer(1, buf, floats) and sttode_twgrad_defer(0, ..) (the training engine brackets a backward pass with them) the partial
-// sums are bump-allocated from `buf` instead -- a buffer nothing else writes -- and the reductions run as ONE launch per TG_RED_MAX
-// gradients, or earlier: buf full, a destination that is already pending, another stream.  Host-side state only; inside a hipGraph capture
-// the flush is captured like any other launch.
-static std::mutex g_red_mu;
-static struct { TGRed r; int blocks; long used; float* buf; long cap; void* stream; bool defer; } g_red = {{}, 0, 0, nullptr, 0, nullptr, false};
-
-static void tg_red_flush_locked() {
-    if (g_red.r.n > 0) hipLaunchKernelGGL(tgemm_reduce_kernel, dim3((unsigned)g_red.blocks), dim3(256), 0, (hipStream_t)g_red.stream, g_red.r);
-    g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0;
-}
-
-// fills g for dW (+)= dY^T [X | 1] with the reduction over the columns split S ways (about want_blocks workgroups); false: no room for partial sums
-static bool tg_wgrad_fill(TG& g, const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,
-                          int K, float* scratch, long scratch_floats, int want_blocks, void* stream) {
-    const long per = (long)N * (K + 1);
-    const int tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
-    int S = (want_blocks + tiles - 1) / tiles;
-    if (S > 64) S = 64;
-    if (S > (cols + 127) / 128) S = (cols + 127) / 128;      // >= 128 columns per split
-    if (S < 1) S = 1;
-    if (g_red.r.n > 0 && (g_red.stream != stream || !g_red.defer)) tg_red_flush_locked();
-    const bool defer = g_red.defer && g_red.buf && g_red.cap >= 2 * per;
-    if (defer && g_red.r.n > 0) {
-        bool again = g_red.r.n == TG_RED_MAX || (S > 1 && g_red.used + per * S > g_red.cap);
-        for (int i = 0; i < g_red.r.n && !again; ++i) {   // one launch adds every pending gradient: none of them may share a destination
-            const TGRedItem& t = g_red.r.it[i];
-            const float* lo = t.dW; const float* hi = t.dW + (t.per / t.K1) * t.ldw;
-            again = (dW < hi && lo < dW + (long)N * ldw) || (db && db == t.db);
-        }
-        if (again) tg_red_flush_locked();   // (also in front of an unsplit gradient to a pending destination: it adds into dW itself)
-    }
-    float* part = defer ? g_red.buf + g_red.used : scratch;
-    const long room = defer ? g_red.cap - g_red.used : scratch_floats;
-    if (S > 1 && (!part || per * S > room)) S = part ? (int)(room / per) : 1;
-    if (S < 1) return false;
-    g_red.stream = stream;
-    g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
-    g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
-    g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
-    g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
-    g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true); g.dbg = nullptr;
-    g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
-    return true;
-}
-// after the launch that wrote g's partial sums: queue (or run) their reduction
-static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db) {
-    if (g.S <= 1) return;
-    const long per = (long)g.M * g.N;
-    TGRedItem& t = g_red.r.it[g_red.r.n++];
-    t.part = g.scratch; t.dW = dW; t.db = db; t.ldw = ldw; t.per = per; t.K1 = g.N; t.S = g.S; t.blk0 = g_red.blocks;
-    g_red.blocks += (int)((per + 255) / 256);
-    const bool in_buf = g_red.buf && g.scratch >= g_red.buf && g.scratch < g_red.buf + g_red.cap;
-    if (in_buf) g_red.used += per * g.S;
-    if (!g_red.defer || !in_buf) tg_red_flush_locked();
-}
-extern "C" int sttode_twgrad_defer(int on, float* buf, long floats) {
-    std::lock_guard<std::mutex> lk(g_red_mu);
-    if (on < 0) { g_red.r.n = 0; g_red.blocks = 0; g_red.used = 0; }      // error paths: forget what is pending
-    tg_red_flush_locked();
-    g_red.defer = on > 0 && buf && floats > 0;
-    g_red.buf = g_red.defer ? buf : nullptr; g_red.cap = g_red.defer ? floats : 0;
-    STT_HIP(hipGetLastError());
-    return 0;
-}
-extern "C" int sttode_twgrad_flush(void) {
-    std::lock_guard<std::mutex> lk(g_red_mu);
-    tg_red_flush_locked();
-    STT_HIP(hipGetLastError());
-    return 0;
-}
-
 extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db,
                              int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dY && X && dW, "sttode_twgrad: null pointer");
@@ -782,9 +870,7 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
         std::lock_guard<std::mutex> lk(g_red_mu);
         TG g;
         if (tg_wgrad_fill(g, dY, ldy, X, ldx, xdiv, dW, ldw, db, cols, N, K, scratch, scratch_floats, 480, stream)) {
-            dim3 grid((N + 63) / 64, (K + 1 + 63) / 64, g.S);
-            hipLaunchKernelGGL((tgemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            tg_wgrad_done(g, dW, ldw, db);
+            tg_submit(g, 2, (N + 63) / 64, (K + 1 + 63) / 64, g.S, stream, dW, ldw, db);
             STT_HIP(hipGetLastError());
             return 0;
         }
@@ -823,10 +909,16 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
         gx.evec = tg_evec(gx); gx.fast = tg_fast(gx, false, true); gx.dbg = nullptr;
         const int gxx = (cols + 63) / 64, nx = gxx * ((Kdx + 63) / 64);
         TG gw;
-        if (tg_wgrad_fill(gw, dY, ldy, X, ldx, 1, dW, ldgw, db, cols, N, K, scratch, scratch_floats, nx < 680 ? 1000 - nx : 320, stream)) {
+        if (tg_wgrad_fill(gw, dY, ldy, X, ldx, 1, dW, ldgw, db, cols, N, K, scratch, scratch_floats,
+                          g_grp.on ? 400 : (nx < 680 ? 1000 - nx : 320), stream)) {
             const int gxw = (N + 63) / 64, gyw = (K + 1 + 63) / 64, nw = gxw * gyw * gw.S;
-            hipLaunchKernelGGL(tgemm_bwd_kernel, dim3(nw + nx), dim3(256), 0, (hipStream_t)stream, gw, gxw, gyw, nw, gx, gxx);
-            tg_wgrad_done(gw, dW, ldgw, db);
+            if (g_grp.on) {   // (an open group: the two products join it as two of its problems)
+                tg_submit(gw, 2, gxw, gyw, gw.S, stream, dW, ldgw, db);
+                tg_submit(gx, 1, gxx, (Kdx + 63) / 64, 1, stream);
+            } else {
+                hipLaunchKernelGGL(tgemm_bwd_kernel, dim3(nw + nx), dim3(256), 0, (hipStream_t)stream, gw, gxw, gyw, nw, gx, gxx);
+                tg_wgrad_done(gw, dW, ldgw, db);
+            }
             STT_HIP(hipGetLastError());
             return 0;
         }

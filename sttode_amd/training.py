@@ -22,6 +22,7 @@ ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
 
+_PAIRED = os.environ.get('STTODE_TRAIN_PAIRED', '1') != '0'   # decoder_x / decoder_y of a block layer by layer, grouped launches (0: A/B)
 _SCRATCH_BATCH = 32 << 20     # floats (128 MB): split sums of one backward pass at batch sizes (more than 2048 GEMM columns)
 
 
@@ -289,6 +290,41 @@ class Engine:
         out = self.lin(a2, P[pre + 'layers.2.weight'], P[pre + 'layers.2.bias'])
         return out, (a1, a2)
 
+    def mlp_fwd_pair(self, pre_a, pre_b, inp):
+        """decoder_y and decoder_x of a block (same input, separate weights, model/STTODE.py:71-77) layer by layer: at batch sizes the two
+        products of a layer leave as one launch (sttode_tgemm_group)."""
+        P = self.P
+        acts = []
+        xa = xb = inp
+        for li, act in ((0, 'relu'), (1, 'relu'), (2, None)):
+            capi.call('sttode_tgemm_group', 1)
+            try:
+                xa = self.lin(xa, P[f'{pre_a}layers.{li}.weight'], P[f'{pre_a}layers.{li}.bias'], act=act)
+                xb = self.lin(xb, P[f'{pre_b}layers.{li}.weight'], P[f'{pre_b}layers.{li}.bias'], act=act)
+            except BaseException:
+                capi.call('sttode_tgemm_group', -1)
+                raise
+            capi.call('sttode_tgemm_group', 0)
+            acts.append((xa, xb))
+        return (acts[2][0], (acts[0][0], acts[1][0])), (acts[2][1], (acts[0][1], acts[1][1]))
+
+    def mlp_bwd_pair(self, pre_a, pre_b, inp, saved_a, saved_b, dout_a, dout_b, din):
+        """Backward of the pair: layers 2 and 1 of both MLPs side by side (four products per launch at batch sizes); their layer-0 input
+        gradients add into the same ``din``, so those two stay launches of their own, in order."""
+        P, g = self.P, self.grad
+        da, db_ = dout_a, dout_b
+        for li, (sa, sb) in ((2, (saved_a[1], saved_b[1])), (1, (saved_a[0], saved_b[0]))):
+            capi.call('sttode_tgemm_group', 1)
+            try:
+                da = self.lin_bwd(da, P[f'{pre_a}layers.{li}.weight'], sa, g(f'{pre_a}layers.{li}.weight'), g(f'{pre_a}layers.{li}.bias'), mask=sa)
+                db_ = self.lin_bwd(db_, P[f'{pre_b}layers.{li}.weight'], sb, g(f'{pre_b}layers.{li}.weight'), g(f'{pre_b}layers.{li}.bias'), mask=sb)
+            except BaseException:
+                capi.call('sttode_tgemm_group', -1)
+                raise
+            capi.call('sttode_tgemm_group', 0)
+        self.lin_bwd(da, P[pre_a + 'layers.0.weight'], inp, g(pre_a + 'layers.0.weight'), g(pre_a + 'layers.0.bias'), out=din, accumulate=False)
+        self.lin_bwd(db_, P[pre_b + 'layers.0.weight'], inp, g(pre_b + 'layers.0.weight'), g(pre_b + 'layers.0.bias'), out=din, accumulate=True)
+
     def mlp_bwd(self, pre, inp, saved, dout, din, accumulate):
         P, g = self.P, self.grad
         a1, a2 = saved
@@ -312,8 +348,11 @@ class Engine:
                   inp[:, 160:], 256, m, Tp, self.st)                                                     # all Tp steps, one launch
         capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
         capi.call('sttode_rows_copy', inp[:, 128:], 256, z, _ld(z), m, 32, 1, m, self.st)
-        yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp)
-        xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp) if want_x else (None, None)
+        if want_x and _PAIRED:
+            (yh, sy), (xh, sx) = self.mlp_fwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', inp)
+        else:
+            yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp)
+            xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp) if want_x else (None, None)
         return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx)
 
     def block_bwd(self, b, dyh, dxh, need_dx):
@@ -321,9 +360,12 @@ class Engine:
         P, g = self.P, self.grad
         pre, m, Tp = b['pre'], b['m'], b['Tp']
         din = self.new(m, 256)
-        self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, accumulate=False)
-        if dxh is not None:
-            self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
+        if dxh is not None and _PAIRED:
+            self.mlp_bwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', b['inp'], b['sy'], b['sx'], dyh, dxh, din)
+        else:
+            self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, accumulate=False)
+            if dxh is not None:
+                self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
         dgi = self.new(m * Tp, 288)
         dgh = self.new(Tp, m, 288)
         capi.call('sttode_gru_seq_bwd', din[:, 160:], 256, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)

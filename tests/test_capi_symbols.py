@@ -81,7 +81,7 @@ def test_every_entry_point_rejects_null_arguments():
     L = capi.lib()
     skip = {'sttode_abi_version', 'sttode_last_error', 'sttode_model_destroy', 'sttode_timing_enable', 'sttode_chain_prog_len',
             'sttode_set_latency_tiles', 'sttode_async_device_latents', 'sttode_async_fused_metrics', 'sttode_async_is_lagged',
-            'sttode_twgrad_defer', 'sttode_twgrad_flush'}   # (the last two are queries: 0 = not armed, also for a NULL model)
+            'sttode_twgrad_defer', 'sttode_twgrad_flush', 'sttode_tgemm_group'}   # (the last two are queries: 0 = not armed, also for a NULL model)
     checked = 0
     for name, argtypes in capi.SIGNATURES.items():
         if name in skip:

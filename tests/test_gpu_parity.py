@@ -2057,6 +2057,47 @@ def test_layer_backward_at_batch_sizes_one_launch_and_deferred_reductions(defer)
         assert_close(c['gb'].cpu().numpy(), refb, rtol=1e-5, atol=tol, what=f"layer backward db {c['cols']}x{c['N']}")
 
 
+@pytest.mark.gpu
+def test_grouped_launch_of_independent_products_equals_the_separate_launches():
+    """sttode_tgemm_group: two forward layers on the same input, a layer's backward (two products) and a fifth product that overflows the
+    group leave as grouped launches; forward and input-gradient outputs carry the bits of the same calls made one by one, the weight gradient
+    (split differently) the same sum."""
+    from sttode_amd import capi
+    dev = _gpu()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    cols = 5000
+    X, Wa, ba, Wb, bb = r(cols, 256), r(512, 256) / 16, r(512), r(512, 256) / 16, r(512)
+    dY, W2, X2, mask = r(cols, 256), r(256, 512) / 16, r(cols, 512), r(cols, 512)
+    W3, b3 = r(24, 256), r(24)
+    scratch = torch.empty(4 << 20, device=dev)
+    st = capi.stream_ptr()
+
+    def run(group):
+        Ya, Yb, Yc = torch.empty(cols, 512, device=dev), torch.empty(cols, 512, device=dev), torch.empty(cols, 24, device=dev)
+        dX, gW, gb = torch.empty(cols, 512, device=dev), torch.zeros(256, 512, device=dev), torch.zeros(256, device=dev)
+        if group:
+            capi.call('sttode_tgemm_group', 1)
+        capi.call('sttode_tlinear', X, 256, 1, Wa, 256, 0, ba, None, 0, Ya, 512, cols, 256, 512, 1, 0, st)
+        capi.call('sttode_tlinear', X, 256, 1, Wb, 256, 0, bb, None, 0, Yb, 512, cols, 256, 512, 2, 0, st)
+        capi.call('sttode_tlinear_bwd', dY, 256, W2, 512, mask, 512, dX, 512, 512, 0, X2, 512, 1, gW, 512, gb, cols, 256, 512, scratch, scratch.numel(), st)
+        capi.call('sttode_tlinear', X, 256, 1, W3, 256, 0, b3, None, 0, Yc, 24, cols, 256, 24, 0, 0, st)      # the fifth product: next launch
+        if group:
+            capi.call('sttode_tgemm_group', 0)
+        torch.cuda.synchronize()
+        return Ya, Yb, Yc, dX, gW, gb
+    one, grp = run(False), run(True)
+    for a, b, name in zip(one[:4], grp[:4], ('Ya', 'Yb', 'Yc', 'dX')):
+        assert torch.equal(a, b), name
+    # (the weight gradient's reduction is split differently inside a group -- fewer splits, the launch is full anyway: same sum, another order)
+    refW, refb = dY.double().T @ X2.double(), dY.double().sum(0)
+    for got in (one, grp):
+        assert_close(got[4].cpu().numpy(), refW.cpu().numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(cols), what='grouped / separate dW vs float64')
+        assert_close(got[5].cpu().numpy(), refb.cpu().numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(cols), what='grouped / separate db vs float64')
+    ref = torch.relu(X.double() @ Wa.double().T + ba.double())
+    assert_close(one[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-5, what='grouped forward vs float64')
+
+
 def _hip_grads(tag, dataset, Tp, Tf, g, drop=None, train_mode=False):
     m = hip_model(dataset, Tp, Tf)
     m.zero_grad()
