@@ -718,7 +718,7 @@ def main():
             dist.destroy_process_group()
         return 0
 
-    if os.environ.get('STTODE_LAGGED') in ('2', '3'):              # (experiments: the library reads the same variable)
+    if os.environ.get('STTODE_LAGGED') in ('2', '3', '4'):              # (experiments: the library reads the same variable)
         Leg.STREAMS = int(os.environ['STTODE_LAGGED'])
     if args.only_leg:
         # one leg alone (profiling passes: `rocprofv3 --kernel-trace --stats -- python3 bench.py --only-leg sdd_1024 --serial` gives that

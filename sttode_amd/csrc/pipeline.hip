@@ -56,7 +56,7 @@ struct SttodeModel {
     int lag_streams;                 // 0: lagged form off; 2 / 3 (default): pipeline streams the lagged calls rotate over
     long lag_calls;
     LagPending lag[STT_MAX_SLOTS];   // per slot
-    int lag_q[3][STT_MAX_SLOTS]; int lag_qn[3];   // per stream: slots with outstanding groups, oldest first
+    int lag_q[4][STT_MAX_SLOTS]; int lag_qn[4];   // per stream: slots with outstanding groups, oldest first
     hipStream_t sX[3];   // extra streams of the fused rotation (STTODE_FUSED_STREAMS = 4..6; experiments: they share the runtime's hardware queues)
     int fused_streams;
     int b_streams;  // 1: all per-trajectory stages on sB; 2: alternate calls between sB and sB2
@@ -108,9 +108,9 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { m->slot_stream[p] = nullptr; m->lag[p].valid = false; }
-    m->lag_streams = 3; m->lag_calls = 0;   // 3 streams: the small legs gain 3-9 % over 2, 512 scenes tie (profiles/r04/streams_2_vs_3.txt) m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
-    for (int i = 0; i < 3; ++i) m->lag_qn[i] = 0;
-    if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0;
+    m->lag_streams = 3; m->lag_calls = 0;   // 3 streams: the small legs gain 3-9 % over 2, 512 scenes tie (profiles/r04/streams_2_vs_3.txt); 4: -5..-12 % everywhere -- the fourth shares a hardware queue (streams_3_vs_4.txt) m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
+    for (int i = 0; i < 4; ++i) m->lag_qn[i] = 0;
+    if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) >= 2 && atoi(e) <= 4 ? atoi(e) : 0;
     m->scene_launch = 128;
     if (const char* e = getenv("STTODE_SCENE_LAUNCH")) m->scene_launch = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("STTODE_FUSED")) m->fused_mode = atoi(e) != 0;
@@ -160,7 +160,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
         m->fused_streams = 3;
         if (const char* e = getenv("STTODE_FUSED_STREAMS")) m->fused_streams = atoi(e) < 1 ? 1 : atoi(e) > 6 ? 6 : atoi(e);
         static hipStream_t g_sX[STT_MAX_DEVICES][3] = {};
-        for (int i = 0; ok && i < m->fused_streams - 3; ++i) {
+        for (int i = 0; ok && i < (m->fused_streams > 4 ? m->fused_streams - 3 : 1); ++i) {   // (sX[0]: also the fourth stream of the lagged rotation)
             if (!g_sX[dev][i]) ok = hipStreamCreateWithFlags(&g_sX[dev][i], hipStreamNonBlocking) == hipSuccess;
             m->sX[i] = g_sX[dev][i];
         }
@@ -250,7 +250,7 @@ extern "C" int sttode_set_fused(SttodeModel* m, int mode) {
 static int lag_flush_all(SttodeModel* m);
 extern "C" int sttode_set_lagged(SttodeModel* m, int streams) {
     STT_REQUIRE(m, "sttode_set_lagged: null model");
-    STT_REQUIRE(streams == 0 || streams == 2 || streams == 3, "sttode_set_lagged: streams must be 0 (off), 2 or 3");
+    STT_REQUIRE(streams == 0 || (streams >= 2 && streams <= 4), "sttode_set_lagged: streams must be 0 (off), 2, 3 or 4");
     if (int rc = lag_flush_all(m)) return rc;   // outstanding groups belong to the old rotation
     m->lag_streams = streams;
     m->lag_calls = 0;
@@ -652,7 +652,7 @@ static bool use_lagged(const SttodeModel* m, int n) {
     const bool chain = m->chain_mode == 1 || (m->chain_mode < 0 && ncols_all >= 16384);
     return m->lag_streams > 0 && m->fused_mode == 1 && chain && m->ode_method == 0 && m->ode_steps == 1 && stt_chain_lagged_covers(m->Tp);
 }
-static hipStream_t lag_stream(const SttodeModel* m, int si) { return si == 0 ? m->sB : si == 1 ? m->sB2 : m->sA; }
+static hipStream_t lag_stream(const SttodeModel* m, int si) { return si == 0 ? m->sB : si == 1 ? m->sB2 : si == 2 ? m->sA : m->sX[0]; }
 static void lag_unqueue(SttodeModel* m, int slot) {
     const int si = m->lag[slot].si;
     int w = 0;
