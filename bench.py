@@ -767,7 +767,9 @@ def main():
     if rank == 0:
         out['ade_fde_synthetic'] = [float(acc[0] / acc[2]), float(acc[1] / acc[2])]
     # D2H-inclusive figure (second key, not the headline): same steps with every step's futures copied to pinned host memory
-    r2 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, d2h=True)
+    # (the region of the headline: as many steps, as much warm-up -- half of them made filling / draining the pipeline and the last copies
+    # behind the drain weigh twice as much as they do in `value`)
+    r2 = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial, d2h=True)
     out['value_incl_d2h'] = r2['value']
     if not args.serial and not args.no_sustained:
         # the same workload, the same step, as a LONG run: 80 steps, so that filling and draining the pipeline and the shader clock's climb
