@@ -164,10 +164,12 @@ LEGS = {
 
 class Leg:
     FUSED_METRICS = os.environ.get('STTODE_FUSED_METRICS', '1') != '0'
-    # futures to the host (value_incl_d2h): 'own' = a D2H copy on the call's own stream (default: 63 M traj/s); experiment switches: 'copy' = a
-    # D2H copy on a dedicated stream (55 M), 'zero' = the launch writes them straight to pinned host memory (inference_async(pred_host=True):
-    # no copy, but the epilogue's 32-byte pieces at a 96-byte stride make poor PCIe writes: 36-45 M; profiles/r04/d2h_placement_ab.txt)
-    D2H = os.environ.get('STTODE_BENCH_D2H', 'own')
+    # futures to the host (value_incl_d2h): 'kernel' (default) = STTODENet.futures_to_host_async: a few persistent workgroups copy them to pinned
+    # memory on the call's own stream (75-76 M traj/s beside a 77 M headline, profiles/r04/d2h_copy_kernel_ab.txt); experiment switches: 'own' =
+    # hipMemcpyAsync on the call's own stream (63 M: the copy costs the pipeline its whole duration), 'copy' = on a dedicated stream (55 M),
+    # 'zero' = the launch writes them straight to pinned host memory (inference_async(pred_host=True): 13-45 M; d2h_placement_ab.txt)
+    D2H = os.environ.get('STTODE_BENCH_D2H', 'kernel')
+    D2H_WGS = int(os.environ.get('STTODE_BENCH_D2H_WGS', '8'))
     STREAMS = 3      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -237,7 +239,9 @@ class Leg:
         self.unsettled = h
         out = self.model.best_of_k_async(h, gt=h['gt'])        # per-agent (ade, fde) of the slot; summed ONCE, after the last step
         if self.d2h_bufs is not None and Leg.D2H != 'zero':
-            if Leg.D2H == 'own':                                # D2H of the call's futures on ITS stream, behind its groups and metrics
+            if Leg.D2H == 'kernel':                             # by a few persistent workgroups on ITS stream, behind its groups (default)
+                self.model.futures_to_host_async(h, out=self.d2h_bufs[h['slot'] % len(self.d2h_bufs)], workgroups=Leg.D2H_WGS)
+            elif Leg.D2H == 'own':                              # D2H of the call's futures on ITS stream, behind its groups and metrics
                 with torch.cuda.stream(h['stream']):
                     self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
             else:                                               # ... or on a copy stream of its own that waits for the call's event

@@ -458,6 +458,9 @@ int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt, float* ad
 /* Measurement aid: the shader clock at this moment.  out[0] = shader cycles, out[1] = ticks of the constant 100 MHz clock over ~20 us on
  * one lane (device memory, two int64): GHz = out[0] / (10 out[1]). */
 int sttode_clock_probe(long long* out, void* stream);
+/* Device -> pinned host copy of `bytes` (multiple of 16; both pointers 16-byte aligned; dst: device-accessible host memory) by `wgs`
+ * persistent workgroups (<= 0: 8) on `stream`: a copy that leaves the chip's workgroup slots to the kernels running beside it. */
+int sttode_copy_to_host(void* dst, const void* src, long bytes, int wgs, void* stream);
 /* Enqueue the outstanding trajectory-group launch of the call in `slot` now (no-op when a later call has carried it already). */
 int sttode_async_enqueue(SttodeModel* m, int slot);
 /* Enqueue every outstanding trajectory-group launch of the lagged form (before buffers of pending calls are released or reused). */

@@ -101,6 +101,7 @@ SIGNATURES = {
     'sttode_set_lagged': [_P, _I],
     'sttode_async_flush': [_P],
     'sttode_clock_probe': [_P, _P],
+    'sttode_copy_to_host': [_P, _P, _L, _I, _P],
     'sttode_async_enqueue': [_P, _I],
     'sttode_async_device_latents': [_P, _I, ctypes.c_ulonglong],
     'sttode_async_fused_metrics': [_P, _I, _P, _P, _P, _F],

@@ -226,6 +226,28 @@ extern "C" int sttode_clock_probe(long long* out, void* stream) {
     return 0;
 }
 
+// Device -> pinned host copy by a FEW workgroups (a metric path that wants every future on the host, test.py:194,526, beside a full chip):
+// hipMemcpyAsync of a 17-MB prediction tensor costs the pipelined step its whole duration (62.9 against 76.0 M trajectories/s,
+// profiles/r04/final_bench.json -- whatever executes it holds the chip's workgroup slots while it waits for the bus); `wgs` persistent
+// workgroups (default 8: 1.5 % of the slots) move 16 bytes per lane per trip instead, and the rest of the chip keeps computing.  dst must
+// be device-accessible host memory (hipHostMalloc / torch pin_memory), both pointers 16-byte aligned.
+typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void host_copy_kernel(hc_f32x4* __restrict__ dst, const hc_f32x4* __restrict__ src, long n16) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const hc_f32x4 v = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(v, dst + i);
+    }
+}
+extern "C" int sttode_copy_to_host(void* dst, const void* src, long bytes, int wgs, void* stream) {
+    STT_REQUIRE(dst && src && bytes > 0 && bytes % 16 == 0, "sttode_copy_to_host: null pointer or size not a multiple of 16 bytes");
+    STT_REQUIRE(((size_t)dst | (size_t)src) % 16 == 0, "sttode_copy_to_host: pointers must be 16-byte aligned");
+    if (wgs <= 0) wgs = 8;
+    if (wgs > 256) wgs = 256;
+    hipLaunchKernelGGL(host_copy_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (hc_f32x4*)dst, (const hc_f32x4*)src, bytes / 16);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host staging of ONE scene for the reference's one-scene-per-call loop (test.py:171-188 -> STTODENet.set_data, model/STTODE.py:397-404):
 // the loader's pageable [N][2][T] tracks are transposed into a pinned ring slot as [N][T][2] (past, then future) and travel to the device

@@ -195,6 +195,7 @@ class STTODENet(nn.Module):
         # EXPLORATORY, opt-in: 'bf16x3' runs the two block-0 decoder MLPs of the fused launch as a three-way bf16 split on the bf16 matrix
         # cores (fp32-class accuracy, fp32 accumulate; csrc/chain32.hip B3M); 'f32' (default) = fp32 MFMA everywhere.  env STTODE_BF16X3=1
         self.mfma_mode = 'bf16x3' if os.environ.get('STTODE_BF16X3', '0') not in ('', '0') else 'f32'
+        self._host_futures = {}  # slot -> pinned [n, K, Tf, 2] (futures_to_host_async)
         self.async_depth = 6     # calls in flight of the inference_async pipeline (workspace / prediction slots, <= 8; 2 x pipeline streams)
         # inference_async(z=None) in the lagged form: latents drawn by the call's own launch (csrc/role32.hpp); env STTODE_DEVICE_LATENTS=0: torch.randn
         self.device_latents = os.environ.get('STTODE_DEVICE_LATENTS', '1') != '0'
@@ -807,6 +808,39 @@ class STTODENet(nn.Module):
         returns predictions [K, n, Tf, 2]."""
         capi.call('sttode_wait_host', self.native().h, handle['slot'])
         return handle['pred'].permute(1, 0, 2, 3)
+
+    def futures_to_host_async(self, handle, out=None, workgroups=8):
+        """Enqueue the device -> host copy of an inference_async() call's futures behind its trajectory groups, on the pipeline stream the call
+        runs on, and return the pinned tensor [n, K, Tf, 2] (``out``: a pinned float32 tensor of that shape to copy into; default: one
+        per slot, reused by the slot's next call).  The copy is made by ``workgroups`` persistent workgroups (csrc/frontend.hip
+        sttode_copy_to_host), not by hipMemcpyAsync: beside a full chip the latter costs the pipeline the copy's whole duration
+        (62.9 against 76.0 M trajectories/s at 512 scenes), a few workgroups cost 1-2 % (profiles/r04/d2h_copy_kernel_ab.txt).  The host may
+        read the tensor after ``wait_host_copy(handle)``; what test.py:186-188 does with a ``.cpu()`` per call."""
+        pred = handle['pred']
+        if out is None:
+            out = self._host_futures.get(handle['slot'])
+            if out is None or out.shape != pred.shape:
+                out = self._host_futures[handle['slot']] = torch.empty(pred.shape, dtype=torch.float32).pin_memory()
+        elif not (out.is_pinned() and out.dtype == torch.float32 and out.is_contiguous() and out.shape == pred.shape):
+            raise ValueError('futures_to_host_async: out must be a pinned contiguous float32 tensor of shape %s' % (tuple(pred.shape),))
+        nat = self.native()
+        capi.call('sttode_async_enqueue', nat.h, handle['slot'])        # (lagged form: the call's groups may still be waiting for a later call)
+        st = handle['stream']
+        raw = st.cuda_stream if st is not None else capi.stream_ptr()
+        if st is None:
+            capi.call('sttode_wait', nat.h, handle['slot'], raw)
+        capi.call('sttode_copy_to_host', out, pred, pred.numel() * 4, int(workgroups), raw)
+        ev = handle.get('host_event')
+        if ev is None:
+            ev = handle['host_event'] = torch.cuda.Event()
+        ev.record(st if st is not None else torch.cuda.current_stream(self.device))
+        handle['host'] = out
+        return out
+
+    def wait_host_copy(self, handle):
+        """The HOST waits for the copy enqueued by futures_to_host_async(); returns the pinned tensor as [K, n, Tf, 2]."""
+        handle['host_event'].synchronize()
+        return handle['host'].permute(1, 0, 2, 3)
 
     def next_async_stream(self, n):
         """torch stream (an ExternalStream over the pipeline's own) the next inference_async() call of ``n`` agents will run on, or None

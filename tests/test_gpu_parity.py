@@ -75,6 +75,43 @@ def test_serial_inference_sees_a_weight_change_made_between_two_calls():
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
 
 
+@pytest.mark.gpu
+def test_futures_to_host_by_the_copy_kernel_are_the_device_futures():
+    """futures_to_host_async: the pinned copies of six pipelined (lagged) calls, made by a few persistent workgroups on the calls' own
+    streams, are bitwise the device predictions; odd sizes (n K Tf 2 floats not a multiple of the copy's trip) and a caller-owned pinned
+    buffer included; sttode_copy_to_host refuses unaligned / odd-sized arguments."""
+    from sttode_amd import scenes, capi
+    dev = _gpu()
+    m = hip_model('eth')
+    sbs = [scenes.make_scene_batch(list(range(7000 + 50 * i, 7000 + 50 * i + 37 + i)), 'eth') for i in range(6)]
+    hs, mine = [], torch.empty(sbs[2].n_agents, 20, 12, 2).pin_memory()
+    m.native().set_chain(1)
+    try:
+        for i, sb in enumerate(sbs):
+            m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+            h = m.inference_async(z=torch.from_numpy(scenes.latents(i, sb.n_agents)))
+            hs.append(h)
+            if i >= 3:
+                m.futures_to_host_async(hs[i - 3], out=mine if i - 3 == 2 else None, workgroups=3 + i)
+        for i in range(3, 6):
+            m.futures_to_host_async(hs[i])
+        for i, h in enumerate(hs):
+            host = m.wait_host_copy(h)
+            assert host.is_pinned() or host._base is not None
+            dev_pred = m.wait(h)
+            torch.cuda.synchronize()
+            assert torch.equal(host, dev_pred.cpu()), i
+        assert torch.equal(mine, hs[2]['pred'].cpu())
+    finally:
+        m.reset_async()
+        m.native().set_chain(-1)
+    buf = torch.empty(64, device=dev)
+    with pytest.raises(capi.SttodeError):
+        capi.call('sttode_copy_to_host', mine, buf, 40, 8, capi.stream_ptr())          # not a multiple of 16 bytes
+    with pytest.raises(capi.SttodeError):
+        capi.call('sttode_copy_to_host', mine.data_ptr() + 4, buf, 64, 8, capi.stream_ptr())   # unaligned destination
+
+
 def test_library_loaded_and_fails_loudly_on_cpu():
     from sttode_amd import STTODENet, capi
     _gpu()
