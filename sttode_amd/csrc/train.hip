@@ -603,7 +603,11 @@ static struct {
     struct { float* dW; long ldw; float* db; } post[TG_MULTI_MAX];   // weight gradients: their split sums are queued for reduction AFTER the launch
     void* stream; bool on;
 } g_grp = {};
+struct TWg;
 static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db);
+static void ts_group_launch_locked();   // the scene-size queue (defined below the kernel it launches)
+static void ts_group_launch_locked_forget();
+static void ts_submit(const TLin& a, const TWg* w, int ksplit, int gxA, int nA, int gxW, int gyW, int nB, void* stream);
 static void tg_group_launch_locked() {
     TGMulti& M = g_grp.M;
     if (M.n == 0) return;
@@ -636,8 +640,9 @@ static void tg_submit(const TG& g, int kind, int gx, int gy, int gz, void* strea
 }
 extern "C" int sttode_tgemm_group(int on) {
     std::lock_guard<std::mutex> lk(g_red_mu);
-    if (on < 0) g_grp.M.n = 0;            // error paths: forget what is queued
+    if (on < 0) { g_grp.M.n = 0; ts_group_launch_locked_forget(); }   // error paths: forget what is queued
     tg_group_launch_locked();
+    ts_group_launch_locked();
     g_grp.on = on > 0;
     STT_HIP(hipGetLastError());
     return 0;
@@ -751,6 +756,12 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
         const int ksplit = J > 256 ? 4 : (J > 128 ? 2 : 1);
         const int blocks_per_wg = 4 / ksplit;
         dim3 grid((cols + 15) / 16, ((I + 15) / 16 + blocks_per_wg - 1) / blocks_per_wg);
+        if (g_grp.on) {   // an open group: queued, leaves with the group's other scene-size layers as one launch
+            std::lock_guard<std::mutex> lk(g_red_mu);
+            ts_submit(a, nullptr, ksplit, (int)grid.x, (int)(grid.x * grid.y), 0, 0, 0, stream);
+            STT_HIP(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL((tlinear_kernel<1, 1, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, ksplit);
     } else if ((long)((cols + 63) / 64) * ((I + 63) / 64) < TLIN_MEDIUM_BELOW) {
         // medium mode: 32 columns x 32 outputs per wave -- 4x the waves of the throughput tiling, for launches that would
@@ -855,6 +866,34 @@ __global__ void twgrad_reduce_kernel(TWg a) {
     else if (a.db) a.db[n] += tot;
 }
 
+// Scene sizes (cols <= 1024), grouped (sttode_tgemm_group): up to four independent layers -- forward (kind 0) or a whole backward (kind 1:
+// input-gradient blocks, then weight-gradient blocks, as tbwd_kernel) -- in ONE launch.  A one-scene training step is bound by the NUMBER
+// of launches (~5 us per dependent graph node whatever it does): decoder_x / decoder_y of a block and the two encoder trunks walk through
+// the same layers with different weights.
+#define TS_MULTI_MAX 4
+struct TSProb { TLin a; TWg w; int ksplit, gxA, nA, gxW, gyW, kind; };
+struct TSMulti { TSProb p[TS_MULTI_MAX]; int blk0[TS_MULTI_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void tsmall_multi_kernel(TSMulti M) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 33 * 4];
+    int p = 0;
+    while (p + 1 < M.n && (int)blockIdx.x >= M.blk0[p + 1]) ++p;
+    p = __builtin_amdgcn_readfirstlane(p);
+    TSProb P;   // the problem's descriptor out of the kernel-argument segment (uniform index: scalar loads)
+    {
+        const __attribute__((address_space(4))) int* src = (const __attribute__((address_space(4))) int*)(
+            (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TSMulti, p) + (size_t)p * sizeof(TSProb));
+        int* dst = reinterpret_cast<int*>(&P);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(TSProb) / 4; ++i) dst[i] = src[i];
+    }
+    int id = (int)blockIdx.x - M.blk0[p];
+    if (P.kind == 0 || id < P.nA) tlinear_body<1, 1, 8>(P.a, P.ksplit, id % P.gxA, id / P.gxA, reinterpret_cast<f32x4(*)[1][64]>(sm));
+    else {
+        id -= P.nA;
+        twgrad_body(P.w, id % P.gxW, (id / P.gxW) % P.gyW, id / (P.gxW * P.gyW), reinterpret_cast<float(*)[32][33]>(sm));
+    }
+}
+
 extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db,
                              int cols, int N, int K, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dY && X && dW, "sttode_twgrad: null pointer");
@@ -949,10 +988,35 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     w.chunks_per_split = (chunks + S - 1) / S;
     const int gxW = (N + 31) / 32, gyW = (K + 1 + 31) / 32;
     const int nA = gxA * gyA, nB = gxW * gyW * S;
+    if (g_grp.on && S == 1) {
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        ts_submit(a, &w, ksplit, gxA, nA, gxW, gyW, nB, stream);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(tbwd_kernel, dim3(nA + nB), dim3(256), 0, (hipStream_t)stream, a, ksplit, gxA, nA, w, gxW, gyW);
     if (S > 1) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w);
     STT_HIP(hipGetLastError());
     return 0;
+}
+
+static struct { TSMulti M; void* stream; } g_ts = {};
+static void ts_group_launch_locked_forget() { g_ts.M.n = 0; }
+static void ts_group_launch_locked() {
+    if (g_ts.M.n == 0) return;
+    hipLaunchKernelGGL(tsmall_multi_kernel, dim3((unsigned)g_ts.M.blk0[g_ts.M.n]), dim3(256), 0, (hipStream_t)g_ts.stream, g_ts.M);
+    g_ts.M.n = 0;
+}
+static void ts_submit(const TLin& a, const TWg* w, int ksplit, int gxA, int nA, int gxW, int gyW, int nB, void* stream) {
+    TSMulti& M = g_ts.M;
+    if (M.n == TS_MULTI_MAX || (M.n > 0 && g_ts.stream != stream)) ts_group_launch_locked();
+    const int i = M.n++;
+    if (i == 0) M.blk0[0] = 0;
+    TSProb& P = M.p[i];
+    P.a = a; P.ksplit = ksplit; P.gxA = gxA; P.nA = nA; P.gxW = gxW; P.gyW = gyW; P.kind = w ? 1 : 0;
+    if (w) P.w = *w; else P.w = TWg{};
+    M.blk0[i + 1] = M.blk0[i] + nA + nB;
+    g_ts.stream = stream;
 }
 
 // ---------------------------------------------------------------------------------------------------

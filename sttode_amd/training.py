@@ -9,6 +9,7 @@ kernels over the row-major nn.Parameter storage, plus the element-wise pieces). 
 one ``autograd.Function``, hands the finished gradients to ``.grad`` so that ``optimizer.step()`` works unchanged.
 There is no eager / CPU fallback.
 """
+import contextlib
 import os
 
 import torch
@@ -241,46 +242,97 @@ class Engine:
         t.update(X0=X0, drop=drop_mask, attn=out['qkv'][:, 128:], L=1, Nb=n, **out)
         return t
 
+    @contextlib.contextmanager
+    def group(self):
+        """Independent layers issued inside leave as ONE launch (sttode_tgemm_group: up to four per launch, scene sizes and batch sizes)."""
+        capi.call('sttode_tgemm_group', 1)
+        try:
+            yield
+        except BaseException:
+            capi.call('sttode_tgemm_group', -1)
+            raise
+        capi.call('sttode_tgemm_group', 0)
+
     def trunk_bwd(self, t, dfeat):
         """dfeat [n,128] (row stride free) = grad wrt cat(ftraj_input, ode_out).  Accumulates parameter grads."""
+        self.trunk_bwd_multi([(t, dfeat)])
+
+    def trunk_bwd_multi(self, items):
+        """Backward of one or several trunks (the past and the future encoder: the same layers, separate weights, independent of each
+        other) walked through TOGETHER: layer i of every trunk is issued inside one group, i.e. one launch -- a one-scene step is bound by
+        the number of launches, and the two trunks are 2 x 10 linear-layer backward launches otherwise."""
         P, g, net = self.P, self.grad, self.net
-        pre, n, T = t['pre'], t['n'], t['T']
-        a = pre + _ATT
-        dx = dfeat[:, :64].contiguous()
-        dode = dfeat[:, 64:128].contiguous()
-        dy = self.new(n, 64)
-        self.ew(EW_EULER_BWD, dode, t['ode'], None, dx, dy, f0=net.ODE_TIME)
-        dsum2 = self.new(n, 64)
-        capi.call('sttode_ln_bwd', dy, t['xh2'], t['rs2'], P[a + 'norm2.weight'], dsum2, g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
-                  self.scratch, self.scratch.numel(), self.st)
-        df1 = self.lin_bwd(dsum2, P[a + 'linear2.weight'], t['f1'], g(a + 'linear2.weight'), g(a + 'linear2.bias'), mask=t['f1'])
-        dh = dsum2                                           # residual branch of LN2(h + f)
-        self.lin_bwd(df1, P[a + 'linear1.weight'], t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'), out=dh, accumulate=True)
-        dsum1 = self.new(n, 64)
-        capi.call('sttode_ln_bwd', dh, t['xh1'], t['rs1'], P[a + 'norm1.weight'], dsum1, g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
-                  self.scratch, self.scratch.numel(), self.st)
-        self.ew(EW_AXPY, dx, dsum1, f0=1.0)                  # residual branch of LN1(x + gated)
-        du, dv = self.new(n, 64), self.new(n, 64)
-        self.ew(EW_GATE_BWD, dsum1, t['tt'], t['ss'], du, dv)
-        dao = self.lin_bwd(du, P[a + 'self_attn.temporal_info.weight'], t['ao'], g(a + 'self_attn.temporal_info.weight'),
-                           g(a + 'self_attn.temporal_info.bias'))
-        self.lin_bwd(dv, P[a + 'self_attn.temporal_gate.weight'], t['ao'], g(a + 'self_attn.temporal_gate.weight'),
-                     g(a + 'self_attn.temporal_gate.bias'), out=dao, accumulate=True)
-        op = a + 'self_attn.temporal_attention_before.'
-        dattn = self.lin_bwd(dao, P[op + 'out_proj.weight'], t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
-        dqkv = self.new(n, 192)
-        capi.call('sttode_mhgsa_attn_bwd', t['qkv'], dattn, dqkv, t['L'], t['Nb'], self.st)
-        self.lin_bwd(dqkv, P[op + 'in_proj_weight'], t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'), out=dx, accumulate=True)
+        S = []
+        for t, dfeat in items:
+            pre = t['pre']
+            S.append(dict(t=t, pre=pre, a=pre + _ATT, op=pre + _ATT + 'self_attn.temporal_attention_before.', n=t['n'], T=t['T'],
+                          dx=dfeat[:, :64].contiguous(), dode=dfeat[:, 64:128].contiguous()))
+        for s in S:
+            t, a, n = s['t'], s['a'], s['n']
+            s['dy'] = self.new(n, 64)
+            self.ew(EW_EULER_BWD, s['dode'], t['ode'], None, s['dx'], s['dy'], f0=net.ODE_TIME)
+            s['dsum2'] = self.new(n, 64)
+            capi.call('sttode_ln_bwd', s['dy'], t['xh2'], t['rs2'], P[a + 'norm2.weight'], s['dsum2'], g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
+                      self.scratch, self.scratch.numel(), self.st)
+        with self.group():
+            for s in S:
+                t, a = s['t'], s['a']
+                s['df1'] = self.lin_bwd(s['dsum2'], P[a + 'linear2.weight'], t['f1'], g(a + 'linear2.weight'), g(a + 'linear2.bias'), mask=t['f1'])
+        with self.group():
+            for s in S:                                          # dh = dsum2 (residual branch of LN2(h + f)) + W1^T df1
+                t, a = s['t'], s['a']
+                self.lin_bwd(s['df1'], P[a + 'linear1.weight'], t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'), out=s['dsum2'], accumulate=True)
+        for s in S:
+            t, a, n = s['t'], s['a'], s['n']
+            s['dsum1'] = self.new(n, 64)
+            capi.call('sttode_ln_bwd', s['dsum2'], t['xh1'], t['rs1'], P[a + 'norm1.weight'], s['dsum1'], g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
+                      self.scratch, self.scratch.numel(), self.st)
+            self.ew(EW_AXPY, s['dx'], s['dsum1'], f0=1.0)        # residual branch of LN1(x + gated)
+            s['du'], s['dv'] = self.new(n, 64), self.new(n, 64)
+            self.ew(EW_GATE_BWD, s['dsum1'], t['tt'], t['ss'], s['du'], s['dv'])
+        with self.group():
+            for s in S:
+                t, a = s['t'], s['a']
+                s['dao'] = self.lin_bwd(s['du'], P[a + 'self_attn.temporal_info.weight'], t['ao'], g(a + 'self_attn.temporal_info.weight'),
+                                        g(a + 'self_attn.temporal_info.bias'))
+        with self.group():
+            for s in S:
+                t, a = s['t'], s['a']
+                self.lin_bwd(s['dv'], P[a + 'self_attn.temporal_gate.weight'], t['ao'], g(a + 'self_attn.temporal_gate.weight'),
+                             g(a + 'self_attn.temporal_gate.bias'), out=s['dao'], accumulate=True)
+        with self.group():
+            for s in S:
+                t, op = s['t'], s['op']
+                s['dattn'] = self.lin_bwd(s['dao'], P[op + 'out_proj.weight'], t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
+        for s in S:
+            t = s['t']
+            s['dqkv'] = self.new(s['n'], 192)
+            capi.call('sttode_mhgsa_attn_bwd', t['qkv'], s['dattn'], s['dqkv'], t['L'], t['Nb'], self.st)
+        with self.group():
+            for s in S:
+                t, op = s['t'], s['op']
+                self.lin_bwd(s['dqkv'], P[op + 'in_proj_weight'], t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'), out=s['dx'], accumulate=True)
         # dx is now the gradient wrt ftraj_input
-        dh2 = self.lin_bwd(dx, P[pre + 'input_fc3.weight'], t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'),
-                           in_features=64)
-        dtp = self.lin_bwd(dh2, P[pre + 'input_fc2.weight'], t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'),
-                           g(pre + 'input_fc2.bias')).view(n * T, 64)
-        if t['drop'] is not None:
-            self.ew(EW_MUL, dtp, dtp, t['drop'])
-        dtf = self.lin_bwd(dtp, P[pre + 'pos_encoder.fc.weight'], t['posin'], g(pre + 'pos_encoder.fc.weight'),
-                           g(pre + 'pos_encoder.fc.bias'), in_features=64)
-        self.wgrad(dtf, t['X0'], g(pre + 'input_fc.weight'), g(pre + 'input_fc.bias'))
+        with self.group():
+            for s in S:
+                t, pre = s['t'], s['pre']
+                s['dh2'] = self.lin_bwd(s['dx'], P[pre + 'input_fc3.weight'], t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'),
+                                        in_features=64)
+        with self.group():
+            for s in S:
+                t, pre, n, T = s['t'], s['pre'], s['n'], s['T']
+                s['dtp'] = self.lin_bwd(s['dh2'], P[pre + 'input_fc2.weight'], t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'),
+                                        g(pre + 'input_fc2.bias')).view(n * T, 64)
+        for s in S:
+            if s['t']['drop'] is not None:
+                self.ew(EW_MUL, s['dtp'], s['dtp'], s['t']['drop'])
+        with self.group():
+            for s in S:
+                t, pre = s['t'], s['pre']
+                s['dtf'] = self.lin_bwd(s['dtp'], P[pre + 'pos_encoder.fc.weight'], t['posin'], g(pre + 'pos_encoder.fc.weight'),
+                                        g(pre + 'pos_encoder.fc.bias'), in_features=64)
+        for s in S:
+            self.wgrad(s['dtf'], s['t']['X0'], g(s['pre'] + 'input_fc.weight'), g(s['pre'] + 'input_fc.bias'))
 
     # ---------------------------------------------------------------- decoder (Decoder.forward, model/STTODE.py:320-347)
     def mlp_fwd(self, pre, inp):
@@ -517,12 +569,16 @@ class Engine:
                                                 g('future_encoder.out_mlp.affine_layers.0.bias')))
 
         def b_future():
-            self.trunk_bwd(T['tf'], W['dhcat'][:, 128:])
+            if not (_PAIRED and not self.multi):
+                self.trunk_bwd(T['tf'], W['dhcat'][:, 128:])
 
         def b_past():
             dpf = W['dpf']
             self.ew(EW_AXPY, dpf, self.hold(W['dhcat'][:, :128].contiguous()), f0=1.0)
-            self.trunk_bwd(T['tp'], dpf)
+            if _PAIRED and not self.multi:                              # one stream: both trunks layer by layer, grouped launches
+                self.trunk_bwd_multi([(T['tf'], W['dhcat'][:, 128:]), (T['tp'], dpf)])
+            else:
+                self.trunk_bwd(T['tp'], dpf)
             capi.call('sttode_twgrad_defer', 0, None, 0)                # the pending reductions run here, behind the last gradient
             self.tape = None
 
