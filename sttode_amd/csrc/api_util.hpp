@@ -72,3 +72,4 @@ struct LagGroups {
 };
 int stt_chain_lagged(const float* const* W, const LagRoles& r, const LagGroups& g, int K, int Tp, int Tf, int prog_len, int b3, void* stream);
 bool stt_chain_lagged_covers(int Tp);
+int stt_trunk_group(int on);   // train_trunk.hip: the trunk-forward half of sttode_tgemm_group (train.hip)

@@ -644,6 +644,7 @@ extern "C" int sttode_tgemm_group(int on) {
     tg_group_launch_locked();
     ts_group_launch_locked();
     g_grp.on = on > 0;
+    if (int rc = stt_trunk_group(on)) return rc;   // (a fused trunk forward queued in this group, train_trunk.hip)
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -8,6 +8,7 @@
 // bound by the NUMBER of launches.  Here one workgroup (4 waves) owns a 16-agent tile, wave w computes output row tile w of
 // every layer from the row-major nn.Parameter storage (an A fragment of v_mfma_f32_16x16x4_f32 is a float4 of a weight row), tiles are
 // exchanged through LDS, and every tensor the backward pass needs is written on the way -- the same tape trunk_bwd reads.
+#include <mutex>
 #include "chain.hpp"
 #include "api_util.hpp"
 #include "../../include/sttode_hip.h"
@@ -28,15 +29,14 @@ __device__ __forceinline__ f32x4 wfrag(const float* __restrict__ W, long ld, int
     return r;
 }
 
-__global__ __launch_bounds__(256) void ttrunk_fwd_kernel(TrunkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+static __device__ __forceinline__ void ttrunk_fwd_body(const TrunkArgs& a, int tile, char* smem_t) {
     f32x4* sPt = reinterpret_cast<f32x4*>(smem_t);          // [T][4][64]  post-dropout positional features of every frame
     f32x4* sX = sPt + (size_t)a.T * 256;                    // [4][4][64]  exchange slots
     const float* const* P = a.p;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = a.n, T = a.T;
-    const int col = blockIdx.x * 16 + c;
+    const int col = tile * 16 + c;
     const int colc = col < n ? col : n - 1;
     const bool live = col < n;
     // ---- frames: input_fc (K = 4: one MFMA per row tile) -> cat(., pe[t]) -> pos fc -> dropout
@@ -283,6 +283,35 @@ __global__ __launch_bounds__(256) void ttrunk_fwd_kernel(TrunkArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void ttrunk_fwd_kernel(TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    ttrunk_fwd_body(a, blockIdx.x, smem_t);
+}
+// Two trunks (the past and the future encoder: independent of each other) in ONE launch: the first n0 workgroups walk trunk 0's tiles, the
+// rest trunk 1's.  A trunk's forward is one or two workgroups busy for ~40 us; side by side the two cost one of them (sttode_tgemm_group).
+__global__ __launch_bounds__(256) void ttrunk_fwd2_kernel(TrunkArgs a0, TrunkArgs a1, int n0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    if ((int)blockIdx.x < n0) ttrunk_fwd_body(a0, blockIdx.x, smem_t);
+    else ttrunk_fwd_body(a1, (int)blockIdx.x - n0, smem_t);
+}
+
+// group mode (sttode_tgemm_group -> stt_trunk_group): a trunk launch waits for a second one of the same group
+static struct { TrunkArgs a; size_t lds; void* stream; bool have, on; } g_tq = {};
+static std::mutex g_tq_mu;
+static void tq_flush_locked() {
+    if (!g_tq.have) return;
+    g_tq.have = false;
+    hipLaunchKernelGGL(ttrunk_fwd_kernel, dim3((g_tq.a.n + 15) / 16), dim3(256), g_tq.lds, (hipStream_t)g_tq.stream, g_tq.a);
+}
+int stt_trunk_group(int on) {
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    if (on < 0) g_tq.have = false;
+    tq_flush_locked();
+    g_tq.on = on > 0;
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, void* stream) {
     STT_REQUIRE(ptrs && count == STT_TT_COUNT, "sttode_ttrunk_fwd: pointer table must have STT_TT_COUNT entries");
     STT_REQUIRE(n > 0 && T >= 1 && ld_feat >= 128 && (ld_feat % 4) == 0, "sttode_ttrunk_fwd: bad n / T / ld_feat");
@@ -294,6 +323,17 @@ extern "C" int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int 
         STT_REQUIRE(a.p[i] || i == STT_TT_DROP || i == STT_TT_LAST, "sttode_ttrunk_fwd: null pointer in the table");
     }
     a.n = n; a.T = T; a.ld_feat = ld_feat; a.ode_time = ode_time;
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    if (g_tq.on && g_tq.have && g_tq.stream == stream) {   // the group's second trunk: both in one launch
+        g_tq.have = false;
+        const int n0 = (g_tq.a.n + 15) / 16;
+        const size_t l = lds > g_tq.lds ? lds : g_tq.lds;
+        hipLaunchKernelGGL(ttrunk_fwd2_kernel, dim3(n0 + (n + 15) / 16), dim3(256), l, (hipStream_t)stream, g_tq.a, a, n0);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
+    tq_flush_locked();
+    if (g_tq.on) { g_tq.a = a; g_tq.lds = lds; g_tq.stream = stream; g_tq.have = true; return 0; }
     hipLaunchKernelGGL(ttrunk_fwd_kernel, dim3((n + 15) / 16), dim3(256), lds, (hipStream_t)stream, a);
     STT_HIP(hipGetLastError());
     return 0;

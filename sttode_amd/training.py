@@ -493,11 +493,21 @@ class Engine:
             enc_f = self.new(n, Tf, 4)
             capi.call('sttode_frontend_future', net._future, V['lastpos'], n, Tf, mode, net._N or 1, ws.get('scene_orig'),
                       ws.get('agent_scene'), net._scene_ptr if mode == 0 else None, enc_f, self.st)
-            V['tf'] = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
+            if _PAIRED and not self.multi:
+                V['enc_f'] = enc_f                                   # one stream: the two trunks' forward as ONE launch (f_past)
+            else:
+                V['tf'] = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
 
         def f_past():
             ws, hcat = V['ws'], V['hcat']
-            V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+            if _PAIRED and not self.multi:
+                # (a group holds INDEPENDENT launches only: the fused trunk forward is one launch per trunk, the layer-by-layer form is not)
+                fused = net._mode != 'nba' and Tp <= 12 and Tf <= 12 and self.fused_trunk
+                with (self.group() if fused else contextlib.nullcontext()):
+                    V['tf'] = self.trunk_fwd('future_encoder.', V['enc_f'], ws['last'], hcat[:, 128:], drop_future)
+                    V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+            else:
+                V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
 
         def f_dec():
             ws, hcat, fut, past = V['ws'], V['hcat'], V['fut'], V['past']
