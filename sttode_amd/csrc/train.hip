@@ -607,6 +607,8 @@ struct TWg;
 static void tg_wgrad_done(const TG& g, float* dW, long ldw, float* db);
 static void ts_group_launch_locked();   // the scene-size queue (defined below the kernel it launches)
 static void ts_group_launch_locked_forget();
+static void ew_group_launch_locked();   // the element-wise queue (defined with its kernel)
+static void ew_group_forget();
 static void ts_submit(const TLin& a, const TWg* w, int ksplit, int gxA, int nA, int gxW, int gyW, int nB, void* stream);
 static void tg_group_launch_locked() {
     TGMulti& M = g_grp.M;
@@ -640,9 +642,10 @@ static void tg_submit(const TG& g, int kind, int gx, int gy, int gz, void* strea
 }
 extern "C" int sttode_tgemm_group(int on) {
     std::lock_guard<std::mutex> lk(g_red_mu);
-    if (on < 0) { g_grp.M.n = 0; ts_group_launch_locked_forget(); }   // error paths: forget what is queued
+    if (on < 0) { g_grp.M.n = 0; ts_group_launch_locked_forget(); ew_group_forget(); }   // error paths: forget what is queued
     tg_group_launch_locked();
     ts_group_launch_locked();
+    ew_group_launch_locked();
     g_grp.on = on > 0;
     if (int rc = stt_trunk_group(on)) return rc;   // (a fused trunk forward queued in this group, train_trunk.hip)
     STT_HIP(hipGetLastError());
@@ -1074,8 +1077,8 @@ enum {
     EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
 };
 
-__global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ __forceinline__ void ewise_body(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
+                                                  float f0, long i) {
     if (i >= count) return;
     switch (op) {
         case EW_MUL: p0[i] = p1[i] * p2[i]; break;
@@ -1126,9 +1129,44 @@ __global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2
     }
 }
 
+__global__ void ewise_kernel(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0) {
+    ewise_body(op, p0, p1, p2, p3, p4, count, i0, f0, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// up to four independent element-wise pieces in one launch (sttode_tgemm_group: the same piece of the two encoder trunks)
+#define EW_MULTI_MAX 4
+struct EwProb { float* p0; const float* p1; const float* p2; float* p3; float* p4; long count; int op, i0; float f0; int blk0; };
+struct EwMulti { EwProb p[EW_MULTI_MAX]; int n, blocks; };
+__global__ void ewise_multi_kernel(EwMulti M) {
+#pragma unroll
+    for (int k = 0; k < EW_MULTI_MAX; ++k) {
+        if (k >= M.n) break;
+        const EwProb& e = M.p[k];
+        const int last = k + 1 < M.n ? M.p[k + 1 < EW_MULTI_MAX ? k + 1 : k].blk0 : M.blocks;
+        if ((int)blockIdx.x >= e.blk0 && (int)blockIdx.x < last)
+            ewise_body(e.op, e.p0, e.p1, e.p2, e.p3, e.p4, e.count, e.i0, e.f0, (long)((int)blockIdx.x - e.blk0) * blockDim.x + threadIdx.x);
+    }
+}
+static struct { EwMulti M; void* stream; } g_ewq = {};
+static void ew_group_launch_locked() {
+    if (g_ewq.M.n == 0) return;
+    hipLaunchKernelGGL(ewise_multi_kernel, dim3((unsigned)g_ewq.M.blocks), dim3(256), 0, (hipStream_t)g_ewq.stream, g_ewq.M);
+    g_ewq.M.n = 0; g_ewq.M.blocks = 0;
+}
+static void ew_group_forget() { g_ewq.M.n = 0; g_ewq.M.blocks = 0; }
+
 extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
                                   float f0, void* stream) {
     STT_REQUIRE(op >= 0 && op <= EW_SUM_CUR && p0 && count > 0, "sttode_train_ewise: bad argument");
+    if (g_grp.on && count <= (1L << 24)) {   // an open group: queued, leaves with the group's other pieces
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        EwMulti& M = g_ewq.M;
+        if (M.n == EW_MULTI_MAX || (M.n > 0 && g_ewq.stream != stream)) ew_group_launch_locked();
+        EwProb& e = M.p[M.n++];
+        e.p0 = p0; e.p1 = p1; e.p2 = p2; e.p3 = p3; e.p4 = p4; e.count = count; e.op = op; e.i0 = i0; e.f0 = f0; e.blk0 = M.blocks;
+        M.blocks += (int)((count + 255) / 256);
+        g_ewq.stream = stream;
+        return 0;
+    }
     hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, p0, p1, p2, p3, p4, count, i0, f0);
     STT_HIP(hipGetLastError());
     return 0;
@@ -1160,7 +1198,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* x, const f
 // dsum = grad wrt (x + r); dgamma / dbeta accumulated deterministically: WG g sums its rows, a single last pass adds the
 // per-WG partials in order (grid is small: rows <= a few thousand).
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                                                     float* dsum, float* part, int rows, int rows_per_wg) {
+                                                     float* dsum, float* part, int rows, int rows_per_wg, float* dgamma, float* dbeta) {
     __shared__ float sg[4][64], sb[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, rows);
@@ -1178,8 +1216,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
     sb[wave][lane] = ab;
     __syncthreads();
     if (wave == 0) {
-        part[(long)blockIdx.x * 128 + lane] = ((sg[0][lane] + sg[1][lane]) + sg[2][lane]) + sg[3][lane];
-        part[(long)blockIdx.x * 128 + 64 + lane] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+        const float tg = ((sg[0][lane] + sg[1][lane]) + sg[2][lane]) + sg[3][lane], tb = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+        if (dgamma) {   // a single workgroup (rows <= 64: scene sizes): no partials, no second launch
+            dgamma[lane] += tg;
+            dbeta[lane] += tb;
+        } else {
+            part[(long)blockIdx.x * 128 + lane] = tg;
+            part[(long)blockIdx.x * 128 + 64 + lane] = tb;
+        }
     }
 }
 __global__ void ln_bwd_reduce_kernel(const float* part, int G, float* dgamma, float* dbeta) {
@@ -1204,8 +1248,9 @@ extern "C" int sttode_ln_bwd(const float* dy, const float* xhat, const float* rs
     if (G > 64) G = 64;
     STT_REQUIRE(scratch_floats >= (long)G * 128, "sttode_ln_bwd: scratch too small");
     const int rpw = (rows + G - 1) / G;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, scratch, G, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw,
+                       G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
+    if (G > 1) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, scratch, G, dgamma, dbeta);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -267,10 +267,12 @@ class Engine:
             pre = t['pre']
             S.append(dict(t=t, pre=pre, a=pre + _ATT, op=pre + _ATT + 'self_attn.temporal_attention_before.', n=t['n'], T=t['T'],
                           dx=dfeat[:, :64].contiguous(), dode=dfeat[:, 64:128].contiguous()))
+        with self.group():
+            for s in S:
+                s['dy'] = self.new(s['n'], 64)
+                self.ew(EW_EULER_BWD, s['dode'], s['t']['ode'], None, s['dx'], s['dy'], f0=net.ODE_TIME)
         for s in S:
             t, a, n = s['t'], s['a'], s['n']
-            s['dy'] = self.new(n, 64)
-            self.ew(EW_EULER_BWD, s['dode'], t['ode'], None, s['dx'], s['dy'], f0=net.ODE_TIME)
             s['dsum2'] = self.new(n, 64)
             capi.call('sttode_ln_bwd', s['dy'], t['xh2'], t['rs2'], P[a + 'norm2.weight'], s['dsum2'], g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
                       self.scratch, self.scratch.numel(), self.st)
@@ -287,9 +289,11 @@ class Engine:
             s['dsum1'] = self.new(n, 64)
             capi.call('sttode_ln_bwd', s['dsum2'], t['xh1'], t['rs1'], P[a + 'norm1.weight'], s['dsum1'], g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
                       self.scratch, self.scratch.numel(), self.st)
-            self.ew(EW_AXPY, s['dx'], s['dsum1'], f0=1.0)        # residual branch of LN1(x + gated)
-            s['du'], s['dv'] = self.new(n, 64), self.new(n, 64)
-            self.ew(EW_GATE_BWD, s['dsum1'], t['tt'], t['ss'], s['du'], s['dv'])
+        with self.group():
+            for s in S:
+                self.ew(EW_AXPY, s['dx'], s['dsum1'], f0=1.0)    # residual branch of LN1(x + gated)
+                s['du'], s['dv'] = self.new(s['n'], 64), self.new(s['n'], 64)
+                self.ew(EW_GATE_BWD, s['dsum1'], s['t']['tt'], s['t']['ss'], s['du'], s['dv'])
         with self.group():
             for s in S:
                 t, a = s['t'], s['a']
@@ -323,9 +327,10 @@ class Engine:
                 t, pre, n, T = s['t'], s['pre'], s['n'], s['T']
                 s['dtp'] = self.lin_bwd(s['dh2'], P[pre + 'input_fc2.weight'], t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'),
                                         g(pre + 'input_fc2.bias')).view(n * T, 64)
-        for s in S:
-            if s['t']['drop'] is not None:
-                self.ew(EW_MUL, s['dtp'], s['dtp'], s['t']['drop'])
+        with self.group():
+            for s in S:
+                if s['t']['drop'] is not None:
+                    self.ew(EW_MUL, s['dtp'], s['dtp'], s['t']['drop'])
         with self.group():
             for s in S:
                 t, pre = s['t'], s['pre']
@@ -713,7 +718,7 @@ class _GraphedStep:
 
     def run(self, inputs):
         for k, v in inputs.items():
-            if v is not None:
+            if v is not None and v is not self.static[k]:           # (the step's random draws are made into the static buffers directly)
                 self.static[k].copy_(v)
         self._bind()
         if self.graph is None:
@@ -768,28 +773,38 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     ``net.train_graphs`` (default True): after one eager step per shape the whole step is captured into a hipGraph."""
     a, dev = net.args, net.device
     n = net._past.shape[0]
-    eps_q = torch.randn(n, a.zdim, device=dev) if eps_q is None else eps_q.to(dev, torch.float32).contiguous()
-    if eps_p is None:
-        torch.randn(n, a.zdim, device=dev)                          # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
-    eps20 = torch.randn(n * 20, a.zdim, device=dev) if eps20 is None else eps20.to(dev, torch.float32).contiguous()
-    if net.training:                                                # nn.Dropout(0.1) after the positional fc, both encoders
-        keep = 0.9
-        if drop_past is None:
-            drop_past = torch.empty(n * a.past_length, 64, device=dev).bernoulli_(keep).div_(keep)
-        if drop_future is None:
-            drop_future = torch.empty(n * a.future_length, 64, device=dev).bernoulli_(keep).div_(keep)
     eng = getattr(net, '_engine', None)
     if eng is None or eng.dev != dev:
         eng = net._engine = Engine(net)
         net._graphs, net._graph_seen = {}, set()
     names, params, ptr_token = _names_params(eng, net)
     ready = None
-    key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None, drop_future is not None,
+    keep = 0.9                                                      # nn.Dropout(0.1) after the positional fc, both encoders (train mode)
+    key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None or net.training,
+           drop_future is not None or net.training,
            ptr_token, params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
            float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
     # a step is ~170 launches of 5-30 us each and the host needs ~15 us to enqueue one: replay wins as long as the launches are short
     # (one scene: launch-bound; an NBA batch of 32 x 11 agents: 3.5 ms eager for 2.5 ms of kernels)
-    if getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= _GRAPH_MAX_AGENTS:
+    graphs = getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= _GRAPH_MAX_AGENTS
+    gs = net._graphs.get(key) if graphs else None
+    st = gs.static if gs is not None and gs.graph is not None else None   # a captured step: the draws land in its static inputs (no copies)
+
+    def draw(given, name, rows, cols, bern=False):
+        if given is not None:
+            return given.to(dev, torch.float32).contiguous()
+        out = st[name] if st is not None and st.get(name) is not None and st[name].shape == (rows, cols) else torch.empty(rows, cols, device=dev)
+        return out.bernoulli_(keep).div_(keep) if bern else out.normal_()
+    eps_q = draw(eps_q, 'eps_q', n, a.zdim)
+    if eps_p is None:
+        torch.randn(n, a.zdim, device=dev)                          # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
+    eps20 = draw(eps20, 'eps20', n * 20, a.zdim)
+    if net.training:
+        if drop_past is None:
+            drop_past = draw(None, 'drop_past', n * a.past_length, 64, bern=True)
+        if drop_future is None:
+            drop_future = draw(None, 'drop_future', n * a.future_length, 64, bern=True)
+    if graphs:
         if key in net._graphs or key in net._graph_seen:
             inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,
                           eps_q=eps_q, eps20=eps20, drop_past=drop_past, drop_future=drop_future)
