@@ -1074,6 +1074,7 @@ enum {
     EW_TANH_BWD = 10,  // p0[i] = p1[i] * (1 - p2[i]^2)      (p2 = tanh output)
     EW_LATENT_BWD = 11,  // sampler.py:51-53: dz=p0, dlogvar=p1, A=p2, eps p3 (mode i0: 0 none | 1 shared [nz] | 2 per agent) -> dA=p4
     EW_SUM_CUR = 12,   // p0[c, d] = p1 + p2 (+ p3[c / K, d % 2] if p3)   row length i0, K = (int)f0  (Decoder.forward :336-344)
+    EW_EULER_BWD_CAT = 13,   // op 4 reading dout = cat(dx0 | dode) as rows of p0 with leading dimension i0: d = dode * (out(p1) > 0); p3 = dx0 + d; p4 = f0 * d
     EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
 };
 
@@ -1092,6 +1093,13 @@ static __device__ __forceinline__ void ewise_body(int op, float* p0, const float
         case EW_EULER_BWD: {
             const float d = p1[i] > 0.f ? p0[i] : 0.f;
             p3[i] += d;
+            p4[i] = f0 * d;
+        } break;
+        case EW_EULER_BWD_CAT: {
+            const long r = i >> 6;
+            const int c = (int)(i & 63);
+            const float d = p1[i] > 0.f ? p0[r * i0 + 64 + c] : 0.f;
+            p3[i] = p0[r * i0 + c] + d;
             p4[i] = f0 * d;
         } break;
         case EW_RSAMPLE: {
@@ -1156,7 +1164,7 @@ static void ew_group_forget() { g_ewq.M.n = 0; g_ewq.M.blocks = 0; }
 
 extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
                                   float f0, void* stream) {
-    STT_REQUIRE(op >= 0 && op <= EW_SUM_CUR && p0 && count > 0, "sttode_train_ewise: bad argument");
+    STT_REQUIRE(op >= 0 && op <= EW_EULER_BWD_CAT && p0 && count > 0, "sttode_train_ewise: bad argument");
     if (g_grp.on && count <= (1L << 24)) {   // an open group: queued, leaves with the group's other pieces
         std::lock_guard<std::mutex> lk(g_red_mu);
         EwMulti& M = g_ewq.M;

@@ -18,7 +18,7 @@ from . import capi
 from .capi import SttodeError
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
-EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR = 10, 11, 12
+EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR, EW_EULER_BWD_CAT = 10, 11, 12, 13
 ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
@@ -265,12 +265,13 @@ class Engine:
         S = []
         for t, dfeat in items:
             pre = t['pre']
-            S.append(dict(t=t, pre=pre, a=pre + _ATT, op=pre + _ATT + 'self_attn.temporal_attention_before.', n=t['n'], T=t['T'],
-                          dx=dfeat[:, :64].contiguous(), dode=dfeat[:, 64:128].contiguous()))
+            assert dfeat.stride(1) == 1 and dfeat.shape[1] >= 128
+            S.append(dict(t=t, pre=pre, a=pre + _ATT, op=pre + _ATT + 'self_attn.temporal_attention_before.', n=t['n'], T=t['T'], dfeat=dfeat))
         with self.group():
-            for s in S:
-                s['dy'] = self.new(s['n'], 64)
-                self.ew(EW_EULER_BWD, s['dode'], s['t']['ode'], None, s['dx'], s['dy'], f0=net.ODE_TIME)
+            for s in S:                                          # dx = dfeat[:, :64] + d, dy = T d, d = dfeat[:, 64:128] * (ode > 0): one piece,
+                n = s['n']                                       # reading the strided rows of dfeat (no .contiguous() copies)
+                s['dx'], s['dy'] = self.new(n, 64), self.new(n, 64)
+                self.ew(EW_EULER_BWD_CAT, s['dfeat'], s['t']['ode'], None, s['dx'], s['dy'], i0=s['dfeat'].stride(0), f0=net.ODE_TIME, count=n * 64)
         for s in S:
             t, a, n = s['t'], s['a'], s['n']
             s['dsum2'] = self.new(n, 64)
