@@ -170,6 +170,7 @@ class Leg:
     # 'zero' = the launch writes them straight to pinned host memory (inference_async(pred_host=True): 13-45 M; d2h_placement_ab.txt)
     D2H = os.environ.get('STTODE_BENCH_D2H', 'kernel')
     D2H_WGS = int(os.environ.get('STTODE_BENCH_D2H_WGS', '8'))
+    H2D = os.environ.get('STTODE_BENCH_H2D', 'memcpy')   # the step's inputs: 'memcpy' (default: hipMemcpyAsync inside the step) | 'kernel' | 'resident' (experiments)
     STREAMS = 3      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -224,7 +225,12 @@ class Leg:
     def _load(self):
         """H2D of this step's inputs (pinned -> one of two device slots, on the caller's stream) + the data-entry call."""
         slot = self.slots[self.calls % self.depth]
-        self.slot_bufs[self.calls % self.depth].copy_(self.host_buf, non_blocking=True)
+        if Leg.H2D == 'memcpy' or self.calls < self.depth:
+            self.slot_bufs[self.calls % self.depth].copy_(self.host_buf, non_blocking=True)
+        elif Leg.H2D == 'kernel':                                   # (experiment: the same bytes by a few persistent workgroups reading pinned memory)
+            from sttode_amd import capi
+            b = self.slot_bufs[self.calls % self.depth]
+            capi.call('sttode_copy_to_host', b, self.host_buf, (b.numel() // 16) * 16, 4, capi.stream_ptr())
         self.calls += 1
         if self.kind == 'scenes':
             self.model.set_scene_batch(slot[0], slot[1], slot[2])
