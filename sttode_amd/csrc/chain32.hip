@@ -74,6 +74,7 @@ struct Role32Args {   // throughput-form per-agent roles (role32.hpp)
     float* pf; float* state0; float* A0x; float* A0y; float* A1y;             // [n][128], [n][96], [n][512] x 3
     int n, Tp, kte, nwg;                                                      // agents, observed frames, k-tiles of x, role workgroups in the grid
     float ode_time;
+    int prio;       // > 0: the role waves run at s_setprio 3 (default; STTODE_ROLE_PRIO=0: A/B)
     int* counter;   // work queue of THIS call's trajectory groups (a later launch of the same stream): zeroed by role workgroup 0
     float* zgen; unsigned zkey0, zkey1; int K;   // zgen != nullptr: the roles draw this call's latents z [n K][32] ~ N(0, I) themselves (role32.hpp latents32)
     // past != nullptr (scene batches): the roles run STTODENet.set_data for their own 128 agents first (role32.hpp frontend32) -- no front-end
@@ -1254,6 +1255,8 @@ int stt_chain_lagged(const float* const* W, const LagRoles& lr, const LagGroups&
         r.pf = ws_r + off_r[STT_B_PF]; r.state0 = ws_r + off_r[STT_B_STATE0];
         r.A0x = ws_r + off_r[STT_B_A0X]; r.A0y = ws_r + off_r[STT_B_A0Y]; r.A1y = ws_r + off_r[STT_B_A1Y];
         r.n = n_r; r.Tp = Tp; r.nwg = (n_r + 127) / 128; r.ode_time = ode_time;
+        static const int role_prio = getenv("STTODE_ROLE_PRIO") ? atoi(getenv("STTODE_ROLE_PRIO")) : 3;   // role waves outlast the groups of a small launch: SDD-256 / NBA-128 +1..2 %, 512 scenes the same (profiles/r04/role_prio_ab.txt)
+        r.prio = role_prio;
         r.counter = (int*)(ws_r + off_r[STT_B_QUEUE]);
         r.zgen = zgen; r.zkey0 = (unsigned)zkey; r.zkey1 = (unsigned)(zkey >> 32); r.K = K;
         STT_REQUIRE(!past || (scene_ptr && S > 0 && !attn), "stt_chain_lagged: the in-role front-end needs scene_ptr, S > 0 and attention length 1");

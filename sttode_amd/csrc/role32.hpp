@@ -174,6 +174,7 @@ __device__ __forceinline__ void role32_body(KRole32Args& R, int wg, char* smem) 
     int2* lprog = reinterpret_cast<int2*>(cst + R32C::total);
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (R.prio > 0) __builtin_amdgcn_s_setprio(3);     // (uniform) the role waves win their SIMD's issue arbitration: they are the long pole of a small launch
     if (wg == 0 && threadIdx.x == 0) *R.counter = 0;   // the work queue of this call's trajectory groups (read by a LATER launch of this stream)
     if (R.m_ade && threadIdx.x < 128 && wg * 128 + (int)threadIdx.x < R.n) {   // fused metrics of this call: the minimum starts at +inf
         R.m_ade[wg * 128 + threadIdx.x] = INFINITY;
