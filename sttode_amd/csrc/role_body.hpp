@@ -125,11 +125,15 @@ __device__ __forceinline__ void agent_role(const RoleArgs& R, int nag, int Tp, i
 // ONE agent-scope acquire drops this CU's stale L1 lines; the caller's barrier releases the other waves.  The spin is bounded (~1 s): a
 // producer that never arrives -- it cannot, in-order dispatch puts every producer in front of its consumers -- would poison this group's
 // predictions with NaN and set the time-out word instead of hanging the device.
-__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane) {
+// want == 0: a flag is up when it is non-zero (the flag words are zeroed in front of every launch); want != 0: when it EQUALS `want` --
+// the launch's epoch (scene_lat.hip): words left by earlier launches on the same workspace are older epochs, so no memset is needed
+__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane, unsigned want = 0u) {
     bool ok = true;
     for (int t = t_lo + lane; t <= t_hi; t += 64) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (true) {
+            const unsigned v = __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (want ? v == want : v != 0u) break;
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 20)) { ok = false; break; }
         }
@@ -142,10 +146,10 @@ __device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, 
 }
 
 // publish (guide section 6 G16 R1): every storing wave drains its sc1 stores, the workgroup meets, ONE lane stores the flag (agent scope)
-__device__ __forceinline__ void role_publish(unsigned* flag, bool really) {
+__device__ __forceinline__ void role_publish(unsigned* flag, bool really, unsigned val = 1u) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && really) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && really) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Split roles of the fused chain launch (RoleArgs::split).  Block r < 2 T: tile r / 2, E (even) or G (odd); 2 T <= r < 5 T: table

@@ -23,6 +23,7 @@
 // in-order dispatch has made resident (or finished) before it starts: no deadlock whatever the grid size; the bounded spin poisons the
 // tile's predictions with NaN and raises the time-out word instead of hanging.  The bodies are the separate launches' code
 // (latency_bodies.hpp), every output element summed in the same order: the predictions carry the bits of the six-launch path.
+#include <mutex>
 #include "chain.hpp"
 #include "role_body.hpp"
 #include "api_util.hpp"
@@ -35,6 +36,7 @@ struct SceneLatArgs {
     const float* xpad; int ldx;
     unsigned *tmo, *gflags, *e2flags, *yflags;   // flag words: E [A] | time-out | G [A] | E2 [A] | Y [C]
     int n, K, Tp, Tf2, ntiles_c;
+    unsigned epoch;             // this launch's flag value (stt_scene_lat): a flag is up when it EQUALS it -- no memset in front of the launch
     long long* dbg;             // diagnostic build only (SL_DIAG_TRACE): [block][8] phase stamps (100 MHz)
 };
 
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
 #ifdef SL_DIAG_TRACE
     if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + 7] = __builtin_amdgcn_s_memtime();   // core-clock counter at the start
 #endif
+    if (b == 0 && threadIdx.x == 0) __hip_atomic_store(A.tmo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the first workgroup of the grid; a time-out is raised milliseconds later)
     if (b < 2 * A_tiles) {   // (uniform) per-agent roles
         const int tile = b >> 1;
         if ((b & 1) == 0) {  // E: encoder
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             SL_STAMP(1);
             post_attn_body<false, true>(R.pw, R.g, R.qkv + 128, 192, R.pf, A.n, R.ode_time, 0, 1, nullptr, nullptr, tile,
                                         reinterpret_cast<f32x4(*)[4][64]>(smem));
-            role_publish(R.flags + tile, tile != R.drop_tile);
+            role_publish(R.flags + tile, tile != R.drop_tile, A.epoch);
             SL_STAMP(2);
             // block-1 layer-1 table of the tile's agents: off the critical path (its readers first run block 0 and the GRU)
             const int col = tile * 16 + c;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
 #pragma unroll
             for (int T = 8; T < 14; ++T) B[T] = B[0];
             preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < A.n, lane, q, wave);
-            role_publish(A.e2flags + tile, true);
+            role_publish(A.e2flags + tile, true, A.epoch);
             SL_STAMP(3);
         } else {             // G: block-0 conv + GRU
             f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             };
             gru_bal_body<TPX, false, true, decltype(fe)>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, A.n, A.Tp, tile, sH, sX,
                                                          nullptr, fe);
-            role_publish(A.gflags + tile, true);
+            role_publish(A.gflags + tile, true, A.epoch);
             SL_STAMP(2);
         }
         return;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     for (int j = 0; j < 8; ++j) acc[j] = ld4(b1 + 16 * (wave + 4 * j) + 4 * q);
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
-    if (wave == 0 && !wait_tiles(R.flags, t_lo, t_hi, A.tmo, lane) && lane == 0) s_ok = 0;   // pf of the tile's agents
+    if (wave == 0 && !wait_tiles(R.flags, t_lo, t_hi, A.tmo, lane, A.epoch) && lane == 0) s_ok = 0;   // pf of the tile's agents
     __syncthreads();
     SL_STAMP(1);
     f32x4* sA0 = reinterpret_cast<f32x4*>(smem + SL_A0);
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     }
     preact_prime<14, 8, 14, 6>(WA, w2, lane, wave);
     if (s_ok) preact_run<14, 0, 8, 8>(WA, w1, acc, B, lane, wave);
-    if (wave == 0 && !wait_tiles(A.gflags, t_lo, t_hi, A.tmo, lane) && lane == 0) s_ok = 0;   // state0, xpad, cur, orig
+    if (wave == 0 && !wait_tiles(A.gflags, t_lo, t_hi, A.tmo, lane, A.epoch) && lane == 0) s_ok = 0;   // state0, xpad, cur, orig
     __syncthreads();
     if (s_ok) {
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             mlp_lat_run<2, NOY, 1, true, true, true>(y0, sH1, sH2, tile);
         }
         // (after a time-out the flag is still published: the X role has seen the same time-out and poisons the tile)
-        role_publish(A.yflags + tile, true);
+        role_publish(A.yflags + tile, true, A.epoch);
         SL_STAMP(3);
         return;
     }
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
         const int cur = gru_bal_body<TPX, true>(nullptr, A.convP, A.convB, A.wihP, A.whhP, A.gbias, nullptr, ncols, A.Tp, tile, sH, sX, sD);
         SL_STAMP(4);
         if (wave == 0) {   // A1y rows of this tile's agents and y_hat0 of this tile (both producers started long ago)
-            const bool ok1 = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane);   // (both waits run: each ends with the acquire its data needs)
-            const bool ok = wait_tiles(A.yflags, tile, tile, A.tmo, lane) && ok1;
+            const bool ok1 = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane, A.epoch);   // (both waits run: each ends with the acquire its data needs)
+            const bool ok = wait_tiles(A.yflags, tile, tile, A.tmo, lane, A.epoch) && ok1;
             if (!ok && lane == 0) s_ok = 0;
         }
         __syncthreads();
@@ -240,8 +243,25 @@ int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int 
     a.whhP = (const f32x4*)W[STT_W_B1_WHHP]; a.gbias = W[STT_W_B1_GBIAS];
     a.xpad = xpad; a.ldx = 16 * TPX; a.n = n; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.ntiles_c = C_tiles;
     hipStream_t s = (hipStream_t)stream;
-    // E [A] + time-out word + G [A] + E2 [A] + Y [C]
-    STT_HIP(hipMemsetAsync(r.flags, 0, (((size_t)3 * A_tiles + 1 + C_tiles) * 4 + 15) / 16 * 16, s));
+    // E [A] + time-out word + G [A] + E2 [A] + Y [C].  The flags are compared with the launch's EPOCH (0x80000000 + a process-wide call
+    // count: the bit patterns of tiny negative denormals, which neither an older epoch nor recycled tensor contents hold), so they are
+    // zeroed only the first time a workspace is seen (and when the count wraps) instead of in front of every launch -- one stream
+    // operation less on the critical path of the one-scene loop (test.py:171-188).
+    static std::mutex mu;
+    static const float* known[16];
+    static unsigned count = 0, slot = 0;
+    unsigned epoch;
+    bool fresh = true;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (++count >= (1u << 24)) { count = 1; for (auto& k : known) k = nullptr; }
+        epoch = 0x80000000u + count;
+        for (const float* k : known) fresh = fresh && k != ws;
+        if (fresh) known[slot++ & 15] = ws;
+    }
+    static const bool always = getenv("STTODE_SCENE_MEMSET") && atoi(getenv("STTODE_SCENE_MEMSET")) != 0;   // (A/B: zero the flags per launch as before)
+    if (fresh || always) STT_HIP(hipMemsetAsync(r.flags, 0, (((size_t)3 * A_tiles + 1 + C_tiles) * 4 + 15) / 16 * 16, s));
+    a.epoch = epoch;
     const dim3 grid(2 * A_tiles + 2 * C_tiles);
 #define SLK(TX, NY)                                                                                   \
     do {                                                                                              \
