@@ -197,13 +197,15 @@ int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, long ldw, cons
  * writes) and the reductions run as ONE launch per 16 gradients -- or earlier: buf full, a destination that is already pending, another
  * stream.  sttode_twgrad_defer(0, NULL, 0): run what is pending (on the stream of the gradients that queued it), back to a reduction per
  * gradient; sttode_twgrad_defer(-1, NULL, 0): forget what is pending (error paths).  sttode_twgrad_flush(): run what is pending, keep the
- * mode.  Process-wide host-side state; a training step brackets its backward pass with defer(1) / defer(0) (sttode_amd/training.py). */
+ * mode.  Host-side state of the calling thread; a training step brackets its backward pass with defer(1) / defer(0) (sttode_amd/training.py). */
 int sttode_twgrad_defer(int on, float* buf, long floats);
 int sttode_twgrad_flush(void);
 /* Grouped launches: between sttode_tgemm_group(1) and sttode_tgemm_group(0) the batch-size products (cols > 2048) of sttode_tlinear,
  * sttode_twgrad and sttode_tlinear_bwd are queued and leave as ONE launch (at most 4 products per launch; a fifth starts the next).  The
  * caller promises that the products of a group do not depend on each other and do not write the same output; calls below the batch
- * size launch at once as usual.  sttode_tgemm_group(-1): forget what is queued (error paths).  Process-wide host-side state. */
+ * size launch at once as usual.  sttode_tgemm_group(-1): forget what is queued (error paths).  Host-side state of the calling thread (a group is
+ * opened, filled and closed by one thread).  Also queued inside a group: scene-size layers (cols <= 1024) of sttode_tlinear /
+ * sttode_tlinear_bwd, element-wise pieces (sttode_train_ewise) and a second sttode_ttrunk_fwd. */
 int sttode_tgemm_group(int on);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);

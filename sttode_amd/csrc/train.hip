@@ -590,7 +590,9 @@ static inline int tg_evec(const TG& g) {
 // gradients, or earlier: buf full, a destination that is already pending, another stream.  Host-side state only; inside a hipGraph capture
 // the flush is captured like any other launch.
 static std::mutex g_red_mu;
-static struct { TGRed r; int blocks; long used; float* buf; long cap; void* stream; bool defer; } g_red = {{}, 0, 0, nullptr, 0, nullptr, false};
+// (per HOST THREAD: a training step -- its group brackets, its backward pass with the deferred reductions -- is issued by one thread; two
+// threads that train two models must not see each other's open group)
+static thread_local struct { TGRed r; int blocks; long used; float* buf; long cap; void* stream; bool defer; } g_red = {{}, 0, 0, nullptr, 0, nullptr, false};
 
 static void tg_red_flush_locked() {
     if (g_red.r.n > 0) hipLaunchKernelGGL(tgemm_reduce_kernel, dim3((unsigned)g_red.blocks), dim3(256), 0, (hipStream_t)g_red.stream, g_red.r);
@@ -598,7 +600,7 @@ static void tg_red_flush_locked() {
 }
 
 // ---- grouped launches (sttode_tgemm_group): batch-size products queued between group(1) and group(0) leave as ONE tgemm_multi_kernel launch ----
-static struct {
+static thread_local struct {
     TGMulti M; int gz[TG_MULTI_MAX];
     struct { float* dW; long ldw; float* db; } post[TG_MULTI_MAX];   // weight gradients: their split sums are queued for reduction AFTER the launch
     void* stream; bool on;
@@ -1004,7 +1006,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     return 0;
 }
 
-static struct { TSMulti M; void* stream; } g_ts = {};
+static thread_local struct { TSMulti M; void* stream; } g_ts = {};
 static void ts_group_launch_locked_forget() { g_ts.M.n = 0; }
 static void ts_group_launch_locked() {
     if (g_ts.M.n == 0) return;
@@ -1154,7 +1156,7 @@ __global__ void ewise_multi_kernel(EwMulti M) {
             ewise_body(e.op, e.p0, e.p1, e.p2, e.p3, e.p4, e.count, e.i0, e.f0, (long)((int)blockIdx.x - e.blk0) * blockDim.x + threadIdx.x);
     }
 }
-static struct { EwMulti M; void* stream; } g_ewq = {};
+static thread_local struct { EwMulti M; void* stream; } g_ewq = {};
 static void ew_group_launch_locked() {
     if (g_ewq.M.n == 0) return;
     hipLaunchKernelGGL(ewise_multi_kernel, dim3((unsigned)g_ewq.M.blocks), dim3(256), 0, (hipStream_t)g_ewq.stream, g_ewq.M);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void ttrunk_fwd2_kernel(TrunkArgs a0, TrunkArg
 }
 
 // group mode (sttode_tgemm_group -> stt_trunk_group): a trunk launch waits for a second one of the same group
-static struct { TrunkArgs a; size_t lds; void* stream; bool have, on; } g_tq = {};
+static thread_local struct { TrunkArgs a; size_t lds; void* stream; bool have, on; } g_tq = {};   // (per host thread, like the group state of train.hip)
 static std::mutex g_tq_mu;
 static void tq_flush_locked() {
     if (!g_tq.have) return;
