@@ -207,6 +207,10 @@ int sttode_twgrad_flush(void);
  * opened, filled and closed by one thread).  Also queued inside a group: scene-size layers (cols <= 1024) of sttode_tlinear /
  * sttode_tlinear_bwd, element-wise pieces (sttode_train_ewise) and a second sttode_ttrunk_fwd. */
 int sttode_tgemm_group(int on);
+/* inp0 / inp1 [n K1, ld] (inp1 may be NULL), row (a, k): columns 0..127 = pf[a] (rows of ldpf floats), 128..159 = qz[a] for k = 0, else
+ * eps[a, k - 1] (eps [n (K1 - 1), 32]): the layer-1 input prefix of both decompose blocks (model/STTODE.py:322-331, 553-566). */
+int sttode_decoder_inputs(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n, int K1,
+                          void* stream);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
 /* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */

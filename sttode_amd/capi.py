@@ -48,6 +48,7 @@ SIGNATURES = {
     'sttode_twgrad_flush': [],
     'sttode_tgemm_group': [_I],
     'sttode_tlinear_bwd': [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
+    'sttode_decoder_inputs': [_P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
     'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_train_ewise': [_I, _P, _P, _P, _P, _P, _L, _I, _F, _P],

@@ -1026,6 +1026,33 @@ static void ts_submit(const TLin& a, const TWg* w, int ksplit, int gxA, int nA, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The decoder's layer-1 input prefix of BOTH decompose blocks in one launch: row c = (agent a, sample k) of inp0 / inp1 [n K1, ld] gets
+// cat(past_feature[a] (128), z (32)) with z = the posterior draw qz[a] for k = 0 and the prior draw eps[a, k - 1] otherwise
+// (model/STTODE.py:322-331, 553-566; the blocks' own state fills columns 160.. later).  Replaces two repeat_interleave copies per block
+// and the two that assembled z: six launches of a launch-bound step.
+// ---------------------------------------------------------------------------------------------------
+__global__ void decoder_inputs_kernel(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n, int K1) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of a row's 160-float prefix
+    if (id >= (long)n * K1 * 40) return;
+    const int f = (int)(id % 40) * 4;
+    const long c = id / 40;
+    const int a = (int)(c / K1), k = (int)(c % K1);
+    const float* src = f < 128 ? pf + (long)a * ldpf + f : (k == 0 ? qz + (long)a * 32 : eps + ((long)a * (K1 - 1) + k - 1) * 32) + (f - 128);
+    const f32x4 v = {src[0], src[1], src[2], src[3]};
+    st4(inp0 + c * ld + f, v);
+    if (inp1) st4(inp1 + c * ld + f, v);
+}
+extern "C" int sttode_decoder_inputs(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n,
+                                     int K1, void* stream) {
+    STT_REQUIRE(inp0 && pf && qz && eps && n > 0 && K1 >= 1 && ld >= 160 && ld % 4 == 0 && ldpf >= 128, "sttode_decoder_inputs: bad argument");
+    STT_REQUIRE(((size_t)inp0 | (size_t)inp1) % 16 == 0, "sttode_decoder_inputs: inp0 / inp1 must be 16-byte aligned");
+    const long tot = (long)n * K1 * 40;
+    hipLaunchKernelGGL(decoder_inputs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inp0, inp1, ld, pf, ldpf, qz, eps, n, K1);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // row shuffles
 // ---------------------------------------------------------------------------------------------------
 __global__ void rows_copy_kernel(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod) {
@@ -1348,6 +1375,7 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
         bias[g] = ld4(bhh + g * 96 + f);
     }
     for (int i = threadIdx.x; i < 16 * GSEQ_LDH; i += 384) sH[i] = 0.f;
+    if (ok) st4(H + (long)col * 96 + f, splat4(0.f));   // H[0] = h_{-1} = 0: the backward pass reads it (the caller need not zero H)
     __syncthreads();
     for (int t = 0; t < Tp; ++t) {
         f32x4 acc[3] = {bias[0], bias[1], bias[2]};

@@ -391,7 +391,7 @@ class Engine:
         self.lin_bwd(da1, P[pre + 'layers.0.weight'], inp, g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias'), out=din,
                      accumulate=accumulate)
 
-    def block_fwd(self, i, past, K, xhat_prev, pf, z, want_x):
+    def block_fwd(self, i, past, K, xhat_prev, pf, z, want_x, inp=None):
         P = self.P
         pre = f'decoder.decompose.{i}.'
         n, Tp = past.shape[0], past.shape[1]
@@ -399,13 +399,16 @@ class Engine:
         x, e = self.new(m, Tp, 2), self.new(m * Tp, 32)
         capi.call('sttode_conv_fwd', past, K, xhat_prev, P[pre + 'conv_past.weight'], P[pre + 'conv_past.bias'], x, e, m, Tp, self.st)
         gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [m*Tp, 288], row c*Tp + t
-        H = self.zeros(Tp + 1, m, 96)                                                                    # H[0] = 0, H[t+1] = h_t
+        H = self.new(Tp + 1, m, 96)                                                                      # H[0] = 0 (written by the launch), H[t+1] = h_t
         tapes = self.new(Tp, m, 384)
-        inp = self.new(m, 256)                                                                           # cat(pf_rep, z, state)
+        prefix = inp is None                                                                             # cat(pf_rep, z, state): the prefix may come filled (decoder_fwd)
+        if prefix:
+            inp = self.new(m, 256)
         capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
                   inp[:, 160:], 256, m, Tp, self.st)                                                     # all Tp steps, one launch
-        capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
-        capi.call('sttode_rows_copy', inp[:, 128:], 256, z, _ld(z), m, 32, 1, m, self.st)
+        if prefix:
+            capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
+            capi.call('sttode_rows_copy', inp[:, 128:], 256, z, _ld(z), m, 32, 1, m, self.st)
         if want_x and _PAIRED:
             (yh, sy), (xh, sx) = self.mlp_fwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', inp)
         else:
@@ -435,12 +438,18 @@ class Engine:
                   m, Tp, self.scratch, self.scratch.numel(), self.st)
         return din, dx
 
-    def decoder_fwd(self, pf, z, K, past, cur, want_recover):
+    def decoder_fwd(self, pf, z, K, past, cur, want_recover, qz_eps=None):
+        """``qz_eps`` = (qz [n, 32], eps [n (K - 1), 32]) instead of ``z`` [n K, 32]: the blocks' input prefix cat(pf, z) is written for BOTH
+        blocks by one launch (sttode_decoder_inputs) and z is never assembled."""
         n, Tp = past.shape[0], past.shape[1]
         Tf = self.net.args.future_length
         m = n * K
-        b0 = self.block_fwd(0, past, K, None, pf, z, True)
-        b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover)
+        inps = (None, None)
+        if qz_eps is not None:
+            inps = (self.new(m, 256), self.new(m, 256))
+            capi.call('sttode_decoder_inputs', inps[0], inps[1], 256, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.st)
+        b0 = self.block_fwd(0, past, K, None, pf, z, True, inp=inps[0])
+        b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover, inp=inps[1])
         pred = self.new(m, 2 * Tf)
         self.ew(EW_SUM_CUR, pred, b0['yh'], b1['yh'], cur, i0=2 * Tf, f0=K)
         rec = None
@@ -521,11 +530,10 @@ class Engine:
             qzp = self.lin(hq, P['future_encoder.qz_layer.weight'], P['future_encoder.qz_layer.bias'])
             qz = self.new(n, zd)
             self.ew(EW_RSAMPLE, qz, qzp, eps_q, i0=zd)
-            z21 = self.new(n * K1, zd)                              # [agent][sample 0 = q draw | samples 1..20 = prior draws]
-            zrow = z21.view(n, K1 * zd)
-            capi.call('sttode_rows_copy', zrow, K1 * zd, qz, zd, n, zd, 1, n, self.st)
-            capi.call('sttode_rows_copy', zrow[:, zd:], K1 * zd, eps20, 20 * zd, n, 20 * zd, 1, n, self.st)
-            d = self.decoder_fwd(hcat[:, :128], z21, K1, past, ws['cur'], True)
+            # z per (agent, sample): sample 0 = the posterior draw, samples 1..20 = the prior draws -- read where they are by the launch that
+            # fills both blocks' input prefix
+            assert zd == 32 and eps20.is_contiguous() and qz.is_contiguous()
+            d = self.decoder_fwd(hcat[:, :128], None, K1, past, ws['cur'], True, qz_eps=(qz, eps20))
             losses = self.new(5)                                    # the four terms and their sum
             dpred, drec, dqzp = self.new(n * K1, 2 * Tf), self.new(n * K1, 2 * Tp), self.new(n, 2 * zd)
             # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
