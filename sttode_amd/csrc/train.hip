@@ -1377,7 +1377,16 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
     for (int i = threadIdx.x; i < 16 * GSEQ_LDH; i += 384) sH[i] = 0.f;
     if (ok) st4(H + (long)col * 96 + f, splat4(0.f));   // H[0] = h_{-1} = 0: the backward pass reads it (the caller need not zero H)
     __syncthreads();
+    // the input-gate rows of step t + 1 travel while step t runs (requested inside the step they cost an L2 round trip per step: 8 of them
+    // were a third of the launch at scene sizes)
+    const float* gic0 = gi + (long)(ok ? col : 0) * Tp * 288;
+    f32x4 gr_n = ld4(gic0 + f), gz_n = ld4(gic0 + 96 + f), gn_n = ld4(gic0 + 192 + f);
     for (int t = 0; t < Tp; ++t) {
+        const f32x4 gr = gr_n, gz = gz_n, gn = gn_n;
+        if (t + 1 < Tp) {
+            const float* gn1 = gic0 + (long)(t + 1) * 288;
+            gr_n = ld4(gn1 + f); gz_n = ld4(gn1 + 96 + f); gn_n = ld4(gn1 + 192 + f);
+        }
         f32x4 acc[3] = {bias[0], bias[1], bias[2]};
 #pragma unroll
         for (int T = 0; T < 6; ++T) {
@@ -1388,8 +1397,6 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
         const f32x4 hp = ld4(sH + c * GSEQ_LDH + f);
         f32x4 hn = hp;
         if (ok) {
-            const float* gic = gi + ((long)col * Tp + t) * 288;
-            const f32x4 gr = ld4(gic + f), gz = ld4(gic + 96 + f), gn = ld4(gic + 192 + f);
             f32x4 r, z, n;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1424,12 +1431,23 @@ __global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[T][r] = Whh[(long)(16 * T + 4 * q + r) * 96 + 16 * j + c];
     f32x4 dh = ok ? ld4(dh_last + (long)col * lddh + f) : splat4(0.f);
+    // the tape of step t - 1 travels while step t runs (as in the forward launch)
+    const int cc = ok ? col : 0;
+    f32x4 r_n, z_n, n_n, hn_n, hp_n;
+    {
+        const float* tp = tapes + ((long)(Tp - 1) * m + cc) * 384;
+        r_n = ld4(tp + f); z_n = ld4(tp + 96 + f); n_n = ld4(tp + 192 + f); hn_n = ld4(tp + 288 + f);
+        hp_n = ld4(H + ((long)(Tp - 1) * m + cc) * 96 + f);
+    }
     for (int t = Tp - 1; t >= 0; --t) {
         f32x4 dr = splat4(0.f), dz = dr, dn = dr, dhn = dr, dhz = dr;
+        const f32x4 r = r_n, z = z_n, n = n_n, hn = hn_n, hp = hp_n;
+        if (t > 0) {
+            const float* tp = tapes + ((long)(t - 1) * m + cc) * 384;
+            r_n = ld4(tp + f); z_n = ld4(tp + 96 + f); n_n = ld4(tp + 192 + f); hn_n = ld4(tp + 288 + f);
+            hp_n = ld4(H + ((long)(t - 1) * m + cc) * 96 + f);
+        }
         if (ok) {
-            const float* tp = tapes + ((long)t * m + col) * 384;
-            const f32x4 r = ld4(tp + f), z = ld4(tp + 96 + f), n = ld4(tp + 192 + f), hn = ld4(tp + 288 + f);
-            const f32x4 hp = ld4(H + ((long)t * m + col) * 96 + f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = dh[e];

@@ -458,8 +458,9 @@ class Engine:
             self.ew(EW_SUM_CUR, rec, b0['xh'], b1['xh'], None, i0=2 * Tp, f0=K)
         return dict(b0=b0, b1=b1, n=n, K=K, m=m, pred=pred, rec=rec)
 
-    def decoder_bwd(self, d, dpred, drec, dpf, dz):
-        """Accumulates dpf [n,128] (+=); writes dz [m,32] if not None."""
+    def decoder_bwd(self, d, dpred, drec, dpf, dz, dpf_accumulate=True):
+        """Accumulates dpf [n,128] (+=; ``dpf_accumulate=False``: writes it); writes dz [m,32] if not None.  Returns the gradient of the
+        blocks' summed layer-1 input [m, 256] = cat(d pf_rep | d z | d state) (its columns 128..159 are dz)."""
         n, K, m = d['n'], d['K'], d['m']
         din1, dx1 = self.block_bwd(d['b1'], dpred, drec, True)
         # x_1 = x_true - x_hat_0  =>  d x_hat_0 = (d recover) - d x_1
@@ -469,9 +470,10 @@ class Engine:
             self.ew(EW_AXPY, dxh0, drec, f0=1.0)
         din0, _ = self.block_bwd(d['b0'], dpred, dxh0, False)
         self.ew(EW_AXPY, din0, din1, f0=1.0)
-        capi.call('sttode_rows_reduce', dpf, _ld(dpf), din0, 256, n, 128, K, 1, self.st)
+        capi.call('sttode_rows_reduce', dpf, _ld(dpf), din0, 256, n, 128, K, int(dpf_accumulate), self.st)
         if dz is not None:
             dz.copy_(din0[:, 128:160])
+        return din0
 
     # ---------------------------------------------------------------- the objective (model/STTODE.py:553-568)
     def forward_segments(self, eps_q, eps20, drop_past=None, drop_future=None, streams=None):
@@ -579,11 +581,10 @@ class Engine:
             self._grad_views()
             if self.red_scratch is not None:                            # batch sizes: the split weight gradients' reductions as one launch per 16
                 capi.call('sttode_twgrad_defer', 1, self.red_scratch, self.red_scratch.numel())
-            W['dpf'] = dpf = self.zeros(n, 128)
-            dz = self.new(n * K1, zd)
-            self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, dz)
-            dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent
-            capi.call('sttode_rows_copy', dqz, zd, dz, K1 * zd, n, zd, 1, n, self.st)
+            W['dpf'] = dpf = self.new(n, 128)
+            din = self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, None, dpf_accumulate=False)
+            dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent: dz of row a K1
+            capi.call('sttode_rows_copy', dqz, zd, din[:, 128:], K1 * 256, n, zd, 1, n, self.st)
             dqzp = T['dqzp']                                            # starts as the KL gradient
             self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
             dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
