@@ -1400,9 +1400,11 @@ __global__ __launch_bounds__(384) void gru_seq_fwd_kernel(const float* __restric
             f32x4 r, z, n;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                r[e] = 1.0f / (1.0f + expf(-(gr[e] + acc[0][e])));
-                z[e] = 1.0f / (1.0f + expf(-(gz[e] + acc[1][e])));
-                n[e] = tanhf(gn[e] + r[e] * acc[2][e]);
+                // (the hardware's exp2 / rcp forms of chain.hpp, as in the inference GRU: absolute error ~1e-7; expf / tanhf / IEEE division
+                // were ~1 500 vector instructions per lane and step -- most of a 4.7-us step at scene sizes)
+                r[e] = sigmoidf_(gr[e] + acc[0][e]);
+                z[e] = sigmoidf_(gz[e] + acc[1][e]);
+                n[e] = tanhf_(gn[e] + r[e] * acc[2][e]);
                 hn[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
             }
             float* tp = tapes + ((long)t * m + col) * 384;
