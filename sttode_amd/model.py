@@ -829,7 +829,11 @@ class STTODENet(nn.Module):
         raw = st.cuda_stream if st is not None else capi.stream_ptr()
         if st is None:
             capi.call('sttode_wait', nat.h, handle['slot'], raw)
-        capi.call('sttode_copy_to_host', out, pred, pred.numel() * 4, int(workgroups), raw)
+        if (pred.numel() * 4) % 16 == 0:
+            capi.call('sttode_copy_to_host', out, pred, pred.numel() * 4, int(workgroups), raw)
+        else:                                                        # (an odd number of floats: the copy kernel moves 16-byte pieces)
+            with torch.cuda.stream(st if st is not None else torch.cuda.current_stream(self.device)):
+                out.copy_(pred, non_blocking=True)
         ev = handle.get('host_event')
         if ev is None:
             ev = handle['host_event'] = torch.cuda.Event()
