@@ -567,6 +567,12 @@ __global__ __launch_bounds__(256) void tgemm_reduce_kernel(TGRed r) {
 #define TLIN_MEDIUM_BELOW 4096   // throughput-mode wave count below which the 32 x 32 tiling is used instead
 #endif
 
+// columns above which the LDS-tiled kernel takes over from the generic ones (STTODE_TGEMM_MIN_COLS: experiments; measured at 1024: the
+// one-scene step the same 1.04-1.08 ms, and the NBA 16 x 11 gradient yardstick fails -- profiles/r04/tgemm_min_cols_ab.txt)
+static inline int tg_min_cols() {
+    static const int v = getenv("STTODE_TGEMM_MIN_COLS") ? atoi(getenv("STTODE_TGEMM_MIN_COLS")) : 2048;
+    return v;
+}
 static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
 // tg_fetch_fast: aligned operands without broadcast rows; the contiguous index of each operand (k, or the row index of a transposed one)
 // a multiple of 4 and at least 4; every split of the reduction a multiple of 4 long
@@ -742,7 +748,7 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
     a.evec = I % 4 == 0 && a.yvec && (!bias || aligned16(bias, 4)) && (!mask || aligned16(mask, ldm));
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);   // STTODE_TGEMM=0: the generic kernels (A/B)
-    if (tg_on && cols > 2048) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
+    if (tg_on && cols > tg_min_cols()) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
         TG g;
         g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
         g.M = cols; g.N = I; g.Kt = J; g.adiv = xdiv; g.bkdiv = 1; g.ones_row = -1;
@@ -911,7 +917,7 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
-    if (tg_on && cols > 2048) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
+    if (tg_on && cols > tg_min_cols()) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
         std::lock_guard<std::mutex> lk(g_red_mu);
         TG g;
         if (tg_wgrad_fill(g, dY, ldy, X, ldx, xdiv, dW, ldw, db, cols, N, K, scratch, scratch_floats, 480, stream)) {
@@ -942,7 +948,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     STT_REQUIRE(cols > 0 && N > 0 && K > 0 && Kdx > 0 && Kdx <= K && xdiv > 0, "sttode_tlinear_bwd: bad sizes");
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
     static const bool fuse_on = !(getenv("STTODE_TGEMM_BWD") && atoi(getenv("STTODE_TGEMM_BWD")) == 0);   // =0: the two products as two launches (A/B)
-    if (tg_on && fuse_on && cols > 2048 && xdiv == 1) {   // batch sizes: both products of the layer's backward in ONE launch
+    if (tg_on && fuse_on && cols > tg_min_cols() && xdiv == 1) {   // batch sizes: both products of the layer's backward in ONE launch
         STT_REQUIRE(ldy >= N && ldx >= K && ldgw >= K && ldw >= K && lddx >= Kdx, "sttode_tlinear_bwd: leading dimension smaller than the row length");
         std::lock_guard<std::mutex> lk(g_red_mu);
         TG gx;
