@@ -166,54 +166,100 @@ class Engine:
     # ---------------------------------------------------------------- encoder trunk (PastEncoder / FutureEncoder shared part)
     def trunk_fwd(self, pre, enc_in, last, feat, drop_mask):
         """enc_in [n,T,4] -> feat[:, :64] = ftraj_input, feat[:, 64:128] = ODE encoder output.  Returns the tape."""
+        return self.trunk_fwd_multi([(pre, enc_in, last, feat, drop_mask)])[0]
+
+    def trunk_fwd_multi(self, items):
+        """Forward of one or several trunks (past and future encoder: the same layers, separate weights, independent of each other).  Scene
+        batches with T <= 12: each trunk is ONE launch (csrc/train_trunk.hip), two of them inside a group one launch together.  Otherwise
+        (NBA: attention over the batch) layer by layer, layer i of every trunk inside one group -- one launch at scene sizes."""
         P, net = self.P, self.net
-        n, T = enc_in.shape[0], enc_in.shape[1]
-        t = {'n': n, 'T': T, 'pre': pre, 'feat': feat}
-        X0 = enc_in.reshape(n * T, 4)
-        if net._mode != 'nba' and T <= 12 and self.fused_trunk:
-            return self._trunk_fwd_fused(t, X0, last, feat, drop_mask)
-        posin = self.new(n * T, 128)
-        self.lin(X0, P[pre + 'input_fc.weight'], P[pre + 'input_fc.bias'], out=posin[:, :64])
-        pe = getattr(net, pre[:-1]).pos_encoder.pe
-        capi.call('sttode_rows_copy', posin[:, 64:], 128, pe, 64, n * T, 64, 1, T, self.st)
-        tp = self.lin(posin, P[pre + 'pos_encoder.fc.weight'], P[pre + 'pos_encoder.fc.bias'])
-        if drop_mask is not None:                       # nn.Dropout(0.1) of PositionalAgentEncoding (model/STTODE.py:140,176)
-            self.ew(EW_MUL, tp, tp, drop_mask)
-        h3in = self.zeros(n, 68)
-        self.lin(tp.view(n, T * 64), P[pre + 'input_fc2.weight'], P[pre + 'input_fc2.bias'], out=h3in[:, :64])
-        h3in[:, 66] = self.hold(last.to(torch.float32))  # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
-        x = feat[:, :64]
-        self.lin(h3in[:, :67], P[pre + 'input_fc3.weight'], P[pre + 'input_fc3.bias'], out=x)
-        a = pre + _ATT
-        qkv = self.lin(x, P[a + 'self_attn.temporal_attention_before.in_proj_weight'],
-                       P[a + 'self_attn.temporal_attention_before.in_proj_bias'])
-        L, Nb = (net.batch_size, net._N) if net._mode == 'nba' else (1, n)
-        if L > 1:
-            attn = self.new(n, 64)
-            e = qkv.element_size()
-            capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, None, None, L, L,
-                      Nb, Nb * 192, 192, Nb * 192, 192, Nb * 192, 192, Nb * 64, 64, 1.0, 8.0 ** -0.5, self.st)
-        else:
-            attn = qkv[:, 128:]                         # softmax over a single key == 1  =>  output == v
-        ao = self.lin(attn, P[a + 'self_attn.temporal_attention_before.out_proj.weight'],
-                      P[a + 'self_attn.temporal_attention_before.out_proj.bias'])
-        tt = self.lin(ao, P[a + 'self_attn.temporal_info.weight'], P[a + 'self_attn.temporal_info.bias'], act='tanh')
-        ss = self.lin(ao, P[a + 'self_attn.temporal_gate.weight'], P[a + 'self_attn.temporal_gate.bias'], act='sigmoid')
-        gated = self.new(n, 64)
-        self.ew(EW_MUL, gated, tt, ss)
-        xc = x.contiguous()
-        h, xh1, rs1 = self.new(n, 64), self.new(n, 64), self.new(n)
-        capi.call('sttode_add_ln_fwd', xc, gated, P[a + 'norm1.weight'], P[a + 'norm1.bias'], h, xh1, rs1, n, self.st)
-        f1 = self.lin(h, P[a + 'linear1.weight'], P[a + 'linear1.bias'], act='relu')
-        f2 = self.lin(f1, P[a + 'linear2.weight'], P[a + 'linear2.bias'])
-        y, xh2, rs2 = self.new(n, 64), self.new(n, 64), self.new(n)
-        capi.call('sttode_add_ln_fwd', h, f2, P[a + 'norm2.weight'], P[a + 'norm2.bias'], y, xh2, rs2, n, self.st)
-        ode = self.new(n, 64)
-        self.ew(EW_EULER_FWD, ode, xc, y, f0=net.ODE_TIME)
-        feat[:, 64:128] = ode
-        t.update(X0=X0, posin=posin, tp=tp, drop=drop_mask, h3in=h3in, xc=xc, qkv=qkv, attn=attn, ao=ao, tt=tt, ss=ss, h=h, xh1=xh1,
-                 rs1=rs1, f1=f1, xh2=xh2, rs2=rs2, ode=ode, L=L, Nb=Nb)
-        return t
+        S = []
+        for pre, enc_in, last, feat, drop_mask in items:
+            n, T = enc_in.shape[0], enc_in.shape[1]
+            S.append(dict(t={'n': n, 'T': T, 'pre': pre, 'feat': feat}, pre=pre, a=pre + _ATT, n=n, T=T, X0=enc_in.reshape(n * T, 4), last=last, feat=feat,
+                          drop=drop_mask))
+        if net._mode != 'nba' and all(s['T'] <= 12 for s in S) and self.fused_trunk:
+            with (self.group() if len(S) > 1 else contextlib.nullcontext()):
+                return [self._trunk_fwd_fused(s['t'], s['X0'], s['last'], s['feat'], s['drop']) for s in S]
+        L, Nb = (net.batch_size, net._N) if net._mode == 'nba' else (1, None)
+        with self.group():
+            for s in S:
+                s['posin'] = self.new(s['n'] * s['T'], 128)
+                self.lin(s['X0'], P[s['pre'] + 'input_fc.weight'], P[s['pre'] + 'input_fc.bias'], out=s['posin'][:, :64])
+        for s in S:
+            pe = getattr(net, s['pre'][:-1]).pos_encoder.pe
+            capi.call('sttode_rows_copy', s['posin'][:, 64:], 128, pe, 64, s['n'] * s['T'], 64, 1, s['T'], self.st)
+        with self.group():
+            for s in S:
+                s['tp'] = self.lin(s['posin'], P[s['pre'] + 'pos_encoder.fc.weight'], P[s['pre'] + 'pos_encoder.fc.bias'])
+        with self.group():
+            for s in S:
+                if s['drop'] is not None:                        # nn.Dropout(0.1) of PositionalAgentEncoding (model/STTODE.py:140,176)
+                    self.ew(EW_MUL, s['tp'], s['tp'], s['drop'])
+        for s in S:
+            s['h3in'] = self.zeros(s['n'], 68)
+            s['h3in'][:, 66] = self.hold(s['last'].to(torch.float32))   # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
+        with self.group():
+            for s in S:
+                self.lin(s['tp'].view(s['n'], s['T'] * 64), P[s['pre'] + 'input_fc2.weight'], P[s['pre'] + 'input_fc2.bias'], out=s['h3in'][:, :64])
+        with self.group():
+            for s in S:
+                s['x'] = s['feat'][:, :64]
+                self.lin(s['h3in'][:, :67], P[s['pre'] + 'input_fc3.weight'], P[s['pre'] + 'input_fc3.bias'], out=s['x'])
+        with self.group():
+            for s in S:
+                sa = s['a'] + 'self_attn.temporal_attention_before.'
+                s['qkv'] = self.lin(s['x'], P[sa + 'in_proj_weight'], P[sa + 'in_proj_bias'])
+        for s in S:
+            n, qkv = s['n'], s['qkv']
+            if L > 1:
+                s['attn'] = self.new(n, 64)
+                e = qkv.element_size()
+                capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, s['attn'], None, None, L, L,
+                          Nb, Nb * 192, 192, Nb * 192, 192, Nb * 192, 192, Nb * 64, 64, 1.0, 8.0 ** -0.5, self.st)
+            else:
+                s['attn'] = qkv[:, 128:]                          # softmax over a single key == 1  =>  output == v
+        with self.group():
+            for s in S:
+                sa = s['a'] + 'self_attn.temporal_attention_before.'
+                s['ao'] = self.lin(s['attn'], P[sa + 'out_proj.weight'], P[sa + 'out_proj.bias'])
+        with self.group():                                       # temporal_info and temporal_gate read the same input: four layers, one launch
+            for s in S:
+                a = s['a']
+                s['tt'] = self.lin(s['ao'], P[a + 'self_attn.temporal_info.weight'], P[a + 'self_attn.temporal_info.bias'], act='tanh')
+                s['ss'] = self.lin(s['ao'], P[a + 'self_attn.temporal_gate.weight'], P[a + 'self_attn.temporal_gate.bias'], act='sigmoid')
+        with self.group():
+            for s in S:
+                s['gated'] = self.new(s['n'], 64)
+                self.ew(EW_MUL, s['gated'], s['tt'], s['ss'])
+        for s in S:
+            a, n = s['a'], s['n']
+            s['xc'] = s['x'].contiguous()
+            s['h'], s['xh1'], s['rs1'] = self.new(n, 64), self.new(n, 64), self.new(n)
+            capi.call('sttode_add_ln_fwd', s['xc'], s['gated'], P[a + 'norm1.weight'], P[a + 'norm1.bias'], s['h'], s['xh1'], s['rs1'], n, self.st)
+        with self.group():
+            for s in S:
+                s['f1'] = self.lin(s['h'], P[s['a'] + 'linear1.weight'], P[s['a'] + 'linear1.bias'], act='relu')
+        with self.group():
+            for s in S:
+                s['f2'] = self.lin(s['f1'], P[s['a'] + 'linear2.weight'], P[s['a'] + 'linear2.bias'])
+        for s in S:
+            a, n = s['a'], s['n']
+            s['y'], s['xh2'], s['rs2'] = self.new(n, 64), self.new(n, 64), self.new(n)
+            capi.call('sttode_add_ln_fwd', s['h'], s['f2'], P[a + 'norm2.weight'], P[a + 'norm2.bias'], s['y'], s['xh2'], s['rs2'], n, self.st)
+        with self.group():
+            for s in S:
+                s['ode'] = self.new(s['n'], 64)
+                self.ew(EW_EULER_FWD, s['ode'], s['xc'], s['y'], f0=net.ODE_TIME)
+        out = []
+        for s in S:
+            s['feat'][:, 64:128] = s['ode']
+            t = s['t']
+            t.update(X0=s['X0'], posin=s['posin'], tp=s['tp'], drop=s['drop'], h3in=s['h3in'], xc=s['xc'], qkv=s['qkv'], attn=s['attn'], ao=s['ao'],
+                     tt=s['tt'], ss=s['ss'], h=s['h'], xh1=s['xh1'], rs1=s['rs1'], f1=s['f1'], xh2=s['xh2'], rs2=s['rs2'], ode=s['ode'], L=L,
+                     Nb=Nb if Nb is not None else s['n'])
+            out.append(t)
+        return out
 
     def _trunk_fwd_fused(self, t, X0, last, feat, drop_mask):
         """The same forward and the same tape in ONE launch (csrc/train_trunk.hip, attention length 1): the step is bound by the number of
@@ -517,12 +563,9 @@ class Engine:
 
         def f_past():
             ws, hcat = V['ws'], V['hcat']
-            if _PAIRED and not self.multi:
-                # (a group holds INDEPENDENT launches only: the fused trunk forward is one launch per trunk, the layer-by-layer form is not)
-                fused = net._mode != 'nba' and Tp <= 12 and Tf <= 12 and self.fused_trunk
-                with (self.group() if fused else contextlib.nullcontext()):
-                    V['tf'] = self.trunk_fwd('future_encoder.', V['enc_f'], ws['last'], hcat[:, 128:], drop_future)
-                    V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+            if _PAIRED and not self.multi:                           # one stream: both trunks together (grouped launches)
+                V['tf'], V['tp'] = self.trunk_fwd_multi([('future_encoder.', V['enc_f'], ws['last'], hcat[:, 128:], drop_future),
+                                                         ('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)])
             else:
                 V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
 
