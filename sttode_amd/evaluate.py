@@ -11,20 +11,45 @@ import torch
 
 
 @torch.no_grad()
-def eval_scenes(model, dataset, traj_scale=1.0, scenes_per_call=512, z_fn=None):
+def eval_scenes(model, dataset, traj_scale=1.0, scenes_per_call=512, z_fn=None, pipelined=True):
     """dataset: sttode_amd.datasets.TrajectoryDataset / SDD_Dataset (or anything with ``scene_batch(indices)``).
-    Returns (ADE, FDE, n_agents).  ``z_fn(n_rows)`` may supply latents (tests); otherwise torch.randn like the reference."""
+    Returns (ADE, FDE, n_agents).  ``z_fn(n_rows)`` may supply latents (tests); otherwise torch.randn like the reference.
+    ``pipelined`` (default): the calls go through ``inference_async`` -- up to four in flight, best-of-K ADE / FDE computed by the calls' own
+    trajectory groups (what bench.py times) -- instead of one serial ``inference()`` + ``best_of_k`` per batch."""
     tot_a = tot_f = 0.0
     tot_n = 0
+    K, zd = model.args.sample_k, model.args.zdim
+    pend = []
+
+    def finish(h):
+        nonlocal tot_a, tot_f
+        ade, fde = model.best_of_k_async(h, scale=traj_scale)
+        model.wait(h)
+        tot_a += float(ade.double().sum())
+        tot_f += float(fde.double().sum())
     for s0 in range(0, len(dataset), scenes_per_call):
         sb = dataset.scene_batch(range(s0, min(s0 + scenes_per_call, len(dataset))))
         model.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
-        z = z_fn(sb.n_agents * model.args.sample_k) if z_fn is not None else None
+        rows = sb.n_agents * K
+        z = z_fn(rows) if z_fn is not None else torch.randn(rows, zd, device=model.device)
+        tot_n += sb.n_agents
+        if pipelined:
+            if len(model._async_bufs) > 12:                               # batches of ever new sizes: per-shape slot buffers are dropped in time
+                while pend:
+                    finish(pend.pop(0))
+                model.reset_async()
+            pend.append(model.inference_async(z=z, metrics_gt=model._future, metrics_scale=traj_scale))
+            if len(pend) > 4:
+                finish(pend.pop(0))
+            continue
         pred = model.inference(None, z=z)                                  # [K, n, Tf, 2]
         ade, fde = model.best_of_k(pred.permute(1, 0, 2, 3), scale=traj_scale)
         tot_a += float(ade.double().sum())
         tot_f += float(fde.double().sum())
-        tot_n += sb.n_agents
+    while pend:
+        finish(pend.pop(0))
+    if pipelined:
+        model.reset_async()
     return tot_a / tot_n, tot_f / tot_n, tot_n
 
 
