@@ -222,7 +222,8 @@ int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int row
  * K = f0: "+ cur_location", model/STTODE.py:343-344) | 10 p0=p1*(1-p2^2) (tanh backward from its output) | 11 stage-2 latent
  * backward (sampler.py:51-53): dz p0, dlogvar p1, A p2, eps p3 -> dA p4 = dz*eps + dlogvar*2A/(A^2+1e-8); i0 = nz*4 + eps_mode,
  * f0 = K*nz | 12 p0[c,d] = p1 + p2 (+ p3[c / K, d % 2]) (row length i0, K = f0: sum of the blocks' outputs + cur_location) |
- * 13 op 4 on dout = cat(dx0 | dode), rows of p0 with leading dimension i0 (64 features): d = dode*(out p1 > 0), p3 = dx0 + d, p4 = f0*d.
+ * 13 op 4 on dout = cat(dx0 | dode), rows of p0 with leading dimension i0 (64 features): d = dode*(out p1 > 0), p3 = dx0 + d, p4 = f0*d |
+ * 14 p0 = f0*p0 (+ p1) | 15 p0[r, c] += f0*p1[r*ld + c], c < width (width = i0 & 0xffff, ld = i0 >> 16).
  * Inside a group (sttode_tgemm_group) up to four pieces leave as one launch. */
 int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0,
                        void* stream);

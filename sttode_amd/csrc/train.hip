@@ -933,6 +933,12 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     a.S = S;
     a.chunks_per_split = (chunks + S - 1) / S;
     dim3 grid((N + 31) / 32, (K + 1 + 31) / 32, S);
+    if (g_grp.on && S == 1 && cols <= 1024) {   // an open group: a weight gradient alone is a layer backward without input-gradient blocks
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        ts_submit(TLin{}, &a, 1, 1, 0, (int)grid.x, (int)grid.y, (int)(grid.x * grid.y), stream);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(twgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (S > 1) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     STT_HIP(hipGetLastError());
@@ -1109,6 +1115,8 @@ enum {
     EW_TANH_BWD = 10,  // p0[i] = p1[i] * (1 - p2[i]^2)      (p2 = tanh output)
     EW_LATENT_BWD = 11,  // sampler.py:51-53: dz=p0, dlogvar=p1, A=p2, eps p3 (mode i0: 0 none | 1 shared [nz] | 2 per agent) -> dA=p4
     EW_SUM_CUR = 12,   // p0[c, d] = p1 + p2 (+ p3[c / K, d % 2] if p3)   row length i0, K = (int)f0  (Decoder.forward :336-344)
+    EW_SCALE_ADD = 14,       // p0[i] = f0 * p0[i] + (p1 ? p1[i] : 0)
+    EW_AXPY_ROWS = 15,       // p0[r, c] += f0 * p1[r * ld + c], c < width: width = i0 & 0xffff, ld = i0 >> 16 (a column block of a wider matrix)
     EW_EULER_BWD_CAT = 13,   // op 4 reading dout = cat(dx0 | dode) as rows of p0 with leading dimension i0: d = dode * (out(p1) > 0); p3 = dx0 + d; p4 = f0 * d
     EW_RSAMPLE_BWD = 8,  // dz=p0 (in), params p1, eps p2 -> dparams p3 [rows, 2*i0]: dmu += dz ; dlogvar += dz * eps * exp(logvar/2) / 2
 };
@@ -1129,6 +1137,11 @@ static __device__ __forceinline__ void ewise_body(int op, float* p0, const float
             const float d = p1[i] > 0.f ? p0[i] : 0.f;
             p3[i] += d;
             p4[i] = f0 * d;
+        } break;
+        case EW_SCALE_ADD: p0[i] = f0 * p0[i] + (p1 ? p1[i] : 0.f); break;
+        case EW_AXPY_ROWS: {
+            const int width = i0 & 0xffff, ld = i0 >> 16;
+            p0[i] += f0 * p1[(i / width) * ld + i % width];
         } break;
         case EW_EULER_BWD_CAT: {
             const long r = i >> 6;
@@ -1199,7 +1212,7 @@ static void ew_group_forget() { g_ewq.M.n = 0; g_ewq.M.blocks = 0; }
 
 extern "C" int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0,
                                   float f0, void* stream) {
-    STT_REQUIRE(op >= 0 && op <= EW_EULER_BWD_CAT && p0 && count > 0, "sttode_train_ewise: bad argument");
+    STT_REQUIRE(op >= 0 && op <= EW_AXPY_ROWS && p0 && count > 0, "sttode_train_ewise: bad argument");
     if (g_grp.on && count <= (1L << 24)) {   // an open group: queued, leaves with the group's other pieces
         std::lock_guard<std::mutex> lk(g_red_mu);
         EwMulti& M = g_ewq.M;

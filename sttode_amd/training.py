@@ -18,7 +18,7 @@ from . import capi
 from .capi import SttodeError
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
-EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR, EW_EULER_BWD_CAT = 10, 11, 12, 13
+EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR, EW_EULER_BWD_CAT, EW_SCALE_ADD, EW_AXPY_ROWS = 10, 11, 12, 13, 14, 15
 ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
@@ -383,8 +383,9 @@ class Engine:
                 t, pre = s['t'], s['pre']
                 s['dtf'] = self.lin_bwd(s['dtp'], P[pre + 'pos_encoder.fc.weight'], t['posin'], g(pre + 'pos_encoder.fc.weight'),
                                         g(pre + 'pos_encoder.fc.bias'), in_features=64)
-        for s in S:
-            self.wgrad(s['dtf'], s['t']['X0'], g(s['pre'] + 'input_fc.weight'), g(s['pre'] + 'input_fc.bias'))
+        with self.group():
+            for s in S:
+                self.wgrad(s['dtf'], s['t']['X0'], g(s['pre'] + 'input_fc.weight'), g(s['pre'] + 'input_fc.bias'))
 
     # ---------------------------------------------------------------- decoder (Decoder.forward, model/STTODE.py:320-347)
     def mlp_fwd(self, pre, inp):
@@ -497,11 +498,12 @@ class Engine:
         b0 = self.block_fwd(0, past, K, None, pf, z, True, inp=inps[0])
         b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover, inp=inps[1])
         pred = self.new(m, 2 * Tf)
-        self.ew(EW_SUM_CUR, pred, b0['yh'], b1['yh'], cur, i0=2 * Tf, f0=K)
         rec = None
-        if want_recover:
-            rec = self.new(m, 2 * Tp)
-            self.ew(EW_SUM_CUR, rec, b0['xh'], b1['xh'], None, i0=2 * Tp, f0=K)
+        with self.group():                                          # two independent pieces: one launch
+            self.ew(EW_SUM_CUR, pred, b0['yh'], b1['yh'], cur, i0=2 * Tf, f0=K)
+            if want_recover:
+                rec = self.new(m, 2 * Tp)
+                self.ew(EW_SUM_CUR, rec, b0['xh'], b1['xh'], None, i0=2 * Tp, f0=K)
         return dict(b0=b0, b1=b1, n=n, K=K, m=m, pred=pred, rec=rec)
 
     def decoder_bwd(self, d, dpred, drec, dpf, dz, dpf_accumulate=True):
@@ -511,9 +513,7 @@ class Engine:
         din1, dx1 = self.block_bwd(d['b1'], dpred, drec, True)
         # x_1 = x_true - x_hat_0  =>  d x_hat_0 = (d recover) - d x_1
         dxh0 = dx1.view(m, -1)
-        self.ew(EW_AXPY, dxh0, dxh0, f0=-2.0)                       # dxh0 = -dx1
-        if drec is not None:
-            self.ew(EW_AXPY, dxh0, drec, f0=1.0)
+        self.ew(EW_SCALE_ADD, dxh0, drec, f0=-1.0)                  # dxh0 = -dx1 (+ drec)
         din0, _ = self.block_bwd(d['b0'], dpred, dxh0, False)
         self.ew(EW_AXPY, din0, din1, f0=1.0)
         capi.call('sttode_rows_reduce', dpf, _ld(dpf), din0, 256, n, 128, K, int(dpf_accumulate), self.st)
@@ -642,7 +642,9 @@ class Engine:
 
         def b_past():
             dpf = W['dpf']
-            self.ew(EW_AXPY, dpf, self.hold(W['dhcat'][:, :128].contiguous()), f0=1.0)
+            dh = W['dhcat']
+            assert dh.stride(1) == 1 and dh.stride(0) < 65536
+            self.ew(EW_AXPY_ROWS, dpf, dh, i0=(dh.stride(0) << 16) | 128, f0=1.0, count=n * 128)   # dpf += dhcat[:, :128] (read where it is)
             if _PAIRED and not self.multi:                              # one stream: both trunks layer by layer, grouped launches
                 self.trunk_bwd_multi([(T['tf'], W['dhcat'][:, 128:]), (T['tp'], dpf)])
             else:
