@@ -335,6 +335,21 @@ class STTODENet(nn.Module):
         scene about ``scene_orig`` (``theta`` may be injected; otherwise torch.rand(1)*2pi, or a multiple of pi/12 when
         ``discrete_rot``).  This is data preparation on a [N, T, 2] track, done with torch ops before the kernels run."""
         dev = self.device
+        # the evaluation loop's call (test.py:171-188: eval mode, the loader's float32 host tensors): staged natively, attributes set directly --
+        # every microsecond here is on the loop's critical path (the GPU idles until inference() has enqueued its launch)
+        if (not self.training and theta is None and type(pre_motion) is torch.Tensor and type(fut_motion) is torch.Tensor
+                and pre_motion.dtype is torch.float32 and fut_motion.dtype is torch.float32 and not pre_motion.is_cuda and not fut_motion.is_cuda
+                and dev.type == 'cuda' and pre_motion.dim() == 3 and pre_motion.shape[1] == 2 and pre_motion.shape[2] == self.args.past_length
+                and pre_motion.shape[0] > 0 and fut_motion.shape == (pre_motion.shape[0], 2, self.args.future_length)):
+            N = pre_motion.shape[0]
+            past, fut = self._stage_scene(pre_motion, fut_motion)
+            ptr = self._ptr_cache.get(N)
+            if ptr is None or not _on(ptr, dev):
+                ptr = self._ptr_cache[N] = torch.tensor([0, N], dtype=torch.int32).to(dev)
+            d = self.__dict__
+            d['_past'], d['_future'], d['_scene_ptr'], d['_mode'], d['batch_size'], d['agent_num'], d['_S'], d['_N'] = past, fut, ptr, 'scenes', 1, N, 1, 0
+            d['pre_motion_mask'], d['fut_motion_mask'] = pre_motion_mask, fut_motion_mask
+            return
 
         def to_dev(x):      # [N, 2, T] loader layout -> [N, T, 2]; a host tensor is transposed on the host (one H2D copy, no kernel)
             x = torch.as_tensor(x, dtype=torch.float32)
@@ -390,7 +405,11 @@ class STTODENet(nn.Module):
         need = N * (Tp + Tf) * 2
         dev = torch.empty(need, dtype=torch.float32, device=self.device)
         # transposes into a pinned ring slot + ONE asynchronous H2D copy, natively (csrc/frontend.hip: sttode_stage_scene)
-        capi.call('sttode_stage_scene', pre.contiguous(), fut.contiguous() if fut is not None else None, N, Tp, Tf, dev, capi.stream_ptr())
+        if capi.TIMING is None and fut is not None:
+            if capi.lib().sttode_stage_scene(pre.contiguous().data_ptr(), fut.contiguous().data_ptr(), N, Tp, Tf, dev.data_ptr(), capi.stream_ptr()):
+                raise capi.SttodeError('sttode_stage_scene failed: ' + capi.lib().sttode_last_error().decode())
+        else:
+            capi.call('sttode_stage_scene', pre.contiguous(), fut.contiguous() if fut is not None else None, N, Tp, Tf, dev, capi.stream_ptr())
         return dev[:N * Tp * 2].view(N, Tp, 2), (dev[N * Tp * 2:].view(N, Tf, 2) if fut is not None else None)
 
     def set_scene_batch(self, past, future, scene_ptr):
@@ -666,7 +685,12 @@ class STTODENet(nn.Module):
         st = capi.stream_ptr()
         for attempt in (0, 1):
             if self._mode == 'scenes':
-                capi.call('sttode_inference_scenes', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, st)
+                if capi.TIMING is None:                            # (the generic capi.call: ~3 us of argument conversion on the loop's critical path)
+                    if capi.lib().sttode_inference_scenes(nat.h, self._past.data_ptr(), self._scene_ptr.data_ptr(), n, S, z.data_ptr(),
+                                                          buf.data_ptr(), pred.data_ptr(), st):
+                        raise capi.SttodeError('sttode_inference_scenes failed: ' + capi.lib().sttode_last_error().decode())
+                else:
+                    capi.call('sttode_inference_scenes', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, st)
             else:
                 capi.call('sttode_inference_nba', nat.h, self._past, self.batch_size, self._N, z, buf, pred, st)
             # the weight-version comparison runs while the GPU works: on the one-scene evaluation loop (test.py:171-188) the host is the
