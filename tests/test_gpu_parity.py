@@ -112,6 +112,39 @@ def test_futures_to_host_by_the_copy_kernel_are_the_device_futures():
         capi.call('sttode_copy_to_host', mine.data_ptr() + 4, buf, 64, 8, capi.stream_ptr())   # unaligned destination
 
 
+@pytest.mark.gpu
+def test_eval_scenes_pipelined_equals_serial_over_many_batch_shapes():
+    """evaluate.eval_scenes over a stored dataset whose 22 batches all have different agent counts (chain-sized: lagged launches, fused
+    metrics): the pipelined loop -- which has to drop its per-shape slot buffers on the way -- returns the serial loop's ADE / FDE."""
+    from sttode_amd import datasets, scenes
+    from sttode_amd.evaluate import eval_scenes
+    _gpu()
+
+    class DS(datasets._SceneDataset):
+        def __init__(self):
+            sb = scenes.make_scene_batch(range(3000, 3000 + 22 * 70), 'eth')
+            cnt = np.diff(sb.scene_ptr)
+            ends = np.cumsum(cnt)
+            self.seq_start_end = list(zip((ends - cnt).tolist(), ends.tolist()))
+            self.num_seq = len(cnt)
+            self.obs_traj = torch.from_numpy(np.ascontiguousarray(sb.past.transpose(0, 2, 1)))
+            self.pred_traj = torch.from_numpy(np.ascontiguousarray(sb.future.transpose(0, 2, 1)))
+    ds = DS()
+    m = hip_model('eth')
+    zall = scenes.latents(77, int(ds.obs_traj.shape[0]))
+    pos = [0]
+
+    def z_fn(rows):                      # the same latents for the same batch in both loops
+        z = torch.from_numpy(zall[pos[0]:pos[0] + rows])
+        pos[0] += rows
+        return z
+    a_p, f_p, n_p = eval_scenes(m, ds, scenes_per_call=70, z_fn=z_fn, pipelined=True)
+    pos[0] = 0
+    a_s, f_s, n_s = eval_scenes(m, ds, scenes_per_call=70, z_fn=z_fn, pipelined=False)
+    assert n_p == n_s == ds.obs_traj.shape[0]
+    assert abs(a_p - a_s) <= 1e-5 * abs(a_s) and abs(f_p - f_s) <= 1e-5 * abs(f_s), (a_p, a_s, f_p, f_s)
+
+
 def test_library_loaded_and_fails_loudly_on_cpu():
     from sttode_amd import STTODENet, capi
     _gpu()
