@@ -76,23 +76,53 @@ def oracle_sampler(dataset='eth', Tp=8, Tf=12):
     return s
 
 
-def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode, grads=False):
+def yardstick_close(got, ref, f64, rtol, atol, what='', factor=4.0):
+    """Host-independent comparison of two correct fp32 evaluations (``got``: the oracle on THIS host, ``ref``: the reference's fixture made on
+    the authoring container) of an ill-conditioned quantity: each may sit as far from the rounding-free value as fp32 summation order
+    puts it, so the band is  atol + rtol |ref| + factor * max|ref - f64|  (``f64``: the same graph evaluated in float64 here)."""
+    got, ref, f64 = (np.asarray(v, np.float64) for v in (got, ref, f64))
+    assert got.shape == ref.shape == f64.shape, (what, got.shape, ref.shape, f64.shape)
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all(), what
+    spread = np.abs(ref - f64)[fin].max() if fin.any() else 0.0
+    err = np.abs(got - ref)[fin]
+    bound = atol + rtol * np.abs(ref)[fin] + factor * spread
+    assert (err <= bound).all(), f'{what}: max err {err.max():.3e}, fixture-vs-float64 spread {spread:.3e}'
+
+
+def oracle_sampler_case(g, tag, dataset, Tp, Tf, mode, grads=False, double=False):
     """Runs one sampler.npz case on the oracle: returns (dec, mu, logvar, pred_traj, [total, kld, diverse]) and, with
-    ``grads``, additionally name -> gradient of the Sampler's parameters (trainsampler.py:148-150)."""
+    ``grads``, additionally name -> gradient of the Sampler's parameters (trainsampler.py:148-150).
+    ``double``: the same graph in float64 (the rounding-free yardstick for two fp32 evaluations)."""
     from oracle import sampler_ref as SR
     net, smp = oracle_model(dataset, Tp, Tf), oracle_sampler(dataset, Tp, Tf)
+    if double:                                       # fresh float64 copies (the cached fp32 oracle keeps graph tensors as attributes)
+        from oracle.sttode_ref import STTODENetRef
+        net64 = STTODENetRef(make_args(dataset, Tp, Tf)).eval()
+        net64.load_state_dict(net.state_dict(), strict=True)
+        net, smp = net64.double(), smp.double()
     inp, fut = sampler_case_inputs(g, tag, dataset)
     smp.share_eps = mode != 'peragent'
     smp.zero_grad()
-    with torch.set_grad_enabled(grads):
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64 if double else torch.float32)
+    cast = (lambda t: t.double()) if double else (lambda t: t)
+    try:
+      with torch.set_grad_enabled(grads):
         if dataset == 'eth':
             net.set_data(None, torch.from_numpy(inp['obs']), torch.from_numpy(inp['pred']))
         else:
             net.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp['data'].items()})
-        dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=torch.from_numpy(g[f'{tag}_{mode}_eps']))
-        tot, ld = SR.compute_sampler_loss(smp.args, torch.from_numpy(fut), dec.reshape(-1, 20, Tf, 2), vd, sd, {'weight': 1, 'scale': 1.0})
+        if double:
+            for attr in ('inputs', 'inputs_for_posterior', 'past_traj', 'future_traj', 'cur_location', 'scene_orig'):
+                if isinstance(getattr(net, attr, None), torch.Tensor):
+                    setattr(net, attr, getattr(net, attr).double())
+        dec, sd, vd, aw = smp.forward(net, mean=(mode == 'mean'), eps=cast(torch.from_numpy(g[f'{tag}_{mode}_eps'])))
+        tot, ld = SR.compute_sampler_loss(smp.args, cast(torch.from_numpy(fut)), dec.reshape(-1, 20, Tf, 2), vd, sd, {'weight': 1, 'scale': 1.0})
         if grads:
             tot.backward()
+    finally:
+        torch.set_default_dtype(prev)
     res = (dec.detach().numpy(), sd.mu.detach().numpy(), sd.logvar.detach().numpy(), aw.detach().numpy(),
            np.array([float(tot.detach()), float(ld['kld'].detach()), float(ld['diverse'].detach())]))
     if grads:

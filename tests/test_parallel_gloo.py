@@ -44,7 +44,9 @@ def _worker(rank, world, port, q):
     ade, fde = best_of_k_ade_fde(pred.numpy(), local.future)
     g = parallel.reduce_metrics(float(ade.sum()), float(fde.sum()), local.n_agents)
     if rank == 0:
-        q.put((full.numpy(), g))
+        # the unsharded reference from the SAME process settings (thread count, BLAS blocking) as the sharded computation: the bitwise claim
+        # is about the shard / gather logic, not about two hosts' (or two thread counts') fp32 summation orders
+        q.put((full.numpy(), g, _local_predictions(sb, z)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,14 +60,14 @@ def test_shard_gather_equals_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, (ade, fde, cnt) = q.get(timeout=240)
+    full, (ade, fde, cnt), ref = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     sb = scenes.make_scene_batch(range(7), 'sdd')
-    z = scenes.latents(5, sb.n_agents)
-    ref = _local_predictions(sb, z)
     assert full.shape == ref.shape and np.array_equal(full, ref)
+    # ... and the parent's own evaluation (whatever its thread count) agrees to fp32 rounding
+    np.testing.assert_allclose(full, _local_predictions(sb, scenes.latents(5, sb.n_agents)), rtol=1e-4, atol=1e-4)
     ra, rf = best_of_k_ade_fde(ref, sb.future)
     assert cnt == sb.n_agents and abs(ade - ra.mean()) < 1e-6 and abs(fde - rf.mean()) < 1e-6
 
@@ -111,7 +113,8 @@ def _empty_rank_worker(rank, world, port, q):
     z = scenes.latents(6, sb.n_agents)
     pred, metrics = parallel.infer_sharded(_OracleAsModel(), sb, rank, world, z=z)
     if rank == 0:
-        q.put((pred.numpy(), metrics, [parallel.shard_scene_batch(sb, r, world)[0].n_agents for r in range(world)]))
+        q.put((pred.numpy(), metrics, [parallel.shard_scene_batch(sb, r, world)[0].n_agents for r in range(world)],
+               _local_predictions(sb, z)))                        # (the reference from the same process settings: see _worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,13 +130,12 @@ def test_more_ranks_than_scenes_does_not_hang():
     procs = [ctx.Process(target=_empty_rank_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    full, (ade, fde, cnt), loads = q.get(timeout=240)
+    full, (ade, fde, cnt), loads, ref = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     sb = scenes.make_scene_batch(range(40, 42), 'sdd')
     assert loads[2] == 0 and loads[0] > 0 and loads[1] > 0 and sum(loads) == sb.n_agents
-    ref = _local_predictions(sb, scenes.latents(6, sb.n_agents))
     assert np.array_equal(full, ref.transpose(1, 0, 2, 3))
     ra, rf = best_of_k_ade_fde(ref, sb.future)
     assert cnt == sb.n_agents and abs(ade - ra.mean()) < 1e-6 and abs(fde - rf.mean()) < 1e-6
