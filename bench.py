@@ -72,7 +72,7 @@ def self_launch(args):
     """--gpus N > 1 without a launcher: start ``torch.distributed.run`` with N ranks as a child and exit with its status.
     Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise HIP on this image)."""
     import torch
-    backend_cpu = bool(args.selftest_dist)
+    backend_cpu = bool(args.selftest_dist) or args.dist_backend == 'gloo'   # (gloo rehearsal: the ranks share cuda:0)
     have = torch.cuda.device_count()
     if not backend_cpu and have < args.gpus:
         sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run fewer ranks '
@@ -100,6 +100,13 @@ def init_dist(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.selftest_dist:
+            dist.init_process_group('gloo')
+        elif args.dist_backend == 'gloo':
+            # REHEARSAL (hidden flag, tests/test_gpu_parity.py): every rank computes on cuda:0, the collectives run under gloo on host copies --
+            # every multi-rank branch of this file (legs, train with average_gradients, the gather leg) executes with HIP kernels on a
+            # one-GPU box.  Its numbers are not a scaling measurement.
+            local = 0
+            torch.cuda.set_device(0)
             dist.init_process_group('gloo')
         else:
             torch.cuda.set_device(local)
@@ -162,15 +169,23 @@ LEGS = {
 }
 
 
+def allreduce(dist, t, op=None):
+    """dist.all_reduce of a device tensor under whatever backend the group runs on (gloo rehearsal: through a host copy)."""
+    import torch.distributed as td
+    op = td.ReduceOp.SUM if op is None else op
+    if dist.get_backend() == 'gloo' and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 class Leg:
-    FUSED_METRICS = os.environ.get('STTODE_FUSED_METRICS', '1') != '0'
-    # futures to the host (value_incl_d2h): 'kernel' (default) = STTODENet.futures_to_host_async: a few persistent workgroups copy them to pinned
-    # memory on the call's own stream (75-76 M traj/s beside a 77 M headline, profiles/r04/d2h_copy_kernel_ab.txt); experiment switches: 'own' =
-    # hipMemcpyAsync on the call's own stream (63 M: the copy costs the pipeline its whole duration), 'copy' = on a dedicated stream (55 M),
-    # 'zero' = the launch writes them straight to pinned host memory (inference_async(pred_host=True): 13-45 M; d2h_placement_ab.txt)
-    D2H = os.environ.get('STTODE_BENCH_D2H', 'kernel')
-    D2H_WGS = int(os.environ.get('STTODE_BENCH_D2H_WGS', '8'))
-    H2D = os.environ.get('STTODE_BENCH_H2D', 'memcpy')   # the step's inputs: 'memcpy' (default: hipMemcpyAsync inside the step) | 'kernel' | 'resident' (experiments)
+    # futures to the host (value_incl_d2h) = STTODENet.futures_to_host_async: a few persistent workgroups copy them to pinned memory on the
+    # call's own stream (75-76 M traj/s beside a 77 M headline; the alternatives measured in round 4 -- hipMemcpyAsync on the call's stream 63 M,
+    # on a dedicated stream 55 M, zero-copy 13-45 M -- are in profiles/r04/d2h_placement_ab.txt and profiles/exp_d2h_placement.py, not here)
     STREAMS = 3      # pipeline streams the lagged calls rotate over (the library default); calls in flight = 2 x STREAMS slots
 
     def __init__(self, name, rank, dev, size=None):
@@ -218,6 +233,7 @@ class Leg:
         self.slots = [views(b) for b in self.slot_bufs]
         self.n_dev = torch.tensor(float(self.n), dtype=torch.float32, device=dev)
         self.calls = 0
+        self.gather_counts = None
         self.pending = []
         self.d2h_bufs = None
         self.model.packed()
@@ -225,12 +241,7 @@ class Leg:
     def _load(self):
         """H2D of this step's inputs (pinned -> one of two device slots, on the caller's stream) + the data-entry call."""
         slot = self.slots[self.calls % self.depth]
-        if Leg.H2D == 'memcpy' or self.calls < self.depth:
-            self.slot_bufs[self.calls % self.depth].copy_(self.host_buf, non_blocking=True)
-        elif Leg.H2D == 'kernel':                                   # (experiment: the same bytes by a few persistent workgroups reading pinned memory)
-            from sttode_amd import capi
-            b = self.slot_bufs[self.calls % self.depth]
-            capi.call('sttode_copy_to_host', b, self.host_buf, (b.numel() // 16) * 16, 4, capi.stream_ptr())
+        self.slot_bufs[self.calls % self.depth].copy_(self.host_buf, non_blocking=True)
         self.calls += 1
         if self.kind == 'scenes':
             self.model.set_scene_batch(slot[0], slot[1], slot[2])
@@ -244,17 +255,25 @@ class Leg:
         self.last_pred = h['pred']
         self.unsettled = h
         out = self.model.best_of_k_async(h, gt=h['gt'])        # per-agent (ade, fde) of the slot; summed ONCE, after the last step
-        if self.d2h_bufs is not None and Leg.D2H != 'zero':
-            if Leg.D2H == 'kernel':                             # by a few persistent workgroups on ITS stream, behind its groups (default)
-                self.model.futures_to_host_async(h, out=self.d2h_bufs[h['slot'] % len(self.d2h_bufs)], workgroups=Leg.D2H_WGS)
-            elif Leg.D2H == 'own':                              # D2H of the call's futures on ITS stream, behind its groups and metrics
-                with torch.cuda.stream(h['stream']):
-                    self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
-            else:                                               # ... or on a copy stream of its own that waits for the call's event
-                with torch.cuda.stream(self.copy_stream):
-                    self.model.wait(h)
-                    self.d2h_bufs[h['slot'] % len(self.d2h_bufs)].copy_(h['pred'], non_blocking=True)
+        if self.d2h_bufs is not None:                           # by a few persistent workgroups on ITS stream, behind its groups
+            self.model.futures_to_host_async(h, out=self.d2h_bufs[h['slot'] % len(self.d2h_bufs)], workgroups=8)
+        if self.gather_counts is not None:
+            self._gather(h)
         return out
+
+    def _gather(self, h):
+        """All-gather of a finished call's futures on the COMMUNICATION stream: it waits for the call's event (sttode_wait: no kernel), later
+        calls keep launching under it; `gather_counts` were exchanged once before the region -- no count collective, no .tolist() sync per step.
+        The slot's next user waits for this gather's event before its launch may overwrite the futures (step())."""
+        import torch
+        from sttode_amd import parallel
+        with torch.cuda.stream(self.comm_stream):
+            self.model.wait(h)
+            self.gathered = parallel.gather_futures(h['pred'], counts=self.gather_counts, reuse=True)
+            ev = self.gather_events.get(h['slot'])
+            if ev is None:
+                ev = self.gather_events[h['slot']] = torch.cuda.Event()
+            ev.record(self.comm_stream)
 
     def settle(self):
         """(an event wait on the caller's stream, no kernel) the latest finished call's launch and metrics are complete: its futures may be
@@ -285,11 +304,14 @@ class Leg:
         if st is None:
             raise RuntimeError('bench.py: the workload does not take the pipelined chain form')
         with torch.cuda.stream(st):
+            if self.gather_counts is not None:                  # the slot this call takes: its previous futures have been gathered
+                ev = self.gather_events.get(self.model._async_calls % self.depth)
+                if ev is not None:
+                    st.wait_event(ev)
             self._load()
             # latents z ~ N(0, I) like Normal.rsample in the reference, drawn by the call's own launch; best-of-K ADE / FDE against the
-            # batch's futures computed by the call's trajectory groups (STTODE_FUSED_METRICS=0: a best_of_k kernel on the call's stream)
-            h = self.model.inference_async(metrics_gt=self.model._future if Leg.FUSED_METRICS else None,
-                                           pred_host=self.d2h_bufs is not None and Leg.D2H == 'zero')
+            # batch's futures computed by the call's trajectory groups
+            h = self.model.inference_async(metrics_gt=self.model._future)
         h['gt'] = self.model._future
         self.pending.append(h)
         return self._finish(self.pending.pop(0)) if len(self.pending) > Leg.STREAMS else None
@@ -310,8 +332,18 @@ class Leg:
         dev = self.dev
         hostbuf = torch.empty((self.n, K, self.Tf, 2), dtype=torch.float32).pin_memory() if d2h else None   # contiguous D2H targets
         self.d2h_bufs = [hostbuf] + [torch.empty_like(hostbuf).pin_memory() for _ in range(Leg.STREAMS - 1)] if d2h and not serial else None   # (one per pipeline stream)
-        if d2h and not serial and not hasattr(self, 'copy_stream'):
-            self.copy_stream = torch.cuda.Stream()
+        self.gather_counts = None
+        if gather and dist is not None:
+            # every rank's row count, exchanged ONCE in front of the region (weak scaling: the shards are fixed for the whole run)
+            cnt = torch.zeros(dist.get_world_size(), dtype=torch.int64)
+            cnt[dist.get_rank()] = self.n
+            cnt = cnt.to(dev) if dist.get_backend() != 'gloo' else cnt
+            dist.all_reduce(cnt)
+            counts = [int(c) for c in cnt.tolist()]
+            if not hasattr(self, 'comm_stream'):
+                self.comm_stream, self.gather_events = torch.cuda.Stream(), {}
+            if not serial:
+                self.gather_counts = counts
         acc = None
         import gc
         gc.collect()                                              # before the warm-up: a collector run between warm-up and region would idle the GPU
@@ -331,26 +363,24 @@ class Leg:
             r = self.step(serial)
             if r is not None:
                 acc = r
-                if gather or (d2h and serial):
-                    self.settle()                                 # the futures about to be copied are complete
                 if d2h and serial:
+                    self.settle()                                 # the futures about to be copied are complete
                     hostbuf.copy_(self.last_pred, non_blocking=True)
-                if gather:
-                    self.gathered = parallel.gather_futures(self.last_pred)
+                if gather and serial and dist is not None:
+                    self.gathered = parallel.gather_futures(self.last_pred, counts=counts, reuse=True)
         t_host = time.perf_counter() - t0                         # the host's share: enqueueing `steps` steps (no device sync inside)
         r = self.drain()                                          # every one of the K steps completes inside the timed region
         if r is not None:
             acc = r
-            if gather or (d2h and serial):
-                self.settle()
             if d2h and serial:
+                self.settle()
                 hostbuf.copy_(self.last_pred, non_blocking=True)
-            if gather:
-                self.gathered = parallel.gather_futures(self.last_pred)
-        self.d2h_bufs = None
+        if self.gather_counts is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)   # the last gathers complete inside the timed region
+        self.d2h_bufs, self.gather_counts = None, None
         acc = self.sums(acc)                                      # the last step's per-agent best-of-K values -> (sum ADE, sum FDE, agents)
         if dist is not None:
-            dist.all_reduce(acc)                                  # metrics of the last step over all ranks
+            allreduce(dist, acc)                                  # metrics of the last step over all ranks
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -367,8 +397,8 @@ class Leg:
         total = float(self.m)
         if dist is not None:
             tmax = tt.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            allreduce(dist, tmax, op=dist.ReduceOp.MAX)
+            allreduce(dist, tt, op=dist.ReduceOp.SUM)
             dt, total = float(tmax[0]), float(tt[1])
         return {'dt': dt, 'total_traj': total, 'value': total * steps / dt, 'ms_per_step': 1e3 * dt / steps, 'stage_ms': stage_ms,
                 'metrics': acc, 'host_ms_per_step': 1e3 * t_host / steps, 'clock_ghz': clock}
@@ -417,6 +447,27 @@ class Leg:
                     'path_flop_per_trajectory': self.F['path_per_traj']}
         return roof, kern
 
+    def timed_form_call(self, set_inputs, n):
+        """ONE call through the form the timed regions run -- inference_async on its pipeline stream: lagged launch, throughput-form roles,
+        latents drawn by the launch itself (Philox), fused metrics -- and what the parity sample needs of it: predictions [K, n, Tf, 2], the
+        latents the call REPORTS (fed to the oracle), the per-agent ADE its own groups computed, and the form's name."""
+        import torch
+        from sttode_amd import capi
+        m = self.model
+        nat = m.native()
+        lagged = bool(capi.lib().sttode_async_is_lagged(nat.h, n))
+        st = m.next_async_stream(n)
+        with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            set_inputs()
+            h = m.inference_async(metrics_gt=m._future)
+        ade, _ = m.best_of_k_async(h, gt=m._future)
+        pred = m.wait(h)
+        torch.cuda.synchronize()
+        out = pred.cpu().numpy(), h['z'].cpu().numpy(), ade.cpu().numpy(), ('pipelined: lagged launch, throughput-form roles, in-launch Philox latents, '
+                                                                             'fused metrics' if lagged else 'pipelined (round-3 form: below the chain threshold)')
+        m.reset_async()
+        return out
+
     # ---- CPU oracle sample + parity (rank 0, N = 1 only; outside every timed region) ----
     def cpu_sample(self, seconds, threads):
         import torch
@@ -428,11 +479,12 @@ class Leg:
         out = {'cores': torch.get_num_threads(), 'unit': 'trajectories/s', 'kind': 'port'}
         if self.kind == 'scenes':
             sb = self.sb
-            z_all = scenes.latents(99, self.n)
-            self.model.set_scene_batch(torch.from_numpy(sb.past).to(self.dev), torch.from_numpy(sb.future).to(self.dev), torch.from_numpy(sb.scene_ptr).to(self.dev))
-            hip = self.model.inference(None, z=torch.from_numpy(z_all)).cpu().numpy()
+            # the TIMED form is what is held to the oracle (round-4 review: the sample used to go through the serial inference()): the oracle
+            # is fed the latents the call reports
+            dv = [torch.from_numpy(a).to(self.dev) for a in (sb.past, sb.future, sb.scene_ptr)]
+            hip, z_all, ade_dev, form = self.timed_form_call(lambda: self.model.set_scene_batch(*dv), self.n)
             max_rel, traj_cpu, t_cpu, s = 0.0, 0, 0.0, 0
-            ade_o, ade_h = [], []
+            ade_o, ade_h, ade_d = [], [], []
             while t_cpu < seconds or s < 2:                       # bounded sample: scenes of this workload, cycled
                 i = s % sb.n_scenes
                 a, b = int(sb.scene_ptr[i]), int(sb.scene_ptr[i + 1])
@@ -447,20 +499,26 @@ class Leg:
                     gt = sb.future[a:b]
                     ade_o.append(best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), gt)[0])
                     ade_h.append(best_of_k_ade_fde(hip[:, a:b].transpose(1, 0, 2, 3), gt)[0])
+                    ade_d.append(ade_dev[a:b])
                 s += 1
             ao, ah = float(np.concatenate(ade_o).mean()), float(np.concatenate(ade_h).mean())
             out.update(value=traj_cpu / t_cpu, sample=f'{s} scene evaluations cycling over the {sb.n_scenes} scenes of this workload, per-scene '
                        f'set_data+inference loop (test.py:171-184 structure), PyTorch-eager fp32 oracle, {t_cpu:.1f} s of CPU time')
             par = {'scenes_checked': min(s, sb.n_scenes), 'max_err_over_1_plus_abs_ref': max_rel, 'ade_oracle': ao, 'ade_hip': ah,
-                   'ade_abs_diff': abs(ao - ah)}
+                   'ade_abs_diff': abs(ao - ah), 'ade_fused_by_the_call': float(np.concatenate(ade_d).mean()), 'form_checked': form,
+                   'latents': 'drawn by the call (reported z fed to the oracle)'}
             return out, par
         # NBA: one forward call on a reduced batch (the attention group is the batch, so HIP runs the SAME reduced batch for parity)
         Bs = min(self.size, 16 if self.Tf > 12 else 32)
         d = {k: (v[:Bs] if isinstance(v, np.ndarray) else v) for k, v in self.batch.items()}
         nn_ = Bs * self.N
-        z = scenes.latents(98, nn_)
-        self.model.set_data_nba({k: (torch.from_numpy(v).to(self.dev) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
-        hip = self.model.inference(None, z=torch.from_numpy(z)).cpu().numpy()
+        dd = {k: (torch.from_numpy(v).to(self.dev) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+        nat = self.model.native()
+        nat.set_chain(1)                                           # the reduced batch through the chain launch the full batch takes
+        try:
+            hip, z, ade_dev, form = self.timed_form_call(lambda: self.model.set_data_nba(dd), nn_)
+        finally:
+            nat.set_chain(-1)
         t_cpu, reps = 0.0, 0
         while t_cpu < seconds or reps < 1:
             tc = time.perf_counter()
@@ -476,7 +534,8 @@ class Leg:
         ah = float(best_of_k_ade_fde(hip.transpose(1, 0, 2, 3), gt)[0].mean())
         out.update(value=reps * nn_ * K / t_cpu, sample=f'{reps} forward call(s) of a reduced batch (B={Bs} of {self.size} scenes x {self.N} agents: the attention '
                    f'group is the batch, so the CPU cost per trajectory is a lower bound for the full group), PyTorch-eager fp32 oracle, {t_cpu:.1f} s')
-        par = {'batch_checked': Bs, 'max_err_over_1_plus_abs_ref': float(err.max()), 'ade_oracle': ao, 'ade_hip': ah, 'ade_abs_diff': abs(ao - ah)}
+        par = {'batch_checked': Bs, 'max_err_over_1_plus_abs_ref': float(err.max()), 'ade_oracle': ao, 'ade_hip': ah, 'ade_abs_diff': abs(ao - ah),
+               'ade_fused_by_the_call': float(ade_dev.mean()), 'form_checked': form, 'latents': 'drawn by the call (reported z fed to the oracle)'}
         return out, par
 
     def config(self, world):
@@ -496,24 +555,27 @@ def gather_futures_leg(head, dist, rank, world, acc, args):
     balance: agents per rank; (3) value_incl_gather: the timed region once more with the gather inside every step."""
     import torch
     from sttode_amd import parallel
-    pred_all = parallel.gather_futures(head.last_pred)                               # [sum n_r, K, Tf, 2], rank order
-    gt_all = parallel.gather_futures(head.model._future.contiguous())                # [sum n_r, Tf, 2]
-    counts = [torch.zeros(1, dtype=torch.int64, device=head.dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([head.n], dtype=torch.int64, device=head.dev))
-    counts = [int(c) for c in counts]
+    cnt = torch.zeros(world, dtype=torch.int64)
+    cnt[rank] = head.n
+    cnt = cnt if dist.get_backend() == 'gloo' else cnt.to(head.dev)
+    dist.all_reduce(cnt)                                                             # every rank's row count: exchanged once
+    counts = [int(c) for c in cnt.tolist()]
+    pred_all = parallel.gather_futures(head.last_pred, counts=counts)               # [sum n_r, K, Tf, 2], rank order
+    gt_all = parallel.gather_futures(head.model._future.contiguous(), counts=counts)   # [sum n_r, Tf, 2]
     ade, fde = head.model.best_of_k(pred_all, gt=gt_all)
     got = torch.stack((ade.double().sum(), fde.double().sum())).cpu()
     la, lf = head.model.best_of_k(head.last_pred, gt=head.model._future)             # the same futures, rank by rank: local sums, all-reduced
     want = torch.stack((la.double().sum(), lf.double().sum()))
-    dist.all_reduce(want)
+    allreduce(dist, want)
     want = want.cpu()
     rel = float(((got - want).abs() / want.abs().clamp_min(1e-12)).max())
     ok = pred_all.shape[0] == sum(counts) and int(acc[2]) == sum(counts) and rel < 1e-6
-    r3 = head.timed(max(4, args.steps // 2), 1, dist, 0, serial=args.serial, gather=True)
+    r3 = head.timed(args.steps, args.warmup, dist, 0, serial=args.serial, gather=True)   # the headline's region, with the gather inside every step
     res = {'collective': 'all_gather of the futures [n_r, K, Tf, 2] fp32, padded to the largest shard (sttode_amd.parallel.gather_futures)',
            'backend': dist.get_backend(), 'ranks': world, 'agents_per_rank': counts, 'gathered_rows': int(pred_all.shape[0]),
            'bytes_per_rank_per_step': int(head.n * K * head.Tf * 2 * 4),
            'sums_from_gathered_vs_allreduced_rel_err': rel, 'check': 'ok' if ok else 'MISMATCH',
+           'gather_form': 'on a communication stream behind the call\'s event, counts exchanged once before the region, later calls launch under it',
            'ms_per_step_incl_gather': r3['ms_per_step'], 'value_incl_gather': r3['value']}
     if not ok:
         sys.stderr.write(f'bench.py: gathered futures disagree with the all-reduced metric sums on rank {rank}: {res}\n')
@@ -579,7 +641,7 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
     dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allreduce(dist, tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     out = {'metric': 'training-steps/sec (one scene per step, forward + backward + Adam)' if TB == 1 else
                      f'training-scenes/sec ({TB} scenes per step, forward + backward + Adam)', 'value': world * steps * TB / dt,
@@ -705,6 +767,7 @@ def main():
     ap.add_argument('--no-serial-check', action='store_true', help='skip the few serial steps that give roofline.frac_serial_equivalent')
     ap.add_argument('--no-gather-futures', action='store_true', help='multi-rank runs: skip the all-gather of the futures (check + value_incl_gather)')
     ap.add_argument('--selftest-dist', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--dist-backend', choices=('nccl', 'gloo'), default='nccl', help=argparse.SUPPRESS)   # gloo: rehearsal, all ranks on cuda:0
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -717,6 +780,8 @@ def main():
 
     import torch
     rank, world, local, dist = init_dist(args)
+    if args.dist_backend == 'gloo':
+        local = 0                                               # rehearsal: every rank computes on cuda:0
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -763,7 +828,8 @@ def main():
             roof['ms_per_step_serial'] = rs['ms_per_step']
     acc = r['metrics']
     out = {'metric': 'predicted-trajectories/sec (20-sample best-of-K)', 'value': r['value'], 'unit': 'trajectories/s',
-           'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None else 0, 'steps': args.steps, 'warmup': args.warmup,
+           'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None and dist.get_backend() == 'nccl' else 0,
+           'dist_backend': dist.get_backend() if dist is not None else None, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': r['ms_per_step'], 'host_enqueue_ms_per_step': r['host_ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'clock_ghz': r['clock_ghz'],
            'config': head.config(world), 'roofline': roof, 'kernels': kern,

@@ -4,7 +4,13 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 (or int32 where noted) owned by the caller;
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream), nothing
- *     synchronises, nothing allocates: all workspaces are caller-provided (graph-capturable);
+ *     synchronises, nothing allocates: all workspaces are caller-provided (graph-capturable; a workspace of the native pipeline is
+ *     initialised ONCE with sttode_workspace_init before its first use);
+ *   - threads: the per-kernel entry points are re-entrant (no state); the asynchronous entry points of ONE SttodeModel (sttode_inference_*_async,
+ *     sttode_wait*, sttode_async_*, sttode_set_lagged) are serialised by a mutex inside the model and take everything a call needs as
+ *     arguments (no arm-then-call state) -- but the ORDER of calls decides which slot's groups a launch carries and which stream
+ *     sttode_async_next_stream names, so a model's pipelined calls belong to one host thread at a time; serial calls on different
+ *     workspaces may come from different threads;
  *   - return 0 on success, non-zero on failure; sttode_last_error() gives the calling thread's message;
  *   - "PK16" = weights pre-packed in MFMA fragment order by sttode_amd/packing.py (csrc/chain.hpp);
  *   - "columns" are agents (n) or trajectories (m = n*K, row = agent*K + k, model/STTODE.py:322-328).
@@ -18,7 +24,7 @@ extern "C" {
 #endif
 
 /* Version of this header: the library returns it from sttode_abi_version(); a binding compares before its first call (round 1-2: 1). */
-#define STTODE_ABI_VERSION 6
+#define STTODE_ABI_VERSION 7
 int sttode_abi_version(void);
 const char* sttode_last_error(void);
 
@@ -63,6 +69,12 @@ int sttode_embed_qkv(const float* fc1P, const float* fc1b, const float* posP, co
 int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out, float* rowsum, float* wout, int rows,
                       int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b, long os_seq,
                       long os_b, float rscale, float cscale, void* stream);
+/* The same core over `groups` independent problems of one shape in ONE launch: group g reads R + g gs_r, C + g gs_c, V + g gs_v and writes
+ * out + g gs_o (strides in floats).  The NBA branch attends over the batch dimension of ONE forward call (hyptransformerlib.py:261-265); a
+ * test set is many such batches (test.py:520-524), and one launch over all of them fills the chip. */
+int sttode_mhgsa_attn_groups(const float* R, const float* C, const float* V, float* out, int groups, long gs_r, long gs_c, long gs_v, long gs_o,
+                             int rows, int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b, long os_seq,
+                             long os_b, float rscale, float cscale, void* stream);
 
 /* out_proj (hyptransformerlib.py:305) -> Hypattention gate tanh(info)*sigmoid(gate) (hypertransformer.py:81-83)
  * -> TransformerEncoderLayer post-LN + FFN (hypertransformer.py:148-152) -> ODEG_Encoder: one explicit Euler step of
@@ -156,6 +168,10 @@ int sttode_gru_cols32(const float* xin, int ldx, const float* pool, const int* p
 
 /* compute_ADE / compute_FDE per agent (utils/metrics.py:7-26): pred [n,K,Tf,2], gt [n,Tf,2] -> ade [n], fde [n]. */
 int sttode_best_of_k(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* ade, float* fde, void* stream);
+/* The NBA evaluation's per-horizon metric (test.py:530-551): pred [n,K,Tf,2], gt [n,Tf,2] -> out [n,Tf,2]: for agent a and horizon h (frame
+ * h - 1) out[a][h-1] = (min_k mean_{t < h} |scale (pred - gt)|, min_k |scale (pred_h - gt_h)|); the caller averages over agents and weighs by
+ * the batch size like the reference.  K <= 64, K Tf <= 2048. */
+int sttode_horizon_metrics(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* out, void* stream);
 
 /* Stage-2 latent sampler (sampler.py:47-54): z = b (eps_mode 0) or A*eps + b with eps shared [nz] (1, share_eps) or per agent
  * [n,nz] (2); logvar = log(A^2 + 1e-8).  A, b, z, logvar [n*K, nz] (row = agent*K + k). */
@@ -365,6 +381,11 @@ int sttode_model_create(SttodeModel** out, const void* const* weights, int count
 int sttode_model_set_weight(SttodeModel* m, int index, const void* ptr);
 int sttode_model_destroy(SttodeModel* m);
 int sttode_workspace_layout(const SttodeModel* m, int n, int S, long* offsets /*[STT_B_COUNT]*/, long* total_floats);
+/* ONCE per workspace (after allocation, before its first use by sttode_inference_*): zeroes the hand-off flag words (STT_B_FLAGS) and marks
+ * the workspace initialised.  The one-launch scene form (sttode_set_scene_launch) keeps its flag words zero from then on -- the last
+ * workgroup of every launch zeroes them again -- so it needs no memset in front of a launch and a captured sttode_inference_scenes replays
+ * correctly; launched on a workspace that was never initialised it refuses the flag words it finds: NaN predictions, time-out word 2. */
+int sttode_workspace_init(SttodeModel* m, float* workspace, int n, int S, void* stream);
 /* number of column parts (1..8) the per-trajectory kernels are pipelined over on separate streams (default 1,
  * or env STTODE_COL_PARTS); results are bitwise independent of it. */
 int sttode_set_col_parts(SttodeModel* m, int parts);
@@ -391,7 +412,7 @@ int sttode_set_mfma_mode(SttodeModel* m, int mode);
  * its tables but never publishes its flag (-1: off, the default).  The trajectory groups that read that tile then run into the bound of
  * their spin (~1 s), write NaN into their predictions and set the time-out word (workspace buffer STT_B_FLAGS, word [tiles]; with the split roles of
  * mode 4 the flag words are E [tiles] | time-out | G [tiles] | tables [3 tiles] and the withheld flags are the tile's three table flags) -- the
- * launch ends, it never hangs; every other group is unaffected. */
+ * launch ends, it never hangs; every other group is unaffected.  The model's host-visible word (sttode_timeout_word) is set as well. */
 int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
 /* Host staging of one scene for the one-scene-per-call loop (test.py:171-188 -> set_data, model/STTODE.py:397-404): pre [N][2][Tp] and
  * fut [N][2][Tf] (HOST pointers, the loader's layout; fut may be NULL with Tf = 0) are transposed into a pinned ring slot and copied to
@@ -437,6 +458,12 @@ int sttode_inference_scenes(SttodeModel* m, const float* past, const int* scene_
  * past [B*N,Tp,2]; attention length = B over the N agent slots. */
 int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                          void* stream);
+/* G forward-call batches of the NBA branch in ONE call (what G sttode_inference_nba calls compute; the reference's evaluation loop makes one
+ * model call per DataLoader batch, test.py:520-524): past [G][B][N][Tp][2], z [G B N K][32] -> pred [G B N][K][Tf][2].  The attention
+ * (Hyp_mhsa over the batch dimension, hyptransformerlib.py:261-265) runs within each batch of B scenes -- one launch with a group dimension
+ * -- and everything per agent / per trajectory over all G B N agents: a test set of 128-scene batches fills the chip. */
+int sttode_inference_nba_groups(SttodeModel* m, const float* past, int G, int B, int N, const float* z, float* workspace, float* pred,
+                                void* stream);
 
 /* Pipelined forms (STTODENet.inference as a stream of calls, model/STTODE.py:574-623; caller loop test.py:171-184): consecutive calls run
  * on the pipeline's internal streams so that the grid tail of one call's big launch is filled by the next call's.
@@ -452,18 +479,27 @@ int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const 
  *   the serial forms.  Calls below the chain threshold or with a non-default integrator always take those forms.
  * workspace, pred and z of a slot must stay untouched until sttode_wait(slot) has been enqueued on the consuming stream. */
 int sttode_set_lagged(SttodeModel* m, int streams /* 0 = off, 2 or 3 (default, or env STTODE_LAGGED) */);
-/* Latents on device (lagged form; replaces the torch.randn_like of Normal.rsample, model/STTODE.py:89-93,609-616, for that call): returns 1
- * -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged form; that call then treats its `z`
- * argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples (Philox4x32-10, 64-bit key, counter = the
- * float4's index; two Box-Muller pairs per block) before its trajectory groups read it.  Returns 0, nothing armed, for every other form
- * (the caller then supplies z).  NOTE: the one entry point that does not return a status. */
-int sttode_async_device_latents(SttodeModel* m, int n, unsigned long long key);
-/* Fused metrics (lagged form; replaces a sttode_best_of_k launch per call): returns 1 -- and arms it -- if the next
- * sttode_inference_*_async call of n agents will take the lagged form: that call's trajectory groups then also compute its min-over-K
- * ADE / FDE (compute_ADE / compute_FDE, utils/metrics.py:7-26; the values of sttode_best_of_k on the same predictions, bit for bit)
- * against gt [n][Tf][2] into ade / fde [n], valid once sttode_wait(slot) has passed.  Returns 0, nothing armed, otherwise.  Like
- * sttode_async_device_latents this is a query, not a status. */
-int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt, float* ade, float* fde, float scale);
+/* Per-call options of the asynchronous entry points (NULL = none).  Everything a call needs travels WITH the call: a request the call's
+ * form cannot honour makes the call fail before anything is enqueued or any state of the model changes (ABI <= 6 armed the model with
+ * sttode_async_device_latents / sttode_async_fused_metrics before the call; a failed check in between left the request armed).
+ *   device_latents != 0 (lagged form only; replaces the torch.randn_like of Normal.rsample, model/STTODE.py:89-93,609-616, for that call): the
+ *     call treats its `z` argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples (Philox4x32-10, 64-bit
+ *     key zkey, counter = the float4's index; two Box-Muller pairs per block) before its trajectory groups read it.
+ *   metrics_gt != NULL (lagged form only; replaces a sttode_best_of_k launch per call): the call's trajectory groups also compute its
+ *     min-over-K ADE / FDE (compute_ADE / compute_FDE, utils/metrics.py:7-26; the values of sttode_best_of_k on the same predictions, bit for
+ *     bit) against metrics_gt [n][Tf][2], scaled by metrics_scale, into ade / fde [n]; valid once sttode_wait(slot) has passed.
+ *   nba_groups > 1 (sttode_inference_nba_async only): the call carries that many forward-call batches [G][B][N][Tp][2]; the attention runs
+ *     within each batch of B scenes (sttode_inference_nba_groups).
+ * sttode_async_is_lagged(m, n) tells beforehand whether a call of n agents will take the lagged form. */
+typedef struct SttodeAsyncOpts {
+    int device_latents;
+    unsigned long long zkey;
+    const float* metrics_gt;
+    float* ade;
+    float* fde;
+    float metrics_scale;
+    int nba_groups;
+} SttodeAsyncOpts;
 /* Measurement aid: the shader clock at this moment.  out[0] = shader cycles, out[1] = ticks of the constant 100 MHz clock over ~20 us on
  * one lane (device memory, two int64): GHz = out[0] / (10 out[1]). */
 int sttode_clock_probe(long long* out, void* stream);
@@ -475,9 +511,12 @@ int sttode_async_enqueue(SttodeModel* m, int slot);
 /* Enqueue every outstanding trajectory-group launch of the lagged form (before buffers of pending calls are released or reused). */
 int sttode_async_flush(SttodeModel* m);
 int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
-                                  float* workspace, float* pred, int slot, void* stream);
+                                  float* workspace, float* pred, int slot, const SttodeAsyncOpts* opts, void* stream);
 int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
-                               int slot, void* stream);
+                               int slot, const SttodeAsyncOpts* opts, void* stream);
+/* sttode_horizon_metrics of an asynchronous call's predictions on the pipeline stream the call of `slot` runs on (as sttode_async_best_of_k:
+ * starts the moment the call's groups drain; the slot's completion event is re-recorded behind it). */
+int sttode_async_horizon_metrics(SttodeModel* m, int slot, const float* pred, const float* gt, int n, int K, int Tf, float scale, float* out);
 int sttode_wait(SttodeModel* m, int slot, void* stream);
 /* Zero-copy futures (lagged form): the trajectory groups of a lagged call only WRITE `pred` (block 0's y_hat0 waits in the workspace), so
  * `pred` may be pinned host memory addressed by its host pointer: the futures reach the host with the launch itself, no D2H copy
@@ -486,9 +525,17 @@ int sttode_wait(SttodeModel* m, int slot, void* stream);
 int sttode_async_is_lagged(SttodeModel* m, int n);
 int sttode_wait_host(SttodeModel* m, int slot);
 /* Health of the in-launch hand-off (round-3 fused launches and the one-launch scene form: a group whose producer never signalled gives up
- * after ~1 s, poisons its predictions with NaN and sets the launch's time-out word).  Reads the time-out word of the LAST launch that used
- * `workspace` (laid out for n agents / S scenes) after synchronising `stream`: returns 0 if it is clear, 3 (and sttode_last_error) if a
- * group gave up -- the caller's predictions of that call are not valid.  Lagged launches have no hand-off and always pass. */
+ * after ~1 s, poisons its predictions with NaN and sets the launch's time-out word -- in the workspace AND in the model's word in pinned
+ * host memory).
+ * sttode_timeout_word: *word = address of the model's host-visible time-out word (valid for the model's life): non-zero once ANY launch of
+ * this model gave up since the last sttode_timeout_clear.  Reading it costs a host load -- no stream operation, no synchronisation -- so a
+ * caller checks it at its next call and before handing results out (STTODENet.inference() / wait() do, and raise).  The word is set when
+ * the group gives up, i.e. it is seen by whoever looks after the launch has finished.
+ * sttode_check: reads the time-out word of the LAST launch that used `workspace` (laid out for n agents / S scenes) after synchronising
+ * `stream`: returns 0 if it is clear, 3 (and sttode_last_error) if a group gave up or the workspace was never initialised -- the caller's
+ * predictions of that call are not valid.  Lagged launches have no hand-off and always pass. */
+int sttode_timeout_word(SttodeModel* m, const unsigned** word);
+int sttode_timeout_clear(SttodeModel* m);
 int sttode_check(SttodeModel* m, const float* workspace, int n, int S, void* stream);
 
 #ifdef __cplusplus

@@ -32,3 +32,24 @@ def nba_horizon_errors(pred_kn, gt, horizons):
     for h in horizons:
         out[h] = (float(d[:, :, :h].mean(axis=2).min(axis=0).mean()), float(d[:, :, h - 1].min(axis=0).mean()))
     return out
+
+
+def nba_eval_printed(batches, traj_scale=1.0, future_length=10):
+    """The eight figures test.py:495-587 prints for an NBA test set: ``batches`` = [(pred_kn [K, B*N, Tf, 2], future [B, N, Tf, 2]), ...] one per
+    DataLoader batch.  Per batch and horizon h: mean over agents of min_k (mean displacement over the first h frames / displacement of frame
+    h), times the batch size B; summed over batches, divided by the number of scenes (:530-575).  Printed (:577-586, 0.4 s per frame):
+    ADE 1.0s = (avg_2 + avg_3) / 2, ADE 2.0s = avg_5, ADE 3.0s = (avg_8 + avg_7) / 2, ADE 4.0s = avg_10; FDE likewise with dest_h.
+    Returns float64 [8] = ADE 1..4 s, FDE 1..4 s."""
+    assert future_length == 10, 'the reference hard-codes ten horizons'
+    avg, dest, all_num = np.zeros(11), np.zeros(11), 0
+    for pred_kn, fut in batches:
+        B = fut.shape[0]
+        y = np.asarray(fut, np.float32).reshape(-1, future_length, 2) * traj_scale
+        e = nba_horizon_errors(np.asarray(pred_kn) * traj_scale, y, range(1, 11))
+        for h in range(1, 11):
+            avg[h] += e[h][0] * B
+            dest[h] += e[h][1] * B
+        all_num += B
+    avg, dest = avg / all_num, dest / all_num
+    return np.array([(avg[2] + avg[3]) / 2, avg[5], (avg[8] + avg[7]) / 2, avg[10],
+                     (dest[2] + dest[3]) / 2, dest[5], (dest[7] + dest[8]) / 2, dest[10]], np.float64)

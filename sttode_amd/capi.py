@@ -11,7 +11,7 @@ _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 6   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
+ABI_VERSION = 7   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
 SIGNATURES = {
@@ -22,6 +22,7 @@ SIGNATURES = {
     'sttode_frontend_future': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'sttode_embed_qkv': [_P] * 11 + [_P, _P, _P, _P, _I, _I, _P],
     'sttode_mhgsa_attn': [_P, _P, _P, _P, _P, _P, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
+    'sttode_mhgsa_attn_groups': [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_post_attn_ode': [_P] * 16 + [_P, _P, _I, _F, _I, _I, _P],
     'sttode_post_attn_rhs': [_P] * 14 + [_P, _P, _I, _P, _I, _P],
@@ -37,6 +38,7 @@ SIGNATURES = {
     'sttode_chain_prog_len': [_I, _I],
     'sttode_gru_cols32': [_P, _I, _P, _P, _I, _P, _P, _I, _I, _P],
     'sttode_best_of_k': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
+    'sttode_horizon_metrics': [_P, _P, _I, _I, _I, _F, _P, _P],
     # stage-2 sampler (csrc/sampler.hip)
     'sttode_sampler_latent': [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     'sttode_sampler_loss': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
@@ -79,6 +81,9 @@ SIGNATURES = {
     'sttode_model_destroy': [_P],
     'sttode_model_set_weight': [_P, _I, _P],
     'sttode_workspace_layout': [_P, _I, _I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)],
+    'sttode_workspace_init': [_P, _P, _I, _I, _P],
+    'sttode_timeout_word': [_P, ctypes.POINTER(ctypes.c_void_p)],
+    'sttode_timeout_clear': [_P],
     'sttode_set_col_parts': [_P, _I],
     'sttode_set_chain': [_P, _I],
     'sttode_set_fused': [_P, _I],
@@ -94,8 +99,10 @@ SIGNATURES = {
     'sttode_timing_read': [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     'sttode_inference_scenes': [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     'sttode_inference_nba': [_P, _P, _I, _I, _P, _P, _P, _P],
-    'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
-    'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P],
+    'sttode_inference_nba_groups': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    'sttode_inference_scenes_async': [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P],
+    'sttode_inference_nba_async': [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P],
+    'sttode_async_horizon_metrics': [_P, _I, _P, _P, _I, _I, _I, _F, _P],
     'sttode_wait': [_P, _I, _P],
     'sttode_async_is_lagged': [_P, _I],
     'sttode_wait_host': [_P, _I],
@@ -104,8 +111,6 @@ SIGNATURES = {
     'sttode_clock_probe': [_P, _P],
     'sttode_copy_to_host': [_P, _P, _L, _I, _P],
     'sttode_async_enqueue': [_P, _I],
-    'sttode_async_device_latents': [_P, _I, ctypes.c_ulonglong],
-    'sttode_async_fused_metrics': [_P, _I, _P, _P, _P, _F],
     'sttode_check': [_P, _P, _I, _I, _P],
 }
 
@@ -127,6 +132,12 @@ STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,a
           'gru_cols[block1,trajectories]', 'mlp_block1', 'trajectory_chain', 'agents_fused[encoder+block0 GRU]', 'agents+trajectory_chain[fused launch]')
 
 
+class AsyncOpts(ctypes.Structure):
+    """struct SttodeAsyncOpts of include/sttode_hip.h: everything an asynchronous call needs travels with the call."""
+    _fields_ = [('device_latents', ctypes.c_int), ('zkey', ctypes.c_ulonglong), ('metrics_gt', ctypes.c_void_p), ('ade', ctypes.c_void_p),
+                ('fde', ctypes.c_void_p), ('metrics_scale', ctypes.c_float), ('nba_groups', ctypes.c_int)]
+
+
 class NativeModel:
     """Owner of a SttodeModel handle (csrc/pipeline.hip) plus the packed weight tensors it points into."""
 
@@ -140,6 +151,23 @@ class NativeModel:
             raise SttodeError('sttode_model_create failed: ' + lib().sttode_last_error().decode())
         self.h = h
         self._layouts = {}
+        w = ctypes.c_void_p()
+        if lib().sttode_timeout_word(h, ctypes.byref(w)) != 0 or not w.value:
+            raise SttodeError('sttode_timeout_word failed: ' + lib().sttode_last_error().decode())
+        self.timeout_word = ctypes.c_uint.from_address(w.value)   # the model's host-visible time-out word: a plain host load per check
+
+    def raise_if_timed_out(self):
+        """Raise if any launch of this model gave up on its in-launch hand-off since the last check (include/sttode_hip.h: the word in
+        pinned host memory is set by the group that gives up; no stream operation, no synchronisation here)."""
+        v = self.timeout_word.value
+        if v:
+            lib().sttode_timeout_clear(self.h)
+            raise SttodeError('a trajectory group of an earlier launch gave up waiting for its per-agent role (time-out word %d): the '
+                              'predictions of that call are NaN-poisoned, not valid' % v if v != 2 else
+                              'an earlier launch ran on a workspace that was never initialised (sttode_workspace_init): its predictions are NaN')
+
+    def init_workspace(self, buf, n, S):
+        call('sttode_workspace_init', self.h, buf, int(n), int(S), stream_ptr())
 
     def layout(self, n, S):
         key = (n, S)
@@ -182,7 +210,6 @@ class NativeModel:
 
     def check(self, workspace, n, S):
         """Raise if a group of the last launch on `workspace` gave up waiting for its producer (in-launch hand-off forms only)."""
-        import torch
         call('sttode_check', self.h, workspace, int(n), int(S), stream_ptr())
 
     def set_weights(self, group, tensors):

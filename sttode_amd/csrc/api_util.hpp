@@ -11,10 +11,17 @@ int stt_agents_fused(const float* const* W, const float* enc_in, const int* last
                      float* state0, int n, int Tp, int TPX, float ode_time, void* stream);   // encoder.hip
 bool stt_agents_fused_covers(int Tp, int TPX);                                          // encoder.hip: shapes the fused per-agent kernel is built for
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
-                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, int lead, int drop_tile, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
+                    float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3, int lead, int drop_tile,
+                    unsigned* tmo_host, void* stream);   // chain32.hip: per-agent roles + trajectory groups in one launch
 bool stt_chain_fused_covers(int Tp);
 int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int TPX, int NOY, int n_chunks0, int n_chunks1,
-                  const float* z, float* pred, float ode_time, const float* past, const int* scene_ptr, int S, int drop_tile, void* stream);   // scene_lat.hip: a scene call as ONE launch
+                  const float* z, float* pred, float ode_time, const float* past, const int* scene_ptr, int S, int drop_tile, unsigned* tmo_host,
+                  void* stream);   // scene_lat.hip: a scene call as ONE launch
+// STT_B_FLAGS of a workspace for n agents, in 32-bit words: [fused launch: E [T] | time-out | G [T] | P [3 T], T = tiles of 16 agents, zeroed in
+// front of every launch] [4 words] [one-launch scene form: E [T] | time-out | G [T] | E2 [T] | Y [C] | exit counter | initialised word: zeroed
+// ONCE by sttode_workspace_init, kept zero by the form's own last workgroup]
+static inline int stt_scene_flags_offset(int n) { return 5 * ((n + 15) / 16) + 4; }
+int stt_scene_flags_init(float* ws, const long* off, int n, int K, void* stream);   // scene_lat.hip
 bool stt_scene_lat_covers(int Tp, int TPX, int NOY);
 int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, const float* pool, const int* prog, int prog_len,
                       const float* consts, const float* z, const float* xpad, int ldx, const float* cur, const float* orig,

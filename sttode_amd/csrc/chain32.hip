@@ -732,8 +732,8 @@ __global__ __launch_bounds__(256, 2) void traj_chain_kernel(ChainArgs A) {
         const int c_lo = g0 * 128, c_hi = (c_lo + 127 < A.ncols ? c_lo + 127 : A.ncols - 1);
         const int t_lo = (c_lo / A.K) >> 4, t_hi = (c_hi / A.K) >> 4;
         if (wave == 0) {
-            const bool ok = A.R.split ? wait_tiles(A.R.pflags, 3 * t_lo, 3 * t_hi + 2, A.R.flags + A.R.ntiles, lane)   // the three tables of every tile
-                                      : wait_tiles(A.R.flags, t_lo, t_hi, A.R.flags + A.R.ntiles, lane);
+            const bool ok = A.R.split ? wait_tiles(A.R.pflags, 3 * t_lo, 3 * t_hi + 2, A.R.flags + A.R.ntiles, lane, A.R.tmo_host)   // the three tables of every tile
+                                      : wait_tiles(A.R.flags, t_lo, t_hi, A.R.flags + A.R.ntiles, lane, A.R.tmo_host);
             if (!ok && lane == 0) sq[0] = -1;
         }
     }
@@ -1143,7 +1143,7 @@ int stt_traj_chain_b3(const float* A0x, const float* A0y, const float* A1y, cons
 bool stt_chain_fused_covers(int Tp) { return Tp >= 2 && 2 * Tp <= 32 && role_lds(Tp) <= 80 * 1024; }
 int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int prog_len, const float* z, float* pred,
                     float ode_time, const float* attn, int ld_attn, const float* past, const int* scene_ptr, int S, int wgs_per_cu, int b3,
-                    int lead, int drop_tile, void* stream) {
+                    int lead, int drop_tile, unsigned* tmo_host, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred, "stt_chain_fused: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && stt_chain_fused_covers(Tp) && Tf >= 1, "stt_chain_fused: shape outside the fused launch");
     STT_REQUIRE(!attn || (ld_attn >= 64 && ld_attn % 4 == 0), "stt_chain_fused: bad attention leading dimension");
@@ -1167,6 +1167,7 @@ int stt_chain_fused(const float* const* W, float* ws, const long* off, int n, in
     STT_REQUIRE(!past || (scene_ptr && S > 0 && !attn), "stt_chain_fused: the in-role front-end needs scene_ptr, S > 0 and attention length 1");
     r.past = past; r.scene_ptr = scene_ptr; r.S = S;
     r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = (n + 15) / 16; r.ode_time = ode_time;
+    r.tmo_host = tmo_host;
     // grid order: `lead` groups of head start of a role over its first consumer; < 0 (default): all roles first.  Measured on one box
     // (profiles/r03/ab_lead_frontend_depth.txt): pipelined 73.4-74.6 M trajectories/s for lead 64 / 160 / 400 / roles first alike, but a
     // SERIAL launch is 5 % slower interleaved (0.65 vs 0.69 of peak): a role beside a trajectory group runs 2x longer than beside

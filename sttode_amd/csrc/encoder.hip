@@ -143,7 +143,12 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
                                                          const float* __restrict__ V, float* __restrict__ out,
                                                          float* __restrict__ rowsum,  // optional [Nb][8][rows]
                                                          int rows, int cols, long rs_seq, long rs_b, long cs_seq, long cs_b,
-                                                         long vs_seq, long vs_b, long os_seq, long os_b, float rscale, float cscale) {
+                                                         long vs_seq, long vs_b, long os_seq, long os_b, float rscale, float cscale,
+                                                         long gs_r, long gs_c, long gs_v, long gs_o) {
+    // blockIdx.z: the attention GROUP (round 5: several forward-call batches of the NBA branch per launch -- the reference attends over the
+    // batch dimension of ONE forward call, hyptransformerlib.py:261-265; a test set is many such batches, test.py:520-524)
+    R += blockIdx.z * gs_r; C += blockIdx.z * gs_c; V += blockIdx.z * gs_v; out += blockIdx.z * gs_o;
+    if (rowsum) rowsum += (size_t)blockIdx.z * gridDim.y * rows;
     __shared__ __attribute__((aligned(16))) float sC[ATT_TJ][8];
     __shared__ __attribute__((aligned(16))) float sV[ATT_TJ][8];
     __shared__ float sP[3][64][9];                                   // partials of waves 1..3: l, acc[8]
@@ -415,6 +420,19 @@ int stt_embed_qkv_fe(const float* const* W, const float* past, int n, int N, int
     return 0;
 }
 
+// `groups` independent attention problems of the same shape in ONE launch (group g at base + g * gs_*): see sttode_mhgsa_attn_groups
+extern "C" int sttode_mhgsa_attn_groups(const float* R, const float* C, const float* V, float* out, int groups, long gs_r, long gs_c, long gs_v,
+                                        long gs_o, int rows, int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq,
+                                        long vs_b, long os_seq, long os_b, float rscale, float cscale, void* stream) {
+    STT_REQUIRE(R && C && V && out, "sttode_mhgsa_attn_groups: null pointer");
+    STT_REQUIRE(rows > 0 && cols > 0 && Nb > 0 && Nb * 8 <= 65535 && groups > 0 && groups <= 65535,
+                "sttode_mhgsa_attn_groups: bad rows/cols/Nb/groups (Nb*8 and groups must fit gridDim.y / .z)");
+    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 63) / 64, Nb * 8, groups), dim3(256), 0, (hipStream_t)stream, R, C, V, out, (float*)nullptr,
+                       rows, cols, rs_seq, rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale, gs_r, gs_c, gs_v, gs_o);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out, float* rowsum, float* wout, int rows,
                                  int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b,
                                  long os_seq, long os_b, float rscale, float cscale, void* stream) {
@@ -423,7 +441,7 @@ extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V,
     STT_REQUIRE(!wout || rowsum, "sttode_mhgsa_attn: weights output needs the rowsum workspace");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 63) / 64, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
-                       rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale);
+                       rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale, 0L, 0L, 0L, 0L);
     STT_HIP(hipGetLastError());
     if (wout) {
         const long tot = (long)Nb * rows * cols;

@@ -129,6 +129,45 @@ __global__ __launch_bounds__(256) void best_of_k_kernel(const float* __restrict_
     if (lane == 0) { ade[a] = best_a; fde[a] = best_f; }
 }
 
+// NBA evaluation metric (test.py:530-551): for every horizon h = 1 .. Tf, min over the K samples of the mean displacement over the first h
+// frames and of the displacement of frame h.  One wave per agent: the K Tf displacement norms are staged in LDS (coalesced 8-byte reads,
+// best_of_k_kernel's bok_dist), lane k walks sample k's frames with a running fp32 sum in frame order (sum_h / h: the NumPy restatement
+// tests/helpers.py horizon_metrics_np sums in the same order), and the wave takes the minimum per frame by xor shuffles.
+// out [n][Tf][2] = (avg_h, dest_h).  K <= 64, K Tf <= 2048.
+__global__ __launch_bounds__(256) void horizon_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n, int K,
+                                                              int Tf, float scale, float* __restrict__ out) {
+    __shared__ float sd[4][2048];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int a = blockIdx.x * 4 + w;
+    if (a >= n) return;
+    const float2* g = reinterpret_cast<const float2*>(gt + (size_t)a * Tf * 2);
+    const float2* p = reinterpret_cast<const float2*>(pred + (size_t)a * K * Tf * 2);
+    const int tot = K * Tf;
+    for (int i = lane; i < tot; i += 64) {
+        const float2 v = p[i], r = g[i % Tf];
+        sd[w][i] = bok_dist(v.x, v.y, r.x, r.y, scale);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sum = 0.f;
+    for (int t = 0; t < Tf; ++t) {
+        float va = INFINITY, vd = INFINITY;
+        if (lane < K) {
+            vd = sd[w][lane * Tf + t];
+            sum += vd;
+            va = sum / (float)(t + 1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            va = fminf(va, __shfl_xor(va, o, 64));
+            vd = fminf(vd, __shfl_xor(vd, o, 64));
+        }
+        if (lane == 0) {
+            out[((size_t)a * Tf + t) * 2] = va;
+            out[((size_t)a * Tf + t) * 2 + 1] = vd;
+        }
+    }
+}
+
 // Train-mode augmentation of set_data (model/STTODE.py:417-426): the scene's tracks rotated IN PLACE about scene_orig = mean over the agents
 // of the last observed position, x' = R (x - orig) + orig, R = [[c, -s], [s, c]] (rotation_2d_torch, :6-14).  One workgroup: every thread
 // forms the mean itself, in agent order, before any position is overwritten.
@@ -207,6 +246,14 @@ extern "C" int sttode_best_of_k(const float* pred, const float* gt, int n, int K
     return 0;
 }
 
+extern "C" int sttode_horizon_metrics(const float* pred, const float* gt, int n, int K, int Tf, float scale, float* out, void* stream) {
+    STT_REQUIRE(pred && gt && out, "sttode_horizon_metrics: null pointer");
+    STT_REQUIRE(n > 0 && K > 0 && K <= 64 && Tf > 0 && K * Tf <= 2048, "sttode_horizon_metrics: need 0 < K <= 64 and K * Tf <= 2048");
+    hipLaunchKernelGGL(horizon_metrics_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, gt, n, K, Tf, scale, out);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
 // Shader clock right now: one lane counts shader cycles (s_memtime) over ~20 us of the constant 100 MHz clock (s_memrealtime).  bench.py
 // reads it on both sides of a timed region: after an idle gap the clock needs ~25-40 ms of load to climb from ~2.1 to 2.4 GHz
 // (profiles/r04/clock_ramp.txt), which a 20-step region feels and an 80-step one hardly does.
@@ -269,6 +316,11 @@ extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int
     if (hipPointerGetAttributes(&pa, dev) == hipSuccess) d = pa.device;
     else { (void)hipGetLastError(); STT_HIP(hipGetDevice(&d)); }
     STT_REQUIRE(d >= 0 && d < STT_ATTR_DEVICES, "sttode_stage_scene: device index beyond the staging table");
+    // the ring's event and pinned buffer belong to device d and the event is recorded on the caller's stream: all three must be device d's
+    // (round-4 advice: created on the current device they mixed devices for a model on another one)
+    int cur_dev = 0;
+    STT_HIP(hipGetDevice(&cur_dev));
+    STT_REQUIRE(cur_dev == d, "sttode_stage_scene: the current device must be the one that owns `dev` (hipSetDevice / torch.cuda.device first)");
     std::lock_guard<std::mutex> lock(g_stage_mu[d]);
     StageSlot& s = g_stage[d][g_stage_k[d] = (g_stage_k[d] + 1) & 3];
     const size_t need = (size_t)N * (Tp + Tf) * 2;

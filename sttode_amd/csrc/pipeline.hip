@@ -51,8 +51,8 @@ struct SttodeModel {
     // cross-call software pipeline (sttode_inference_*_async): stage A (per agent) of call i+1 runs on sA beside stage B
     // (per trajectory) of call i on sB; two workspace slots alternate.
     hipStream_t sA, sB, sB2;
-    bool met_armed; const float* met_gt; float* met_ade; float* met_fde; float met_scale;   // fused metrics of the next lagged call
-    bool zgen_armed; unsigned long long zgen_key;   // the next lagged call draws its own latents with this Philox key (sttode_async_device_latents)
+    std::mutex mu;                   // serialises the asynchronous entry points of ONE model (slot tables, lag queues, stream rotation)
+    unsigned* tmo_host;              // pinned host word: set by any launch of this model whose in-launch hand-off gave up (sttode_timeout_word)
     int lag_streams;                 // 0: lagged form off; 2 / 3 (default): pipeline streams the lagged calls rotate over
     long lag_calls;
     LagPending lag[STT_MAX_SLOTS];   // per slot
@@ -108,7 +108,11 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     m->role_lead = getenv("STTODE_ROLE_LEAD") ? atoi(getenv("STTODE_ROLE_LEAD")) : -1;   // -1: one role workgroup per tile, all in front (default); -2: split roles
     m->drop_tile = -1;
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { m->slot_stream[p] = nullptr; m->lag[p].valid = false; }
-    m->lag_streams = 3; m->lag_calls = 0;   // 3 streams: the small legs gain 3-9 % over 2, 512 scenes tie (profiles/r04/streams_2_vs_3.txt); 4: -5..-12 % everywhere -- the fourth shares a hardware queue (streams_3_vs_4.txt) m->zgen_armed = false; m->zgen_key = 0; m->met_armed = false;
+    // 3 streams: the small legs gain 3-9 % over 2, 512 scenes tie (profiles/r04/streams_2_vs_3.txt); 4: -5..-12 % everywhere -- the fourth
+    // shares a hardware queue (streams_3_vs_4.txt)
+    m->lag_streams = 3;
+    m->lag_calls = 0;
+    m->tmo_host = nullptr;
     for (int i = 0; i < 4; ++i) m->lag_qn[i] = 0;
     if (const char* e = getenv("STTODE_LAGGED")) m->lag_streams = atoi(e) >= 2 && atoi(e) <= 4 ? atoi(e) : 0;
     m->scene_launch = 128;
@@ -157,7 +161,7 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
             if (!ok) g_sA[dev] = nullptr;
         }
         if (ok) { m->sA = g_sA[dev]; m->sB = g_sB[dev]; m->sB2 = g_sB2[dev]; }
-        m->fused_streams = 3;
+        m->fused_streams = 1;
         if (const char* e = getenv("STTODE_FUSED_STREAMS")) m->fused_streams = atoi(e) < 1 ? 1 : atoi(e) > 6 ? 6 : atoi(e);
         static hipStream_t g_sX[STT_MAX_DEVICES][3] = {};
         for (int i = 0; ok && i < (m->fused_streams > 4 ? m->fused_streams - 3 : 1); ++i) {   // (sX[0]: also the fourth stream of the lagged rotation)
@@ -166,10 +170,15 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
         }
     }
     ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
+    // the model's time-out word lives in pinned host memory (device-visible): a group that gives up stores to it with system scope, the
+    // host reads it without any synchronisation (sttode_timeout_word)
+    ok = ok && hipHostMalloc((void**)&m->tmo_host, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) memset(m->tmo_host, 0, 64);
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evB_done[p], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
+        if (m->tmo_host) (void)hipHostFree(m->tmo_host);
         delete m;
         stt_set_error("sttode_model_create: could not create streams / events");
         return 2;
@@ -194,6 +203,7 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     // sA / sB / sB2 are process-wide (sttode_model_create)
     (void)hipEventDestroy(m->ev_call);
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
+    if (m->tmo_host) (void)hipHostFree(m->tmo_host);
     delete m;
     return 0;
 }
@@ -223,9 +233,10 @@ extern "C" int sttode_workspace_layout(const SttodeModel* m, int n, int S, long*
     put(STT_B_YBUF, mm * 16 * m->NOY);
     put(STT_B_STATE1, mm * 96);
     put(STT_B_QUEUE, 64);
-    // fused launches: five flags per 16-agent tile (E, G, three tables) + the time-out word; one-launch scene form: three per agent tile + one per
-    // 16-trajectory tile; zeroed per call
-    put(STT_B_FLAGS, (size_t)5 * ((n + 15) / 16) + 4 + (mm + 15) / 16);
+    // fused launches: five flags per 16-agent tile (E, G, three tables) + the time-out word, zeroed per call; behind them the one-launch scene
+    // form's: three per agent tile + time-out word + one per 16-trajectory tile + exit counter + initialised word (stt_scene_flags_offset)
+    // (+ the one-launch scene form's exit counter and "initialised" word: sttode_workspace_init)
+    put(STT_B_FLAGS, (size_t)8 * ((n + 15) / 16) + 8 + (mm + 15) / 16);
     put(STT_B_ODE, (size_t)6 * n * 64);   // multi-stage integrator with attention groups > 1 (always laid out: sttode_set_ode may come later)
     *total_floats = (long)o;
     return 0;
@@ -251,6 +262,7 @@ static int lag_flush_all(SttodeModel* m);
 extern "C" int sttode_set_lagged(SttodeModel* m, int streams) {
     STT_REQUIRE(m, "sttode_set_lagged: null model");
     STT_REQUIRE(streams == 0 || (streams >= 2 && streams <= 4), "sttode_set_lagged: streams must be 0 (off), 2, 3 or 4");
+    std::lock_guard<std::mutex> lk(m->mu);
     if (int rc = lag_flush_all(m)) return rc;   // outstanding groups belong to the old rotation
     m->lag_streams = streams;
     m->lag_calls = 0;
@@ -368,7 +380,15 @@ struct StageTimer {
     } while (0)
 
 // stage A: everything per AGENT (encoder, block-0 GRU on the side stream, layer-1 pre-activations), on stream s
-static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, hipStream_t s, bool use_side) {
+// self-attention of `groups` forward-call batches (attention groups; 1 = the reference's one batch per call) in one launch:
+// L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk); group g = agents [g attn_len attn_slots, (g + 1) attn_len attn_slots)
+static int attention(float* qkv, float* attn, int groups, int attn_len, int attn_slots, hipStream_t s) {
+    const long st_seq = (long)attn_slots * 192, gq = (long)attn_len * st_seq, go = (long)attn_len * attn_slots * 64;
+    return sttode_mhgsa_attn_groups(qkv + 64, qkv, qkv + 128, attn, groups, gq, gq, gq, go, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
+                                    st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s);
+}
+
+static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int groups, int attn_len, int attn_slots, hipStream_t s, bool use_side) {
     const float* const* W = m->w;
     const int Tp = m->Tp, TPX = m->TPX;
     float* xpad = ws + off[STT_B_XPAD];
@@ -440,11 +460,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
     const float* attn_src = qkv + 128;
     int ld_attn = 192;
     if (attn_len > 1) {
-        // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
-        const long st_seq = (long)attn_slots * 192;
-        RUN(STT_STAGE_ATTN, s,
-            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, attn, nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
-                              st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+        RUN(STT_STAGE_ATTN, s, attention(qkv, attn, groups, attn_len, attn_slots, s));
         attn_src = attn;
         ld_attn = 64;
     }
@@ -455,14 +471,11 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
         float* ob = ws + off[STT_B_ODE];
         const size_t nf = (size_t)n * 64;
         float *y = ob, *k1 = ob + nf, *k2 = ob + 2 * nf, *k3 = ob + 3 * nf, *t = ob + 5 * nf;
-        const long st_seq = (long)attn_slots * 192;
         // Round 4: every stage = ONE fused launch (right-hand side at the stage's state -> next state by the stage's Butcher row ->
         // its in-projection; the last stage of the last step writes past_feature) + the attention of the next state: 2 launches per stage,
         // 8 per RK4 step (the op-level sequence of round 3: ~30).  y0 = g; qkv / attn of y0 are the launches above.
-        auto attention = [&]() -> int {
-            RUN(STT_STAGE_ATTN, s,
-                sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, attn, nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
-                                  st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+        auto attention_of_state = [&]() -> int {
+            RUN(STT_STAGE_ATTN, s, attention(qkv, attn, groups, attn_len, attn_slots, s));
             return 0;
         };
         // stage(state, base, kA cA, kB cB, kC cC, cN, kout, out, last): `last` = the integration ends here (no next attention, pf written)
@@ -471,7 +484,7 @@ static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int a
             RUN(STT_STAGE_POST, s,
                 stt_post_attn_stage(W, state, attn, 64, base, kA, (float)cA, kB, (float)cB, kC, (float)cC, (float)cN, kout, out, last ? nullptr : qkv,
                                     g, last ? pf : nullptr, n, s));
-            return last ? 0 : attention();
+            return last ? 0 : attention_of_state();
         };
 #define ODE_DO(call) do { if (int _rc = (call)) return _rc; } while (0)
         const double h = 12.0 / (double)m->ode_steps;
@@ -594,7 +607,7 @@ static bool use_scene_launch(const SttodeModel* m, int n, const int* scene_ptr) 
     return scene_ptr != nullptr && !chain && m->scene_launch > 0 && (ncols_all + 15) / 16 <= m->scene_launch && m->ode_method == 0 &&
            m->ode_steps == 1 && m->col_parts <= 1 && stt_scene_lat_covers(m->Tp, m->TPX, m->NOY);
 }
-static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int attn_len, int attn_slots, const float* z, float* pred,
+static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int groups, int attn_len, int attn_slots, const float* z, float* pred,
                        const float* past, const int* scene_ptr, int S, hipStream_t s) {
     const float* const* W = m->w;
     const float* attn = nullptr;
@@ -604,13 +617,11 @@ static int stage_fused(SttodeModel* m, float* ws, const long* off, int n, int at
             sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
                              W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],
                              (const int*)(ws + off[STT_B_LAST]), ws + off[STT_B_G], qkv, n, m->Tp, s));
-        const long st_seq = (long)attn_slots * 192;   // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
-        RUN(STT_STAGE_ATTN, s,
-            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, ws + off[STT_B_ATTN], nullptr, nullptr, attn_len, attn_len, attn_slots, st_seq, 192,
-                              st_seq, 192, st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s));
+        RUN(STT_STAGE_ATTN, s, attention(qkv, ws + off[STT_B_ATTN], groups, attn_len, attn_slots, s));
         attn = ws + off[STT_B_ATTN];
     }
-    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, m->b3, m->role_lead, m->drop_tile, s));
+    RUN(STT_STAGE_FUSED, s, stt_chain_fused(W, ws, off, n, m->K, m->Tp, m->Tf, m->prog_len, z, pred, 12.0f, attn, 64, past, scene_ptr, S, 2, m->b3, m->role_lead, m->drop_tile,
+                                            m->tmo_host, s));
     return 0;
 }
 
@@ -620,7 +631,7 @@ static inline void arm_timing(SttodeModel* m) {
     ++m->calls;
 }
 
-static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
+static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int G, int B, int N, const float* z, float* ws,
                       float* pred, hipStream_t s) {
     arm_timing(m);
     long off[STT_B_COUNT], tot;
@@ -628,7 +639,7 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     if (use_scene_launch(m, n, scene_ptr)) {   // a scene or a few: the whole call as ONE launch of cooperating workgroups (scene_lat.hip)
         RUN(STT_STAGE_FUSED, s,
             stt_scene_lat(m->w, ws, off, n, m->K, m->Tp, m->Tf, m->TPX, m->NOY, m->n_chunks0, m->n_chunks1, z, pred, 12.0f, past, scene_ptr, S,
-                          m->drop_tile, s));
+                          m->drop_tile, m->tmo_host, s));
         return 0;
     }
     // scene batches on the fused launch: the roles run the front-end of their own tiles (the call is ONE launch); otherwise it is a launch
@@ -636,8 +647,8 @@ static int run_serial(SttodeModel* m, const float* past, const int* scene_ptr, i
     if (!fe_in_role)
         if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, s)) return rc;
     if (use_fused(m, n))
-        return stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, s);
-    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
+        return stage_fused(m, ws, off, n, G, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, s);
+    if (int rc = stage_agents(m, ws, off, n, G, scene_ptr ? 1 : B, scene_ptr ? 1 : N, s, true)) return rc;
     return stage_trajectories(m, ws, off, n, z, pred, s, false);
 }
 
@@ -677,8 +688,8 @@ static int lag_flush_all(SttodeModel* m) {
         if (int rc = lag_flush(m, p)) return rc;
     return 0;
 }
-static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
-                      float* pred, int slot, const long* off, hipStream_t s) {
+static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int G, int B, int N, const float* z, float* ws,
+                      float* pred, int slot, const long* off, const SttodeAsyncOpts& o, hipStream_t s) {
     const float* const* W = m->w;
     const int si = (int)(m->lag_calls % m->lag_streams);
     hipStream_t sf = lag_stream(m, si);
@@ -704,20 +715,15 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
             sttode_embed_qkv(W[STT_W_FC1P], W[STT_W_FC1B], W[STT_W_POSP], W[STT_W_PEB], W[STT_W_FC2P], W[STT_W_FC2B], W[STT_W_FC3P],
                              W[STT_W_FC3B], W[STT_W_FC3LAST], W[STT_W_INP], W[STT_W_INB], ws + off[STT_B_ENC_IN],
                              (const int*)(ws + off[STT_B_LAST]), ws + off[STT_B_G], qkv, n, m->Tp, sf));
-        const long st_seq = (long)N * 192;   // self-attention, L == S: rows = keys, columns = queries (hyptransformerlib.py:261-265 quirk)
-        RUN(STT_STAGE_ATTN, sf,
-            sttode_mhgsa_attn(qkv + 64, qkv, qkv + 128, ws + off[STT_B_ATTN], nullptr, nullptr, B, B, N, st_seq, 192, st_seq, 192, st_seq, 192,
-                              (long)N * 64, 64, 1.0f, 0.35355339059327373f, sf));
+        RUN(STT_STAGE_ATTN, sf, attention(qkv, ws + off[STT_B_ATTN], G, B, N, sf));
         attn = ws + off[STT_B_ATTN];
     }
     const int gs = m->lag_qn[si] > 0 ? m->lag_q[si][0] : -1;     // the oldest call of this stream whose groups are outstanding
     LagPending* g = gs >= 0 ? &m->lag[gs] : nullptr;
-    float* zgen = m->zgen_armed ? const_cast<float*>(z) : nullptr;   // armed: `z` is this call's latent BUFFER, filled by its roles
-    m->zgen_armed = false;
-    const bool met = m->met_armed;                                   // armed: this call's groups will compute its best-of-K metrics
-    m->met_armed = false;
-    LagRoles lr = {ws, off, n, attn, 64, 12.0f, zgen, m->zgen_key, fe_role ? past : nullptr, fe_role ? scene_ptr : nullptr, fe_role ? S : 0,
-                   met ? m->met_ade : nullptr, met ? m->met_fde : nullptr};
+    float* zgen = o.device_latents ? const_cast<float*>(z) : nullptr;   // `z` is this call's latent BUFFER, filled by its roles
+    const bool met = o.metrics_gt != nullptr;                           // this call's groups will compute its best-of-K metrics
+    LagRoles lr = {ws, off, n, attn, 64, 12.0f, zgen, o.zkey, fe_role ? past : nullptr, fe_role ? scene_ptr : nullptr, fe_role ? S : 0,
+                   met ? o.ade : nullptr, met ? o.fde : nullptr};
     LagGroups lg = {};
     if (g) lg = LagGroups{g->ws, g->off, g->n, g->z, g->pred, g->gt, g->ade, g->fde, g->scale, fe_role && g->one_launch};
     RUN(STT_STAGE_FUSED, sf, stt_chain_lagged(W, lr, lg, m->K, m->Tp, m->Tf, m->prog_len, m->b3, sf));
@@ -729,7 +735,7 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
     LagPending& p = m->lag[slot];
     p.valid = true; p.ws = ws; p.n = n; p.z = z; p.pred = pred; p.s = sf; p.si = si;
     p.one_launch = fe_role;
-    p.gt = met ? m->met_gt : nullptr; p.ade = met ? m->met_ade : nullptr; p.fde = met ? m->met_fde : nullptr; p.scale = met ? m->met_scale : 1.0f;
+    p.gt = met ? o.metrics_gt : nullptr; p.ade = met ? o.ade : nullptr; p.fde = met ? o.fde : nullptr; p.scale = met ? o.metrics_scale : 1.0f;
     memcpy(p.off, off, sizeof(p.off));
     m->lag_q[si][m->lag_qn[si]++] = slot;
     m->slot_stream[slot] = sf;
@@ -737,20 +743,29 @@ static int run_lagged(SttodeModel* m, const float* past, const int* scene_ptr, i
 }
 
 // pipelined form: stage A on sA, stage B on sB, two workspace slots; the caller later waits with sttode_wait(slot)
-static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int B, int N, const float* z, float* ws,
-                     float* pred, int slot, hipStream_t s) {
+static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, int G, int B, int N, const float* z, float* ws,
+                     float* pred, int slot, const SttodeAsyncOpts* opts, hipStream_t s) {
     STT_REQUIRE(slot >= 0 && slot < STT_MAX_SLOTS, "sttode_inference_*_async: slot must be in [0, 8)");
+    std::lock_guard<std::mutex> lk(m->mu);
+    // Everything the options ask for is checked BEFORE anything is enqueued or any state of the model changes (round-4 advice: the
+    // arm-then-call entry points left a request armed when a later check failed): a refused call has no effect at all.
+    SttodeAsyncOpts o = {};
+    if (opts) o = *opts;
+    if (o.device_latents || o.metrics_gt) {
+        STT_REQUIRE(use_lagged(m, n), "sttode_inference_*_async: device latents / fused metrics need the lagged form (sttode_async_is_lagged)");
+        STT_REQUIRE(!o.metrics_gt || (o.ade && o.fde), "sttode_inference_*_async: fused metrics need the ade / fde outputs");
+    }
     arm_timing(m);
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
     if (int rc = lag_flush(m, slot)) return rc;                  // the slot is wanted back: its outstanding groups (if any) go first
-    if (m->met_armed && !use_lagged(m, n)) { m->met_armed = false; STT_REQUIRE(false, "sttode_inference_*_async: fused metrics were armed for a call of another form"); }
-    if (m->zgen_armed && !use_lagged(m, n)) { m->zgen_armed = false; STT_REQUIRE(false, "sttode_inference_*_async: device latents were armed for a call of another form"); }
     STT_HIP(hipEventRecord(m->ev_call, s));                      // inputs and z of this call are ready once this fires
-    if (use_lagged(m, n)) return run_lagged(m, past, scene_ptr, n, S, B, N, z, ws, pred, slot, off, s);
+    if (use_lagged(m, n)) return run_lagged(m, past, scene_ptr, n, S, G, B, N, z, ws, pred, slot, off, o, s);
     if (use_fused(m, n)) {
-        // ONE stream per call, three in rotation: the call is front-end + one launch, so up to three launches share the chip and each
-        // fills the others' tails (two resident chain workgroups per CU throughout: nothing waits for a chain-free CU any more)
+        // ONE stream per call.  Round 5: these launches hand tables over INSIDE the launch (tile flags, bounded spin), and workgroups are
+        // dispatched in index order per XCD only -- several of them in flight on different queues could wait on each other across XCDs
+        // (round-3/4 advice) -- so by default they run one at a time on ONE stream (STTODE_FUSED_STREAMS > 1 restores the rotation for A/B).
+        // The product's pipelined path is the lagged form above, which has no hand-off.
         const int si = (int)(m->acalls % m->fused_streams);
         hipStream_t sf = si == 0 ? m->sB : si == 1 ? m->sB2 : si == 2 ? m->sA : m->sX[si - 3];
         ++m->acalls;
@@ -759,7 +774,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
         const bool fe_in_role = scene_ptr != nullptr && m->fe_in_role;
         if (!fe_in_role)
             if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, sf)) return rc;
-        if (int rc = stage_fused(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, sf)) return rc;
+        if (int rc = stage_fused(m, ws, off, n, G, scene_ptr ? 1 : B, scene_ptr ? 1 : N, z, pred, fe_in_role ? past : nullptr, scene_ptr, S, sf)) return rc;
         STT_HIP(hipEventRecord(m->evB_done[slot], sf));
         m->slot_stream[slot] = sf;
         return 0;
@@ -767,7 +782,7 @@ static int run_async(SttodeModel* m, const float* past, const int* scene_ptr, in
     STT_HIP(hipStreamWaitEvent(m->sA, m->ev_call, 0));
     STT_HIP(hipStreamWaitEvent(m->sA, m->evB_done[slot], 0));    // the slot's previous user (call i-2) has drained
     if (int rc = frontend(m, ws, off, past, scene_ptr, n, S, N, m->sA)) return rc;
-    if (int rc = stage_agents(m, ws, off, n, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA, false)) return rc;
+    if (int rc = stage_agents(m, ws, off, n, G, scene_ptr ? 1 : B, scene_ptr ? 1 : N, m->sA, false)) return rc;
     STT_HIP(hipEventRecord(m->evA_done[slot], m->sA));
     // per-trajectory stages of consecutive calls alternate between two streams (b_streams == 2): the persistent chain kernel of
     // call i+1 then starts on the compute units its predecessor's last workgroups leave (no chip-wide resource is held)
@@ -784,28 +799,38 @@ extern "C" int sttode_inference_scenes(SttodeModel* m, const float* past, const 
                                        float* workspace, float* pred, void* stream) {
     STT_REQUIRE(m && past && scene_ptr && z && workspace && pred, "sttode_inference_scenes: null pointer");
     STT_REQUIRE(n > 0 && S > 0, "sttode_inference_scenes: n and S must be positive");
-    return run_serial(m, past, scene_ptr, n, S, 1, 1, z, workspace, pred, (hipStream_t)stream);
+    return run_serial(m, past, scene_ptr, n, S, 1, 1, 1, z, workspace, pred, (hipStream_t)stream);
 }
 
 extern "C" int sttode_inference_nba(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace, float* pred,
                                     void* stream) {
     STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba: null pointer");
     STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba: B and N must be positive");
-    return run_serial(m, past, nullptr, B * N, 0, B, N, z, workspace, pred, (hipStream_t)stream);
+    return run_serial(m, past, nullptr, B * N, 0, 1, B, N, z, workspace, pred, (hipStream_t)stream);
+}
+
+// G forward-call batches of the NBA branch in ONE call: past [G][B][N][Tp][2]; the attention runs within each batch of B scenes (what G
+// separate sttode_inference_nba calls compute, test.py:520-524), everything else is per agent / per trajectory over all G B N agents.
+extern "C" int sttode_inference_nba_groups(SttodeModel* m, const float* past, int G, int B, int N, const float* z, float* workspace,
+                                           float* pred, void* stream) {
+    STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba_groups: null pointer");
+    STT_REQUIRE(G > 0 && B > 0 && N > 0 && (long)G * B * N <= 0x7fffffffL / 64, "sttode_inference_nba_groups: G, B and N must be positive (and G B N small enough)");
+    return run_serial(m, past, nullptr, G * B * N, 0, G, B, N, z, workspace, pred, (hipStream_t)stream);
 }
 
 extern "C" int sttode_inference_scenes_async(SttodeModel* m, const float* past, const int* scene_ptr, int n, int S, const float* z,
-                                             float* workspace, float* pred, int slot, void* stream) {
+                                             float* workspace, float* pred, int slot, const SttodeAsyncOpts* opts, void* stream) {
     STT_REQUIRE(m && past && scene_ptr && z && workspace && pred, "sttode_inference_scenes_async: null pointer");
     STT_REQUIRE(n > 0 && S > 0, "sttode_inference_scenes_async: n and S must be positive");
-    return run_async(m, past, scene_ptr, n, S, 1, 1, z, workspace, pred, slot, (hipStream_t)stream);
+    return run_async(m, past, scene_ptr, n, S, 1, 1, 1, z, workspace, pred, slot, opts, (hipStream_t)stream);
 }
 
 extern "C" int sttode_inference_nba_async(SttodeModel* m, const float* past, int B, int N, const float* z, float* workspace,
-                                          float* pred, int slot, void* stream) {
+                                          float* pred, int slot, const SttodeAsyncOpts* opts, void* stream) {
     STT_REQUIRE(m && past && z && workspace && pred, "sttode_inference_nba_async: null pointer");
-    STT_REQUIRE(B > 0 && N > 0, "sttode_inference_nba_async: B and N must be positive");
-    return run_async(m, past, nullptr, B * N, 0, B, N, z, workspace, pred, slot, (hipStream_t)stream);
+    const int G = opts && opts->nba_groups > 1 ? opts->nba_groups : 1;
+    STT_REQUIRE(B > 0 && N > 0 && (long)G * B * N <= 0x7fffffffL / 64, "sttode_inference_nba_async: B and N must be positive (and groups x B x N small enough)");
+    return run_async(m, past, nullptr, G * B * N, 0, G, B, N, z, workspace, pred, slot, opts, (hipStream_t)stream);
 }
 
 // Follow-up work of an asynchronous call ON THE CALL'S OWN pipeline stream: best-of-K metrics of its predictions (utils/metrics.py:7-26) run
@@ -815,6 +840,7 @@ extern "C" int sttode_inference_nba_async(SttodeModel* m, const float* past, int
 extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pred, const float* gt, int n, int K, int Tf, float scale,
                                       float* ade, float* fde) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_best_of_k: bad model / slot");
+    std::lock_guard<std::mutex> lk(m->mu);
     STT_REQUIRE(m->slot_stream[slot] != nullptr, "sttode_async_best_of_k: no asynchronous call has used this slot");
     if (int rc = lag_flush(m, slot)) return rc;   // (lagged form) nobody has enqueued this call's groups yet: they go first
     if (int rc = sttode_best_of_k(pred, gt, n, K, Tf, scale, ade, fde, m->slot_stream[slot])) return rc;
@@ -822,11 +848,26 @@ extern "C" int sttode_async_best_of_k(SttodeModel* m, int slot, const float* pre
     return 0;
 }
 
-// The pipeline stream the NEXT asynchronous call of n agents will run on (fused launches: one stream per call, three in rotation), or NULL
+// The NBA evaluation's per-horizon metric (test.py:530-551) of an asynchronous call, on the call's own pipeline stream like
+// sttode_async_best_of_k: out [n][Tf][2] = per agent and horizon h the min over K of (mean displacement over the first h frames, displacement
+// of frame h) -- sttode_horizon_metrics on the slot's predictions.
+extern "C" int sttode_async_horizon_metrics(SttodeModel* m, int slot, const float* pred, const float* gt, int n, int K, int Tf, float scale,
+                                            float* out) {
+    STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_horizon_metrics: bad model / slot");
+    std::lock_guard<std::mutex> lk(m->mu);
+    STT_REQUIRE(m->slot_stream[slot] != nullptr, "sttode_async_horizon_metrics: no asynchronous call has used this slot");
+    if (int rc = lag_flush(m, slot)) return rc;
+    if (int rc = sttode_horizon_metrics(pred, gt, n, K, Tf, scale, out, m->slot_stream[slot])) return rc;
+    STT_HIP(hipEventRecord(m->evB_done[slot], m->slot_stream[slot]));
+    return 0;
+}
+
+// The pipeline stream the NEXT asynchronous call of n agents will run on (lagged launches: one stream per call, three in rotation), or NULL
 // when that call is not of the one-stream form.  A caller that prepares the call's inputs ON that stream (H2D copy, latents) and issues the
 // call from it needs no cross-stream event at all: the call's wait for the caller's stream is then a wait for itself.
 extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
     STT_REQUIRE(m && stream && n > 0, "sttode_async_next_stream: bad arguments");
+    std::lock_guard<std::mutex> lk(m->mu);
     *stream = nullptr;
     if (use_lagged(m, n)) { *stream = lag_stream(m, (int)(m->lag_calls % m->lag_streams)); return 0; }
     if (!use_fused(m, n)) return 0;
@@ -835,42 +876,29 @@ extern "C" int sttode_async_next_stream(SttodeModel* m, int n, void** stream) {
     return 0;
 }
 
-// Latents on device (lagged form): returns 1 -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged
-// form: that call then treats its `z` argument as an OUTPUT buffer [n K][32] which its own per-agent roles fill with N(0, I) samples
-// (Philox4x32-10 keyed by `key`, csrc/role32.hpp latents32) before its trajectory groups read it; returns 0 (nothing armed) otherwise.
-extern "C" int sttode_async_device_latents(SttodeModel* m, int n, unsigned long long key) {
-    if (!m || n <= 0 || !use_lagged(m, n)) return 0;
-    m->zgen_armed = true;
-    m->zgen_key = key;
-    return 1;
-}
-
-// Fused metrics (lagged form): returns 1 -- and arms it -- if the next sttode_inference_*_async call of n agents will take the lagged form:
-// that call's trajectory groups then also compute its best-of-K ADE / FDE (utils/metrics.py:7-26, the values of sttode_best_of_k bit for
-// bit) against gt [n][Tf][2] into ade / fde [n] -- no metrics kernel; valid once sttode_wait(slot) has passed.  0: nothing armed.
-extern "C" int sttode_async_fused_metrics(SttodeModel* m, int n, const float* gt, float* ade, float* fde, float scale) {
-    if (!m || n <= 0 || !gt || !ade || !fde || !use_lagged(m, n)) return 0;
-    m->met_armed = true;
-    m->met_gt = gt; m->met_ade = ade; m->met_fde = fde; m->met_scale = scale;
-    return 1;
-}
-
-// 1 if the next sttode_inference_*_async call of n agents will take the lagged form (whose trajectory groups never READ the prediction
-// buffer: it may then be pinned host memory -- the futures arrive on the host with the launch, no D2H copy), else 0
+// 1 if the next sttode_inference_*_async call of n agents will take the lagged form -- the form that honours SttodeAsyncOpts' device latents
+// and fused metrics, and whose trajectory groups never READ the prediction buffer (it may then be pinned host memory: the futures arrive
+// on the host with the launch, no D2H copy) -- else 0.  A query, not a status.
 extern "C" int sttode_async_is_lagged(SttodeModel* m, int n) { return m && n > 0 && use_lagged(m, n) ? 1 : 0; }
 
 // the HOST waits until the async call that used `slot` has produced its predictions (outstanding groups are enqueued first): for
 // predictions written straight to pinned host memory
 extern "C" int sttode_wait_host(SttodeModel* m, int slot) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait_host: bad arguments");
-    if (int rc = lag_flush(m, slot)) return rc;
-    STT_HIP(hipEventSynchronize(m->evB_done[slot]));
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (int rc = lag_flush(m, slot)) return rc;
+        ev = m->evB_done[slot];
+    }
+    STT_HIP(hipEventSynchronize(ev));
     return 0;
 }
 
 // make `stream` wait until the async call that used `slot` has produced its predictions
 extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_wait: bad arguments");
+    std::lock_guard<std::mutex> lk(m->mu);
     if (int rc = lag_flush(m, slot)) return rc;   // (lagged form) no later call carried this call's groups: they are enqueued now
     STT_HIP(hipStreamWaitEvent((hipStream_t)stream, m->evB_done[slot], 0));
     return 0;
@@ -879,25 +907,54 @@ extern "C" int sttode_wait(SttodeModel* m, int slot, void* stream) {
 // the outstanding trajectory-group launch of ONE slot's call is enqueued now (no-op if a later call carried it already)
 extern "C" int sttode_async_enqueue(SttodeModel* m, int slot) {
     STT_REQUIRE(m && slot >= 0 && slot < STT_MAX_SLOTS, "sttode_async_enqueue: bad model / slot");
+    std::lock_guard<std::mutex> lk(m->mu);
     return lag_flush(m, slot);
 }
 
 // every outstanding trajectory-group launch of the lagged form is enqueued (before buffers of pending calls are released or reused)
 extern "C" int sttode_async_flush(SttodeModel* m) {
     STT_REQUIRE(m, "sttode_async_flush: null model");
+    std::lock_guard<std::mutex> lk(m->mu);
     return lag_flush_all(m);
 }
 
-// time-out word of the in-launch hand-off forms (chain32.hip FUSE == 1: word [tiles] of STT_B_FLAGS; split roles and scene_lat.hip keep theirs
-// at the same index): see include/sttode_hip.h
+// once per workspace, before its first use: see include/sttode_hip.h
+extern "C" int sttode_workspace_init(SttodeModel* m, float* workspace, int n, int S, void* stream) {
+    STT_REQUIRE(m && workspace && n > 0 && S >= 0, "sttode_workspace_init: bad arguments");
+    long off[STT_B_COUNT], tot;
+    if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
+    STT_HIP(hipMemsetAsync(workspace + off[STT_B_FLAGS], 0, (size_t)(off[STT_B_ODE] - off[STT_B_FLAGS]) * 4, (hipStream_t)stream));
+    return stt_scene_flags_init(workspace, off, n, m->K, stream);
+}
+
+// the model's time-out word (pinned host memory): see include/sttode_hip.h
+extern "C" int sttode_timeout_word(SttodeModel* m, const unsigned** word) {
+    STT_REQUIRE(m && word && m->tmo_host, "sttode_timeout_word: bad arguments");
+    *word = m->tmo_host;
+    return 0;
+}
+extern "C" int sttode_timeout_clear(SttodeModel* m) {
+    STT_REQUIRE(m && m->tmo_host, "sttode_timeout_clear: bad arguments");
+    __atomic_store_n(m->tmo_host, 0u, __ATOMIC_RELAXED);
+    return 0;
+}
+
+// time-out word of the in-launch hand-off forms (fused launch: word [tiles] of STT_B_FLAGS; one-launch scene form: word [tiles] of its own
+// region behind it, stt_scene_flags_offset): see include/sttode_hip.h
 extern "C" int sttode_check(SttodeModel* m, const float* workspace, int n, int S, void* stream) {
     STT_REQUIRE(m && workspace && n > 0 && S >= 0, "sttode_check: bad arguments");
     long off[STT_B_COUNT], tot;
     if (int rc = sttode_workspace_layout(m, n, S, off, &tot)) return rc;
-    unsigned word = 0;
-    STT_HIP(hipMemcpyAsync(&word, workspace + off[STT_B_FLAGS] + (n + 15) / 16, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    unsigned word[2] = {0, 0};
+    const float* f = workspace + off[STT_B_FLAGS];
+    STT_HIP(hipMemcpyAsync(&word[0], f + (n + 15) / 16, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    STT_HIP(hipMemcpyAsync(&word[1], f + stt_scene_flags_offset(n) + (n + 15) / 16, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
     STT_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (word != 0) {
+    if (word[1] == 2u) {
+        stt_set_error("sttode_check: the workspace was never initialised (sttode_workspace_init): the one-launch scene form refused its flag words; the predictions of that call are not valid");
+        return 3;
+    }
+    if (word[0] != 0 || word[1] != 0) {
         stt_set_error("sttode_check: a trajectory group gave up waiting for its per-agent role (time-out word set): the predictions of that call are not valid");
         return 3;
     }

@@ -30,6 +30,7 @@ struct RoleArgs {
     const float* attn; int ld_attn;   // attention output of an EARLIER launch (attention groups > 1, the NBA branch): the role then starts
                                       // at the post-attention layer; nullptr: attention length 1, the role runs the embedding too
     unsigned* flags;     // [ntiles] tile flags + [1] time-out word, zeroed by the launcher before every launch
+    unsigned* tmo_host;  // the model's time-out word in pinned host memory (sttode_timeout_word), or nullptr: set (system scope) with the workspace's
     int ntiles; float ode_time;
     int lead;            // grid order: the role of tile t sits `lead` groups ahead of the first group that needs it (fused_block_of)
     int drop_tile;       // fault injection (tests): the role of this tile never publishes its flag (-1: none) -- exercises the give-up path
@@ -125,21 +126,26 @@ __device__ __forceinline__ void agent_role(const RoleArgs& R, int nag, int Tp, i
 // ONE agent-scope acquire drops this CU's stale L1 lines; the caller's barrier releases the other waves.  The spin is bounded (~1 s): a
 // producer that never arrives -- it cannot, in-order dispatch puts every producer in front of its consumers -- would poison this group's
 // predictions with NaN and set the time-out word instead of hanging the device.
-// want == 0: a flag is up when it is non-zero (the flag words are zeroed in front of every launch); want != 0: when it EQUALS `want` --
-// the launch's epoch (scene_lat.hip): words left by earlier launches on the same workspace are older epochs, so no memset is needed
-__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane, unsigned want = 0u) {
+// A flag is up when it is non-zero: the flag words are zero when a launch starts (fused launch: zeroed by the launcher in front of every
+// launch; one-launch scene form: zeroed once by sttode_workspace_init and again by the LAST workgroup of every launch, scene_lat.hip).
+// tmo_host (optional): the model's pinned host word, set with system scope beside the workspace's time-out word -- the host sees a give-up
+// without synchronising or copying anything (sttode_timeout_word).
+__device__ __forceinline__ bool wait_tiles(unsigned* flags, int t_lo, int t_hi, unsigned* tmo, int lane, unsigned* tmo_host = nullptr) {
     bool ok = true;
     for (int t = t_lo + lane; t <= t_hi; t += 64) {
         unsigned spins = 0;
         while (true) {
             const unsigned v = __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (want ? v == want : v != 0u) break;
+            if (v != 0u) break;
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 20)) { ok = false; break; }
         }
     }
     ok = __all(ok);
-    if (!ok && lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok && lane == 0) {
+        __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tmo_host) __hip_atomic_store(tmo_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return ok;
@@ -216,6 +222,7 @@ __device__ __forceinline__ void split_role(const RoleArgs& R, int nag, int Tp, i
 // Host side: the weight fragments (model table W, STT_W_*) and workspace rows (ws + off[STT_B_*]) every launch that carries per-agent
 // roles hands to them; the caller sets what differs (attention input, scene front-end inputs, flags, fault injection).
 static inline void role_args_fill(RoleArgs& r, const float* const* W, float* ws, const long* off) {
+    r.tmo_host = nullptr;
     r.ew.fc1P = W[STT_W_FC1P]; r.ew.fc1b = W[STT_W_FC1B]; r.ew.posP = (const f32x4*)W[STT_W_POSP]; r.ew.peb = W[STT_W_PEB];
     r.ew.fc2P = (const f32x4*)W[STT_W_FC2P]; r.ew.fc2b = W[STT_W_FC2B]; r.ew.fc3P = (const f32x4*)W[STT_W_FC3P]; r.ew.fc3b = W[STT_W_FC3B];
     r.ew.fc3last = W[STT_W_FC3LAST]; r.ew.inP = (const f32x4*)W[STT_W_INP]; r.ew.inb = W[STT_W_INB];

@@ -23,7 +23,6 @@
 // in-order dispatch has made resident (or finished) before it starts: no deadlock whatever the grid size; the bounded spin poisons the
 // tile's predictions with NaN and raises the time-out word instead of hanging.  The bodies are the separate launches' code
 // (latency_bodies.hpp), every output element summed in the same order: the predictions carry the bits of the six-launch path.
-#include <mutex>
 #include "chain.hpp"
 #include "role_body.hpp"
 #include "api_util.hpp"
@@ -34,9 +33,9 @@ struct SceneLatArgs {
     MlpLatArgs x0, y0, y1;      // block-0 decoder_x / decoder_y, block-1 decoder_y (the LDS operands are set by the kernel)
     const f32x4* convP; const float* convB; const f32x4* wihP; const f32x4* whhP; const float* gbias;   // block-1 conv + GRU
     const float* xpad; int ldx;
-    unsigned *tmo, *gflags, *e2flags, *yflags;   // flag words: E [A] | time-out | G [A] | E2 [A] | Y [C]
+    unsigned *tmo, *gflags, *e2flags, *yflags;   // flag words: E [A] | time-out | G [A] | E2 [A] | Y [C] | exit counter | "initialised" word
+    unsigned *done, *magic;     // exit counter of the launch; SL_MAGIC once sttode_workspace_init has zeroed the flag words
     int n, K, Tp, Tf2, ntiles_c;
-    unsigned epoch;             // this launch's flag value (stt_scene_lat): a flag is up when it EQUALS it -- no memset in front of the launch
     long long* dbg;             // diagnostic build only (SL_DIAG_TRACE): [block][8] phase stamps (100 MHz)
 };
 
@@ -47,7 +46,8 @@ struct SceneLatArgs {
 #define SL_SH (56 * 1024)
 #define SL_GX (68 * 1024)
 #define SL_D (78 * 1024)
-#define SL_TOTAL (80 * 1024)          // + 16 B: the workgroup's go / time-out word
+#define SL_TOTAL (80 * 1024)          // + 16 B: the workgroup's go / time-out word, its "last to leave" word
+#define SL_MAGIC 0x5774F1A6u          // the workspace's flag words were zeroed by sttode_workspace_init
 
 #ifdef SL_DIAG_TRACE
 #define SL_STAMP(k) do { if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -56,8 +56,7 @@ struct SceneLatArgs {
 #endif
 
 template <int TPX, int NOY>
-__global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void scene_lat_body(const SceneLatArgs& A, char* smem) {
     const RoleArgs& R = A.R;
     const int A_tiles = R.ntiles;
     const int b = blockIdx.x;
@@ -67,7 +66,15 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
 #ifdef SL_DIAG_TRACE
     if (threadIdx.x == 0 && A.dbg) A.dbg[(size_t)b * 8 + 7] = __builtin_amdgcn_s_memtime();   // core-clock counter at the start
 #endif
-    if (b == 0 && threadIdx.x == 0) __hip_atomic_store(A.tmo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the first workgroup of the grid; a time-out is raised milliseconds later)
+    // The flag words of this workspace are ZERO when the launch starts: sttode_workspace_init zeroed them once (and left SL_MAGIC), the last
+    // workgroup of every launch zeroes them again (scene_lat_kernel) -- no memset in front of the launch, and a captured launch replays
+    // correctly (round-4 advice: a host-side epoch did not).  A workspace that was never initialised holds arbitrary flags: the trajectory
+    // roles then poison their predictions and raise the time-out word (value 2) instead of trusting them.
+    const bool inited = __hip_atomic_load(A.magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SL_MAGIC;
+    if (b == 0 && threadIdx.x == 0) {   // (the first workgroup of the grid; a time-out is raised milliseconds later)
+        __hip_atomic_store(A.tmo, inited ? 0u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!inited && R.tmo_host) __hip_atomic_store(R.tmo_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (b < 2 * A_tiles) {   // (uniform) per-agent roles
         const int tile = b >> 1;
         if ((b & 1) == 0) {  // E: encoder
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             SL_STAMP(1);
             post_attn_body<false, true>(R.pw, R.g, R.qkv + 128, 192, R.pf, A.n, R.ode_time, 0, 1, nullptr, nullptr, tile,
                                         reinterpret_cast<f32x4(*)[4][64]>(smem));
-            role_publish(R.flags + tile, tile != R.drop_tile, A.epoch);
+            role_publish(R.flags + tile, tile != R.drop_tile);
             SL_STAMP(2);
             // block-1 layer-1 table of the tile's agents: off the critical path (its readers first run block 0 and the GRU)
             const int col = tile * 16 + c;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
 #pragma unroll
             for (int T = 8; T < 14; ++T) B[T] = B[0];
             preact_rows<8, true>(R.WA1, R.b11, R.A1y, B, col, col < A.n, lane, q, wave);
-            role_publish(A.e2flags + tile, true, A.epoch);
+            role_publish(A.e2flags + tile, true);
             SL_STAMP(3);
         } else {             // G: block-0 conv + GRU
             f32x4 (*sH)[6][64] = reinterpret_cast<f32x4(*)[6][64]>(smem);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             };
             gru_bal_body<TPX, false, true, decltype(fe)>(A.xpad, R.convP, R.convB, R.wihP, R.whhP, R.gbias, R.state0, A.n, A.Tp, tile, sH, sX,
                                                          nullptr, fe);
-            role_publish(A.gflags + tile, true, A.epoch);
+            role_publish(A.gflags + tile, true);
             SL_STAMP(2);
         }
         return;
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     preact_prime<14, 0, 8, 8>(WA, w1, lane, wave);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = ld4(b1 + 16 * (wave + 4 * j) + 4 * q);
-    if (threadIdx.x == 0) s_ok = 1;
+    if (threadIdx.x == 0) s_ok = inited ? 1 : 0;
     __syncthreads();
-    if (wave == 0 && !wait_tiles(R.flags, t_lo, t_hi, A.tmo, lane, A.epoch) && lane == 0) s_ok = 0;   // pf of the tile's agents
+    if (wave == 0 && inited && !wait_tiles(R.flags, t_lo, t_hi, A.tmo, lane, R.tmo_host) && lane == 0) s_ok = 0;   // pf of the tile's agents
     __syncthreads();
     SL_STAMP(1);
     f32x4* sA0 = reinterpret_cast<f32x4*>(smem + SL_A0);
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     }
     preact_prime<14, 8, 14, 6>(WA, w2, lane, wave);
     if (s_ok) preact_run<14, 0, 8, 8>(WA, w1, acc, B, lane, wave);
-    if (wave == 0 && !wait_tiles(A.gflags, t_lo, t_hi, A.tmo, lane, A.epoch) && lane == 0) s_ok = 0;   // state0, xpad, cur, orig
+    if (wave == 0 && inited && !wait_tiles(A.gflags, t_lo, t_hi, A.tmo, lane, R.tmo_host) && lane == 0) s_ok = 0;   // state0, xpad, cur, orig
     __syncthreads();
     if (s_ok) {
 #pragma unroll
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
             mlp_lat_run<2, NOY, 1, true, true, true>(y0, sH1, sH2, tile);
         }
         // (after a time-out the flag is still published: the X role has seen the same time-out and poisons the tile)
-        role_publish(A.yflags + tile, true, A.epoch);
+        role_publish(A.yflags + tile, true);
         SL_STAMP(3);
         return;
     }
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
         const int cur = gru_bal_body<TPX, true>(nullptr, A.convP, A.convB, A.wihP, A.whhP, A.gbias, nullptr, ncols, A.Tp, tile, sH, sX, sD);
         SL_STAMP(4);
         if (wave == 0) {   // A1y rows of this tile's agents and y_hat0 of this tile (both producers started long ago)
-            const bool ok1 = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane, A.epoch);   // (both waits run: each ends with the acquire its data needs)
-            const bool ok = wait_tiles(A.yflags, tile, tile, A.tmo, lane, A.epoch) && ok1;
+            const bool ok1 = wait_tiles(A.e2flags, t_lo, t_hi, A.tmo, lane, R.tmo_host);   // (both waits run: each ends with the acquire its data needs)
+            const bool ok = wait_tiles(A.yflags, tile, tile, A.tmo, lane, R.tmo_host) && ok1;
             if (!ok && lane == 0) s_ok = 0;
         }
         __syncthreads();
@@ -195,10 +202,39 @@ __global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
     }
 }
 
+// The launch: every workgroup runs its role (scene_lat_body), then leaves through the exit counter; the LAST one to leave -- nobody polls a flag
+// any more -- zeroes the flag words for the next launch on this workspace (the time-out word stays: sttode_check reads it).
+template <int TPX, int NOY>
+__global__ __launch_bounds__(256) void scene_lat_kernel(SceneLatArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    scene_lat_body<TPX, NOY>(A, smem);
+    volatile int& s_last = *reinterpret_cast<volatile int*>(smem + SL_TOTAL + 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+    __syncthreads();
+    if (!s_last) return;
+    const int A_tiles = A.R.ntiles, total = 3 * A_tiles + 1 + A.ntiles_c;
+    for (int i = threadIdx.x; i < total; i += blockDim.x)
+        if (i != A_tiles) __hip_atomic_store(A.R.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(A.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef SL_DIAG_TRACE
 static long long* g_scene_dbg = nullptr;
 extern "C" int sttode_scene_debug_buffer(void* p) { g_scene_dbg = (long long*)p; return 0; }   // >= grid * 8 int64
 #endif
+
+// sttode_workspace_init: the scene form's flag words zeroed, the "initialised" word set (once per workspace; the launches keep them zero)
+int stt_scene_flags_init(float* ws, const long* off, int n, int K, void* stream) {
+    const int A_tiles = (n + 15) / 16;
+    const long C_tiles = ((long)n * K + 15) / 16;
+    unsigned* f = (unsigned*)(ws + off[STT_B_FLAGS]) + stt_scene_flags_offset(n);
+    const size_t words = (size_t)3 * A_tiles + 1 + C_tiles + 1;   // E | time-out | G | E2 | Y | exit counter
+    STT_HIP(hipMemsetAsync(f, 0, words * 4, (hipStream_t)stream));
+    STT_HIP(hipMemsetD32Async((hipDeviceptr_t)(f + words), (int)SL_MAGIC, 1, (hipStream_t)stream));
+    return 0;
+}
 
 bool stt_scene_lat_covers(int Tp, int TPX, int NOY) {
     const bool shape = (TPX == 1 && (NOY == 1 || NOY == 2 || NOY == 3)) || (TPX == 2 && (NOY == 2 || NOY == 3));
@@ -208,7 +244,7 @@ bool stt_scene_lat_covers(int Tp, int TPX, int NOY) {
 // W: the model's packed-weight table (STT_W_*); ws / off: workspace and its layout (STT_B_*).  Scene batches with attention length 1 only.
 int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int K, int Tp, int Tf, int TPX, int NOY, int n_chunks0,
                   int n_chunks1, const float* z, float* pred, float ode_time, const float* past, const int* scene_ptr, int S, int drop_tile,
-                  void* stream) {
+                  unsigned* tmo_host, void* stream) {
     STT_REQUIRE(W && ws && off && z && pred && past && scene_ptr, "stt_scene_lat: null pointer");
     STT_REQUIRE(n > 0 && K > 0 && S > 0 && Tf >= 1 && 2 * Tf <= 16 * NOY && stt_scene_lat_covers(Tp, TPX, NOY), "stt_scene_lat: shape outside the one-launch form");
     STT_REQUIRE(n_chunks0 == 64 + TPX + NOY && n_chunks1 == 32 + NOY, "stt_scene_lat: weight streams do not match (TPX, NOY)");
@@ -221,8 +257,12 @@ int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int 
     const long ncols = (long)n * K;
     STT_REQUIRE(ncols <= 0x3fffffffL, "stt_scene_lat: too many trajectories");
     const int C_tiles = (int)((ncols + 15) / 16);
-    r.flags = (unsigned*)(ws + off[STT_B_FLAGS]); r.ntiles = A_tiles; r.ode_time = ode_time; r.lead = 0; r.drop_tile = drop_tile; r.split = 0; r.gflags = nullptr; r.pflags = nullptr;
+    // the scene form's flag words sit BEHIND the fused launch's region of STT_B_FLAGS (5 tiles + 4 words): that form leaves its flags up
+    r.flags = (unsigned*)(ws + off[STT_B_FLAGS]) + stt_scene_flags_offset(n);
+    r.tmo_host = tmo_host;
+    r.ntiles = A_tiles; r.ode_time = ode_time; r.lead = 0; r.drop_tile = drop_tile; r.split = 0; r.gflags = nullptr; r.pflags = nullptr;
     a.tmo = r.flags + A_tiles; a.gflags = a.tmo + 1; a.e2flags = a.gflags + A_tiles; a.yflags = a.e2flags + A_tiles;
+    a.done = a.yflags + C_tiles; a.magic = a.done + 1;
     a.dbg = nullptr;
 #ifdef SL_DIAG_TRACE
     a.dbg = g_scene_dbg;
@@ -243,25 +283,6 @@ int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int 
     a.whhP = (const f32x4*)W[STT_W_B1_WHHP]; a.gbias = W[STT_W_B1_GBIAS];
     a.xpad = xpad; a.ldx = 16 * TPX; a.n = n; a.K = K; a.Tp = Tp; a.Tf2 = 2 * Tf; a.ntiles_c = C_tiles;
     hipStream_t s = (hipStream_t)stream;
-    // E [A] + time-out word + G [A] + E2 [A] + Y [C].  The flags are compared with the launch's EPOCH (0x80000000 + a process-wide call
-    // count: the bit patterns of tiny negative denormals, which neither an older epoch nor recycled tensor contents hold), so they are
-    // zeroed only the first time a workspace is seen (and when the count wraps) instead of in front of every launch -- one stream
-    // operation less on the critical path of the one-scene loop (test.py:171-188).
-    static std::mutex mu;
-    static const float* known[16];
-    static unsigned count = 0, slot = 0;
-    unsigned epoch;
-    bool fresh = true;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (++count >= (1u << 24)) { count = 1; for (auto& k : known) k = nullptr; }
-        epoch = 0x80000000u + count;
-        for (const float* k : known) fresh = fresh && k != ws;
-        if (fresh) known[slot++ & 15] = ws;
-    }
-    static const bool always = getenv("STTODE_SCENE_MEMSET") && atoi(getenv("STTODE_SCENE_MEMSET")) != 0;   // (A/B: zero the flags per launch as before)
-    if (fresh || always) STT_HIP(hipMemsetAsync(r.flags, 0, (((size_t)3 * A_tiles + 1 + C_tiles) * 4 + 15) / 16 * 16, s));
-    a.epoch = epoch;
     const dim3 grid(2 * A_tiles + 2 * C_tiles);
 #define SLK(TX, NY)                                                                                   \
     do {                                                                                              \

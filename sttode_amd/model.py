@@ -125,11 +125,6 @@ _DATA_PTR = torch.Tensor.data_ptr
 _VERSION = operator.attrgetter('_version')
 
 
-def lib_device_latents(handle, n, key):
-    """capi: arm device-side latents for the next async call if it takes the lagged form (1) -- see include/sttode_hip.h."""
-    return capi.lib().sttode_async_device_latents(handle, int(n), int(key))
-
-
 def _on(t, device):
     device = torch.device(device)
     return t.device.type == device.type and (device.index is None or t.device.index == device.index)
@@ -220,7 +215,7 @@ class STTODENet(nn.Module):
 
     # per-call state (tensors of the current batch, views of the workspace): plain attributes.  nn.Module.__setattr__ walks its
     # Parameter / Module / buffer checks on every assignment (~1.5 us each, ~17 per one-scene call of the evaluation loop)
-    _PLAIN = frozenset(('_past', '_future', '_scene_ptr', '_mode', 'batch_size', 'agent_num', '_S', '_N', 'pre_motion_mask', 'fut_motion_mask',
+    _PLAIN = frozenset(('_past', '_future', '_scene_ptr', '_mode', 'batch_size', 'agent_num', '_S', '_N', '_G', 'pre_motion_mask', 'fut_motion_mask',
                         'scene_orig', '_pf', '_pf_thunk', '_ws', '_dbg', 'diverse_pred', '_plist'))
 
     def __setattr__(self, name, value):
@@ -313,6 +308,7 @@ class STTODENet(nn.Module):
                 self._wscache.clear()
             off, tot = self._native.layout(n, S)
             buf = torch.empty(tot, dtype=torch.float32, device=self.device)
+            self._native.init_workspace(buf, n, S)        # once per workspace: the hand-off flag words start (and are kept) zero
             self._wscache[key] = (buf, off)
         return self._wscache[key]
 
@@ -348,6 +344,7 @@ class STTODENet(nn.Module):
                 ptr = self._ptr_cache[N] = torch.tensor([0, N], dtype=torch.int32).to(dev)
             d = self.__dict__
             d['_past'], d['_future'], d['_scene_ptr'], d['_mode'], d['batch_size'], d['agent_num'], d['_S'], d['_N'] = past, fut, ptr, 'scenes', 1, N, 1, 0
+            d['_G'] = 1
             d['pre_motion_mask'], d['fut_motion_mask'] = pre_motion_mask, fut_motion_mask
             return
 
@@ -433,18 +430,26 @@ class STTODENet(nn.Module):
             if int(sp[0]) != 0 or int(sp[-1]) != self._past.shape[0] or bool((sp[1:] <= sp[:-1]).any()):
                 raise ValueError('scene_ptr must start at 0, end at n and be strictly increasing (no empty scenes)')
         self._mode = 'scenes'
+        self._G = 1
         self.batch_size = 1
         self.agent_num = self._past.shape[0]
         self._S = self._scene_ptr.numel() - 1
         self._N = 0
 
     def set_data_nba(self, data):
-        """model/STTODE.py:463-486: dict with past_traj [B,N,Tp,2], future_traj [B,N,Tf,2]."""
+        """model/STTODE.py:463-486: dict with past_traj [B,N,Tp,2], future_traj [B,N,Tf,2].
+        Build-defined: past_traj [G,B,N,Tp,2] (future_traj [G,B,N,Tf,2]) = G forward-call batches in ONE call -- the attention runs within each
+        batch of B scenes (what G reference calls compute, test.py:520-524), everything else over all G B N agents (include/sttode_hip.h
+        sttode_inference_nba_groups); ``batch_size`` / ``agent_num`` stay B / N, results come back for G B N agents in (g, b, n) order."""
         a, dev = self.args, self.device
         pt = _f32(data['past_traj'], dev)
         self.data = data
-        self.batch_size, self.agent_num = pt.shape[0], pt.shape[1]
-        self._past = pt.reshape(self.batch_size * self.agent_num, a.past_length, 2).contiguous()
+        self._G = 1
+        if pt.dim() == 5:
+            self._G = pt.shape[0]
+            pt = pt.reshape(-1, *pt.shape[2:])
+        self.batch_size, self.agent_num = pt.shape[0] // self._G, pt.shape[1]
+        self._past = pt.reshape(pt.shape[0] * self.agent_num, a.past_length, 2).contiguous()
         ft = data.get('future_traj') if hasattr(data, 'get') else None
         self._future = _f32(ft, dev).reshape(-1, a.future_length, 2).contiguous() if ft is not None else None
         self._mode = 'nba'
@@ -486,13 +491,17 @@ class STTODENet(nn.Module):
             # rows = keys, columns = queries, values indexed by the column:  out_i = sum_j softmax_j(-d(k_i, q_j)) v_j
             attn = self._f(n, 64)
             e = qkv.element_size()
-            capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, None, None, L, L,
-                      Nslots, Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192, Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
+            G = getattr(self, '_G', 1)                    # attention groups of the call (set_data_nba with [G,B,N,...]); group stride = B N rows
+            capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, G, L * Nslots * 192,
+                      L * Nslots * 192, L * Nslots * 192, L * Nslots * 64, L, L, Nslots, Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192,
+                      Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
             attn_ptr, ld = attn, 64
         else:
             attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192  # softmax over one element == 1  =>  output == v
         pf = self._f(n, 128)
         if (self.ode_method, self.ode_steps) != ('euler', 1):
+            if L > 1 and getattr(self, '_G', 1) > 1:
+                raise NotImplementedError('staged API: non-default integrators with several attention groups per call go through inference()')
             if L > 1:
                 # every stage is a pass over the whole attention group: in-projection of the state -> geodesic attention -> f(y); the same
                 # stage algebra the native pipeline enqueues (csrc/pipeline.hip stage_agents) and hypertransformer.ode_integrate spells out
@@ -624,6 +633,9 @@ class STTODENet(nn.Module):
         same values come from the fused inference kernels.  ``eps_*`` / ``drop_*`` inject the noises / dropout masks the
         reference draws from torch's generator (Normal.rsample, nn.Dropout(0.1) of the positional encoders)."""
         self._require_gpu()
+        if getattr(self, '_G', 1) > 1:
+            raise NotImplementedError('forward(): one forward-call batch per step, as train.py:59-95 (several attention groups per call are an '
+                                      'evaluation feature: set_data_nba with [G,B,N,...] + inference())')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .training import training_forward
             return training_forward(self, eps_q, eps_p, eps20, drop_past, drop_future)
@@ -668,8 +680,13 @@ class STTODENet(nn.Module):
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference()')
         K = a.sample_k
-        late = self._packed is not None and self._native is not None     # weights compared AFTER the launch is enqueued (below)
+        # weights compared AFTER the launch is enqueued (below): only on the one-scene evaluation loop (test.py:171-188), where the host is the
+        # critical path up to the launch and no optimizer runs between calls; everywhere else (batches, the NBA path, train / eval alternation)
+        # the comparison comes first -- a stale launch there would double the GPU work of every first call after an optimizer step
+        late = (self._packed is not None and self._native is not None and self._mode == 'scenes' and self._S == 1 and not self.training)
         nat = self.native(check_weights=not late)
+        if nat.timeout_word.value:                                       # an EARLIER launch gave up on its hand-off: its futures were NaN (host load, no sync)
+            nat.raise_if_timed_out()
         n = self._past.shape[0]
         if z is None:
             z = torch.randn(n * K, a.zdim, device=self.device)
@@ -691,6 +708,8 @@ class STTODENet(nn.Module):
                         raise capi.SttodeError('sttode_inference_scenes failed: ' + capi.lib().sttode_last_error().decode())
                 else:
                     capi.call('sttode_inference_scenes', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, st)
+            elif getattr(self, '_G', 1) > 1:
+                capi.call('sttode_inference_nba_groups', nat.h, self._past, self._G, self.batch_size, self._N, z, buf, pred, st)
             else:
                 capi.call('sttode_inference_nba', nat.h, self._past, self.batch_size, self._N, z, buf, pred, st)
             # the weight-version comparison runs while the GPU works: on the one-scene evaluation loop (test.py:171-188) the host is the
@@ -769,35 +788,46 @@ class STTODENet(nn.Module):
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference_async()')
         nat = self.native()
+        nat.raise_if_timed_out()
         K, n = a.sample_k, self._past.shape[0]
         S = self._S if self._mode == 'scenes' else 0
+        # every argument is validated BEFORE a slot is taken or anything native is touched (round-4 advice: a check that failed after the
+        # native model had been armed left the request armed for the next call)
+        lagged = bool(capi.lib().sttode_async_is_lagged(nat.h, n))
+        if z is not None:
+            if not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
+                z = _f32(z, self.device)
+            if tuple(z.shape) != (n * K, a.zdim):
+                raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
+        if metrics_gt is not None and not (isinstance(metrics_gt, torch.Tensor) and metrics_gt.is_cuda and metrics_gt.dtype == torch.float32
+                                           and metrics_gt.is_contiguous() and tuple(metrics_gt.shape) == (n, a.future_length, 2)):
+            raise ValueError(f'metrics_gt must be a contiguous float32 device tensor [{n}, {a.future_length}, 2]')
+        if pred_host and not lagged:
+            raise capi.SttodeError('pred_host=True needs the lagged pipelined form (a chain-sized batch, reference integrator)')
         slot = self._async_calls % max(2, min(8, int(self.async_depth)))
-        self._async_calls += 1
         key = (n, S, slot)
         if key not in self._async_bufs:
             if len(self._async_bufs) > 16:
                 raise capi.SttodeError('too many distinct batch shapes in flight for the async pipeline; call reset_async()')
             _, tot = nat.layout(n, S)
-            self._async_bufs[key] = (torch.empty(tot, dtype=torch.float32, device=self.device),
-                                     torch.empty(n, K, a.future_length, 2, dtype=torch.float32, device=self.device),
+            ws = torch.empty(tot, dtype=torch.float32, device=self.device)
+            nat.init_workspace(ws, n, S)
+            self._async_bufs[key] = (ws, torch.empty(n, K, a.future_length, 2, dtype=torch.float32, device=self.device),
                                      torch.empty(n * K, a.zdim, dtype=torch.float32, device=self.device))
+        self._async_calls += 1
+        opts = capi.AsyncOpts()
         if z is None:
             # Latents like Normal.rsample (model/STTODE.py:89-93,609-616).  Lagged form: the call's own launch draws them (Philox4x32-10 on
             # device, csrc/role32.hpp) into the slot's latent buffer, keyed by 64 bits taken from torch's generator here -- reproducible
             # under torch.manual_seed, not the sequence torch.randn would give (device_latents = False: torch.randn on the caller's stream).
             # Every other form: torch.randn.
-            if self.device_latents and lib_device_latents(nat.h, n, int(torch.empty((), dtype=torch.int64).random_()) & 0x7fffffffffffffff):
+            if self.device_latents and lagged:
+                opts.device_latents, opts.zkey = 1, int(torch.empty((), dtype=torch.int64).random_()) & 0x7fffffffffffffff
                 z = self._async_bufs[key][2]
             else:
                 z = torch.randn(n * K, a.zdim, device=self.device)
-        elif not (isinstance(z, torch.Tensor) and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()):
-            z = _f32(z, self.device)
-        if tuple(z.shape) != (n * K, a.zdim):
-            raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
         buf, pred = self._async_bufs[key][:2]
         if pred_host:
-            if not capi.lib().sttode_async_is_lagged(nat.h, n):
-                raise capi.SttodeError('pred_host=True needs the lagged pipelined form (a chain-sized batch, reference integrator)')
             hk = ('host',) + key
             if hk not in self._async_bufs:
                 self._async_bufs[hk] = torch.empty(n, K, a.future_length, 2, dtype=torch.float32).pin_memory()
@@ -809,28 +839,31 @@ class STTODENet(nn.Module):
             t = torch.empty(2, n, dtype=torch.float32, device=self.device)
             mb = self._async_metrics[key] = (t[0], t[1])
         fused = None
-        if metrics_gt is not None:
-            if not (isinstance(metrics_gt, torch.Tensor) and metrics_gt.is_cuda and metrics_gt.dtype == torch.float32 and metrics_gt.is_contiguous()
-                    and tuple(metrics_gt.shape) == (n, a.future_length, 2)):
-                raise ValueError(f'metrics_gt must be a contiguous float32 device tensor [{n}, {a.future_length}, 2]')
-            if capi.lib().sttode_async_fused_metrics(nat.h, n, metrics_gt.data_ptr(), mb[0].data_ptr(), mb[1].data_ptr(), float(metrics_scale)):
-                fused = (metrics_gt, float(metrics_scale))
+        if metrics_gt is not None and lagged:
+            opts.metrics_gt, opts.ade, opts.fde, opts.metrics_scale = metrics_gt.data_ptr(), mb[0].data_ptr(), mb[1].data_ptr(), float(metrics_scale)
+            fused = (metrics_gt, float(metrics_scale))
+        import ctypes
         if self._mode == 'scenes':
-            capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, st)
+            capi.call('sttode_inference_scenes_async', nat.h, self._past, self._scene_ptr, n, S, z, buf, pred, slot, ctypes.addressof(opts), st)
         else:
-            capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, st)
+            opts.nba_groups = getattr(self, '_G', 1)
+            capi.call('sttode_inference_nba_async', nat.h, self._past, self.batch_size, self._N, z, buf, pred, slot, ctypes.addressof(opts), st)
         return {'fused_metrics': fused, 'slot': slot, 'pred': pred, 'z': z, 'inputs': (self._past, getattr(self, '_scene_ptr', None)), 'metrics': mb,
                 'gt_default': self._future, 'stream': pstream}
 
     def wait(self, handle):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
-        capi.call('sttode_wait', self.native().h, handle['slot'], capi.stream_ptr())
+        nat = self.native()
+        nat.raise_if_timed_out()
+        capi.call('sttode_wait', nat.h, handle['slot'], capi.stream_ptr())
         return handle['pred'].permute(1, 0, 2, 3)
 
     def wait_host(self, handle):
         """The HOST waits for an inference_async() result (for ``pred_host=True`` calls: the pinned tensor may be read afterwards);
         returns predictions [K, n, Tf, 2]."""
-        capi.call('sttode_wait_host', self.native().h, handle['slot'])
+        nat = self.native()
+        capi.call('sttode_wait_host', nat.h, handle['slot'])
+        nat.raise_if_timed_out()                                 # (the host has waited: a give-up of that call is visible now)
         return handle['pred'].permute(1, 0, 2, 3)
 
     def futures_to_host_async(self, handle, out=None, workgroups=8):
@@ -868,6 +901,7 @@ class STTODENet(nn.Module):
     def wait_host_copy(self, handle):
         """The HOST waits for the copy enqueued by futures_to_host_async(); returns the pinned tensor as [K, n, Tf, 2]."""
         handle['host_event'].synchronize()
+        self.native().raise_if_timed_out()                       # (the copy has drained: a give-up of that call is visible now)
         return handle['host'].permute(1, 0, 2, 3)
 
     def next_async_stream(self, n):
@@ -905,6 +939,30 @@ class STTODENet(nn.Module):
         mb = handle['metrics']
         capi.call('sttode_async_best_of_k', self.native().h, handle['slot'], pred, gt, n, K, Tf, float(scale), mb[0], mb[1])
         return mb[0], mb[1]
+
+    @torch.no_grad()
+    def horizon_metrics(self, pred_nk, gt=None, scale=1.0):
+        """The NBA evaluation's per-horizon metric (test.py:530-551) on device: pred_nk [n,K,Tf,2], gt [n,Tf,2] -> [n,Tf,2] with
+        [a, h-1] = (min_k mean_{t<h} |scale (pred - gt)|, min_k |scale (pred_h - gt_h)|)."""
+        gt = self._future if gt is None else _f32(gt, self.device)
+        pred_nk = pred_nk.contiguous()
+        n, K, Tf = pred_nk.shape[:3]
+        out = torch.empty(n, Tf, 2, dtype=torch.float32, device=self.device)
+        capi.call('sttode_horizon_metrics', pred_nk, gt, n, K, Tf, float(scale), out, capi.stream_ptr())
+        return out
+
+    def horizon_metrics_async(self, handle, gt=None, scale=1.0, out=None):
+        """horizon_metrics of an inference_async() call, enqueued on the pipeline stream the call runs on (behind its trajectory groups; nothing
+        goes onto the caller's stream).  Returns [n,Tf,2], valid after ``wait(handle)``."""
+        gt = handle.get('gt_default') if gt is None else gt
+        if not (isinstance(gt, torch.Tensor) and gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous()):
+            raise ValueError('horizon_metrics_async needs a contiguous float32 device tensor gt [n, Tf, 2] that was written before the call')
+        pred = handle['pred']
+        n, K, Tf = pred.shape[:3]
+        if out is None:
+            out = torch.empty(n, Tf, 2, dtype=torch.float32, device=self.device)
+        capi.call('sttode_async_horizon_metrics', self.native().h, handle['slot'], pred, gt, n, K, Tf, float(scale), out)
+        return out
 
     def reset_async(self):
         if self._native is not None:

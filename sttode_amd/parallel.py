@@ -45,15 +45,20 @@ def shard_counts(scene_ptr, world):
     return [int(ptr[s1] - ptr[s0]) for s0, s1 in shard_scenes(ptr, world)]
 
 
-def gather_futures(pred_local, group=None, counts=None):
+def gather_futures(pred_local, group=None, counts=None, reuse=False):
     """All-gather of per-rank rows [n_r, ...] (n_r differs per rank, may be 0) -> [sum n_r, ...] in rank order, on the caller's device.
 
     ONE collective: ``all_gather_into_tensor`` of the shard, padded to the largest one, into a preallocated [world * nmax, ...] buffer
     (cached per shape; over xGMI every rank writes its rows to its 7 peers directly -- the result is what the reference's metric path wants
     in one place, test.py:194,526; its only distributed code: core/utils.py:370-389).  ``counts`` = every rank's row count, known on every
     rank whenever the partition is deterministic (shard_counts; equal shards of a weak-scaling run): no count exchange.  Without it the
-    counts travel first as one [world] int64 all-gather.  Equal shards come back as a view of the receive buffer (no copy); ragged ones are
-    compacted by one index_select with a cached index.  The returned tensor aliases the cache until the next call of the same shape."""
+    counts travel first as one [world] int64 all-gather.  Ragged shards are compacted by one index_select with a cached index.
+    The result is a FRESH tensor by default (a caller that collects the gathered futures of successive batches, like the reference's metric
+    path, must not see earlier results overwritten by the next call); ``reuse=True``: equal shards come back as a zero-copy view of the
+    cached receive buffer, valid until the next call of the same shape (a timed loop that consumes each result at once).
+    ``counts`` are validated the same way on EVERY rank before any rank enters the collective (length, non-negativity: properties of the
+    list); the one rank-dependent check -- this rank's own row count -- fails only where the caller passed the wrong shard, a programming
+    error on that rank."""
     world = dist.get_world_size(group)
     if world == 1:
         return pred_local
@@ -64,8 +69,10 @@ def gather_futures(pred_local, group=None, counts=None):
         dist.all_gather_into_tensor(allc, mine, group=group)
         counts = allc.tolist()
     counts = tuple(int(c) for c in counts)
-    if len(counts) != world or counts[dist.get_rank(group)] != pred_local.shape[0]:
-        raise ValueError(f'gather_futures: counts {counts} do not describe {world} ranks with {pred_local.shape[0]} rows on this one')
+    if len(counts) != world or min(counts) < 0:
+        raise ValueError(f'gather_futures: counts {counts} do not describe {world} ranks')
+    if counts[dist.get_rank(group)] != pred_local.shape[0]:
+        raise ValueError(f'gather_futures: counts {counts} give this rank {counts[dist.get_rank(group)]} rows, it holds {pred_local.shape[0]}')
     nmax = max(max(counts), 1)
     row = tuple(pred_local.shape[1:])
     key = (cdev, pred_local.dtype, world, nmax, row)
@@ -81,7 +88,7 @@ def gather_futures(pred_local, group=None, counts=None):
         send[: pred_local.shape[0]].copy_(pred_local)            # (rows past n_r keep their zeros / stale rows: they are never read)
     dist.all_gather_into_tensor(recv, send, group=group)
     if all(c == nmax for c in counts):
-        out = recv
+        out = recv if reuse else recv.clone()
     else:
         ikey = (cdev, counts, nmax)
         if ikey not in _GATHER_INDEX:
@@ -125,9 +132,10 @@ def reduce_metrics(ade_sum, fde_sum, count, group=None):
     """Agent-weighted global ADE / FDE (AverageMeter(n=agent_num) semantics, test.py:205,208)."""
     t = torch.stack([torch.as_tensor(ade_sum, dtype=torch.float64).reshape(()), torch.as_tensor(fde_sum, dtype=torch.float64).reshape(()),
                      torch.as_tensor(float(count), dtype=torch.float64).reshape(())])
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
     if isinstance(ade_sum, torch.Tensor):
-        t = t.to(ade_sum.device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.to(_coll_device(ade_sum, group) if multi else ade_sum.device)
+    if multi:
         dist.all_reduce(t, group=group)
     return float(t[0] / t[2]), float(t[1] / t[2]), int(t[2])
 
@@ -149,7 +157,13 @@ def average_gradients(params, group=None, weight=1.0):
             flat[off: off + p.numel()] = p.grad.reshape(-1) * weight
         off += p.numel()
     flat[-1] = weight
-    dist.all_reduce(flat, group=group)
+    cdev = _coll_device(flat, group)
+    if cdev != flat.device:                                       # gloo rehearsal with the compute on a GPU: the collective on a host copy
+        host = flat.to(cdev)
+        dist.all_reduce(host, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, group=group)
     flat[:-1] /= flat[-1]
     off = 0
     for p in params:

@@ -180,3 +180,22 @@ def oracle_grads(tag, dataset, Tp, Tf, g, drop=None, double=False):
     grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
     m.zero_grad()
     return grads, [float(v.detach()) for v in vals]
+
+
+def horizon_metrics_np(pred_nk, gt, scale=1.0):
+    """NumPy restatement of csrc/frontend.hip horizon_metrics_kernel, fp32 in the kernel's order: d = |scale (pred - gt)| (bok_dist: the two
+    squared differences added, then sqrt), a running sum over the frames, sum_h / h, minimum over the K samples.  pred_nk [n,K,Tf,2],
+    gt [n,Tf,2] -> [n,Tf,2]."""
+    s = np.float32(scale)
+    dx = (pred_nk[..., 0] - gt[:, None, :, 0]).astype(np.float32) * s
+    dy = (pred_nk[..., 1] - gt[:, None, :, 1]).astype(np.float32) * s
+    # sqrtf(fmaf(dx, dx, dy * dy)): the fused multiply-add through float64 (dx^2 is exact there; the sum rounds once more only when the two
+    # terms' exponents differ by more than 5 bits AND the float64 result sits on a float32 tie: never seen, ~2^-29 per element)
+    s2 = dx.astype(np.float64) * dx.astype(np.float64) + (dy * dy).astype(np.float32).astype(np.float64)
+    d = np.sqrt(s2.astype(np.float32)).astype(np.float32)                           # [n, K, Tf]
+    cum = np.zeros_like(d)
+    run = np.zeros(d.shape[:2], np.float32)
+    for t in range(d.shape[2]):
+        run = (run + d[:, :, t]).astype(np.float32)
+        cum[:, :, t] = run / np.float32(t + 1)
+    return np.stack([cum.min(axis=1), d.min(axis=1)], axis=-1)

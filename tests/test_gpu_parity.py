@@ -876,6 +876,10 @@ def test_fused_launch_gives_up_instead_of_hanging_when_a_producer_never_signals(
     m.native().set_chain(1)
     try:
         m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        # round 5: the give-up reaches the drop-in caller -- the call AFTER the poisoned one raises (the model's host-visible time-out word, no
+        # synchronisation on the hot path), once; the next healthy launch on the same workspace is clean again
+        with pytest.raises(capi.SttodeError, match='gave up'):
+            m.inference(None, z=z)
         assert torch.equal(m.inference(None, z=z), good)
     finally:
         m.native().set_chain(-1)
@@ -1066,6 +1070,11 @@ def test_one_launch_scene_form_gives_up_instead_of_hanging():
         assert time.perf_counter() - t0 < 30.0
     finally:
         capi.call('sttode_debug_drop_role_flag', m.native().h, -1)
+    # STTODENet.inference() surfaces it: the call after the dropped flag raises (host load of the model's time-out word), the one after is clean
+    m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+    with pytest.raises(capi.SttodeError, match='gave up'):
+        m.inference(None, z=z)
+    assert torch.equal(m.inference(None, z=z), good)
     flat_bad, flat_good = bad.permute(1, 0, 2, 3).reshape(n * K, -1), good.permute(1, 0, 2, 3).reshape(n * K, -1)
     rows = torch.arange(n * K, device=m.device)
     t_lo, t_hi = rows // 16 * 16, torch.clamp(rows // 16 * 16 + 15, max=n * K - 1)
@@ -1562,6 +1571,10 @@ def test_check_reports_a_given_up_hand_off():
         m.inference(None, z=z)
         with pytest.raises(capi.SttodeError):
             nat.check(buf, sb.n_agents, sb.n_scenes)
+        assert nat.timeout_word.value == 1                       # ... and the model's host-visible word (read without any synchronisation)
+        with pytest.raises(capi.SttodeError, match='gave up'):
+            nat.raise_if_timed_out()
+        assert nat.timeout_word.value == 0                       # reported once
     finally:
         capi.call('sttode_debug_drop_role_flag', nat.h, -1)
         nat.set_chain(-1)
@@ -2952,3 +2965,242 @@ def test_fused_trunk_forward_writes_the_layer_by_layer_tape(golden):
         if k.endswith('h3in'):
             a, b = a[:, :67], b[:, :67]
         assert_close(a, b, rtol=2e-5, atol=2e-5, what='tape ' + k)
+
+
+def test_one_scene_inference_captured_in_a_hip_graph_replays_with_new_inputs():
+    """Round-4 advice: the one-launch scene form compared its hand-off flags with a host-side epoch, so a captured launch replayed with the
+    epoch of its capture and its consumers did not wait.  Now the flag words are zero between launches (sttode_workspace_init once, the
+    launch's last workgroup afterwards): inference() of one scene captured into a hipGraph replays correctly with changed inputs, many times."""
+    from sttode_amd import scenes
+    m = hip_model('eth', 8, 12)
+    scs = [scenes.eth_scene(9100 + i, n_min=9, n_max=9) for i in range(4)]
+    zs = [torch.from_numpy(scenes.latents(40 + i, 9)).to(m.device) for i in range(4)]
+    want = []
+    for (o, p), z in zip(scs, zs):
+        m.set_data(None, torch.from_numpy(o), torch.from_numpy(p))
+        want.append(m.inference(None, z=z).clone())
+    past = torch.from_numpy(np.ascontiguousarray(scs[0][0].transpose(0, 2, 1))).to(m.device)
+    fut = torch.from_numpy(np.ascontiguousarray(scs[0][1].transpose(0, 2, 1))).to(m.device)
+    ptr = torch.tensor([0, 9], dtype=torch.int32, device=m.device)
+    zst = zs[0].clone()
+    m.set_scene_batch(past, fut, ptr)
+    m.inference(None, z=zst)                                     # warm: workspace allocated and initialised, weights packed
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.inference(None, z=zst)
+    for rep in range(3):
+        for i in (1, 2, 3, 0):
+            past.copy_(torch.from_numpy(np.ascontiguousarray(scs[i][0].transpose(0, 2, 1))))
+            zst.copy_(zs[i])
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want[i]), (rep, i)
+    m.native().raise_if_timed_out()
+
+
+def test_uninitialised_workspace_is_refused_by_the_scene_form():
+    """C-ABI contract (include/sttode_hip.h sttode_workspace_init): the one-launch scene form on a workspace whose flag words were never
+    initialised must not trust them -- NaN predictions, time-out word 2, sttode_check fails -- and is healthy once the workspace is initialised."""
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    o, p = scenes.eth_scene(9200, n_min=5, n_max=5)
+    m.set_data(None, torch.from_numpy(o), torch.from_numpy(p))
+    z = torch.from_numpy(scenes.latents(3, 5)).to(m.device)
+    good = m.inference(None, z=z).clone()
+    nat = m.native()
+    _, tot = nat.layout(5, 1)
+    raw = torch.full((tot,), 1.0, dtype=torch.float32, device=m.device)          # every flag word "up" with arbitrary bits
+    pred = torch.zeros(5, 20, 12, 2, device=m.device)
+    capi.call('sttode_inference_scenes', nat.h, m._past, m._scene_ptr, 5, 1, z, raw, pred, capi.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.isnan(pred).all()
+    with pytest.raises(capi.SttodeError, match='never initialised'):
+        nat.check(raw, 5, 1)
+    with pytest.raises(capi.SttodeError, match='never initialised'):
+        nat.raise_if_timed_out()
+    nat.init_workspace(raw, 5, 1)
+    capi.call('sttode_inference_scenes', nat.h, m._past, m._scene_ptr, 5, 1, z, raw, pred, capi.stream_ptr())
+    nat.check(raw, 5, 1)
+    assert torch.equal(pred.permute(1, 0, 2, 3), good)
+
+
+def test_refused_async_call_leaves_no_state_behind():
+    """Round-4 advice: inference_async armed the native model (device latents) before its later argument checks; a check that failed left the
+    request armed and the NEXT call overwrote the caller's z.  Options now travel with the call (SttodeAsyncOpts) and every check comes
+    first: a refused call changes nothing."""
+    from sttode_amd import capi, scenes
+    m = hip_model('eth', 8, 12)
+    sb = scenes.make_scene_batch(range(5200, 5261), 'eth')
+    n = sb.n_agents
+    nat = m.native()
+    try:
+        nat.set_chain(1)
+        m.set_scene_batch(sb.past, sb.future, sb.scene_ptr)
+        calls = m._async_calls
+        with pytest.raises(ValueError):
+            m.inference_async(metrics_gt=torch.zeros(3, 12, 2, device=m.device))     # z=None (device latents would be drawn) + a bad metrics_gt
+        assert m._async_calls == calls                                                # no slot taken
+        z = torch.from_numpy(scenes.latents(12, n)).to(m.device)
+        z0 = z.clone()
+        h = m.inference_async(z=z)
+        out = m.wait(h).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(z, z0)                                                     # the caller's latents were read, not overwritten
+        ref = m.inference(None, z=z0)
+        assert_close(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5, what='async after a refused call vs serial')
+        # the C entry point itself: options its form cannot honour -> refused before anything is enqueued
+        nat.set_lagged(0)
+        import ctypes
+        o = capi.AsyncOpts()
+        o.device_latents = 1
+        buf, pred = m._async_bufs[(n, sb.n_scenes, h['slot'])][:2]
+        with pytest.raises(capi.SttodeError, match='lagged'):
+            capi.call('sttode_inference_scenes_async', nat.h, m._past, m._scene_ptr, n, sb.n_scenes, z, buf, pred, 0, ctypes.addressof(o), capi.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(z, z0)
+    finally:
+        nat.set_lagged(3)
+        nat.set_chain(-1)
+        m.reset_async()
+
+
+def test_horizon_metrics_kernel_vs_numpy_and_reference_golden(golden):
+    """The NBA evaluation's per-horizon metric (test.py:530-551) as ONE HIP kernel: bitwise its NumPy restatement (helpers.horizon_metrics_np)
+    on the same predictions, equal to the oracle's statement of the reference expression, and -- on the canned predictions the reference's
+    own test_model_all was run on (tests/golden/nba_eval.npz) -- the eight figures the reference printed."""
+    from helpers import horizon_metrics_np
+    from oracle.metrics_ref import nba_horizon_errors
+    m = hip_model('nba', 5, 10)
+    g = golden('nba_eval')
+    for scale in (1, 3):
+        avg, dest, tot = np.zeros(11), np.zeros(11), 0
+        for i in range(int(g['n_batches'])):
+            pred_kn, fut = g[f'pred{i}'], g[f'fut{i}']
+            B, N = fut.shape[:2]
+            pred_nk = np.ascontiguousarray(pred_kn.transpose(1, 0, 2, 3))
+            gt = fut.reshape(B * N, 10, 2)
+            hm = m.horizon_metrics(torch.from_numpy(pred_nk).to(m.device), torch.from_numpy(gt).to(m.device), scale=float(scale)).cpu().numpy()
+            assert np.array_equal(hm, horizon_metrics_np(pred_nk, gt, float(scale))), (scale, i)
+            e = nba_horizon_errors(pred_kn * np.float32(scale), gt * np.float32(scale), range(1, 11))
+            for h in range(1, 11):
+                assert abs(hm[:, h - 1, 0].astype(np.float64).mean() - e[h][0]) < 1e-5 and abs(hm[:, h - 1, 1].astype(np.float64).mean() - e[h][1]) < 1e-5
+                avg[h] += hm[:, h - 1, 0].astype(np.float64).mean() * B
+                dest[h] += hm[:, h - 1, 1].astype(np.float64).mean() * B
+            tot += B
+        avg, dest = avg / tot, dest / tot
+        printed = np.array([(avg[2] + avg[3]) / 2, avg[5], (avg[8] + avg[7]) / 2, avg[10], (dest[2] + dest[3]) / 2, dest[5], (dest[7] + dest[8]) / 2, dest[10]])
+        np.testing.assert_allclose(printed, g[f'scale{scale}_printed'], rtol=5e-6)
+    # long horizon, K Tf = 800 staged in LDS
+    rng = np.random.default_rng(5)
+    pr, gt = rng.standard_normal((37, 20, 40, 2)).astype(np.float32), rng.standard_normal((37, 40, 2)).astype(np.float32)
+    hm = m.horizon_metrics(torch.from_numpy(pr).to(m.device), torch.from_numpy(gt).to(m.device), scale=2.0).cpu().numpy()
+    assert np.array_equal(hm, horizon_metrics_np(pr, gt, 2.0))
+
+
+@pytest.mark.parametrize('B,G', [(128, 3), (24, 5)])
+def test_several_attention_groups_per_call_equal_separate_calls(B, G):
+    """sttode_inference_nba_groups / SttodeAsyncOpts.nba_groups: G forward-call batches of the NBA branch in ONE call -- the attention
+    stays within each batch (hyptransformerlib.py:261-265 attends over the batch dimension of one forward call) -- give, batch by batch,
+    the bits of G separate inference() calls in the same form, serial and pipelined."""
+    from sttode_amd import scenes
+    m = hip_model('nba', 5, 10)
+    N = 11
+    ds = [scenes.nba_batch(8800 + g, B, N=N) for g in range(G)]
+    zs = [scenes.latents(600 + g, B * N) for g in range(G)]
+    nat = m.native()
+    try:
+        nat.set_chain(1)                                          # one form of the per-trajectory stage whatever the call's size
+        sep = []
+        for d, z in zip(ds, zs):
+            m.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+            sep.append(m.inference(None, z=torch.from_numpy(z)).clone())
+        want = torch.cat(sep, dim=1)
+        data = {'past_traj': torch.from_numpy(np.stack([d['past_traj'] for d in ds])), 'future_traj': torch.from_numpy(np.stack([d['future_traj'] for d in ds]))}
+        zall = torch.from_numpy(np.concatenate(zs)).to(m.device)
+        m.set_data_nba(data)
+        assert (m._G, m.batch_size, m.agent_num) == (G, B, N)
+        got = m.inference(None, z=zall)
+        assert torch.equal(got, want)
+        # pipelined (lagged form when chain-sized): against separate pipelined calls, bitwise; against the serial form to fp32 rounding
+        hs = []
+        for d, z in zip(ds, zs):
+            m.set_data_nba({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+            hs.append(m.inference_async(z=torch.from_numpy(z)))
+        sep_async = torch.cat([m.wait(h).clone() for h in hs], dim=1)
+        m.set_data_nba(data)
+        h = m.inference_async(z=zall)
+        got_async = m.wait(h).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got_async, sep_async)
+        assert_close(got_async.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5, what='groups, pipelined vs serial')
+    finally:
+        nat.set_chain(-1)
+        m.reset_async()
+
+
+def test_pipelined_nba_evaluation_equals_the_serial_loop_and_the_oracle():
+    """evaluate.eval_nba (test.py:495-552): the pipelined flow -- several loader batches per call, inference_async, the horizon metric as a
+    HIP kernel on the call's stream -- returns the serial loop's values (one inference() per batch, torch ops) and the oracle's on the same latents."""
+    from oracle.metrics_ref import nba_horizon_errors
+    from sttode_amd import evaluate, scenes
+    m = hip_model('nba', 5, 10)
+    N, K = 11, 20
+    sizes = [128, 128, 128, 128, 128, 40]
+    loader = []
+    for i, B in enumerate(sizes):
+        d = scenes.nba_batch(9900 + i, B, N=N)
+        loader.append({'past_traj': torch.from_numpy(d['past_traj']), 'future_traj': torch.from_numpy(d['future_traj'])})
+    zall = scenes.latents(77, sum(sizes) * N)
+
+    def make_zfn():
+        pos = [0]
+
+        def z_fn(rows):
+            z = torch.from_numpy(zall[pos[0]:pos[0] + rows]).to(m.device)
+            pos[0] += rows
+            return z
+        return z_fn
+    serial = evaluate.eval_nba(m, loader, traj_scale=2.0, z_fn=make_zfn(), pipelined=False)
+    piped = evaluate.eval_nba(m, loader, traj_scale=2.0, z_fn=make_zfn(), groups_per_call=2)
+    piped_all = evaluate.eval_nba(m, loader, traj_scale=2.0, z_fn=make_zfn(), groups_per_call=16)
+    for h in range(1, 11):
+        for a, b in ((serial[h], piped[h]), (serial[h], piped_all[h])):
+            assert abs(a[0] - b[0]) < 2e-5 * (1 + abs(a[0])) and abs(a[1] - b[1]) < 2e-5 * (1 + abs(a[1])), (h, a, b)
+    # the oracle on the first batch with the same latents: the metric of that batch alone
+    ora = oracle_model('nba', 5, 10)
+    with torch.no_grad():
+        ora.set_data_nba(loader[0])
+        ref = ora.inference(loader[0], z=torch.from_numpy(zall[:128 * N * K])).numpy()
+    one = evaluate.eval_nba(m, loader[:1], traj_scale=2.0, z_fn=make_zfn())
+    e = nba_horizon_errors(ref * 2.0, loader[0]['future_traj'].numpy().reshape(-1, 10, 2) * 2.0, range(1, 11))
+    for h in range(1, 11):
+        assert abs(one[h][0] - e[h][0]) < 1e-4 and abs(one[h][1] - e[h][1]) < 1e-4, (h, one[h], e[h])
+
+
+def test_bench_default_line_rehearsed_at_world_two_on_one_gpu():
+    """Every multi-rank branch of bench.py with HIP kernels, once: the WHOLE default line at world size 2 -- headline, the four legs, `train`
+    with parallel.average_gradients, the gather leg (futures all-gathered on a communication stream, counts exchanged once, `check: ok`) --
+    as two ranks that share cuda:0 with the collectives under gloo (hidden flag --dist-backend gloo; the round-4 review: no N > 1 path of
+    bench.py had ever executed with kernels).  A rehearsal of the code path, not a scaling measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--steps', '6', '--warmup', '2',
+                        '--scenes', '128', '--leg-steps', '6', '--train-steps', '12', '--train-scenes', '6', '--no-exploratory'],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['dist_backend'] == 'gloo' and d['rccl_ranks'] == 0 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and d['steps'] == 6 and d['ms_per_step'] > 0
+    g = d['gather']
+    assert g['check'] == 'ok' and g['ranks'] == 2 and len(g['agents_per_rank']) == 2 and g['gathered_rows'] == sum(g['agents_per_rank'])
+    assert d['value_incl_gather'] > 0
+    assert set(d['configs']) == {'ucy_2048', 'sdd_1024', 'nba_128', 'nba_long_4096'} and all(v['value'] > 0 for v in d['configs'].values())
+    assert d['train']['steps_per_s'] > 0 and 'all-reduce' in d['train']['config']['parallelism']
+    assert 'cpu_baseline' not in d                                # rank 0 at N = 1 only

@@ -34,8 +34,12 @@ def _worker(rank, world, port, q):
     pred = torch.from_numpy(_local_predictions(local, zl))
     full = parallel.gather_futures(pred, counts=parallel.shard_counts(sb.scene_ptr, world)).clone()   # ONE collective: every rank derives the counts
     assert torch.equal(parallel.gather_futures(pred), full)                      # counts exchanged instead: the same rows
-    same = parallel.gather_futures(torch.full((3, 2), float(rank)), counts=[3] * world)   # equal shards: a view of the receive buffer
+    same = parallel.gather_futures(torch.full((3, 2), float(rank)), counts=[3] * world)   # equal shards: a fresh tensor by default ...
     assert same.shape == (3 * world, 2) and all(float(same[3 * r, 0]) == r for r in range(world))
+    view = parallel.gather_futures(torch.full((3, 2), float(rank) + 10), counts=[3] * world, reuse=True)   # ... reuse=True: a view of the cached receive buffer
+    assert all(float(view[3 * r, 0]) == r + 10 for r in range(world)) and all(float(same[3 * r, 0]) == r for r in range(world))
+    again = parallel.gather_futures(torch.full((3, 2), float(rank) + 20), counts=[3] * world, reuse=True)
+    assert again.data_ptr() == view.data_ptr() and float(view[0, 0]) == 20
     try:
         parallel.gather_futures(pred, counts=[1] * world)
         raise AssertionError('wrong counts were accepted')
