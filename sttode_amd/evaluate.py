@@ -102,7 +102,8 @@ def eval_nba(model, loader, traj_scale=1.0, z_fn=None, pipelined=True, groups_pe
         st = model.next_async_stream(n)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
             model.set_data_nba({'past_traj': past.to(dev, non_blocking=True), 'future_traj': fut.to(dev, non_blocking=True)})
-            z = z_fn(n * K) if z_fn is not None else None
+            # z_fn is asked once per LOADER batch (its rows: B N K), as the serial loop asks it; the call's latents are their concatenation
+            z = torch.cat([torch.as_tensor(z_fn(B * N * K)).to(dev) for _ in group]) if z_fn is not None else None
             h = model.inference_async(z=z)
         hm = model.horizon_metrics_async(h, gt=model._future, scale=traj_scale)
         pend.append((h, hm, B, N, G))

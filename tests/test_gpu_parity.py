@@ -1036,9 +1036,11 @@ def test_one_launch_scene_form_is_bitwise_the_six_launch_form(case):
     buf, off = m._workspace(n, len(ptr) - 1)
     A = (n + 15) // 16
     C = (n * K + 15) // 16
-    flags = m._view(buf, off, 'flags', 3 * A + 1 + C, dtype=torch.int32).cpu().numpy().view(np.uint32)
-    up = np.delete(flags, A)            # a flag is up when it equals the launch's epoch (0x80000000 + a call count): no memset per launch
-    assert flags[A] == 0 and (up == up[0]).all() and up[0] > 0x80000000, 'every producer published (E, G, E2 per agent tile, Y per trajectory tile), nobody timed out'
+    # the scene form's flag words (behind the fused launch's region, api_util.hpp stt_scene_flags_offset): E [A] | time-out | G [A] | E2 [A] |
+    # Y [C] | exit counter | initialised word.  The launch's last workgroup has zeroed them again -- no memset per launch, replayable --
+    # nobody timed out, and the workspace carries the mark sttode_workspace_init left
+    flags = m._view(buf, off, 'flags', 5 * A + 4 + 3 * A + 1 + C + 2, dtype=torch.int32).cpu().numpy().view(np.uint32)[5 * A + 4:]
+    assert (flags[:-1] == 0).all() and flags[-1] == 0x5774F1A6, 'flag words not back to zero after the launch / workspace not marked initialised'
     if case in ('eth_scene', 'three_scenes'):      # and against the CPU oracle, scene by scene (reference call pattern)
         ora = oracle_model('eth', 8, 12)
         out = outs[-1][0].cpu().numpy()
