@@ -71,10 +71,11 @@ int sttode_mhgsa_attn(const float* R, const float* C, const float* V, float* out
                       long os_b, float rscale, float cscale, void* stream);
 /* The same core over `groups` independent problems of one shape in ONE launch: group g reads R + g gs_r, C + g gs_c, V + g gs_v and writes
  * out + g gs_o (strides in floats).  The NBA branch attends over the batch dimension of ONE forward call (hyptransformerlib.py:261-265); a
- * test set is many such batches (test.py:520-524), and one launch over all of them fills the chip. */
+ * test set is many such batches (test.py:520-524), and one launch over all of them fills the chip.  head_dim = hidden_dim / 8: 8 for the
+ * reference default, 4 / 16 for --hidden_dim 32 / 128 (train.py:38; features of head h at offset h head_dim). */
 int sttode_mhgsa_attn_groups(const float* R, const float* C, const float* V, float* out, int groups, long gs_r, long gs_c, long gs_v, long gs_o,
                              int rows, int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq, long vs_b, long os_seq,
-                             long os_b, float rscale, float cscale, void* stream);
+                             long os_b, float rscale, float cscale, int head_dim, void* stream);
 
 /* out_proj (hyptransformerlib.py:305) -> Hypattention gate tanh(info)*sigmoid(gate) (hypertransformer.py:81-83)
  * -> TransformerEncoderLayer post-LN + FFN (hypertransformer.py:148-152) -> ODEG_Encoder: one explicit Euler step of
@@ -223,10 +224,11 @@ int sttode_twgrad_flush(void);
  * opened, filled and closed by one thread).  Also queued inside a group: scene-size layers (cols <= 1024) of sttode_tlinear /
  * sttode_tlinear_bwd, element-wise pieces (sttode_train_ewise) and a second sttode_ttrunk_fwd. */
 int sttode_tgemm_group(int on);
-/* inp0 / inp1 [n K1, ld] (inp1 may be NULL), row (a, k): columns 0..127 = pf[a] (rows of ldpf floats), 128..159 = qz[a] for k = 0, else
- * eps[a, k - 1] (eps [n (K1 - 1), 32]): the layer-1 input prefix of both decompose blocks (model/STTODE.py:322-331, 553-566). */
+/* inp0 / inp1 [n K1, ld] (inp1 may be NULL), row (a, k): columns 0..pfw-1 = pf[a] (rows of ldpf floats; pfw = 2 hidden_dim), pfw..pfw+zd-1 =
+ * qz[a] for k = 0, else eps[a, k - 1] (eps [n (K1 - 1), zd]): the layer-1 input prefix of the decompose blocks (model/STTODE.py:322-331,
+ * 553-566).  pfw, zd multiples of 4 (128 / 32 at the reference's defaults). */
 int sttode_decoder_inputs(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n, int K1,
-                          void* stream);
+                          int pfw, int zd, void* stream);
 /* dst[r, 0:width] = src[(r / div) % mod, 0:width] (repeat_interleave: div = K; per-frame tables: mod = T). */
 int sttode_rows_copy(float* dst, long ldd, const float* src, long lds, int rows, int width, int div, int mod, void* stream);
 /* dst[a, f] (+)= sum_{k<K} src[a*K + k, f]  (backward of repeat_interleave). */
@@ -243,12 +245,12 @@ int sttode_rows_reduce(float* dst, long ldd, const float* src, long lds, int row
  * Inside a group (sttode_tgemm_group) up to four pieces leave as one launch. */
 int sttode_train_ewise(int op, float* p0, const float* p1, const float* p2, float* p3, float* p4, long count, int i0, float f0,
                        void* stream);
-/* y = LayerNorm(x + r) over 64 features (hypertransformer.py:146,151); saves xhat [rows,64], rstd [rows]. */
+/* y = LayerNorm(x + r) over D = hidden_dim features (32 / 64 / 128; hypertransformer.py:146,151); saves xhat [rows,D], rstd [rows]. */
 int sttode_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
-                      int rows, void* stream);
-/* LayerNorm backward: dsum = grad wrt (x + r); dgamma, dbeta += ; scratch >= 64*128 floats. */
+                      int rows, int D, void* stream);
+/* LayerNorm backward: dsum = grad wrt (x + r); dgamma, dbeta += ; scratch >= 64 * 2 D floats. */
 int sttode_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dsum, float* dgamma,
-                  float* dbeta, int rows, float* scratch, long scratch_floats, void* stream);
+                  float* dbeta, int rows, int D, float* scratch, long scratch_floats, void* stream);
 /* nn.GRU cell, gate order r|z|n (model/STTODE.py:68): gi [m rows, ld ldgi] = W_ih e_t + b_ih, gh [m,288] = W_hh h + b_hh;
  * tape [m,384] = r, z, n, gh_n.  hprev NULL = zero state. */
 int sttode_gru_cell_fwd(const float* gi, long ldgi, const float* gh, const float* hprev, float* hnew, float* tape, int m, void* stream);
@@ -270,9 +272,10 @@ int sttode_conv_fwd(const float* xa, int adiv, const float* xb, const float* w, 
  * >= 256*224 floats, then one ordered pass). */
 int sttode_conv_bwd(const float* de, const float* x, const float* w, float* dx, float* dw, float* db, int m, int T, float* scratch,
                     long scratch_floats, void* stream);
-/* Backward of the geodesic self-attention (hyptransformerlib.py:191-300, scores untransposed :261-265): qkv [L*Nb,192] (q|k|v,
- * row = l*Nb + slot), dO [L*Nb,64] (grad wrt the merged-head output before out_proj) -> dqkv [L*Nb,192].  L <= 1024. */
-int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream);
+/* Backward of the geodesic self-attention (hyptransformerlib.py:191-300, scores untransposed :261-265): qkv [L*Nb, 3 D] (q|k|v,
+ * row = l*Nb + slot; D = 8 head_dim), dO [L*Nb, D] (grad wrt the merged-head output before out_proj) -> dqkv [L*Nb, 3 D].
+ * head_dim 4 / 8 / 16; L (4 head_dim + 4) floats of LDS (L <= 1137 at head_dim 8). */
+int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, int head_dim, void* stream);
 /* out[0] = scale * sum (pred - target)^2 (calculate_loss_pred / _recover, :372-376,384-388); dpred optional. */
 int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream);
 /* KL term (:378-382, utils/dist.py:26-29), params [rows,2*zd].  scene_ptr NULL: out[0] = clamp_min(sum KL / denom, min_clip).

@@ -22,7 +22,7 @@ SIGNATURES = {
     'sttode_frontend_future': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'sttode_embed_qkv': [_P] * 11 + [_P, _P, _P, _P, _I, _I, _P],
     'sttode_mhgsa_attn': [_P, _P, _P, _P, _P, _P, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
-    'sttode_mhgsa_attn_groups': [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I] + [_L] * 8 + [_F, _F, _P],
+    'sttode_mhgsa_attn_groups': [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I] + [_L] * 8 + [_F, _F, _I, _P],
     'sttode_post_attn': [_P] * 14 + [_P, _P, _I, _P, _I, _F, _P],
     'sttode_post_attn_ode': [_P] * 16 + [_P, _P, _I, _F, _I, _I, _P],
     'sttode_post_attn_rhs': [_P] * 14 + [_P, _P, _I, _P, _I, _P],
@@ -50,19 +50,19 @@ SIGNATURES = {
     'sttode_twgrad_flush': [],
     'sttode_tgemm_group': [_I],
     'sttode_tlinear_bwd': [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
-    'sttode_decoder_inputs': [_P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
+    'sttode_decoder_inputs': [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     'sttode_rows_copy': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_rows_reduce': [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     'sttode_train_ewise': [_I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
-    'sttode_add_ln_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P],
-    'sttode_ln_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
+    'sttode_add_ln_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'sttode_ln_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P],
     'sttode_gru_cell_fwd': [_P, _L, _P, _P, _P, _P, _I, _P],
     'sttode_gru_cell_bwd': [_P, _P, _P, _P, _L, _P, _P, _I, _P],
     'sttode_gru_seq_fwd': [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     'sttode_gru_seq_bwd': [_P, _L, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P],
-    'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _P],
+    'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _I, _P],
     'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
     'sttode_loss_kl': [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     'sttode_loss_diverse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],

@@ -748,13 +748,17 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
     do {                                                                                                 \
         hipLaunchKernelGGL((mlp0_lat_kernel<TX, NY>), g, dim3(256), 0, sl, ax, ay);                      \
     } while (0)
-        if (TPX == 1 && NOY == 2) L0L(1, 2);
-        else if (TPX == 2 && NOY == 5) L0L(2, 5);
-        else if (TPX == 1 && NOY == 1) L0L(1, 1);
-        else if (TPX == 1 && NOY == 3) L0L(1, 3);
-        else if (TPX == 2 && NOY == 2) L0L(2, 2);
-        else if (TPX == 2 && NOY == 3) L0L(2, 3);
-        else STT_REQUIRE(false, "sttode_mlp_block0: unsupported (TPX, NOY); built: (1,1) (1,2) (1,3) (2,2) (2,3) (2,5)");
+        // every (TPX, NOY) with 2 Tp <= 32, 2 Tf <= 96 (round 5: the reference's --past_length / --future_length are free CLI flags,
+        // train.py:25-26; rounds 1-4 built (1,1) (1,2) (1,3) (2,2) (2,3) (2,5) only)
+#define L0L_ROW(TX)                                                                                              \
+        switch (NOY) {                                                                                           \
+            case 1: L0L(TX, 1); break; case 2: L0L(TX, 2); break; case 3: L0L(TX, 3); break;                     \
+            case 4: L0L(TX, 4); break; case 5: L0L(TX, 5); break; case 6: L0L(TX, 6); break;                     \
+            default: STT_REQUIRE(false, "sttode_mlp_block0: future length beyond the built instantiations (2*Tf <= 96)"); \
+        }
+        if (TPX == 1) { L0L_ROW(1) } else if (TPX == 2) { L0L_ROW(2) }
+        else STT_REQUIRE(false, "sttode_mlp_block0: past length beyond the built instantiations (2*Tp <= 32)");
+#undef L0L_ROW
 #undef L0L
         STT_HIP(hipGetLastError());
         return 0;
@@ -771,13 +775,15 @@ extern "C" int sttode_mlp_block0(const float* A0x, const float* A0y, const float
         hipLaunchKernelGGL((mlp_block0_kernel<TX, NY>), dim3(grid), dim3(256), MLP0_LDS(TX, NY), s, A0x, A0y, (const f32x4*)stream, \
                            total_chunks, z, xpad, dbuf, ybuf, ncols, K);                                                \
     } while (0)
-    if (TPX == 1 && NOY == 2) L0(1, 2);
-    else if (TPX == 2 && NOY == 5) L0(2, 5);
-    else if (TPX == 1 && NOY == 1) L0(1, 1);
-    else if (TPX == 1 && NOY == 3) L0(1, 3);
-    else if (TPX == 2 && NOY == 2) L0(2, 2);
-    else if (TPX == 2 && NOY == 3) L0(2, 3);
-    else STT_REQUIRE(false, "sttode_mlp_block0: unsupported (TPX, NOY); built: (1,1) (1,2) (1,3) (2,2) (2,3) (2,5)");
+#define L0_ROW(TX)                                                                                               \
+    switch (NOY) {                                                                                               \
+        case 1: L0(TX, 1); break; case 2: L0(TX, 2); break; case 3: L0(TX, 3); break;                            \
+        case 4: L0(TX, 4); break; case 5: L0(TX, 5); break; case 6: L0(TX, 6); break;                            \
+        default: STT_REQUIRE(false, "sttode_mlp_block0: future length beyond the built instantiations (2*Tf <= 96)"); \
+    }
+    if (TPX == 1) { L0_ROW(1) } else if (TPX == 2) { L0_ROW(2) }
+    else STT_REQUIRE(false, "sttode_mlp_block0: past length beyond the built instantiations (2*Tp <= 32)");
+#undef L0_ROW
 #undef L0
     STT_HIP(hipGetLastError());
     return 0;
@@ -803,8 +809,10 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
             case 1: L1L(1); break;
             case 2: L1L(2); break;
             case 3: L1L(3); break;
+            case 4: L1L(4); break;
             case 5: L1L(5); break;
-            default: STT_REQUIRE(false, "sttode_mlp_block1: unsupported NOY; built: 1 2 3 5");
+            case 6: L1L(6); break;
+            default: STT_REQUIRE(false, "sttode_mlp_block1: future length beyond the built instantiations (2*Tf <= 96)");
         }
 #undef L1L
         STT_HIP(hipGetLastError());
@@ -824,8 +832,10 @@ extern "C" int sttode_mlp_block1(const float* A1y, const float* stream, int tota
         case 1: L1(1); break;
         case 2: L1(2); break;
         case 3: L1(3); break;
+        case 4: L1(4); break;
         case 5: L1(5); break;
-        default: STT_REQUIRE(false, "sttode_mlp_block1: unsupported NOY; built: 1 2 3 5");
+        case 6: L1(6); break;
+        default: STT_REQUIRE(false, "sttode_mlp_block1: future length beyond the built instantiations (2*Tf <= 96)");
     }
 #undef L1
     STT_HIP(hipGetLastError());
@@ -852,8 +862,10 @@ extern "C" int sttode_mlp_cols(const float* A0, const float* stream, int total_c
         case 1: LC(1); break;
         case 2: LC(2); break;
         case 3: LC(3); break;
+        case 4: LC(4); break;
         case 5: LC(5); break;
-        default: STT_REQUIRE(false, "sttode_mlp_cols: unsupported NO; built: 1 2 3 5");
+        case 6: LC(6); break;
+        default: STT_REQUIRE(false, "sttode_mlp_cols: output width beyond the built instantiations (<= 96)");
     }
 #undef LC
     STT_HIP(hipGetLastError());

@@ -139,6 +139,9 @@ __device__ __forceinline__ float exp_neg_acos(float x) {
 // columns (round 1-3) made a launch as long as one lane's serial loop -- 512 columns x ~35 VALU instructions = 30 us for a 512-long group
 // whatever the chip had free (the grid is rows / 256 x slots x heads workgroups: 160 for config 5's 512 x 10 group); the multi-stage
 // integrator runs one such launch per stage.
+// HD: head dimension = hidden_dim / 8 (8 heads always, model/STTODE.py:188): 8 for the reference's hidden_dim 64; 4 / 16 for --hidden_dim 32 / 128
+// (round 5; the sums run in the same order for every HD, so HD = 8 carries the bits of rounds 1-4).
+template <int HD>
 __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict__ R, const float* __restrict__ C,
                                                          const float* __restrict__ V, float* __restrict__ out,
                                                          float* __restrict__ rowsum,  // optional [Nb][8][rows]
@@ -149,44 +152,46 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
     // batch dimension of ONE forward call, hyptransformerlib.py:261-265; a test set is many such batches, test.py:520-524)
     R += blockIdx.z * gs_r; C += blockIdx.z * gs_c; V += blockIdx.z * gs_v; out += blockIdx.z * gs_o;
     if (rowsum) rowsum += (size_t)blockIdx.z * gridDim.y * rows;
-    __shared__ __attribute__((aligned(16))) float sC[ATT_TJ][8];
-    __shared__ __attribute__((aligned(16))) float sV[ATT_TJ][8];
-    __shared__ float sP[3][64][9];                                   // partials of waves 1..3: l, acc[8]
+    __shared__ __attribute__((aligned(16))) float sC[ATT_TJ][HD];
+    __shared__ __attribute__((aligned(16))) float sV[ATT_TJ][HD];
+    __shared__ float sP[3][64][HD + 1];                              // partials of waves 1..3: l, acc[HD]
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int rl = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + rl;
     const int ic = i < rows ? i : rows - 1;
-    float r[8];
+    float r[HD];
     {
-        const float* p = R + ic * rs_seq + b * rs_b + 8 * h;
+        const float* p = R + ic * rs_seq + b * rs_b + HD * h;
         float ss = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { r[d] = p[d] * rscale; ss += r[d] * r[d]; }
+        for (int d = 0; d < HD; ++d) { r[d] = p[d] * rscale; ss += r[d] * r[d]; }
         const float nrm = sqrtf(ss);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) r[d] = r[d] / nrm;
+        for (int d = 0; d < HD; ++d) r[d] = r[d] / nrm;
     }
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
     float l = 0.f;
     for (int j0 = 0; j0 < cols; j0 += ATT_TJ) {
         __syncthreads();
         if (threadIdx.x < ATT_TJ) {
             const int j = j0 + threadIdx.x;
             if (j < cols) {
-                const float* p = C + j * cs_seq + b * cs_b + 8 * h;
-                float v[8], ss = 0.f;
+                const float* p = C + j * cs_seq + b * cs_b + HD * h;
+                float v[HD], ss = 0.f;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) { v[d] = p[d] * cscale; ss += v[d] * v[d]; }
+                for (int d = 0; d < HD; ++d) { v[d] = p[d] * cscale; ss += v[d] * v[d]; }
                 const float nrm = sqrtf(ss);
 #pragma unroll
-                for (int d = 0; d < 8; ++d) sC[threadIdx.x][d] = v[d] / nrm;
+                for (int d = 0; d < HD; ++d) sC[threadIdx.x][d] = v[d] / nrm;
             }
         } else {
             const int jj = threadIdx.x - ATT_TJ, j = j0 + jj;
             if (j < cols) {
-                const float* p = V + j * vs_seq + b * vs_b + 8 * h;
+                const float* p = V + j * vs_seq + b * vs_b + HD * h;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) sV[jj][d] = p[d];
+                for (int d = 0; d < HD; ++d) sV[jj][d] = p[d];
             }
         }
         __syncthreads();
@@ -194,23 +199,27 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
         const int ja = 32 * w, jb = min(ja + 32, jn);
 #pragma unroll 8
         for (int jj = ja; jj < jb; ++jj) {
-            // all lanes of a wave read the same column (LDS broadcast): two b128 reads for c_j, two for v_j
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[jj][0]), c1 = *reinterpret_cast<const f32x4*>(&sC[jj][4]);
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sV[jj][0]), v1 = *reinterpret_cast<const f32x4*>(&sV[jj][4]);
-            float dot = r[0] * c0[0];
-            dot = fmaf(r[1], c0[1], dot); dot = fmaf(r[2], c0[2], dot); dot = fmaf(r[3], c0[3], dot);
-            dot = fmaf(r[4], c1[0], dot); dot = fmaf(r[5], c1[1], dot); dot = fmaf(r[6], c1[2], dot); dot = fmaf(r[7], c1[3], dot);
+            // all lanes of a wave read the same column (LDS broadcast): HD / 4 b128 reads for c_j, as many for v_j
+            f32x4 cq[HD / 4], vq[HD / 4];
+#pragma unroll
+            for (int q4 = 0; q4 < HD / 4; ++q4) {
+                cq[q4] = *reinterpret_cast<const f32x4*>(&sC[jj][4 * q4]);
+                vq[q4] = *reinterpret_cast<const f32x4*>(&sV[jj][4 * q4]);
+            }
+            float dot = r[0] * cq[0][0];
+#pragma unroll
+            for (int d = 1; d < HD; ++d) dot = fmaf(r[d], cq[d >> 2][d & 3], dot);
             dot = fminf(fmaxf(dot, -1.0f + 1e-4f), 1.0f - 1e-4f);
             const float p = exp_neg_acos(dot);  // scores lie in [-pi, 0]: no running max needed
             l += p;
-            acc[0] = fmaf(p, v0[0], acc[0]); acc[1] = fmaf(p, v0[1], acc[1]); acc[2] = fmaf(p, v0[2], acc[2]); acc[3] = fmaf(p, v0[3], acc[3]);
-            acc[4] = fmaf(p, v1[0], acc[4]); acc[5] = fmaf(p, v1[1], acc[5]); acc[6] = fmaf(p, v1[2], acc[6]); acc[7] = fmaf(p, v1[3], acc[7]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, vq[d >> 2][d & 3], acc[d]);
         }
     }
     if (w > 0) {
         sP[w - 1][rl][0] = l;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) sP[w - 1][rl][1 + d] = acc[d];
+        for (int d = 0; d < HD; ++d) sP[w - 1][rl][1 + d] = acc[d];
     }
     __syncthreads();
     if (w == 0 && i < rows) {
@@ -218,12 +227,12 @@ __global__ __launch_bounds__(256) void mhgsa_attn_kernel(const float* __restrict
         for (int k = 0; k < 3; ++k) {                                // wave order 0 + 1 + 2 + 3
             l += sP[k][rl][0];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) acc[d] += sP[k][rl][1 + d];
+            for (int d = 0; d < HD; ++d) acc[d] += sP[k][rl][1 + d];
         }
-        float* o = out + i * os_seq + b * os_b + 8 * h;
+        float* o = out + i * os_seq + b * os_b + HD * h;
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) o[d] = acc[d] * inv;
+        for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
         if (rowsum) rowsum[((size_t)b * 8 + h) * rows + i] = l;
     }
 }
@@ -423,12 +432,16 @@ int stt_embed_qkv_fe(const float* const* W, const float* past, int n, int N, int
 // `groups` independent attention problems of the same shape in ONE launch (group g at base + g * gs_*): see sttode_mhgsa_attn_groups
 extern "C" int sttode_mhgsa_attn_groups(const float* R, const float* C, const float* V, float* out, int groups, long gs_r, long gs_c, long gs_v,
                                         long gs_o, int rows, int cols, int Nb, long rs_seq, long rs_b, long cs_seq, long cs_b, long vs_seq,
-                                        long vs_b, long os_seq, long os_b, float rscale, float cscale, void* stream) {
+                                        long vs_b, long os_seq, long os_b, float rscale, float cscale, int head_dim, void* stream) {
     STT_REQUIRE(R && C && V && out, "sttode_mhgsa_attn_groups: null pointer");
     STT_REQUIRE(rows > 0 && cols > 0 && Nb > 0 && Nb * 8 <= 65535 && groups > 0 && groups <= 65535,
                 "sttode_mhgsa_attn_groups: bad rows/cols/Nb/groups (Nb*8 and groups must fit gridDim.y / .z)");
-    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 63) / 64, Nb * 8, groups), dim3(256), 0, (hipStream_t)stream, R, C, V, out, (float*)nullptr,
-                       rows, cols, rs_seq, rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale, gs_r, gs_c, gs_v, gs_o);
+    STT_REQUIRE(head_dim == 4 || head_dim == 8 || head_dim == 16, "sttode_mhgsa_attn_groups: head_dim must be 4, 8 or 16 (hidden_dim 32 / 64 / 128)");
+#define ATT_GO(HD)                                                                                                                       \
+    hipLaunchKernelGGL(mhgsa_attn_kernel<HD>, dim3((rows + 63) / 64, Nb * 8, groups), dim3(256), 0, (hipStream_t)stream, R, C, V, out,    \
+                       (float*)nullptr, rows, cols, rs_seq, rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale, gs_r, gs_c, gs_v, gs_o)
+    if (head_dim == 8) ATT_GO(8); else if (head_dim == 4) ATT_GO(4); else ATT_GO(16);
+#undef ATT_GO
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -440,7 +453,7 @@ extern "C" int sttode_mhgsa_attn(const float* R, const float* C, const float* V,
     STT_REQUIRE(rows > 0 && cols > 0 && Nb > 0 && Nb * 8 <= 65535, "sttode_mhgsa_attn: bad rows/cols/Nb (Nb*8 must fit gridDim.y)");
     STT_REQUIRE(!wout || rowsum, "sttode_mhgsa_attn: weights output needs the rowsum workspace");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mhgsa_attn_kernel, dim3((rows + 63) / 64, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
+    hipLaunchKernelGGL(mhgsa_attn_kernel<8>, dim3((rows + 63) / 64, Nb * 8), dim3(256), 0, s, R, C, V, out, rowsum, rows, cols, rs_seq,
                        rs_b, cs_seq, cs_b, vs_seq, vs_b, os_seq, os_b, rscale, cscale, 0L, 0L, 0L, 0L);
     STT_HIP(hipGetLastError());
     if (wout) {

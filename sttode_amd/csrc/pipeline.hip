@@ -385,7 +385,7 @@ struct StageTimer {
 static int attention(float* qkv, float* attn, int groups, int attn_len, int attn_slots, hipStream_t s) {
     const long st_seq = (long)attn_slots * 192, gq = (long)attn_len * st_seq, go = (long)attn_len * attn_slots * 64;
     return sttode_mhgsa_attn_groups(qkv + 64, qkv, qkv + 128, attn, groups, gq, gq, gq, go, attn_len, attn_len, attn_slots, st_seq, 192, st_seq, 192,
-                                    st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, s);
+                                    st_seq, 192, (long)attn_slots * 64, 64, 1.0f, 0.35355339059327373f, 8, s);
 }
 
 static int stage_agents(SttodeModel* m, float* ws, const long* off, int n, int groups, int attn_len, int attn_slots, hipStream_t s, bool use_side) {

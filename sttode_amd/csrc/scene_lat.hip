@@ -237,7 +237,7 @@ int stt_scene_flags_init(float* ws, const long* off, int n, int K, void* stream)
 }
 
 bool stt_scene_lat_covers(int Tp, int TPX, int NOY) {
-    const bool shape = (TPX == 1 && (NOY == 1 || NOY == 2 || NOY == 3)) || (TPX == 2 && (NOY == 2 || NOY == 3));
+    const bool shape = (TPX == 1 || TPX == 2) && NOY >= 1 && NOY <= 6;   // (round 5: every shape with 2 Tp <= 32, 2 Tf <= 96)
     return shape && Tp >= 2 && 2 * Tp <= 16 * TPX && (Tp * 256 + 512) * 16 <= SL_TOTAL;   // (the E role's embedding region)
 }
 
@@ -289,12 +289,15 @@ int stt_scene_lat(const float* const* W, float* ws, const long* off, int n, int 
         STT_SET_LDS_ONCE((scene_lat_kernel<TX, NY>), SL_TOTAL + 16);                                       \
         hipLaunchKernelGGL((scene_lat_kernel<TX, NY>), grid, dim3(256), SL_TOTAL + 16, s, a);              \
     } while (0)
-    if (TPX == 1 && NOY == 2) SLK(1, 2);
-    else if (TPX == 1 && NOY == 1) SLK(1, 1);
-    else if (TPX == 1 && NOY == 3) SLK(1, 3);
-    else if (TPX == 2 && NOY == 2) SLK(2, 2);
-    else if (TPX == 2 && NOY == 3) SLK(2, 3);
-    else STT_REQUIRE(false, "stt_scene_lat: unsupported (TPX, NOY)");
+#define SLK_ROW(TX)                                                                                  \
+    switch (NOY) {                                                                                   \
+        case 1: SLK(TX, 1); break; case 2: SLK(TX, 2); break; case 3: SLK(TX, 3); break;             \
+        case 4: SLK(TX, 4); break; case 5: SLK(TX, 5); break; case 6: SLK(TX, 6); break;             \
+        default: STT_REQUIRE(false, "stt_scene_lat: unsupported NOY");                               \
+    }
+    if (TPX == 1) { SLK_ROW(1) } else if (TPX == 2) { SLK_ROW(2) }
+    else STT_REQUIRE(false, "stt_scene_lat: unsupported TPX");
+#undef SLK_ROW
 #undef SLK
     STT_HIP(hipGetLastError());
     return 0;

@@ -1043,23 +1043,27 @@ static void ts_submit(const TLin& a, const TWg* w, int ksplit, int gxA, int nA, 
 // (model/STTODE.py:322-331, 553-566; the blocks' own state fills columns 160.. later).  Replaces two repeat_interleave copies per block
 // and the two that assembled z: six launches of a launch-bound step.
 // ---------------------------------------------------------------------------------------------------
-__global__ void decoder_inputs_kernel(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n, int K1) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of a row's 160-float prefix
-    if (id >= (long)n * K1 * 40) return;
-    const int f = (int)(id % 40) * 4;
-    const long c = id / 40;
+__global__ void decoder_inputs_kernel(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n, int K1,
+                                      int pfw, int zd) {
+    const int q4 = (pfw + zd) / 4;                                    // float4 pieces of a row's prefix cat(pf [pfw = 2 hidden_dim], z [zdim]): 40 at the defaults
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)n * K1 * q4) return;
+    const int f = (int)(id % q4) * 4;
+    const long c = id / q4;
     const int a = (int)(c / K1), k = (int)(c % K1);
-    const float* src = f < 128 ? pf + (long)a * ldpf + f : (k == 0 ? qz + (long)a * 32 : eps + ((long)a * (K1 - 1) + k - 1) * 32) + (f - 128);
+    const float* src = f < pfw ? pf + (long)a * ldpf + f : (k == 0 ? qz + (long)a * zd : eps + ((long)a * (K1 - 1) + k - 1) * zd) + (f - pfw);
     const f32x4 v = {src[0], src[1], src[2], src[3]};
     st4(inp0 + c * ld + f, v);
     if (inp1) st4(inp1 + c * ld + f, v);
 }
 extern "C" int sttode_decoder_inputs(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n,
-                                     int K1, void* stream) {
-    STT_REQUIRE(inp0 && pf && qz && eps && n > 0 && K1 >= 1 && ld >= 160 && ld % 4 == 0 && ldpf >= 128, "sttode_decoder_inputs: bad argument");
+                                     int K1, int pfw, int zd, void* stream) {
+    STT_REQUIRE(inp0 && pf && qz && eps && n > 0 && K1 >= 1 && pfw > 0 && zd > 0 && pfw % 4 == 0 && zd % 4 == 0 && ld >= pfw + zd && ld % 4 == 0 &&
+                ldpf >= pfw, "sttode_decoder_inputs: bad argument (pfw, zd multiples of 4; ld >= pfw + zd)");
     STT_REQUIRE(((size_t)inp0 | (size_t)inp1) % 16 == 0, "sttode_decoder_inputs: inp0 / inp1 must be 16-byte aligned");
-    const long tot = (long)n * K1 * 40;
-    hipLaunchKernelGGL(decoder_inputs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inp0, inp1, ld, pf, ldpf, qz, eps, n, K1);
+    const long tot = (long)n * K1 * ((pfw + zd) / 4);
+    hipLaunchKernelGGL(decoder_inputs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inp0, inp1, ld, pf, ldpf, qz, eps, n, K1,
+                       pfw, zd);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -1143,11 +1147,12 @@ static __device__ __forceinline__ void ewise_body(int op, float* p0, const float
             const int width = i0 & 0xffff, ld = i0 >> 16;
             p0[i] += f0 * p1[(i / width) * ld + i % width];
         } break;
-        case EW_EULER_BWD_CAT: {
-            const long r = i >> 6;
-            const int c = (int)(i & 63);
-            const float d = p1[i] > 0.f ? p0[r * i0 + 64 + c] : 0.f;
-            p3[i] = p0[r * i0 + c] + d;
+        case EW_EULER_BWD_CAT: {   // i0 = ld | (D << 16); D = 0 means 64 (rounds 3-4 callers)
+            const int D = (i0 >> 16) ? (i0 >> 16) : 64, ld = i0 & 0xffff;
+            const long r = i / D;
+            const int c = (int)(i % D);
+            const float d = p1[i] > 0.f ? p0[r * ld + D + c] : 0.f;
+            p3[i] = p0[r * ld + c] + d;
             p4[i] = f0 * d;
         } break;
         case EW_RSAMPLE: {
@@ -1237,76 +1242,120 @@ static __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// D = hidden_dim (32 / 64 / 128: LayerNorm over the model dimension, hypertransformer.py:119-120); one wave per row, lane l holds elements
+// l, l + 64 (D = 128) or is idle beyond D (D = 32).  D = 64: one element per lane, the sums of rounds 1-4.
+template <int D>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* x, const float* r, const float* gamma, const float* beta,
                                                          float* y, float* xhat, float* rstd, int rows) {
+    constexpr int NE = D > 64 ? D / 64 : 1;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float v = x[(long)row * 64 + lane] + (r ? r[(long)row * 64 + lane] : 0.f);
-    const float mean = wsum(v) * (1.0f / 64.0f);
-    const float d = v - mean;
-    const float rs = 1.0f / sqrtf(wsum(d * d) * (1.0f / 64.0f) + 1e-5f);
-    const float xh = d * rs;
-    xhat[(long)row * 64 + lane] = xh;
+    const bool on = lane < D;
+    float v[NE], tot = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const long o = (long)row * D + lane + 64 * e;
+        v[e] = on ? x[o] + (r ? r[o] : 0.f) : 0.f;
+        tot += v[e];
+    }
+    const float mean = wsum(tot) * (1.0f / D);
+    float d[NE], sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { d[e] = on ? v[e] - mean : 0.f; sq += d[e] * d[e]; }
+    const float rs = 1.0f / sqrtf(wsum(sq) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (!on) continue;
+        const long o = (long)row * D + lane + 64 * e;
+        const float xh = d[e] * rs;
+        xhat[o] = xh;
+        y[o] = xh * gamma[lane + 64 * e] + beta[lane + 64 * e];
+    }
     if (lane == 0) rstd[row] = rs;
-    y[(long)row * 64 + lane] = xh * gamma[lane] + beta[lane];
 }
 
 // dsum = grad wrt (x + r); dgamma / dbeta accumulated deterministically: WG g sums its rows, a single last pass adds the
 // per-WG partials in order (grid is small: rows <= a few thousand).
+template <int D>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                                                      float* dsum, float* part, int rows, int rows_per_wg, float* dgamma, float* dbeta) {
-    __shared__ float sg[4][64], sb[4][64];
+    constexpr int NE = D > 64 ? D / 64 : 1;
+    __shared__ float sg[4][NE * 64], sb[4][NE * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, rows);
-    float ag = 0.f, ab = 0.f;
-    const float g = gamma[lane];
+    const bool on = lane < D;
+    float ag[NE], ab[NE], g[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { ag[e] = ab[e] = 0.f; g[e] = on ? gamma[lane + 64 * e] : 0.f; }
     for (int row = r0 + wave; row < r1; row += 4) {
-        const float d = dy[(long)row * 64 + lane], xh = xhat[(long)row * 64 + lane];
-        ag += d * xh;
-        ab += d;
-        const float dh = d * g;
-        const float m1 = wsum(dh) * (1.0f / 64.0f), m2 = wsum(dh * xh) * (1.0f / 64.0f);
-        dsum[(long)row * 64 + lane] = rstd[row] * (dh - m1 - xh * m2);
+        float dd[NE], xh[NE], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const long o = (long)row * D + lane + 64 * e;
+            dd[e] = on ? dy[o] : 0.f;
+            xh[e] = on ? xhat[o] : 0.f;
+            ag[e] += dd[e] * xh[e];
+            ab[e] += dd[e];
+            const float dh = dd[e] * g[e];
+            s1 += dh;
+            s2 += dh * xh[e];
+        }
+        const float m1 = wsum(s1) * (1.0f / D), m2 = wsum(s2) * (1.0f / D);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (on) dsum[(long)row * D + lane + 64 * e] = rstd[row] * (dd[e] * g[e] - m1 - xh[e] * m2);
     }
-    sg[wave][lane] = ag;
-    sb[wave][lane] = ab;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { sg[wave][lane + 64 * e] = ag[e]; sb[wave][lane + 64 * e] = ab[e]; }
     __syncthreads();
-    if (wave == 0) {
-        const float tg = ((sg[0][lane] + sg[1][lane]) + sg[2][lane]) + sg[3][lane], tb = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
-        if (dgamma) {   // a single workgroup (rows <= 64: scene sizes): no partials, no second launch
-            dgamma[lane] += tg;
-            dbeta[lane] += tb;
-        } else {
-            part[(long)blockIdx.x * 128 + lane] = tg;
-            part[(long)blockIdx.x * 128 + 64 + lane] = tb;
+    if (wave == 0 && on) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + 64 * e;
+            const float tg = ((sg[0][c] + sg[1][c]) + sg[2][c]) + sg[3][c], tb = ((sb[0][c] + sb[1][c]) + sb[2][c]) + sb[3][c];
+            if (dgamma) {   // a single workgroup (rows <= 64: scene sizes): no partials, no second launch
+                dgamma[c] += tg;
+                dbeta[c] += tb;
+            } else {
+                part[(long)blockIdx.x * 2 * D + c] = tg;
+                part[(long)blockIdx.x * 2 * D + D + c] = tb;
+            }
         }
     }
 }
-__global__ void ln_bwd_reduce_kernel(const float* part, int G, float* dgamma, float* dbeta) {
-    const int t = threadIdx.x;  // 128 threads
+__global__ void ln_bwd_reduce_kernel(const float* part, int G, float* dgamma, float* dbeta, int D) {
+    const int t = threadIdx.x;  // 2 D threads
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(long)g * 128 + t];
-    if (t < 64) dgamma[t] += s;
-    else dbeta[t - 64] += s;
+    for (int g = 0; g < G; ++g) s += part[(long)g * 2 * D + t];
+    if (t < D) dgamma[t] += s;
+    else dbeta[t - D] += s;
 }
 
+#define LN_DISPATCH(D_, CALL)                                                                          \
+    do {                                                                                               \
+        if ((D_) == 64) { constexpr int DD = 64; CALL; }                                               \
+        else if ((D_) == 32) { constexpr int DD = 32; CALL; }                                          \
+        else if ((D_) == 128) { constexpr int DD = 128; CALL; }                                        \
+        else STT_REQUIRE(false, "LayerNorm kernels: hidden_dim must be 32, 64 or 128");                \
+    } while (0)
+
 extern "C" int sttode_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* xhat,
-                                 float* rstd, int rows, void* stream) {
+                                 float* rstd, int rows, int D, void* stream) {
     STT_REQUIRE(x && gamma && beta && y && xhat && rstd && rows > 0, "sttode_add_ln_fwd: bad argument");
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y, xhat, rstd, rows);
+    LN_DISPATCH(D, hipLaunchKernelGGL(add_ln_fwd_kernel<DD>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y, xhat, rstd, rows));
     STT_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sttode_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dsum, float* dgamma,
-                             float* dbeta, int rows, float* scratch, long scratch_floats, void* stream) {
+                             float* dbeta, int rows, int D, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dy && xhat && rstd && gamma && dsum && dgamma && dbeta && scratch && rows > 0, "sttode_ln_bwd: bad argument");
     int G = (rows + 63) / 64;
     if (G > 64) G = 64;
-    STT_REQUIRE(scratch_floats >= (long)G * 128, "sttode_ln_bwd: scratch too small");
+    STT_REQUIRE(scratch_floats >= (long)G * 2 * D, "sttode_ln_bwd: scratch too small");
     const int rpw = (rows + G - 1) / G;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw,
-                       G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
-    if (G > 1) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, scratch, G, dgamma, dbeta);
+    LN_DISPATCH(D, hipLaunchKernelGGL(ln_bwd_kernel<DD>, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw,
+                                      G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr));
+    if (G > 1) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(1), dim3(2 * D), 0, (hipStream_t)stream, scratch, G, dgamma, dbeta, D);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -1623,29 +1672,32 @@ extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, 
 //   out_i = sum_j P_ij v_j,  P_ij = softmax_j( -acos(clamp(khat_i . qhat_j)) ),  rows i = keys, columns j = queries.
 // one WG per (slot, head); token (l, slot) is row l*Nb + slot of qkv [L*Nb, 192] = (q | k | v); L <= 1024.
 // ---------------------------------------------------------------------------------------------------
+// HD = hidden_dim / 8 (4 / 8 / 16); token rows are [q | k | v] of 3 * 8 * HD floats.  HD = 8: the sums of rounds 1-4.
+template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* qkv, const float* dO, float* dqkv, int L, int Nb) {
+    constexpr int DM = 8 * HD;
     extern __shared__ float sm[];
-    float* kh = sm;              // [L][8] normalised keys
-    float* qh = kh + L * 8;      // normalised queries
-    float* vv = qh + L * 8;
-    float* dd = vv + L * 8;      // dO
-    float* rinv = dd + L * 8;    // [L] 1 / row sum of exp
+    float* kh = sm;              // [L][HD] normalised keys
+    float* qh = kh + L * HD;      // normalised queries
+    float* vv = qh + L * HD;
+    float* dd = vv + L * HD;      // dO
+    float* rinv = dd + L * HD;    // [L] 1 / row sum of exp
     float* rdot = rinv + L;      // [L] sum_j P_ij dP_ij
     float* kn = rdot + L;        // [L] 1/|k|
     float* qn = kn + L;          // [L] 1/|q|
     const int slot = blockIdx.x / 8, h = blockIdx.x % 8;
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
-        const float* row = qkv + ((long)l * Nb + slot) * 192 + h * 8;
-        float q[8], k[8], sq = 0.f, sk = 0.f;
+        const float* row = qkv + ((long)l * Nb + slot) * (3 * DM) + h * HD;
+        float q[HD], k[HD], sq = 0.f, sk = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { q[d] = row[d]; k[d] = row[64 + d]; sq += q[d] * q[d]; sk += k[d] * k[d]; }
+        for (int d = 0; d < HD; ++d) { q[d] = row[d]; k[d] = row[DM + d]; sq += q[d] * q[d]; sk += k[d] * k[d]; }
         const float iq = 1.0f / sqrtf(sq), ik = 1.0f / sqrtf(sk);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            qh[l * 8 + d] = q[d] * iq;
-            kh[l * 8 + d] = k[d] * ik;
-            vv[l * 8 + d] = row[128 + d];
-            dd[l * 8 + d] = dO[((long)l * Nb + slot) * 64 + h * 8 + d];
+        for (int d = 0; d < HD; ++d) {
+            qh[l * HD + d] = q[d] * iq;
+            kh[l * HD + d] = k[d] * ik;
+            vv[l * HD + d] = row[2 * DM + d];
+            dd[l * HD + d] = dO[((long)l * Nb + slot) * DM + h * HD + d];
         }
         qn[l] = iq;
         kn[l] = ik;
@@ -1658,66 +1710,76 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* qkv, const f
         for (int j = 0; j < L; ++j) {
             float dot = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            for (int d = 0; d < HD; ++d) { dot += kh[i * HD + d] * qh[j * HD + d]; dp += dd[i * HD + d] * vv[j * HD + d]; }
             const float ex = expf(-acosf(fminf(fmaxf(dot, lo), hi)));
             se += ex;
             sp += ex * dp;
         }
         rinv[i] = 1.0f / se;
         rdot[i] = sp / se;
-        float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float dk[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dk[d] = 0.f;
         for (int j = 0; j < L; ++j) {
             float dot = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            for (int d = 0; d < HD; ++d) { dot += kh[i * HD + d] * qh[j * HD + d]; dp += dd[i * HD + d] * vv[j * HD + d]; }
             const bool inside = dot > lo && dot < hi;
             const float cl = fminf(fmaxf(dot, lo), hi);
             const float P = expf(-acosf(cl)) * rinv[i];
             const float dS = P * (dp - rdot[i]);
             const float g = inside ? dS / sqrtf(1.0f - cl * cl) : 0.f;   // d(-acos x)/dx = 1/sqrt(1-x^2)
 #pragma unroll
-            for (int d = 0; d < 8; ++d) dk[d] += g * qh[j * 8 + d];
+            for (int d = 0; d < HD; ++d) dk[d] += g * qh[j * HD + d];
         }
         float pr = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) pr += dk[d] * kh[i * 8 + d];
-        float* o = dqkv + ((long)i * Nb + slot) * 192 + 64 + h * 8;
+        for (int d = 0; d < HD; ++d) pr += dk[d] * kh[i * HD + d];
+        float* o = dqkv + ((long)i * Nb + slot) * (3 * DM) + DM + h * HD;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) o[d] = (dk[d] - kh[i * 8 + d] * pr) * kn[i];
+        for (int d = 0; d < HD; ++d) o[d] = (dk[d] - kh[i * HD + d] * pr) * kn[i];
     }
     __syncthreads();
     // pass 2 (thread = query column j): dqhat_j, dv_j
     for (int j = threadIdx.x; j < L; j += blockDim.x) {
-        float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float dq[HD], dv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = dv[d] = 0.f;
         for (int i = 0; i < L; ++i) {
             float dot = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { dot += kh[i * 8 + d] * qh[j * 8 + d]; dp += dd[i * 8 + d] * vv[j * 8 + d]; }
+            for (int d = 0; d < HD; ++d) { dot += kh[i * HD + d] * qh[j * HD + d]; dp += dd[i * HD + d] * vv[j * HD + d]; }
             const bool inside = dot > lo && dot < hi;
             const float cl = fminf(fmaxf(dot, lo), hi);
             const float P = expf(-acosf(cl)) * rinv[i];
             const float dS = P * (dp - rdot[i]);
             const float g = inside ? dS / sqrtf(1.0f - cl * cl) : 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { dq[d] += g * kh[i * 8 + d]; dv[d] += P * dd[i * 8 + d]; }
+            for (int d = 0; d < HD; ++d) { dq[d] += g * kh[i * HD + d]; dv[d] += P * dd[i * HD + d]; }
         }
         float pr = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) pr += dq[d] * qh[j * 8 + d];
-        float* o = dqkv + ((long)j * Nb + slot) * 192 + h * 8;
+        for (int d = 0; d < HD; ++d) pr += dq[d] * qh[j * HD + d];
+        float* o = dqkv + ((long)j * Nb + slot) * (3 * DM) + h * HD;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            o[d] = (dq[d] - qh[j * 8 + d] * pr) * qn[j];
-            o[128 + d] = dv[d];
+        for (int d = 0; d < HD; ++d) {
+            o[d] = (dq[d] - qh[j * HD + d] * pr) * qn[j];
+            o[2 * DM + d] = dv[d];
         }
     }
 }
-extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, void* stream) {
+extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, int head_dim, void* stream) {
     STT_REQUIRE(qkv && dO && dqkv && L > 0 && Nb > 0, "sttode_mhgsa_attn_bwd: bad argument");
-    STT_REQUIRE(L <= 1024, "sttode_mhgsa_attn_bwd: attention length must be <= 1024 for the training backward");
-    const size_t shm = (size_t)L * (32 + 4) * sizeof(float);
-    STT_SET_LDS_ONCE(attn_bwd_kernel, 160 * 1024);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(Nb * 8), dim3(L < 256 ? ((L + 63) / 64) * 64 : 256), shm, (hipStream_t)stream, qkv, dO, dqkv, L, Nb);
+    STT_REQUIRE(head_dim == 4 || head_dim == 8 || head_dim == 16, "sttode_mhgsa_attn_bwd: head_dim must be 4, 8 or 16 (hidden_dim 32 / 64 / 128)");
+    const size_t shm = (size_t)L * (4 * head_dim + 4) * sizeof(float);
+    STT_REQUIRE(shm <= 160 * 1024, "sttode_mhgsa_attn_bwd: attention length too long for the training backward (L (4 head_dim + 4) floats of LDS)");
+#define ATTB_GO(HD)                                                                                                                   \
+    do {                                                                                                                              \
+        STT_SET_LDS_ONCE(attn_bwd_kernel<HD>, 160 * 1024);                                                                            \
+        hipLaunchKernelGGL(attn_bwd_kernel<HD>, dim3(Nb * 8), dim3(L < 256 ? ((L + 63) / 64) * 64 : 256), shm, (hipStream_t)stream, qkv, dO, dqkv, L, Nb); \
+    } while (0)
+    if (head_dim == 8) ATTB_GO(8); else if (head_dim == 4) ATTB_GO(4); else ATTB_GO(16);
+#undef ATTB_GO
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -494,7 +494,7 @@ class STTODENet(nn.Module):
             G = getattr(self, '_G', 1)                    # attention groups of the call (set_data_nba with [G,B,N,...]); group stride = B N rows
             capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, attn, G, L * Nslots * 192,
                       L * Nslots * 192, L * Nslots * 192, L * Nslots * 64, L, L, Nslots, Nslots * 192, 192, Nslots * 192, 192, Nslots * 192, 192,
-                      Nslots * 64, 64, 1.0, 8.0 ** -0.5, st)
+                      Nslots * 64, 64, 1.0, 8.0 ** -0.5, 8, st)
             attn_ptr, ld = attn, 64
         else:
             attn_ptr, ld = qkv.data_ptr() + 128 * qkv.element_size(), 192  # softmax over one element == 1  =>  output == v

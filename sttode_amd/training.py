@@ -48,6 +48,14 @@ class Engine:
         self.multi = False
         self._hold = []
         self.fused_trunk = os.environ.get('STTODE_TRUNK_FUSED', '1') != '0'   # scene batches: a trunk's forward + tape in one launch
+        # dimensions (train.py:37-40 --zdim / --hidden_dim / --num_decompose; 8 heads, ff 1024, conv 32 and GRU 96 are fixed in the reference:
+        # model/STTODE.py:23-26,188-189): D model width, HD head width, ZD latent width, PFW = width of past_feature = cat(ftraj_input, ode),
+        # ST = column of the GRU state in a decompose block's input cat(pf, z, state), IN = its width
+        a = net.args
+        self.D, self.ZD, self.NBLK = int(a.hidden_dim), int(a.zdim), int(a.num_decompose)
+        self.HD, self.PFW = self.D // 8, 2 * self.D
+        self.ST = self.PFW + self.ZD
+        self.IN = self.ST + 96
 
     # ---------------------------------------------------------------- streams
     def _use_streams(self, n):
@@ -173,22 +181,23 @@ class Engine:
         batches with T <= 12: each trunk is ONE launch (csrc/train_trunk.hip), two of them inside a group one launch together.  Otherwise
         (NBA: attention over the batch) layer by layer, layer i of every trunk inside one group -- one launch at scene sizes."""
         P, net = self.P, self.net
+        D, HD = self.D, self.HD
         S = []
         for pre, enc_in, last, feat, drop_mask in items:
             n, T = enc_in.shape[0], enc_in.shape[1]
             S.append(dict(t={'n': n, 'T': T, 'pre': pre, 'feat': feat}, pre=pre, a=pre + _ATT, n=n, T=T, X0=enc_in.reshape(n * T, 4), last=last, feat=feat,
                           drop=drop_mask))
-        if net._mode != 'nba' and all(s['T'] <= 12 for s in S) and self.fused_trunk:
+        if net._mode != 'nba' and all(s['T'] <= 12 for s in S) and self.fused_trunk and D == 64:
             with (self.group() if len(S) > 1 else contextlib.nullcontext()):
                 return [self._trunk_fwd_fused(s['t'], s['X0'], s['last'], s['feat'], s['drop']) for s in S]
         L, Nb = (net.batch_size, net._N) if net._mode == 'nba' else (1, None)
         with self.group():
             for s in S:
-                s['posin'] = self.new(s['n'] * s['T'], 128)
-                self.lin(s['X0'], P[s['pre'] + 'input_fc.weight'], P[s['pre'] + 'input_fc.bias'], out=s['posin'][:, :64])
+                s['posin'] = self.new(s['n'] * s['T'], 2 * D)
+                self.lin(s['X0'], P[s['pre'] + 'input_fc.weight'], P[s['pre'] + 'input_fc.bias'], out=s['posin'][:, :D])
         for s in S:
             pe = getattr(net, s['pre'][:-1]).pos_encoder.pe
-            capi.call('sttode_rows_copy', s['posin'][:, 64:], 128, pe, 64, s['n'] * s['T'], 64, 1, s['T'], self.st)
+            capi.call('sttode_rows_copy', s['posin'][:, D:], 2 * D, pe, D, s['n'] * s['T'], D, 1, s['T'], self.st)
         with self.group():
             for s in S:
                 s['tp'] = self.lin(s['posin'], P[s['pre'] + 'pos_encoder.fc.weight'], P[s['pre'] + 'pos_encoder.fc.bias'])
@@ -197,15 +206,15 @@ class Engine:
                 if s['drop'] is not None:                        # nn.Dropout(0.1) of PositionalAgentEncoding (model/STTODE.py:140,176)
                     self.ew(EW_MUL, s['tp'], s['tp'], s['drop'])
         for s in S:
-            s['h3in'] = self.zeros(s['n'], 68)
-            s['h3in'][:, 66] = self.hold(s['last'].to(torch.float32))   # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
+            s['h3in'] = self.zeros(s['n'], D + 4)
+            s['h3in'][:, D + 2] = self.hold(s['last'].to(torch.float32))   # add_category: [0, 0, 1] for the last agent (model/STTODE.py:199-210)
         with self.group():
             for s in S:
-                self.lin(s['tp'].view(s['n'], s['T'] * 64), P[s['pre'] + 'input_fc2.weight'], P[s['pre'] + 'input_fc2.bias'], out=s['h3in'][:, :64])
+                self.lin(s['tp'].view(s['n'], s['T'] * D), P[s['pre'] + 'input_fc2.weight'], P[s['pre'] + 'input_fc2.bias'], out=s['h3in'][:, :D])
         with self.group():
             for s in S:
-                s['x'] = s['feat'][:, :64]
-                self.lin(s['h3in'][:, :67], P[s['pre'] + 'input_fc3.weight'], P[s['pre'] + 'input_fc3.bias'], out=s['x'])
+                s['x'] = s['feat'][:, :D]
+                self.lin(s['h3in'][:, :D + 3], P[s['pre'] + 'input_fc3.weight'], P[s['pre'] + 'input_fc3.bias'], out=s['x'])
         with self.group():
             for s in S:
                 sa = s['a'] + 'self_attn.temporal_attention_before.'
@@ -213,12 +222,12 @@ class Engine:
         for s in S:
             n, qkv = s['n'], s['qkv']
             if L > 1:
-                s['attn'] = self.new(n, 64)
+                s['attn'] = self.new(n, D)
                 e = qkv.element_size()
-                capi.call('sttode_mhgsa_attn', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, s['attn'], None, None, L, L,
-                          Nb, Nb * 192, 192, Nb * 192, 192, Nb * 192, 192, Nb * 64, 64, 1.0, 8.0 ** -0.5, self.st)
+                capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + D * e, qkv.data_ptr(), qkv.data_ptr() + 2 * D * e, s['attn'], 1, 0, 0, 0, 0, L, L,
+                          Nb, Nb * 3 * D, 3 * D, Nb * 3 * D, 3 * D, Nb * 3 * D, 3 * D, Nb * D, D, 1.0, float(HD) ** -0.5, HD, self.st)
             else:
-                s['attn'] = qkv[:, 128:]                          # softmax over a single key == 1  =>  output == v
+                s['attn'] = qkv[:, 2 * D:]                        # softmax over a single key == 1  =>  output == v
         with self.group():
             for s in S:
                 sa = s['a'] + 'self_attn.temporal_attention_before.'
@@ -230,13 +239,13 @@ class Engine:
                 s['ss'] = self.lin(s['ao'], P[a + 'self_attn.temporal_gate.weight'], P[a + 'self_attn.temporal_gate.bias'], act='sigmoid')
         with self.group():
             for s in S:
-                s['gated'] = self.new(s['n'], 64)
+                s['gated'] = self.new(s['n'], D)
                 self.ew(EW_MUL, s['gated'], s['tt'], s['ss'])
         for s in S:
             a, n = s['a'], s['n']
             s['xc'] = s['x'].contiguous()
-            s['h'], s['xh1'], s['rs1'] = self.new(n, 64), self.new(n, 64), self.new(n)
-            capi.call('sttode_add_ln_fwd', s['xc'], s['gated'], P[a + 'norm1.weight'], P[a + 'norm1.bias'], s['h'], s['xh1'], s['rs1'], n, self.st)
+            s['h'], s['xh1'], s['rs1'] = self.new(n, D), self.new(n, D), self.new(n)
+            capi.call('sttode_add_ln_fwd', s['xc'], s['gated'], P[a + 'norm1.weight'], P[a + 'norm1.bias'], s['h'], s['xh1'], s['rs1'], n, D, self.st)
         with self.group():
             for s in S:
                 s['f1'] = self.lin(s['h'], P[s['a'] + 'linear1.weight'], P[s['a'] + 'linear1.bias'], act='relu')
@@ -245,15 +254,15 @@ class Engine:
                 s['f2'] = self.lin(s['f1'], P[s['a'] + 'linear2.weight'], P[s['a'] + 'linear2.bias'])
         for s in S:
             a, n = s['a'], s['n']
-            s['y'], s['xh2'], s['rs2'] = self.new(n, 64), self.new(n, 64), self.new(n)
-            capi.call('sttode_add_ln_fwd', s['h'], s['f2'], P[a + 'norm2.weight'], P[a + 'norm2.bias'], s['y'], s['xh2'], s['rs2'], n, self.st)
+            s['y'], s['xh2'], s['rs2'] = self.new(n, D), self.new(n, D), self.new(n)
+            capi.call('sttode_add_ln_fwd', s['h'], s['f2'], P[a + 'norm2.weight'], P[a + 'norm2.bias'], s['y'], s['xh2'], s['rs2'], n, D, self.st)
         with self.group():
             for s in S:
-                s['ode'] = self.new(s['n'], 64)
+                s['ode'] = self.new(s['n'], D)
                 self.ew(EW_EULER_FWD, s['ode'], s['xc'], s['y'], f0=net.ODE_TIME)
         out = []
         for s in S:
-            s['feat'][:, 64:128] = s['ode']
+            s['feat'][:, D:2 * D] = s['ode']
             t = s['t']
             t.update(X0=s['X0'], posin=s['posin'], tp=s['tp'], drop=s['drop'], h3in=s['h3in'], xc=s['xc'], qkv=s['qkv'], attn=s['attn'], ao=s['ao'],
                      tt=s['tt'], ss=s['ss'], h=s['h'], xh1=s['xh1'], rs1=s['rs1'], f1=s['f1'], xh2=s['xh2'], rs2=s['rs2'], ode=s['ode'], L=L,
@@ -308,20 +317,22 @@ class Engine:
         other) walked through TOGETHER: layer i of every trunk is issued inside one group, i.e. one launch -- a one-scene step is bound by
         the number of launches, and the two trunks are 2 x 10 linear-layer backward launches otherwise."""
         P, g, net = self.P, self.grad, self.net
+        D, HD = self.D, self.HD
         S = []
         for t, dfeat in items:
             pre = t['pre']
-            assert dfeat.stride(1) == 1 and dfeat.shape[1] >= 128
+            assert dfeat.stride(1) == 1 and dfeat.shape[1] >= 2 * D and dfeat.stride(0) < 65536
             S.append(dict(t=t, pre=pre, a=pre + _ATT, op=pre + _ATT + 'self_attn.temporal_attention_before.', n=t['n'], T=t['T'], dfeat=dfeat))
         with self.group():
             for s in S:                                          # dx = dfeat[:, :64] + d, dy = T d, d = dfeat[:, 64:128] * (ode > 0): one piece,
                 n = s['n']                                       # reading the strided rows of dfeat (no .contiguous() copies)
-                s['dx'], s['dy'] = self.new(n, 64), self.new(n, 64)
-                self.ew(EW_EULER_BWD_CAT, s['dfeat'], s['t']['ode'], None, s['dx'], s['dy'], i0=s['dfeat'].stride(0), f0=net.ODE_TIME, count=n * 64)
+                s['dx'], s['dy'] = self.new(n, D), self.new(n, D)
+                self.ew(EW_EULER_BWD_CAT, s['dfeat'], s['t']['ode'], None, s['dx'], s['dy'], i0=s['dfeat'].stride(0) | ((D << 16) if D != 64 else 0),
+                        f0=net.ODE_TIME, count=n * D)
         for s in S:
             t, a, n = s['t'], s['a'], s['n']
-            s['dsum2'] = self.new(n, 64)
-            capi.call('sttode_ln_bwd', s['dy'], t['xh2'], t['rs2'], P[a + 'norm2.weight'], s['dsum2'], g(a + 'norm2.weight'), g(a + 'norm2.bias'), n,
+            s['dsum2'] = self.new(n, D)
+            capi.call('sttode_ln_bwd', s['dy'], t['xh2'], t['rs2'], P[a + 'norm2.weight'], s['dsum2'], g(a + 'norm2.weight'), g(a + 'norm2.bias'), n, D,
                       self.scratch, self.scratch.numel(), self.st)
         with self.group():
             for s in S:
@@ -333,13 +344,13 @@ class Engine:
                 self.lin_bwd(s['df1'], P[a + 'linear1.weight'], t['h'], g(a + 'linear1.weight'), g(a + 'linear1.bias'), out=s['dsum2'], accumulate=True)
         for s in S:
             t, a, n = s['t'], s['a'], s['n']
-            s['dsum1'] = self.new(n, 64)
-            capi.call('sttode_ln_bwd', s['dsum2'], t['xh1'], t['rs1'], P[a + 'norm1.weight'], s['dsum1'], g(a + 'norm1.weight'), g(a + 'norm1.bias'), n,
+            s['dsum1'] = self.new(n, D)
+            capi.call('sttode_ln_bwd', s['dsum2'], t['xh1'], t['rs1'], P[a + 'norm1.weight'], s['dsum1'], g(a + 'norm1.weight'), g(a + 'norm1.bias'), n, D,
                       self.scratch, self.scratch.numel(), self.st)
         with self.group():
             for s in S:
                 self.ew(EW_AXPY, s['dx'], s['dsum1'], f0=1.0)    # residual branch of LN1(x + gated)
-                s['du'], s['dv'] = self.new(s['n'], 64), self.new(s['n'], 64)
+                s['du'], s['dv'] = self.new(s['n'], D), self.new(s['n'], D)
                 self.ew(EW_GATE_BWD, s['dsum1'], s['t']['tt'], s['t']['ss'], s['du'], s['dv'])
         with self.group():
             for s in S:
@@ -357,8 +368,8 @@ class Engine:
                 s['dattn'] = self.lin_bwd(s['dao'], P[op + 'out_proj.weight'], t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
         for s in S:
             t = s['t']
-            s['dqkv'] = self.new(s['n'], 192)
-            capi.call('sttode_mhgsa_attn_bwd', t['qkv'], s['dattn'], s['dqkv'], t['L'], t['Nb'], self.st)
+            s['dqkv'] = self.new(s['n'], 3 * D)
+            capi.call('sttode_mhgsa_attn_bwd', t['qkv'], s['dattn'], s['dqkv'], t['L'], t['Nb'], HD, self.st)
         with self.group():
             for s in S:
                 t, op = s['t'], s['op']
@@ -367,13 +378,13 @@ class Engine:
         with self.group():
             for s in S:
                 t, pre = s['t'], s['pre']
-                s['dh2'] = self.lin_bwd(s['dx'], P[pre + 'input_fc3.weight'], t['h3in'][:, :67], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'),
-                                        in_features=64)
+                s['dh2'] = self.lin_bwd(s['dx'], P[pre + 'input_fc3.weight'], t['h3in'][:, :D + 3], g(pre + 'input_fc3.weight'), g(pre + 'input_fc3.bias'),
+                                        in_features=D)
         with self.group():
             for s in S:
                 t, pre, n, T = s['t'], s['pre'], s['n'], s['T']
-                s['dtp'] = self.lin_bwd(s['dh2'], P[pre + 'input_fc2.weight'], t['tp'].view(n, T * 64), g(pre + 'input_fc2.weight'),
-                                        g(pre + 'input_fc2.bias')).view(n * T, 64)
+                s['dtp'] = self.lin_bwd(s['dh2'], P[pre + 'input_fc2.weight'], t['tp'].view(n, T * D), g(pre + 'input_fc2.weight'),
+                                        g(pre + 'input_fc2.bias')).view(n * T, D)
         with self.group():
             for s in S:
                 if s['t']['drop'] is not None:
@@ -382,7 +393,7 @@ class Engine:
             for s in S:
                 t, pre = s['t'], s['pre']
                 s['dtf'] = self.lin_bwd(s['dtp'], P[pre + 'pos_encoder.fc.weight'], t['posin'], g(pre + 'pos_encoder.fc.weight'),
-                                        g(pre + 'pos_encoder.fc.bias'), in_features=64)
+                                        g(pre + 'pos_encoder.fc.bias'), in_features=D)
         with self.group():
             for s in S:
                 self.wgrad(s['dtf'], s['t']['X0'], g(s['pre'] + 'input_fc.weight'), g(s['pre'] + 'input_fc.bias'))
@@ -449,13 +460,14 @@ class Engine:
         H = self.new(Tp + 1, m, 96)                                                                      # H[0] = 0 (written by the launch), H[t+1] = h_t
         tapes = self.new(Tp, m, 384)
         prefix = inp is None                                                                             # cat(pf_rep, z, state): the prefix may come filled (decoder_fwd)
+        IN, ST, PFW, ZD = self.IN, self.ST, self.PFW, self.ZD
         if prefix:
-            inp = self.new(m, 256)
+            inp = self.new(m, IN)
         capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
-                  inp[:, 160:], 256, m, Tp, self.st)                                                     # all Tp steps, one launch
+                  inp[:, ST:], IN, m, Tp, self.st)                                                       # all Tp steps, one launch
         if prefix:
-            capi.call('sttode_rows_copy', inp, 256, pf, _ld(pf), m, 128, K, n, self.st)
-            capi.call('sttode_rows_copy', inp[:, 128:], 256, z, _ld(z), m, 32, 1, m, self.st)
+            capi.call('sttode_rows_copy', inp, IN, pf, _ld(pf), m, PFW, K, n, self.st)
+            capi.call('sttode_rows_copy', inp[:, PFW:], IN, z, _ld(z), m, ZD, 1, m, self.st)
         if want_x and _PAIRED:
             (yh, sy), (xh, sx) = self.mlp_fwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', inp)
         else:
@@ -464,10 +476,10 @@ class Engine:
         return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx)
 
     def block_bwd(self, b, dyh, dxh, need_dx):
-        """Returns (din [m,256], dx [m,Tp,2] | None)."""
+        """Returns (din [m,IN], dx [m,Tp,2] | None)."""
         P, g = self.P, self.grad
         pre, m, Tp = b['pre'], b['m'], b['Tp']
-        din = self.new(m, 256)
+        din = self.new(m, self.IN)
         if dxh is not None and _PAIRED:
             self.mlp_bwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', b['inp'], b['sy'], b['sx'], dyh, dxh, din)
         else:
@@ -476,7 +488,7 @@ class Engine:
                 self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
         dgi = self.new(m * Tp, 288)
         dgh = self.new(Tp, m, 288)
-        capi.call('sttode_gru_seq_bwd', din[:, 160:], 256, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
+        capi.call('sttode_gru_seq_bwd', din[:, self.ST:], self.IN, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
         self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
         de = self.lin_bwd(dgi, P[pre + 'encoder_past.weight_ih_l0'], b['e'], g(pre + 'encoder_past.weight_ih_l0'),
                           g(pre + 'encoder_past.bias_ih_l0'), mask=b['e'])
@@ -486,40 +498,63 @@ class Engine:
         return din, dx
 
     def decoder_fwd(self, pf, z, K, past, cur, want_recover, qz_eps=None):
-        """``qz_eps`` = (qz [n, 32], eps [n (K - 1), 32]) instead of ``z`` [n K, 32]: the blocks' input prefix cat(pf, z) is written for BOTH
-        blocks by one launch (sttode_decoder_inputs) and z is never assembled."""
+        """Decoder.forward (model/STTODE.py:320-347) over ``num_decompose`` blocks: block i reads x_true - x_hat_{i-1} (x_hat_{-1} = 0) and the
+        same cat(pf, z); prediction = sum y_hat_i + cur_location, reconstruction = sum x_hat_i (the last block's decoder_x is needed only for it).
+        ``qz_eps`` = (qz [n, zd], eps [n (K - 1), zd]) instead of ``z`` [n K, zd]: the blocks' input prefix cat(pf, z) is written for the
+        first TWO blocks by one launch (sttode_decoder_inputs; further blocks copy it) and z is never assembled."""
         n, Tp = past.shape[0], past.shape[1]
         Tf = self.net.args.future_length
         m = n * K
-        inps = (None, None)
+        nb = self.NBLK
+        inps = [None] * nb
         if qz_eps is not None:
-            inps = (self.new(m, 256), self.new(m, 256))
-            capi.call('sttode_decoder_inputs', inps[0], inps[1], 256, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.st)
-        b0 = self.block_fwd(0, past, K, None, pf, z, True, inp=inps[0])
-        b1 = self.block_fwd(1, past, K, b0['xh'], pf, z, want_recover, inp=inps[1])
+            inps = [self.new(m, self.IN) for _ in range(nb)]
+            capi.call('sttode_decoder_inputs', inps[0], inps[1] if nb > 1 else None, self.IN, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.PFW, self.ZD, self.st)
+            for i in range(2, nb):
+                capi.call('sttode_rows_copy', inps[i], self.IN, inps[0], self.IN, m, self.ST, 1, m, self.st)
+        blocks, xprev = [], None
+        for i in range(nb):
+            b = self.block_fwd(i, past, K, xprev, pf, z, want_recover or i + 1 < nb, inp=inps[i])
+            blocks.append(b)
+            xprev = b['xh']
         pred = self.new(m, 2 * Tf)
         rec = None
+        ysum, xsum = blocks[0]['yh'], blocks[0]['xh']
+        for b in blocks[1:-1]:                                      # (num_decompose > 2: partial sums of the middle blocks)
+            ysum = ysum + b['yh']
+            if want_recover:
+                xsum = xsum + b['xh']
         with self.group():                                          # two independent pieces: one launch
-            self.ew(EW_SUM_CUR, pred, b0['yh'], b1['yh'], cur, i0=2 * Tf, f0=K)
+            if nb > 1:
+                self.ew(EW_SUM_CUR, pred, ysum, blocks[-1]['yh'], cur, i0=2 * Tf, f0=K)
+            else:
+                self.ew(EW_SUM_CUR, pred, ysum, self.zeros(m, 2 * Tf), cur, i0=2 * Tf, f0=K)
             if want_recover:
                 rec = self.new(m, 2 * Tp)
-                self.ew(EW_SUM_CUR, rec, b0['xh'], b1['xh'], None, i0=2 * Tp, f0=K)
-        return dict(b0=b0, b1=b1, n=n, K=K, m=m, pred=pred, rec=rec)
+                self.ew(EW_SUM_CUR, rec, xsum, blocks[-1]['xh'] if nb > 1 else self.zeros(m, 2 * Tp), None, i0=2 * Tp, f0=K)
+        return dict(blocks=blocks, b0=blocks[0], b1=blocks[-1], n=n, K=K, m=m, pred=pred, rec=rec)
 
     def decoder_bwd(self, d, dpred, drec, dpf, dz, dpf_accumulate=True):
-        """Accumulates dpf [n,128] (+=; ``dpf_accumulate=False``: writes it); writes dz [m,32] if not None.  Returns the gradient of the
-        blocks' summed layer-1 input [m, 256] = cat(d pf_rep | d z | d state) (its columns 128..159 are dz)."""
+        """Accumulates dpf [n, 2 D] (+=; ``dpf_accumulate=False``: writes it); writes dz [m, zd] if not None.  Returns the gradient of the
+        blocks' summed layer-1 input [m, IN] = cat(d pf_rep | d z | d state) (its columns 2 D .. 2 D + zd - 1 are dz)."""
         n, K, m = d['n'], d['K'], d['m']
-        din1, dx1 = self.block_bwd(d['b1'], dpred, drec, True)
-        # x_1 = x_true - x_hat_0  =>  d x_hat_0 = (d recover) - d x_1
-        dxh0 = dx1.view(m, -1)
-        self.ew(EW_SCALE_ADD, dxh0, drec, f0=-1.0)                  # dxh0 = -dx1 (+ drec)
-        din0, _ = self.block_bwd(d['b0'], dpred, dxh0, False)
-        self.ew(EW_AXPY, din0, din1, f0=1.0)
-        capi.call('sttode_rows_reduce', dpf, _ld(dpf), din0, 256, n, 128, K, int(dpf_accumulate), self.st)
+        blocks = d['blocks']
+        # x_{i+1} = x_true - x_hat_i  =>  d x_hat_i = (d recover) - d x_{i+1}; the last block's x_hat only feeds the reconstruction
+        dxh, din_sum = drec, None
+        for i in range(len(blocks) - 1, -1, -1):
+            din, dx = self.block_bwd(blocks[i], dpred, dxh, i > 0)
+            if din_sum is None:
+                din_sum = din
+            else:
+                self.ew(EW_AXPY, din, din_sum, f0=1.0)              # (the running sum ends in block 0's buffer, as in rounds 3-4)
+                din_sum = din
+            if i > 0:
+                dxh = dx.view(m, -1)
+                self.ew(EW_SCALE_ADD, dxh, drec, f0=-1.0)           # d x_hat_{i-1} = -dx_i (+ drec)
+        capi.call('sttode_rows_reduce', dpf, _ld(dpf), din_sum, self.IN, n, self.PFW, K, int(dpf_accumulate), self.st)
         if dz is not None:
-            dz.copy_(din0[:, 128:160])
-        return din0
+            dz.copy_(din_sum[:, self.PFW:self.ST])
+        return din_sum
 
     # ---------------------------------------------------------------- the objective (model/STTODE.py:553-568)
     def forward_segments(self, eps_q, eps20, drop_past=None, drop_future=None, streams=None):
@@ -544,11 +579,13 @@ class Engine:
             self.red_scratch = torch.empty(_SCRATCH_BATCH, dtype=torch.float32, device=self.dev)
         V = self.V = {}
 
+        D, PFW = self.D, self.PFW
+
         def f_front():
             V['ws'] = ws = net._frontend(vel_from_norm=0)
             V['past'] = ws['xpad'][:, :2 * Tp].reshape(n, Tp, 2).contiguous()
             V['fut'] = (net._future - ws['orig'][:, None, :]).contiguous()
-            V['hcat'] = self.new(n, 256)
+            V['hcat'] = self.new(n, 2 * PFW)
             V['lastpos'] = self.hold(net._past[:, -1].contiguous())
 
         def f_future():
@@ -559,15 +596,15 @@ class Engine:
             if _PAIRED and not self.multi:
                 V['enc_f'] = enc_f                                   # one stream: the two trunks' forward as ONE launch (f_past)
             else:
-                V['tf'] = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, 128:], drop_future)
+                V['tf'] = self.trunk_fwd('future_encoder.', enc_f, ws['last'], hcat[:, PFW:], drop_future)
 
         def f_past():
             ws, hcat = V['ws'], V['hcat']
             if _PAIRED and not self.multi:                           # one stream: both trunks together (grouped launches)
-                V['tf'], V['tp'] = self.trunk_fwd_multi([('future_encoder.', V['enc_f'], ws['last'], hcat[:, 128:], drop_future),
-                                                         ('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)])
+                V['tf'], V['tp'] = self.trunk_fwd_multi([('future_encoder.', V['enc_f'], ws['last'], hcat[:, PFW:], drop_future),
+                                                         ('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :PFW], drop_past)])
             else:
-                V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :128], drop_past)
+                V['tp'] = self.trunk_fwd('past_encoder.', ws['enc_in'], ws['last'], hcat[:, :PFW], drop_past)
 
         def f_dec():
             ws, hcat, fut, past = V['ws'], V['hcat'], V['fut'], V['past']
@@ -577,8 +614,8 @@ class Engine:
             self.ew(EW_RSAMPLE, qz, qzp, eps_q, i0=zd)
             # z per (agent, sample): sample 0 = the posterior draw, samples 1..20 = the prior draws -- read where they are by the launch that
             # fills both blocks' input prefix
-            assert zd == 32 and eps20.is_contiguous() and qz.is_contiguous()
-            d = self.decoder_fwd(hcat[:, :128], None, K1, past, ws['cur'], True, qz_eps=(qz, eps20))
+            assert zd % 4 == 0 and eps20.is_contiguous() and qz.is_contiguous()
+            d = self.decoder_fwd(hcat[:, :PFW], None, K1, past, ws['cur'], True, qz_eps=(qz, eps20))
             losses = self.new(5)                                    # the four terms and their sum
             dpred, drec, dqzp = self.new(n * K1, 2 * Tf), self.new(n * K1, 2 * Tp), self.new(n, 2 * zd)
             # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
@@ -593,7 +630,7 @@ class Engine:
             V['losses'] = losses
             # attributes the reference sets (read by callers)
             pr = d['pred'].view(n, K1, Tf, 2)
-            net.past_feature = hcat[:, :128]
+            net.past_feature = hcat[:, :PFW]
             net.qz_param = qzp
             net.qz_sampled = qz
             net.pred_traj = pr[:, 0]
@@ -624,10 +661,10 @@ class Engine:
             self._grad_views()
             if self.red_scratch is not None:                            # batch sizes: the split weight gradients' reductions as one launch per 16
                 capi.call('sttode_twgrad_defer', 1, self.red_scratch, self.red_scratch.numel())
-            W['dpf'] = dpf = self.new(n, 128)
+            W['dpf'] = dpf = self.new(n, self.PFW)
             din = self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, None, dpf_accumulate=False)
             dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent: dz of row a K1
-            capi.call('sttode_rows_copy', dqz, zd, din[:, 128:], K1 * 256, n, zd, 1, n, self.st)
+            capi.call('sttode_rows_copy', dqz, zd, din[:, self.PFW:], K1 * self.IN, n, zd, 1, n, self.st)
             dqzp = T['dqzp']                                            # starts as the KL gradient
             self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
             dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
@@ -638,15 +675,15 @@ class Engine:
 
         def b_future():
             if not (_PAIRED and not self.multi):
-                self.trunk_bwd(T['tf'], W['dhcat'][:, 128:])
+                self.trunk_bwd(T['tf'], W['dhcat'][:, self.PFW:])
 
         def b_past():
             dpf = W['dpf']
             dh = W['dhcat']
             assert dh.stride(1) == 1 and dh.stride(0) < 65536
-            self.ew(EW_AXPY_ROWS, dpf, dh, i0=(dh.stride(0) << 16) | 128, f0=1.0, count=n * 128)   # dpf += dhcat[:, :128] (read where it is)
+            self.ew(EW_AXPY_ROWS, dpf, dh, i0=(dh.stride(0) << 16) | self.PFW, f0=1.0, count=n * self.PFW)   # dpf += dhcat[:, :2 D] (read where it is)
             if _PAIRED and not self.multi:                              # one stream: both trunks layer by layer, grouped launches
-                self.trunk_bwd_multi([(T['tf'], W['dhcat'][:, 128:]), (T['tp'], dpf)])
+                self.trunk_bwd_multi([(T['tf'], W['dhcat'][:, self.PFW:]), (T['tp'], dpf)])
             else:
                 self.trunk_bwd(T['tp'], dpf)
             capi.call('sttode_twgrad_defer', 0, None, 0)                # the pending reductions run here, behind the last gradient
@@ -856,9 +893,9 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
     eps20 = draw(eps20, 'eps20', n * 20, a.zdim)
     if net.training:
         if drop_past is None:
-            drop_past = draw(None, 'drop_past', n * a.past_length, 64, bern=True)
+            drop_past = draw(None, 'drop_past', n * a.past_length, a.hidden_dim, bern=True)
         if drop_future is None:
-            drop_future = draw(None, 'drop_future', n * a.future_length, 64, bern=True)
+            drop_future = draw(None, 'drop_future', n * a.future_length, a.hidden_dim, bern=True)
     if graphs:
         if key in net._graphs or key in net._graph_seen:
             inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,

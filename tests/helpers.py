@@ -199,3 +199,56 @@ def horizon_metrics_np(pred_nk, gt, scale=1.0):
         run = (run + d[:, :, t]).astype(np.float32)
         cum[:, :, t] = run / np.float32(t + 1)
     return np.stack([cum.min(axis=1), d.min(axis=1)], axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Non-default hyper-parameters (round 5): the reference's CLI accepts --hidden_dim / --zdim / --num_decompose / --past_length /
+# --future_length (train.py:25-26,37-40).  The cases of tests/golden/dims.npz (made by tests/golden/make_dims_golden.py from the imported
+# reference): inputs, latents and noises are REGENERATED from seeds here, the fixture stores the reference's outputs only.
+# ---------------------------------------------------------------------------------------------------------------------------------
+DIMS_CASES = {
+    'tf28': dict(Tf_eth=28, Tf_nba=28),          # the future_length 25-32 hole of rounds 1-4 (16-wide output tiles: NOY = 4)
+    'tf36_tp8': dict(Tf_eth=36, Tf_nba=36),      # NOY = 5 with one 16-wide input tile: a (TPX, NOY) pair rounds 1-4 did not build
+    'tp20': dict(Tp_eth=20, Tp_nba=20),          # past_length > 16
+    'tf60': dict(Tf_eth=60, Tf_nba=60),          # future_length > 48
+    'nd1': dict(num_decompose=1),
+    'nd3': dict(num_decompose=3),
+    'zd16': dict(zdim=16),
+    'zd64': dict(zdim=64),
+    'hd32': dict(hidden_dim=32),
+    'hd128': dict(hidden_dim=128),
+    'mix': dict(hidden_dim=32, zdim=16, num_decompose=3, Tp_eth=6, Tf_eth=9, Tp_nba=4, Tf_nba=7),
+}
+DIMS_GRAD_CASES = ('nd3', 'zd16', 'hd32', 'hd128', 'tf28')   # forward() losses + backward() digests as well
+
+
+def dims_case_args(tag, dataset):
+    c = DIMS_CASES[tag]
+    ds = 'nba' if dataset == 'nba' else 'eth'
+    a = make_args(dataset, c.get('Tp_' + ds, 5 if ds == 'nba' else 8), c.get('Tf_' + ds, 10 if ds == 'nba' else 12))
+    a.hidden_dim, a.zdim, a.num_decompose = c.get('hidden_dim', 64), c.get('zdim', 32), c.get('num_decompose', 2)
+    return a
+
+
+def dims_case_weights(a, seed=1234):
+    from sttode_amd.weights import make_weights
+    return make_weights(seed, past_length=a.past_length, future_length=a.future_length, hidden_dim=a.hidden_dim, zdim=a.zdim,
+                        num_decompose=a.num_decompose)
+
+
+def dims_case_inputs(tag, dataset):
+    """-> (args, inputs, z, (eps_q, eps_p1, eps_p20)): inputs = (obs [N,2,Tp], pred [N,2,Tf]) for 'eth', the loader dict for 'nba'."""
+    from sttode_amd import scenes
+    ci = list(DIMS_CASES).index(tag)
+    a = dims_case_args(tag, dataset)
+    Tp, Tf, zd = a.past_length, a.future_length, a.zdim
+    rng = np.random.default_rng(4000 + 10 * ci + (dataset == 'nba'))
+    if dataset == 'eth':
+        inputs = scenes.eth_scene(7300 + ci, n_min=6, n_max=6, obs_len=Tp, pred_len=Tf)
+        n = 6
+    else:
+        inputs = scenes.nba_batch(640 + ci, 3, N=11, obs_len=Tp, pred_len=Tf)
+        n = 33
+    z = rng.standard_normal((n * 20, zd)).astype(np.float32)
+    eps = tuple(rng.standard_normal(sh).astype(np.float32) for sh in ((n, zd), (n, zd), (n * 20, zd)))
+    return a, inputs, z, eps
