@@ -163,12 +163,13 @@ class STTODENet(nn.Module):
 
     def __init__(self, args, device):
         super().__init__()
-        if args.hidden_dim != 64 or args.zdim != 32:
-            raise NotImplementedError('HIP kernels are built for hidden_dim=64, zdim=32 (reference defaults, train.py:21-52)')
-        if args.num_decompose != 2:
-            raise NotImplementedError('HIP decoder is built for num_decompose=2 (reference default)')
-        if packing.tiles_y(args.future_length) not in packing.SUPPORTED_NOY or 2 * args.past_length > 32:
-            raise NotImplementedError('unsupported past/future length for the built kernel instantiations')
+        # what is refused, and why, is listed in ONE place: generic.unsupported_reason.  Everything else the reference's CLI accepts
+        # (train.py:25-26,37-40) is taken: by the fused forms at the reference's default widths, by the generic form otherwise
+        from . import generic
+        why = generic.unsupported_reason(args)
+        if why is not None:
+            raise NotImplementedError(why)
+        self._generic = generic.uses_generic(args)
         self.device = torch.device(device)
         self.args = args
         self.max_train_agent = args.max_train_agent
@@ -244,6 +245,8 @@ class STTODENet(nn.Module):
 
     def packed(self):
         """Fragment-ordered device copies of the weights; re-packed whenever a parameter changes."""
+        if self._generic:
+            return {}                                    # the generic form reads the nn.Parameter storage directly (generic.py)
         key = self._weights_key()
         if self._packed is None or key != self._packed_key:
             if getattr(self, '_native', None) is not None:
@@ -272,7 +275,7 @@ class STTODENet(nn.Module):
         """Drop the native pipeline handle (its events; the pipeline's streams are process-wide), the packed weights and the cached
         workspaces; all are rebuilt on the next call."""
         if self.device.type == 'cuda':
-            if self._native is not None:
+            if getattr(self, '_native', None) is not None:
                 capi.call('sttode_async_flush', self._native.h)
             torch.cuda.synchronize(self.device)
         self._native, self._packed, self._packed_key = None, None, None
@@ -281,6 +284,9 @@ class STTODENet(nn.Module):
     def native(self, check_weights=True):
         """The native pipeline handle on the current weights.  ``check_weights=False``: skip the weight-version comparison (10 us over 88
         parameters) -- for callers that make it themselves AFTER their launch is enqueued and launch again if it fails (inference())."""
+        if self._generic:
+            raise capi.SttodeError('the native pipeline (fused launches, packed weight streams) is built for the reference widths hidden_dim 64, '
+                                   'zdim 32, num_decompose 2, 2 Tp <= 32, 2 Tf <= 96; this model runs the generic form (sttode_amd/generic.py)')
         if check_weights or self._packed is None or self._native is None:
             self.packed()
         ode = (self.ODE_METHODS[self.ode_method], int(self.ode_steps))
@@ -463,7 +469,7 @@ class STTODENet(nn.Module):
     def _frontend(self, vel_from_norm):
         a, dev = self.args, self.device
         n, Tp = self._past.shape[0], a.past_length
-        TPX = packing.tiles_x(Tp)
+        TPX = (2 * Tp + 15) // 16
         ws = {'xpad': self._f(n, 16 * TPX), 'enc_in': self._f(n, Tp, 4), 'cur': self._f(n, 2), 'orig': self._f(n, 2),
               'last': torch.empty(n, dtype=torch.int32, device=dev)}
         st = capi.stream_ptr()
@@ -534,6 +540,11 @@ class STTODENet(nn.Module):
     def encode_history(self):
         """model/STTODE.py:488-496 (self.inputs uses velocities of the un-normalised track, :432-433,456)."""
         self._require_gpu()
+        if self._generic:
+            from . import generic
+            _, self._ws, self.past_feature, self.past_traj = generic.encode(self, 0)
+            self.cur_location = self.past_traj[:, -1:]
+            return self.past_feature
         P = self.packed()
         self._ws = self._frontend(vel_from_norm=0)
         self.past_feature = self._encode(P['past'], self._ws['enc_in'], self._ws['last'], self.args.past_length)
@@ -545,9 +556,12 @@ class STTODENet(nn.Module):
     @torch.no_grad()
     def fu_encoder(self, eps_q=None, eps_p=None):
         """model/STTODE.py:498-525: posterior q(z | past, future) and prior samples."""
-        a, P = self.args, self.packed()
         if self._future is None:
             raise capi.SttodeError('fu_encoder needs the future (set_data / set_scene_batch with future, or set_data_nba)')
+        if self._generic:
+            from . import generic
+            return generic.fu_encoder(self, eps_q, eps_p)
+        a, P = self.args, self.packed()
         n, Tf = self._past.shape[0], a.future_length
         st = capi.stream_ptr()
         enc_f = self._f(n, Tf, 4)
@@ -609,8 +623,12 @@ class STTODENet(nn.Module):
     def decoder_future_0(self, qz_sampled, eps20=None):
         """model/STTODE.py:534-551: K = 1 decode with the posterior sample (normalised coordinates), then draws the 20 prior samples."""
         a = self.args
-        zeros = torch.zeros_like(self._ws['orig'])
-        pred, rec = self._decode(self.past_feature, qz_sampled, self._ws, 1, orig=zeros, want_recover=True)
+        if self._generic:
+            from . import generic
+            pred, rec = generic.decode(self, qz_sampled, 1, True)
+        else:
+            zeros = torch.zeros_like(self._ws['orig'])
+            pred, rec = self._decode(self.past_feature, qz_sampled, self._ws, 1, orig=zeros, want_recover=True)
         self.pred_traj = pred.reshape(pred.shape[0], a.future_length, 2)
         self.recover_traj = rec
         n = self.past_feature.shape[0]
@@ -622,8 +640,12 @@ class STTODENet(nn.Module):
     @torch.no_grad()
     def decoder_future_1(self, pz_sampled):
         """model/STTODE.py:529-532: K = 20 decode with prior samples -> diverse_pred_traj [n,20,Tf,2] (normalised)."""
-        zeros = torch.zeros_like(self._ws['orig'])
-        self.diverse_pred_traj = self._decode(self.past_feature, pz_sampled, self._ws, 20, orig=zeros)
+        if self._generic:
+            from . import generic
+            self.diverse_pred_traj = generic.decode(self, pz_sampled, 20, False)[0]
+        else:
+            zeros = torch.zeros_like(self._ws['orig'])
+            self.diverse_pred_traj = self._decode(self.past_feature, pz_sampled, self._ws, 20, orig=zeros)
         self.attn_weights = None
 
     def forward(self, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
@@ -636,8 +658,8 @@ class STTODENet(nn.Module):
         if getattr(self, '_G', 1) > 1:
             raise NotImplementedError('forward(): one forward-call batch per step, as train.py:59-95 (several attention groups per call are an '
                                       'evaluation feature: set_data_nba with [G,B,N,...] + inference())')
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .training import training_forward
+        if self._generic or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            from .training import training_forward        # (generic widths: the training kernels serve forward() with and without autograd)
             return training_forward(self, eps_q, eps_p, eps20, drop_past, drop_future)
         with torch.no_grad():
             return self._forward_values(eps_q, eps_p, eps20)
@@ -680,6 +702,20 @@ class STTODENet(nn.Module):
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference()')
         K = a.sample_k
+        if self._generic:                                                # widths outside the fused forms: the layer-by-layer form (generic.py)
+            if (self.ode_method, self.ode_steps) != ('euler', 1):
+                raise NotImplementedError('non-default integrators are built for the reference widths (hidden_dim 64, zdim 32, two blocks)')
+            n = self._past.shape[0]
+            z = torch.randn(n * K, a.zdim, device=self.device) if z is None else _f32(z, self.device)
+            if tuple(z.shape) != (n * K, a.zdim):
+                raise ValueError(f'z must be [{n * K}, {a.zdim}], got {tuple(z.shape)}')
+            from . import generic
+            pred = generic.inference(self, z)
+            if self._mode == 'scenes':
+                so = self._ws['scene_orig']
+                self.scene_orig = so[0] if self._S == 1 else so
+            self.diverse_pred = pred
+            return pred.permute(1, 0, 2, 3)
         # weights compared AFTER the launch is enqueued (below): only on the one-scene evaluation loop (test.py:171-188), where the host is the
         # critical path up to the launch and no optimizer runs between calls; everywhere else (batches, the NBA path, train / eval alternation)
         # the comparison comes first -- a stale launch there would double the GPU work of every first call after an optimizer step
@@ -787,6 +823,14 @@ class STTODENet(nn.Module):
         a = self.args
         if self._mode is None:
             raise capi.SttodeError('call set_data / set_data_nba / set_scene_batch before inference_async()')
+        if self._generic:
+            # widths outside the fused forms have no pipelined form: the call runs serially on the caller's stream; the handle keeps the
+            # callers of the pipelined API (evaluate.eval_scenes / eval_nba) working unchanged
+            if pred_host:
+                raise capi.SttodeError('pred_host=True needs the lagged pipelined form (reference widths)')
+            out = self.inference(None, z=z)
+            return {'generic': True, 'fused_metrics': None, 'slot': -1, 'pred': self.diverse_pred, 'z': None, 'metrics': None,
+                    'gt_default': self._future, 'stream': None, 'inputs': (self._past, getattr(self, '_scene_ptr', None))}
         nat = self.native()
         nat.raise_if_timed_out()
         K, n = a.sample_k, self._past.shape[0]
@@ -853,6 +897,8 @@ class STTODENet(nn.Module):
 
     def wait(self, handle):
         """Make the current stream wait for an inference_async() result; returns predictions [K, n, Tf, 2]."""
+        if handle.get('generic'):
+            return handle['pred'].permute(1, 0, 2, 3)
         nat = self.native()
         nat.raise_if_timed_out()
         capi.call('sttode_wait', nat.h, handle['slot'], capi.stream_ptr())
@@ -905,6 +951,11 @@ class STTODENet(nn.Module):
         return handle['host'].permute(1, 0, 2, 3)
 
     def next_async_stream(self, n):
+        if self._generic:
+            return None
+        return self._next_async_stream(n)
+
+    def _next_async_stream(self, n):
         """torch stream (an ExternalStream over the pipeline's own) the next inference_async() call of ``n`` agents will run on, or None
         when that call will not take the one-stream fused form.  Work enqueued there before the call -- the H2D copy of its inputs, the
         latents -- is ordered in front of it without any cross-stream event:  ``with torch.cuda.stream(s): load(); h = m.inference_async()``.
@@ -927,6 +978,8 @@ class STTODENet(nn.Module):
         buffers, valid after ``wait(handle)`` and until the slot's next call.  ``gt`` [n, Tf, 2] must have been written before the
         inference_async() call (default: the futures set with the batch).  Further work on the call's results -- a D2H copy of its
         futures -- may follow on ``handle['stream']`` (stream order: no event; ``wait(handle)`` still covers the metrics only)."""
+        if handle.get('generic'):
+            return self.best_of_k(handle['pred'], gt=handle.get('gt_default') if gt is None else gt, scale=scale)
         fm = handle.get('fused_metrics')
         if fm is not None and (gt is None or gt.data_ptr() == fm[0].data_ptr()) and float(scale) == fm[1]:
             capi.call('sttode_async_enqueue', self.native().h, handle['slot'])   # the call's groups compute them: make sure they are enqueued
@@ -959,13 +1012,15 @@ class STTODENet(nn.Module):
             raise ValueError('horizon_metrics_async needs a contiguous float32 device tensor gt [n, Tf, 2] that was written before the call')
         pred = handle['pred']
         n, K, Tf = pred.shape[:3]
+        if handle.get('generic'):
+            return self.horizon_metrics(pred, gt, scale)
         if out is None:
             out = torch.empty(n, Tf, 2, dtype=torch.float32, device=self.device)
         capi.call('sttode_async_horizon_metrics', self.native().h, handle['slot'], pred, gt, n, K, Tf, float(scale), out)
         return out
 
     def reset_async(self):
-        if self._native is not None:
+        if getattr(self, '_native', None) is not None:
             capi.call('sttode_async_flush', self._native.h)      # outstanding groups of lagged calls read the buffers dropped below
         torch.cuda.synchronize(self.device)
         self._async_bufs = {}

@@ -224,7 +224,9 @@ class Engine:
             if L > 1:
                 s['attn'] = self.new(n, D)
                 e = qkv.element_size()
-                capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + D * e, qkv.data_ptr(), qkv.data_ptr() + 2 * D * e, s['attn'], 1, 0, 0, 0, 0, L, L,
+                G = getattr(net, '_G', 1)                          # forward-call batches per call (set_data_nba with [G,B,N,...]): attention within each
+                gq, go = L * Nb * 3 * D, L * Nb * D
+                capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + D * e, qkv.data_ptr(), qkv.data_ptr() + 2 * D * e, s['attn'], G, gq, gq, gq, go, L, L,
                           Nb, Nb * 3 * D, 3 * D, Nb * 3 * D, 3 * D, Nb * 3 * D, 3 * D, Nb * D, D, 1.0, float(HD) ** -0.5, HD, self.st)
             else:
                 s['attn'] = qkv[:, 2 * D:]                        # softmax over a single key == 1  =>  output == v
@@ -521,9 +523,13 @@ class Engine:
         rec = None
         ysum, xsum = blocks[0]['yh'], blocks[0]['xh']
         for b in blocks[1:-1]:                                      # (num_decompose > 2: partial sums of the middle blocks)
-            ysum = ysum + b['yh']
+            t = self.new(m, 2 * Tf)
+            self.ew(EW_SUM_CUR, t, ysum, b['yh'], None, i0=2 * Tf, f0=K)
+            ysum = t
             if want_recover:
-                xsum = xsum + b['xh']
+                t = self.new(m, 2 * Tp)
+                self.ew(EW_SUM_CUR, t, xsum, b['xh'], None, i0=2 * Tp, f0=K)
+                xsum = t
         with self.group():                                          # two independent pieces: one launch
             if nb > 1:
                 self.ew(EW_SUM_CUR, pred, ysum, blocks[-1]['yh'], cur, i0=2 * Tf, f0=K)

@@ -153,6 +153,18 @@ def test_state_dict_surface_matches_reference_manifest():
         assert all(tuple(sd[k].shape) == tuple(man[k]) for k in man)
         m.load_state_dict(to_torch_state_dict(make_weights(7, past_length=Tp, future_length=Tf)), strict=True)
     assert sum(p.numel() for p in STTODENet(make_args(), 'cpu').parameters()) == 1627792
+    # non-default CLI flags (train.py:25-26,37-40): the manifest for those hyper-parameters is the one tests/golden/make_dims_golden.py loaded
+    # into the IMPORTED REFERENCE with load_state_dict(strict=True) -- i.e. the reference's own names and shapes -- and STTODENet's state_dict
+    # must be exactly that: a checkpoint trained with any accepted flag loads
+    from helpers import DIMS_CASES, dims_case_args, dims_case_weights
+    for tag in DIMS_CASES:
+        for ds in ('eth', 'nba'):
+            a = dims_case_args(tag, ds)
+            m = STTODENet(a, 'cpu')
+            man = manifest(past_length=a.past_length, future_length=a.future_length, hidden_dim=a.hidden_dim, zdim=a.zdim, num_decompose=a.num_decompose)
+            sd = m.state_dict()
+            assert list(sd) == list(man) and all(tuple(sd[k].shape) == tuple(man[k]) for k in man), (tag, ds)
+            m.load_state_dict(to_torch_state_dict(dims_case_weights(a, seed=3)), strict=True)
 
 
 def test_product_package_never_imports_the_oracle():
@@ -179,18 +191,21 @@ def test_input_validation_on_host():
         m.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 4], np.int32))         # CSR does not end at n
     with pytest.raises(capi.SttodeError):
         m.inference(None)                                                                              # nothing set
-    # model shapes outside the built kernel instantiations are refused in ONE place, STTODENet.__init__ (the reference derives every dimension
-    # from args, model/STTODE.py:179-196,246-254,350-366; its defaults -- and every checkpoint its CLI produces with them -- are what is built)
-    for bad in ({'num_decompose': 3}, {'num_decompose': 1}, {'hidden_dim': 128}, {'hidden_dim': 32}, {'zdim': 16}, {'zdim': 64},
-                {'past_length': 17}, {'future_length': 49}):
+    # what STTODENet refuses is listed in ONE place, generic.unsupported_reason (round 5: everything else the reference's CLI accepts --
+    # train.py:25-26,37-40; every dimension derives from args, model/STTODE.py:179-196,246-254,350-366 -- is taken: by the fused forms at the
+    # default widths, by the generic form otherwise)
+    from sttode_amd import generic
+    for bad in ({'hidden_dim': 48}, {'hidden_dim': 256}, {'zdim': 30}, {'zdim': 0}, {'num_decompose': 0}, {'past_length': 1}, {'past_length': 201},
+                {'future_length': 0}, {'future_length': 201}, {'hyper_scales': [5]}, {'learn_prior': True}):
+        a = make_args().__class__(**{**vars(make_args()), **bad})
+        assert generic.unsupported_reason(a)
         with pytest.raises(NotImplementedError):
-            STTODENet(make_args().__class__(**{**vars(make_args()), **bad}), 'cpu')
-    a = make_args()
-    a.learn_prior = True
-    m2 = STTODENet(a, 'cpu')
-    m2.set_scene_batch(np.zeros((5, 8, 2), np.float32), None, np.array([0, 5], np.int32))
-    with pytest.raises((NotImplementedError, capi.SttodeError)):
-        m2.inference(None)
+            STTODENet(a, 'cpu')
+    for ok, gen in (({'num_decompose': 3}, True), ({'num_decompose': 1}, True), ({'hidden_dim': 128}, True), ({'hidden_dim': 32}, True), ({'zdim': 16}, True),
+                    ({'zdim': 64}, True), ({'past_length': 17}, True), ({'future_length': 49}, True), ({'future_length': 28}, False),
+                    ({'past_length': 16, 'future_length': 48}, False)):
+        a = make_args().__class__(**{**vars(make_args()), **ok})
+        assert generic.unsupported_reason(a) is None and STTODENet(a, 'cpu')._generic == gen, ok
 
 
 def test_no_cpu_fallback_anywhere():

@@ -3206,3 +3206,147 @@ def test_bench_default_line_rehearsed_at_world_two_on_one_gpu():
     assert set(d['configs']) == {'ucy_2048', 'sdd_1024', 'nba_128', 'nba_long_4096'} and all(v['value'] > 0 for v in d['configs'].values())
     assert d['train']['steps_per_s'] > 0 and 'all-reduce' in d['train']['config']['parallelism']
     assert 'cpu_baseline' not in d                                # rank 0 at N = 1 only
+
+
+def _dims_model(tag, dataset):
+    from helpers import dims_case_inputs, dims_case_weights
+    from sttode_amd import STTODENet
+    from sttode_amd.weights import to_torch_state_dict
+    a, inputs, z, eps = dims_case_inputs(tag, dataset)
+    m = STTODENet(a, _gpu()).eval()
+    m.load_state_dict(to_torch_state_dict(dims_case_weights(a)), strict=True)
+    return m, a, inputs, z, eps
+
+
+def _dims_set(m, dataset, inputs):
+    if dataset == 'eth':
+        m.set_data(None, torch.from_numpy(inputs[0]), torch.from_numpy(inputs[1]))
+        return None
+    data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inputs.items()}
+    m.set_data_nba(data)
+    return data
+
+
+@pytest.mark.parametrize('tag', ['tf28', 'tf36_tp8', 'tp20', 'tf60', 'nd1', 'nd3', 'zd16', 'zd64', 'hd32', 'hd128', 'mix'])
+def test_non_default_hyperparameters_vs_reference_golden(golden, tag):
+    """What the reference's CLI accepts (train.py:25-26,37-40 --past_length / --future_length / --zdim / --hidden_dim / --num_decompose)
+    through the DEFAULT path of STTODENet -- constructor, load_state_dict(strict=True) of a state_dict with the reference's names and
+    shapes for those flags, set_data / set_data_nba, inference(): one ETH scene and one NBA batch per value against the imported
+    reference (tests/golden/dims.npz) at rtol 1e-4 + atol 1e-4.  tf28 / tf36_tp8 run on the fused forms (the (TPX, NOY) pairs rounds 1-4
+    did not instantiate), the others on the generic form (sttode_amd/generic.py)."""
+    from sttode_amd import generic
+    g = golden('dims')
+    for dataset in ('eth', 'nba'):
+        m, a, inputs, z, _ = _dims_model(tag, dataset)
+        assert m._generic == (tag not in ('tf28', 'tf36_tp8')) and generic.unsupported_reason(a) is None
+        data = _dims_set(m, dataset, inputs)
+        out = m.inference(data, z=torch.from_numpy(z))
+        k = f'{tag}_{dataset}_'
+        assert_close(m.past_feature.cpu().numpy(), g[k + 'past_feature'], what=k + 'past_feature')
+        assert_close(out.cpu().numpy(), g[k + 'out'], what=k + 'inference')
+        if not m._generic:                                        # the fused forms of those shapes: chain launch (forced) and pipelined
+            nat = m.native()
+            try:
+                nat.set_chain(1)
+                _dims_set(m, dataset, inputs)
+                assert_close(m.inference(data, z=torch.from_numpy(z)).cpu().numpy(), g[k + 'out'], what=k + 'chain launch')
+                _dims_set(m, dataset, inputs)
+                h = m.inference_async(z=torch.from_numpy(z))
+                assert_close(m.wait(h).cpu().numpy(), g[k + 'out'], what=k + 'pipelined')
+            finally:
+                nat.set_chain(-1)
+                m.reset_async()
+
+
+@pytest.mark.parametrize('tag', ['nd3', 'zd16', 'hd32', 'hd128', 'tf28'])
+def test_non_default_hyperparameters_training_step_vs_reference(golden, tag):
+    """forward() + backward() with non-default --num_decompose / --zdim / --hidden_dim / --future_length: the five loss values against the
+    imported reference's, every parameter gradient against the float64 autograd of the oracle (the yardstick of the default-width tests)."""
+    from helpers import dims_case_inputs
+    from test_oracle_golden import _dims_set_data, _oracle_for
+    g = golden('dims')
+    for dataset in ('eth', 'nba'):
+        m, a, inputs, z, (eq, ep, e20) = _dims_model(tag, dataset)
+        k = f'{tag}_{dataset}_'
+        _dims_set(m, dataset, inputs)
+        m.zero_grad()
+        vals = m.forward(eps_q=torch.from_numpy(eq), eps_p=torch.from_numpy(ep), eps20=torch.from_numpy(e20))
+        np.testing.assert_allclose([float(vals[0].detach())] + list(vals[1:]), g[k + 'losses'], rtol=1e-4)
+        vals[0].backward()
+        grads = {}
+        for dbl in (False, True):
+            mm = _oracle_for(a, dbl)
+            prev = torch.get_default_dtype()
+            torch.set_default_dtype(torch.float64 if dbl else torch.float32)
+            try:
+                _dims_set_data(mm, dataset, inputs, dbl)
+                cast = (lambda t: torch.from_numpy(t).double()) if dbl else torch.from_numpy
+                mm.forward_loss_tensors(cast(eq), cast(ep), cast(e20))[0].backward()
+            finally:
+                torch.set_default_dtype(prev)
+            grads[dbl] = {n_: (p_.grad.clone() if p_.grad is not None else None) for n_, p_ in mm.named_parameters()}
+        checked = 0
+        for name, p in m.named_parameters():
+            g64 = grads[True][name]
+            if g64 is None:
+                assert p.grad is None or not bool(p.grad.any()), name
+                continue
+            g64n = g64.numpy()
+            err_hip = np.abs(p.grad.cpu().numpy().astype(np.float64) - g64n).max()
+            err_f32 = np.abs(grads[False][name].numpy().astype(np.float64) - g64n).max()
+            assert err_hip <= max(2 * err_f32, 1e-4 * np.abs(g64n).max()) + 1e-12, (k, name, err_hip, err_f32, np.abs(g64n).max())
+            checked += 1
+        assert checked > 80
+        # no-grad forward(): the same values
+        with torch.no_grad():
+            _dims_set(m, dataset, inputs)
+            v2 = m.forward(eps_q=torch.from_numpy(eq), eps_p=torch.from_numpy(ep), eps20=torch.from_numpy(e20))
+        np.testing.assert_allclose([float(v2[0])] + list(v2[1:]), g[k + 'losses'], rtol=1e-4)
+
+
+def test_generic_form_staged_api_and_evaluation_loops():
+    """The staged API (encode_history / fu_encoder / decoder_future_0 / _1: what sampler.py:36-70 drives) and the evaluation loops on a model
+    with non-default widths: against the oracle on the same noises."""
+    from helpers import dims_case_inputs
+    from test_oracle_golden import _dims_set_data, _oracle_for
+    m, a, inputs, z, (eq, ep, e20) = _dims_model('mix', 'nba')
+    ora = _oracle_for(a)
+    data = _dims_set(m, 'nba', inputs)
+    from oracle.sttode_ref import Normal
+    with torch.no_grad():
+        _dims_set_data(ora, 'nba', inputs)
+        ora.encode_history()
+        qzp = ora.future_encoder(ora.inputs_for_posterior, ora.batch_size, ora.agent_num, ora.past_feature)
+        ora.decoder_future_0(Normal(params=qzp).rsample(torch.from_numpy(eq)), torch.from_numpy(e20))
+        ora.decoder_future_1(torch.from_numpy(e20))
+    m.encode_history()
+    m.fu_encoder(eps_q=torch.from_numpy(eq), eps_p=torch.from_numpy(ep))
+    m.decoder_future_0(m.qz_sampled, eps20=torch.from_numpy(e20))
+    m.decoder_future_1(torch.from_numpy(e20))
+    assert_close(m.past_feature.cpu().numpy(), ora.past_feature.numpy(), what='past_feature')
+    assert_close(m.qz_param.cpu().numpy(), qzp.numpy(), what='qz_param')
+    assert_close(m.pred_traj.cpu().numpy(), ora.pred_traj.numpy().reshape(m.pred_traj.shape), what='pred_traj')
+    assert_close(m.recover_traj.cpu().numpy(), ora.recover_traj.numpy().reshape(m.recover_traj.shape), what='recover_traj')
+    assert_close(m.diverse_pred_traj.cpu().numpy(), ora.diverse_pred_traj.numpy().reshape(m.diverse_pred_traj.shape), what='diverse_pred_traj')
+    # the pipelined API degrades to serial calls, the callers keep working
+    h = m.inference_async(z=torch.from_numpy(z))
+    ade, fde = m.best_of_k_async(h)
+    with torch.no_grad():
+        ref = ora.inference(data, z=torch.from_numpy(z)).numpy()
+    assert_close(m.wait(h).cpu().numpy(), ref, what='generic inference_async')
+    from oracle.metrics_ref import best_of_k_ade_fde
+    ra, rf = best_of_k_ade_fde(ref.transpose(1, 0, 2, 3), inputs['future_traj'].reshape(-1, a.future_length, 2))
+    assert_close(ade.cpu().numpy(), ra, what='ade')
+    assert_close(fde.cpu().numpy(), rf, what='fde')
+
+
+def test_unsupported_arguments_are_refused_in_one_place():
+    from sttode_amd import STTODENet, generic
+    for over, frag in ((dict(hidden_dim=48), 'hidden_dim'), (dict(zdim=30), 'zdim'), (dict(num_decompose=0), 'num_decompose'),
+                       (dict(past_length=1), 'past_length'), (dict(hyper_scales=[5]), 'hyper_scales'), (dict(learn_prior=True), 'learn_prior')):
+        a = make_args('eth', 8, 12)
+        for k_, v in over.items():
+            setattr(a, k_, v)
+        assert frag in generic.unsupported_reason(a)
+        with pytest.raises(NotImplementedError, match=frag):
+            STTODENet(a, _gpu())
