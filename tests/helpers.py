@@ -247,7 +247,9 @@ def dims_case_inputs(tag, dataset):
         inputs = scenes.eth_scene(7300 + ci, n_min=6, n_max=6, obs_len=Tp, pred_len=Tf)
         n = 6
     else:
-        inputs = scenes.nba_batch(640 + ci, 3, N=11, obs_len=Tp, pred_len=Tf)
+        # (seed base 1640: no ReLU pre-activation of the encoders' FFN within 6e-6 of zero in any gradient case -- with base 640 one sat at 2.4e-7,
+        # where two correct fp32 forwards disagree about the unit's mask and the gradient, a step function there, differs by 5 %)
+        inputs = scenes.nba_batch(1640 + ci, 3, N=11, obs_len=Tp, pred_len=Tf)
         n = 33
     z = rng.standard_normal((n * 20, zd)).astype(np.float32)
     eps = tuple(rng.standard_normal(sh).astype(np.float32) for sh in ((n, zd), (n, zd), (n * 20, zd)))
