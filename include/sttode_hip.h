@@ -200,6 +200,12 @@ int sttode_sampler_loss_bwd(const float* mu, const float* logvar, const float* p
  * act: 0 none | 1 relu | 2 tanh | 3 sigmoid.  mask (optional, [cols, ldm]): result zeroed where mask <= 0 (relu backward). */
 int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias, const float* mask,
                    long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate, void* stream);
+/* Y[c, 0:I] = act(W X[c] + tab[c / tdiv] (+ bias)): nn.Linear on cat(shared, own) with the shared part's product -- identical for tdiv
+ * consecutive columns -- handed over as a table tab [cols / tdiv, ldt].  The decoder MLPs' layer 1 (model/utils.py:86-95 on
+ * cat(past_feature_rep, z, state), model/STTODE.py:71-75,322-328): tab = W1[:, pf] pf + b1 per AGENT (n rows), W = W1[:, z | state] per
+ * trajectory -- half the layer's products, the inference chain's layer-1 split in the training step. */
+int sttode_tlinear_tab(const float* X, long ldx, const float* W, long ldw, const float* bias, const float* tab, long ldt, int tdiv, float* Y,
+                       long ldy, int cols, int J, int I, int act, void* stream);
 /* dW[n, k] += sum_c dY[c, n] * X[c / xdiv, k];  db[n] += sum_c dY[c, n] (db may be NULL).  Deterministic: fixed column splits,
  * partials in scratch (scratch_floats capacity; NULL = single split). */
 int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx, int xdiv, float* dW, long ldw, float* db, int cols, int N,

@@ -45,6 +45,7 @@ SIGNATURES = {
     'sttode_sampler_loss_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     # training step (csrc/train.hip)
     'sttode_tlinear': [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    'sttode_tlinear_tab': [_P, _L, _P, _L, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P],
     'sttode_twgrad': [_P, _L, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _L, _P],
     'sttode_twgrad_defer': [_I, _P, _L],
     'sttode_twgrad_flush': [],

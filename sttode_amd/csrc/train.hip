@@ -19,6 +19,9 @@ struct TLin {
     const float* X; const float* W; const float* bias; const float* mask; float* Y;
     long ldx, ldw, ldy, ldm;
     int cols, J, I, trans, act, accumulate, xdiv, xvec, wvec, yvec;
+    // what `accumulate` adds: row (col / adiv) of asrc -- Y itself (asrc = Y, adiv = 1: += into the output) or a per-GROUP table broadcast over
+    // adiv consecutive columns (sttode_tlinear_tab: the decoder MLPs' per-agent layer-1 part W1[:, pf] pf + b1, shared by an agent's K samples)
+    const float* asrc; long ldas; int adiv;
     int evec;   // I % 4 == 0 and Y, bias, mask 16-byte aligned: the epilogue runs on 16-byte pieces
 };
 
@@ -127,7 +130,7 @@ static __device__ __forceinline__ void tlinear_body(const TLin& a, int ksplit, i
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const long cc = colok[t] ? col[t] : 0;
-                if (a.accumulate) yv[i][t] = ld4(a.Y + cc * a.ldy + oc);
+                if (a.accumulate) yv[i][t] = ld4(a.asrc + (cc / a.adiv) * a.ldas + oc);
                 if (a.mask) mv[i][t] = ld4(a.mask + cc * a.ldm + oc);
             }
         }
@@ -165,7 +168,7 @@ static __device__ __forceinline__ void tlinear_body(const TLin& a, int ksplit, i
                 if (o + r >= a.I) continue;
                 float x = v[r];
                 if (a.bias) x += a.bias[o + r];
-                if (a.accumulate) x += yp[r];
+                if (a.accumulate) x += a.asrc[(long)(col[t] / a.adiv) * a.ldas + o + r];
                 x = act_apply(x, a.act);
                 if (a.mask && !(a.mask[(long)col[t] * a.ldm + o + r] > 0.f)) x = 0.f;
                 v[r] = x;
@@ -209,6 +212,7 @@ struct TG {
     int fast;                // operands fit tg_fetch_fast (tg_fast below)
     long long* dbg;          // diagnostic (sttode_tgemm_debug_buffer): [workgroup][4] stamps of the 100 MHz clock -- start, first tile in LDS, reduction done, end
     const float* bias; const float* mask; long ldm; int act, accumulate;   // mode 0 (tlinear) epilogue
+    const float* asrc; long ldas; int acdiv;                               // `accumulate` adds row (m / acdiv) of asrc (TLin::asrc)
     float* db; float* scratch; int S, kchunk, mode;                        // mode 1 (twgrad): split s = blockIdx.z reduces k in [s kchunk, (s + 1) kchunk)
 };
 
@@ -441,7 +445,7 @@ static __device__ __forceinline__ void tg_epilogue(const TG& g, const tg_f32x16&
             const int n = n0 + nt * 32 + 8 * a + 4 * h;
             const int nc = n < g.N ? n : 0;                   // (N % 4 == 0: a piece is inside or outside as a whole)
             if (g.bias) bv[a] = ld4(g.bias + nc);
-            if (g.accumulate) yv[a] = ld4(g.C + (long)m * g.ldc + nc);
+            if (g.accumulate) yv[a] = ld4(g.asrc + (long)(m / g.acdiv) * g.ldas + nc);
             if (g.mask) mv[a] = ld4(g.mask + (long)m * g.ldm + nc);
         }
 #pragma unroll
@@ -473,7 +477,7 @@ static __device__ __forceinline__ void tg_epilogue(const TG& g, const tg_f32x16&
                 if (n + e >= g.N) continue;
                 float x = v[e];
                 if (g.bias) x += g.bias[n + e];
-                if (g.accumulate) x += yp[e];
+                if (g.accumulate) x += g.asrc[(long)(m / g.acdiv) * g.ldas + n + e];
                 x = act_apply(x, g.act);
                 if (g.mask && !(g.mask[(long)m * g.ldm + n + e] > 0.f)) x = 0.f;
                 v[e] = x;
@@ -586,7 +590,8 @@ static inline int tg_fast(const TG& g, bool AT, bool BT) {
 static long long* g_tg_dbg = nullptr;
 extern "C" int sttode_tgemm_debug_buffer(void* p) { g_tg_dbg = (long long*)p; return 0; }   // diagnostic: >= grid * 4 int64 (NULL: off); stand-alone launches only
 static inline int tg_evec(const TG& g) {
-    return g.N % 4 == 0 && aligned16(g.C, g.ldc) && (!g.bias || aligned16(g.bias, 4)) && (!g.mask || aligned16(g.mask, g.ldm));
+    return g.N % 4 == 0 && aligned16(g.C, g.ldc) && (!g.bias || aligned16(g.bias, 4)) && (!g.mask || aligned16(g.mask, g.ldm)) &&
+           (!g.accumulate || aligned16(g.asrc, g.ldas));
 }
 
 // ---- split weight gradients of the LDS-tiled kernel: where the partial sums go and when they are added up --------------------------------
@@ -701,7 +706,7 @@ static bool tg_wgrad_fill(TG& g, const float* dY, long ldy, const float* X, long
     g.A = dY; g.lda = ldy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = ldw;
     g.M = N; g.N = K + 1; g.Kt = cols; g.adiv = 1; g.bkdiv = xdiv; g.ones_row = K;
     g.avec = aligned16(dY, ldy); g.bvec = aligned16(X, ldx); g.cvec = 0;
-    g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0;
+    g.bias = nullptr; g.mask = nullptr; g.ldm = 0; g.act = 0; g.accumulate = 0; g.asrc = nullptr; g.ldas = 0; g.acdiv = 1;
     g.db = db; g.scratch = part; g.S = S; g.mode = 1; g.evec = 0; g.fast = tg_fast(g, true, true); g.dbg = nullptr;
     if (defer && S > 1) g_red.used += per * S;     // reserved now: a second gradient of the same group must not get the same piece
     g.kchunk = ((cols + S - 1) / S + 31) / 32 * 32;
@@ -734,9 +739,23 @@ extern "C" int sttode_twgrad_flush(void) {
     return 0;
 }
 
+static int tlinear_impl(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias, const float* mask, long ldm,
+                        float* Y, long ldy, int cols, int J, int I, int act, int accumulate, const float* asrc, long ldas, int adiv, void* stream);
 extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias,
                               const float* mask, long ldm, float* Y, long ldy, int cols, int J, int I, int act, int accumulate,
                               void* stream) {
+    return tlinear_impl(X, ldx, xdiv, W, ldw, trans, bias, mask, ldm, Y, ldy, cols, J, I, act, accumulate, Y, ldy, 1, stream);
+}
+// Y[c] = act(W X[c] + tab[c / tdiv] (+ bias)): nn.Linear whose input is cat(shared, own) with the shared part's product -- the same for tdiv
+// consecutive columns -- precomputed as a table (the decoder MLPs' layer 1, model/utils.py:86-95 on cat(past_feature_rep, z, state),
+// model/STTODE.py:71-75,322-328: tab = W1[:, pf] pf + b1 per AGENT, W = W1[:, z | state]; half the layer's products, as in the inference chain)
+extern "C" int sttode_tlinear_tab(const float* X, long ldx, const float* W, long ldw, const float* bias, const float* tab, long ldt, int tdiv,
+                                  float* Y, long ldy, int cols, int J, int I, int act, void* stream) {
+    STT_REQUIRE(tab && tdiv > 0 && ldt >= I, "sttode_tlinear_tab: bad table");
+    return tlinear_impl(X, ldx, 1, W, ldw, 0, bias, nullptr, 0, Y, ldy, cols, J, I, act, 1, tab, ldt, tdiv, stream);
+}
+static int tlinear_impl(const float* X, long ldx, int xdiv, const float* W, long ldw, int trans, const float* bias, const float* mask, long ldm,
+                        float* Y, long ldy, int cols, int J, int I, int act, int accumulate, const float* asrc, long ldas, int adiv, void* stream) {
     STT_REQUIRE(X && W && Y, "sttode_tlinear: null pointer");
     STT_REQUIRE(cols > 0 && J > 0 && I > 0 && xdiv > 0, "sttode_tlinear: cols, J, I, xdiv must be positive");
     STT_REQUIRE(act >= 0 && act <= 3, "sttode_tlinear: act must be 0 none | 1 relu | 2 tanh | 3 sigmoid");
@@ -745,15 +764,16 @@ extern "C" int sttode_tlinear(const float* X, long ldx, int xdiv, const float* W
     a.X = X; a.W = W; a.bias = bias; a.mask = mask; a.Y = Y;
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldm = ldm;
     a.cols = cols; a.J = J; a.I = I; a.trans = trans; a.act = act; a.accumulate = accumulate; a.xdiv = xdiv;
+    a.asrc = asrc; a.ldas = ldas; a.adiv = adiv;
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
-    a.evec = I % 4 == 0 && a.yvec && (!bias || aligned16(bias, 4)) && (!mask || aligned16(mask, ldm));
+    a.evec = I % 4 == 0 && a.yvec && (!bias || aligned16(bias, 4)) && (!mask || aligned16(mask, ldm)) && (!accumulate || aligned16(asrc, ldas));
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);   // STTODE_TGEMM=0: the generic kernels (A/B)
     if (tg_on && cols > tg_min_cols()) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
         TG g;
         g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
         g.M = cols; g.N = I; g.Kt = J; g.adiv = xdiv; g.bkdiv = 1; g.ones_row = -1;
         g.avec = a.xvec; g.bvec = a.wvec; g.cvec = a.yvec;
-        g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate;
+        g.bias = bias; g.mask = mask; g.ldm = ldm; g.act = act; g.accumulate = accumulate; g.asrc = asrc; g.ldas = ldas; g.acdiv = adiv;
         g.db = nullptr; g.scratch = nullptr; g.S = 1; g.kchunk = 0; g.mode = 0;
         g.evec = tg_evec(g); g.fast = tg_fast(g, false, trans != 0); g.dbg = g_tg_dbg;
         // (NB = 2, 64 x 128 tiles, measured SLOWER at the NBA step's shapes -- 36-38 us against 19-25 us per product: 55 KB of LDS leave two
@@ -961,7 +981,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
         gx.A = dY; gx.lda = ldy; gx.B = W; gx.ldb = ldw; gx.C = dX; gx.ldc = lddx;
         gx.M = cols; gx.N = Kdx; gx.Kt = N; gx.adiv = 1; gx.bkdiv = 1; gx.ones_row = -1;
         gx.avec = aligned16(dY, ldy); gx.bvec = aligned16(W, ldw); gx.cvec = aligned16(dX, lddx);
-        gx.bias = nullptr; gx.mask = mask; gx.ldm = ldm; gx.act = 0; gx.accumulate = accumulate;
+        gx.bias = nullptr; gx.mask = mask; gx.ldm = ldm; gx.act = 0; gx.accumulate = accumulate; gx.asrc = dX; gx.ldas = lddx; gx.acdiv = 1;
         gx.db = nullptr; gx.scratch = nullptr; gx.S = 1; gx.kchunk = 0; gx.mode = 0;
         gx.evec = tg_evec(gx); gx.fast = tg_fast(gx, false, true); gx.dbg = nullptr;
         const int gxx = (cols + 63) / 64, nx = gxx * ((Kdx + 63) / 64);
@@ -988,7 +1008,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     TLin a;
     a.X = dY; a.W = W; a.bias = nullptr; a.mask = mask; a.Y = dX;
     a.ldx = ldy; a.ldw = ldw; a.ldy = lddx; a.ldm = ldm;
-    a.cols = cols; a.J = N; a.I = Kdx; a.trans = 1; a.act = 0; a.accumulate = accumulate; a.xdiv = 1;
+    a.cols = cols; a.J = N; a.I = Kdx; a.trans = 1; a.act = 0; a.accumulate = accumulate; a.xdiv = 1; a.asrc = dX; a.ldas = lddx; a.adiv = 1;
     a.xvec = aligned16(dY, ldy); a.wvec = aligned16(W, ldw); a.yvec = aligned16(dX, lddx);
     a.evec = Kdx % 4 == 0 && a.yvec && (!mask || aligned16(mask, ldm));
     const int ksplit = N > 256 ? 4 : (N > 128 ? 2 : 1);

@@ -24,6 +24,11 @@ _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
 
 _PAIRED = os.environ.get('STTODE_TRAIN_PAIRED', '1') != '0'   # decoder_x / decoder_y of a block layer by layer, grouped launches (0: A/B)
+# Layer 1 of the decoder MLPs split like the inference chain's (round 5): W1 cat(pf_rep, z, state) = (W1[:, pf] pf + b1) per AGENT -- a table of
+# n rows shared by the agent's K samples -- + W1[:, z | state] [z | state] per trajectory: half the layer's products forward and in both
+# gradient products (the pf part of dW1 and of dX is formed from the K-summed gradient rows, n of them).  At batch sizes only: below this
+# many trajectory columns the step is bound by its number of launches and the split adds four per block (STTODE_TRAIN_L1SPLIT=0: A/B).
+_L1SPLIT_MIN_COLS = int(os.environ.get('STTODE_TRAIN_L1SPLIT_MIN', '2048')) if os.environ.get('STTODE_TRAIN_L1SPLIT', '1') != '0' else 1 << 60
 _SCRATCH_BATCH = 32 << 20     # floats (128 MB): split sums of one backward pass at batch sizes (more than 2048 GEMM columns)
 
 
@@ -56,6 +61,8 @@ class Engine:
         self.HD, self.PFW = self.D // 8, 2 * self.D
         self.ST = self.PFW + self.ZD
         self.IN = self.ST + 96
+        self.ZS = self.ZD + 96                    # width of a trajectory's own layer-1 input [z | state] (layer-1 split)
+        self.split = False                        # set per decoder pass (decoder_fwd) from the pass's trajectory count
 
     # ---------------------------------------------------------------- streams
     def _use_streams(self, n):
@@ -119,6 +126,15 @@ class Engine:
         assert X.shape[1] == J
         out = self.new(cols, I) if out is None else out
         capi.call('sttode_tlinear', X, _ld(X), xdiv, W, _ld(W), 0, b, None, 0, out, _ld(out), cols, J, I, ACT[act], 0, self.st)
+        return out
+
+    def lin_tab(self, X, W, tab, tdiv, act=None):
+        """out[c] = act(W X[c] + tab[c / tdiv]) (sttode_tlinear_tab: the decoder MLPs' layer 1 with its per-agent part as a table)."""
+        cols = X.shape[0]
+        I, J = W.shape
+        assert X.shape[1] == J and tab.shape[1] == I and tab.shape[0] * tdiv == cols
+        out = self.new(cols, I)
+        capi.call('sttode_tlinear_tab', X, _ld(X), W, _ld(W), None, tab, _ld(tab), tdiv, out, _ld(out), cols, J, I, ACT[act], self.st)
         return out
 
     def lin_dx(self, dY, W, mask=None, out=None, accumulate=False, in_features=None):
@@ -401,32 +417,58 @@ class Engine:
                 self.wgrad(s['dtf'], s['t']['X0'], g(s['pre'] + 'input_fc.weight'), g(s['pre'] + 'input_fc.bias'))
 
     # ---------------------------------------------------------------- decoder (Decoder.forward, model/STTODE.py:320-347)
-    def mlp_fwd(self, pre, inp):
+    def l1_fwd(self, pre, inp, tab, K):
+        """Layer 1 of a decoder MLP: plain, or -- layer-1 split -- from the agent's table and the trajectory's own [z | state] columns."""
         P = self.P
-        a1 = self.lin(inp, P[pre + 'layers.0.weight'], P[pre + 'layers.0.bias'], act='relu')
+        if tab is None:
+            return self.lin(inp, P[pre + 'layers.0.weight'], P[pre + 'layers.0.bias'], act='relu')
+        return self.lin_tab(inp[:, self.PFW:], P[pre + 'layers.0.weight'][:, self.PFW:], tab, K, act='relu')
+
+    def l1_tables(self, pres, pf):
+        """The per-agent tables W1[:, pf] pf + b1 of the given MLPs (one grouped launch)."""
+        P = self.P
+        with self.group():
+            return [self.lin(pf, P[pre + 'layers.0.weight'][:, :self.PFW], P[pre + 'layers.0.bias']) for pre in pres]
+
+    def l1_bwd(self, pre, da, inp, din, accumulate, pf, dpf, K):
+        """Backward of layer 1: plain (din [m, IN]), or -- layer-1 split -- the trajectory part into din [m, ZS] and the agent part from the
+        K-summed gradient rows into dpf [n, 2 D] (accumulated)."""
+        P, g = self.P, self.grad
+        W, gW, gb = P[pre + 'layers.0.weight'], g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias')
+        if pf is None:
+            self.lin_bwd(da, W, inp, gW, gb, out=din, accumulate=accumulate)
+            return
+        PFW = self.PFW
+        self.lin_bwd(da, W[:, PFW:], inp[:, PFW:], gW[:, PFW:], gb, out=din, accumulate=accumulate)   # (gb: the whole bias gradient = sum over all columns)
+        n = pf.shape[0]
+        dA = self.new(n, da.shape[1])
+        capi.call('sttode_rows_reduce', dA, _ld(dA), da, _ld(da), n, da.shape[1], K, 0, self.st)
+        self.lin_bwd(dA, W[:, :PFW], pf, gW[:, :PFW], None, out=dpf, accumulate=True)
+
+    def mlp_fwd(self, pre, inp, tab=None, K=1):
+        P = self.P
+        a1 = self.l1_fwd(pre, inp, tab, K)
         a2 = self.lin(a1, P[pre + 'layers.1.weight'], P[pre + 'layers.1.bias'], act='relu')
         out = self.lin(a2, P[pre + 'layers.2.weight'], P[pre + 'layers.2.bias'])
         return out, (a1, a2)
 
-    def mlp_fwd_pair(self, pre_a, pre_b, inp):
+    def mlp_fwd_pair(self, pre_a, pre_b, inp, tabs=(None, None), K=1):
         """decoder_y and decoder_x of a block (same input, separate weights, model/STTODE.py:71-77) layer by layer: at batch sizes the two
         products of a layer leave as one launch (sttode_tgemm_group)."""
         P = self.P
         acts = []
         xa = xb = inp
         for li, act in ((0, 'relu'), (1, 'relu'), (2, None)):
-            capi.call('sttode_tgemm_group', 1)
-            try:
-                xa = self.lin(xa, P[f'{pre_a}layers.{li}.weight'], P[f'{pre_a}layers.{li}.bias'], act=act)
-                xb = self.lin(xb, P[f'{pre_b}layers.{li}.weight'], P[f'{pre_b}layers.{li}.bias'], act=act)
-            except BaseException:
-                capi.call('sttode_tgemm_group', -1)
-                raise
-            capi.call('sttode_tgemm_group', 0)
+            with self.group():
+                if li == 0:
+                    xa, xb = self.l1_fwd(pre_a, inp, tabs[0], K), self.l1_fwd(pre_b, inp, tabs[1], K)
+                else:
+                    xa = self.lin(xa, P[f'{pre_a}layers.{li}.weight'], P[f'{pre_a}layers.{li}.bias'], act=act)
+                    xb = self.lin(xb, P[f'{pre_b}layers.{li}.weight'], P[f'{pre_b}layers.{li}.bias'], act=act)
             acts.append((xa, xb))
         return (acts[2][0], (acts[0][0], acts[1][0])), (acts[2][1], (acts[0][1], acts[1][1]))
 
-    def mlp_bwd_pair(self, pre_a, pre_b, inp, saved_a, saved_b, dout_a, dout_b, din):
+    def mlp_bwd_pair(self, pre_a, pre_b, inp, saved_a, saved_b, dout_a, dout_b, din, pf=None, dpf=None, K=1):
         """Backward of the pair: layers 2 and 1 of both MLPs side by side (four products per launch at batch sizes); their layer-0 input
         gradients add into the same ``din``, so those two stay launches of their own, in order."""
         P, g = self.P, self.grad
@@ -440,16 +482,15 @@ class Engine:
                 capi.call('sttode_tgemm_group', -1)
                 raise
             capi.call('sttode_tgemm_group', 0)
-        self.lin_bwd(da, P[pre_a + 'layers.0.weight'], inp, g(pre_a + 'layers.0.weight'), g(pre_a + 'layers.0.bias'), out=din, accumulate=False)
-        self.lin_bwd(db_, P[pre_b + 'layers.0.weight'], inp, g(pre_b + 'layers.0.weight'), g(pre_b + 'layers.0.bias'), out=din, accumulate=True)
+        self.l1_bwd(pre_a, da, inp, din, False, pf, dpf, K)
+        self.l1_bwd(pre_b, db_, inp, din, True, pf, dpf, K)
 
-    def mlp_bwd(self, pre, inp, saved, dout, din, accumulate):
+    def mlp_bwd(self, pre, inp, saved, dout, din, accumulate, pf=None, dpf=None, K=1):
         P, g = self.P, self.grad
         a1, a2 = saved
         da2 = self.lin_bwd(dout, P[pre + 'layers.2.weight'], a2, g(pre + 'layers.2.weight'), g(pre + 'layers.2.bias'), mask=a2)
         da1 = self.lin_bwd(da2, P[pre + 'layers.1.weight'], a1, g(pre + 'layers.1.weight'), g(pre + 'layers.1.bias'), mask=a1)
-        self.lin_bwd(da1, P[pre + 'layers.0.weight'], inp, g(pre + 'layers.0.weight'), g(pre + 'layers.0.bias'), out=din,
-                     accumulate=accumulate)
+        self.l1_bwd(pre, da1, inp, din, accumulate, pf, dpf, K)
 
     def block_fwd(self, i, past, K, xhat_prev, pf, z, want_x, inp=None):
         P = self.P
@@ -468,29 +509,36 @@ class Engine:
         capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
                   inp[:, ST:], IN, m, Tp, self.st)                                                       # all Tp steps, one launch
         if prefix:
-            capi.call('sttode_rows_copy', inp, IN, pf, _ld(pf), m, PFW, K, n, self.st)
+            if not self.split:                                                                           # (layer-1 split: the pf columns of inp are never read)
+                capi.call('sttode_rows_copy', inp, IN, pf, _ld(pf), m, PFW, K, n, self.st)
             capi.call('sttode_rows_copy', inp[:, PFW:], IN, z, _ld(z), m, ZD, 1, m, self.st)
+        tabs = (None, None)
+        if self.split:
+            tabs = self.l1_tables([pre + 'decoder_y.'] + ([pre + 'decoder_x.'] if want_x else []), pf) + [None]
         if want_x and _PAIRED:
-            (yh, sy), (xh, sx) = self.mlp_fwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', inp)
+            (yh, sy), (xh, sx) = self.mlp_fwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', inp, tabs, K)
         else:
-            yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp)
-            xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp) if want_x else (None, None)
-        return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx)
+            yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp, tabs[0], K)
+            xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp, tabs[1], K) if want_x else (None, None)
+        return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx, pf=pf if self.split else None)
 
-    def block_bwd(self, b, dyh, dxh, need_dx):
-        """Returns (din [m,IN], dx [m,Tp,2] | None)."""
+    def block_bwd(self, b, dyh, dxh, need_dx, dpf=None):
+        """Returns (din [m, IN] -- layer-1 split: [m, ZS], the trajectory's own columns [z | state]; the pf part went into dpf -- , dx [m,Tp,2] | None)."""
         P, g = self.P, self.grad
         pre, m, Tp = b['pre'], b['m'], b['Tp']
-        din = self.new(m, self.IN)
+        pf, K = b.get('pf'), b['K']
+        split = pf is not None
+        LD, SO = (self.ZS, self.ZD) if split else (self.IN, self.ST)          # row length of din, column of the GRU state in it
+        din = self.new(m, LD)
         if dxh is not None and _PAIRED:
-            self.mlp_bwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', b['inp'], b['sy'], b['sx'], dyh, dxh, din)
+            self.mlp_bwd_pair(pre + 'decoder_y.', pre + 'decoder_x.', b['inp'], b['sy'], b['sx'], dyh, dxh, din, pf, dpf, K)
         else:
-            self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, accumulate=False)
+            self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, False, pf, dpf, K)
             if dxh is not None:
-                self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, accumulate=True)
+                self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, True, pf, dpf, K)
         dgi = self.new(m * Tp, 288)
         dgh = self.new(Tp, m, 288)
-        capi.call('sttode_gru_seq_bwd', din[:, self.ST:], self.IN, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
+        capi.call('sttode_gru_seq_bwd', din[:, SO:], LD, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
         self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
         de = self.lin_bwd(dgi, P[pre + 'encoder_past.weight_ih_l0'], b['e'], g(pre + 'encoder_past.weight_ih_l0'),
                           g(pre + 'encoder_past.bias_ih_l0'), mask=b['e'])
@@ -508,12 +556,17 @@ class Engine:
         Tf = self.net.args.future_length
         m = n * K
         nb = self.NBLK
+        self.split = m >= _L1SPLIT_MIN_COLS
         inps = [None] * nb
         if qz_eps is not None:
             inps = [self.new(m, self.IN) for _ in range(nb)]
-            capi.call('sttode_decoder_inputs', inps[0], inps[1] if nb > 1 else None, self.IN, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.PFW, self.ZD, self.st)
+            if self.split:        # only z is written, at its usual columns (the pf prefix is replaced by the per-agent tables)
+                capi.call('sttode_decoder_inputs', inps[0][:, self.PFW:], inps[1][:, self.PFW:] if nb > 1 else None, self.IN, pf, _ld(pf), qz_eps[0], qz_eps[1],
+                          n, K, 0, self.ZD, self.st)
+            else:
+                capi.call('sttode_decoder_inputs', inps[0], inps[1] if nb > 1 else None, self.IN, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.PFW, self.ZD, self.st)
             for i in range(2, nb):
-                capi.call('sttode_rows_copy', inps[i], self.IN, inps[0], self.IN, m, self.ST, 1, m, self.st)
+                capi.call('sttode_rows_copy', inps[i][:, self.PFW:], self.IN, inps[0][:, self.PFW:], self.IN, m, self.ZD, 1, m, self.st)
         blocks, xprev = [], None
         for i in range(nb):
             b = self.block_fwd(i, past, K, xprev, pf, z, want_recover or i + 1 < nb, inp=inps[i])
@@ -538,17 +591,20 @@ class Engine:
             if want_recover:
                 rec = self.new(m, 2 * Tp)
                 self.ew(EW_SUM_CUR, rec, xsum, blocks[-1]['xh'] if nb > 1 else self.zeros(m, 2 * Tp), None, i0=2 * Tp, f0=K)
-        return dict(blocks=blocks, b0=blocks[0], b1=blocks[-1], n=n, K=K, m=m, pred=pred, rec=rec)
+        return dict(blocks=blocks, b0=blocks[0], b1=blocks[-1], n=n, K=K, m=m, pred=pred, rec=rec, split=self.split)
 
     def decoder_bwd(self, d, dpred, drec, dpf, dz, dpf_accumulate=True):
         """Accumulates dpf [n, 2 D] (+=; ``dpf_accumulate=False``: writes it); writes dz [m, zd] if not None.  Returns the gradient of the
         blocks' summed layer-1 input [m, IN] = cat(d pf_rep | d z | d state) (its columns 2 D .. 2 D + zd - 1 are dz)."""
         n, K, m = d['n'], d['K'], d['m']
         blocks = d['blocks']
+        split = d.get('split', False)
+        if split and not dpf_accumulate:
+            self.ew(EW_FILL, dpf, f0=0.0)                          # (layer-1 split: every MLP adds its agent part into dpf)
         # x_{i+1} = x_true - x_hat_i  =>  d x_hat_i = (d recover) - d x_{i+1}; the last block's x_hat only feeds the reconstruction
         dxh, din_sum = drec, None
         for i in range(len(blocks) - 1, -1, -1):
-            din, dx = self.block_bwd(blocks[i], dpred, dxh, i > 0)
+            din, dx = self.block_bwd(blocks[i], dpred, dxh, i > 0, dpf)
             if din_sum is None:
                 din_sum = din
             else:
@@ -557,6 +613,10 @@ class Engine:
             if i > 0:
                 dxh = dx.view(m, -1)
                 self.ew(EW_SCALE_ADD, dxh, drec, f0=-1.0)           # d x_hat_{i-1} = -dx_i (+ drec)
+        if split:                                                  # din_sum [m, ZS] = cat(d z | d state); dpf is complete
+            if dz is not None:
+                dz.copy_(din_sum[:, :self.ZD])
+            return din_sum
         capi.call('sttode_rows_reduce', dpf, _ld(dpf), din_sum, self.IN, n, self.PFW, K, int(dpf_accumulate), self.st)
         if dz is not None:
             dz.copy_(din_sum[:, self.PFW:self.ST])
@@ -670,7 +730,10 @@ class Engine:
             W['dpf'] = dpf = self.new(n, self.PFW)
             din = self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, None, dpf_accumulate=False)
             dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent: dz of row a K1
-            capi.call('sttode_rows_copy', dqz, zd, din[:, self.PFW:], K1 * self.IN, n, zd, 1, n, self.st)
+            if T['d'].get('split'):
+                capi.call('sttode_rows_copy', dqz, zd, din, K1 * self.ZS, n, zd, 1, n, self.st)
+            else:
+                capi.call('sttode_rows_copy', dqz, zd, din[:, self.PFW:], K1 * self.IN, n, zd, 1, n, self.st)
             dqzp = T['dqzp']                                            # starts as the KL gradient
             self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
             dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
