@@ -1078,7 +1078,7 @@ __global__ void decoder_inputs_kernel(float* inp0, float* inp1, long ld, const f
 }
 extern "C" int sttode_decoder_inputs(float* inp0, float* inp1, long ld, const float* pf, long ldpf, const float* qz, const float* eps, int n,
                                      int K1, int pfw, int zd, void* stream) {
-    STT_REQUIRE(inp0 && pf && qz && eps && n > 0 && K1 >= 1 && pfw > 0 && zd > 0 && pfw % 4 == 0 && zd % 4 == 0 && ld >= pfw + zd && ld % 4 == 0 &&
+    STT_REQUIRE(inp0 && pf && qz && eps && n > 0 && K1 >= 1 && pfw >= 0 && zd > 0 && pfw % 4 == 0 && zd % 4 == 0 && ld >= pfw + zd && ld % 4 == 0 &&
                 ldpf >= pfw, "sttode_decoder_inputs: bad argument (pfw, zd multiples of 4; ld >= pfw + zd)");
     STT_REQUIRE(((size_t)inp0 | (size_t)inp1) % 16 == 0, "sttode_decoder_inputs: inp0 / inp1 must be 16-byte aligned");
     const long tot = (long)n * K1 * ((pfw + zd) / 4);

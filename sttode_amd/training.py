@@ -28,7 +28,10 @@ _PAIRED = os.environ.get('STTODE_TRAIN_PAIRED', '1') != '0'   # decoder_x / deco
 # n rows shared by the agent's K samples -- + W1[:, z | state] [z | state] per trajectory: half the layer's products forward and in both
 # gradient products (the pf part of dW1 and of dX is formed from the K-summed gradient rows, n of them).  At batch sizes only: below this
 # many trajectory columns the step is bound by its number of launches and the split adds four per block (STTODE_TRAIN_L1SPLIT=0: A/B).
-_L1SPLIT_MIN_COLS = int(os.environ.get('STTODE_TRAIN_L1SPLIT_MIN', '2048')) if os.environ.get('STTODE_TRAIN_L1SPLIT', '1') != '0' else 1 << 60
+# MEASURED NEUTRAL and therefore OFF by default (STTODE_TRAIN_L1SPLIT=1 enables it): 2.301 / 2.308 ms per NBA-size step with, 2.304 / 2.291 ms without
+# (profiles/r05/train_l1split_ab.txt) -- halving the layer's products does not shorten its launches: at 7 392 columns they are bound by one-round
+# quantisation, tile start and the 15 MB tape store, not by the matrix pipe.
+_L1SPLIT_MIN_COLS = int(os.environ.get('STTODE_TRAIN_L1SPLIT_MIN', '2048')) if os.environ.get('STTODE_TRAIN_L1SPLIT', '0') != '0' else 1 << 60
 _SCRATCH_BATCH = 32 << 20     # floats (128 MB): split sums of one backward pass at batch sizes (more than 2048 GEMM columns)
 
 
@@ -565,8 +568,9 @@ class Engine:
                           n, K, 0, self.ZD, self.st)
             else:
                 capi.call('sttode_decoder_inputs', inps[0], inps[1] if nb > 1 else None, self.IN, pf, _ld(pf), qz_eps[0], qz_eps[1], n, K, self.PFW, self.ZD, self.st)
-            for i in range(2, nb):
-                capi.call('sttode_rows_copy', inps[i][:, self.PFW:], self.IN, inps[0][:, self.PFW:], self.IN, m, self.ZD, 1, m, self.st)
+            for i in range(2, nb):                                  # (further blocks: the same prefix)
+                o, w = (self.PFW, self.ZD) if self.split else (0, self.ST)
+                capi.call('sttode_rows_copy', inps[i][:, o:], self.IN, inps[0][:, o:], self.IN, m, w, 1, m, self.st)
         blocks, xprev = [], None
         for i in range(nb):
             b = self.block_fwd(i, past, K, xprev, pf, z, want_recover or i + 1 < nb, inp=inps[i])
