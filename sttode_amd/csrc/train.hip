@@ -1369,8 +1369,10 @@ extern "C" int sttode_add_ln_fwd(const float* x, const float* r, const float* ga
 extern "C" int sttode_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dsum, float* dgamma,
                              float* dbeta, int rows, int D, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(dy && xhat && rstd && gamma && dsum && dgamma && dbeta && scratch && rows > 0, "sttode_ln_bwd: bad argument");
-    int G = (rows + 63) / 64;
-    if (G > 64) G = 64;
+    // one workgroup up to 64 rows (scene sizes: no partials, no second launch); beyond that 16 rows per workgroup (round 5: 6 workgroups for the
+    // 352 rows of an NBA-size step took 11 us; the reduction launch adds the per-workgroup partials in order either way)
+    int G = rows <= 64 ? 1 : (rows + 15) / 16;
+    if (G > 256) G = 256;
     STT_REQUIRE(scratch_floats >= (long)G * 2 * D, "sttode_ln_bwd: scratch too small");
     const int rpw = (rows + G - 1) / G;
     LN_DISPATCH(D, hipLaunchKernelGGL(ln_bwd_kernel<DD>, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, scratch, rows, rpw,
@@ -1911,11 +1913,15 @@ struct ObjArgs {
     const float* pred; const float* rec; const float* fut; const float* past; const float* qzp; const int* scene_ptr; const int* agent_scene;
     float* dpred; float* drec; float* dqzp; float* part;   // part: [3][n] agent partials, then [nb] KL values
     int n, K1, D, Dp, zd, nb;
+    int kl_rows;   // != 0 (no scene_ptr: ONE KL value over all n rows): every agent's block sums its own row's KL terms into part[3 n + a] and writes
+                   // the row's UNCLAMPED gradient; objective_sum adds them up, applies the clamp and -- where it is active -- zeroes dqzp.  (Round 4:
+                   // one block walked all n zd terms twice, 43 us of a 2.3-ms NBA-size step.)
     float scale_mse, scale_rec, kl_denom, min_clip;
 };
 __global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
     __shared__ float red[256];
-    if ((int)blockIdx.x >= o.n) {     // KL block (same arithmetic as kl_kernel)
+    if ((int)blockIdx.x >= o.n) {     // KL block (same arithmetic as kl_kernel): a batch of scenes (one block per scene) -- or the single-scene case
+                                      // when the agents' blocks did not take the term over (o.kl_rows == 0)
         const int b = blockIdx.x - o.n;
         const float ps = 1.0f + 1e-8f;
         const long r0 = o.scene_ptr ? o.scene_ptr[b] : 0, r1 = o.scene_ptr ? o.scene_ptr[b + 1] : o.n;
@@ -1979,13 +1985,37 @@ __global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
         o.dpred[(long)a * K1 * D + i] = k == bk ? 2.0f * (pa[i] - o.fut[(long)a * D + d]) * wgt : 0.f;
     }
     if (t == 0) { o.part[a] = s0; o.part[o.n + a] = s1; o.part[2 * (long)o.n + a] = sv[0] * wgt; }
+    if (o.kl_rows) {                  // this agent's row of the KL term (arithmetic of kl_kernel), gradient as if the clamp were inactive
+        const float ps = 1.0f + 1e-8f;
+        const int zd = o.zd;
+        float acc = 0.f;
+        for (int d = t; d < zd; d += 256) {
+            const float mu = o.qzp[(long)a * 2 * zd + d], lv = o.qzp[(long)a * 2 * zd + zd + d];
+            const float t1 = mu / ps, t2 = expf(0.5f * lv) / ps;
+            acc += 0.5f * (t1 * t1 + t2 * t2) - 0.5f - logf(t2);
+            o.dqzp[(long)a * 2 * zd + d] = (mu / (ps * ps)) / o.kl_denom;
+            o.dqzp[(long)a * 2 * zd + zd + d] = (0.5f * t2 * t2 - 0.5f) / o.kl_denom;
+        }
+        const float sk_ = block_sum(acc, red);
+        if (t == 0) o.part[3 * (long)o.n + a] = sk_;
+    }
 }
-__global__ __launch_bounds__(256) void objective_sum_kernel(const float* part, int n, int nb, float scale_mse, float scale_rec, float* out) {
+__global__ __launch_bounds__(256) void objective_sum_kernel(const float* part, int n, int nb, float scale_mse, float scale_rec, float* out,
+                                                           int kl_rows, float kl_denom, float min_clip, float* dqzp, int zd) {
     __shared__ float red[256];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { a0 += part[i]; a1 += part[n + i]; a2 += part[2 * (long)n + i]; }
-    for (int i = threadIdx.x; i < nb; i += 256) a3 += part[3 * (long)n + i];
-    const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red), s3 = block_sum(a3, red);
+    for (int i = threadIdx.x; i < (kl_rows ? kl_rows : nb); i += 256) a3 += part[3 * (long)n + i];
+    const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red);
+    float s3 = block_sum(a3, red);
+    if (kl_rows) {                    // (uniform) the agents' row sums -> clamp_min(KL / denom, min_clip); an active clamp passes no gradient
+        s3 /= kl_denom;
+        const bool live = s3 >= min_clip;
+        if (!live) {
+            s3 = min_clip;
+            for (long i = threadIdx.x; i < (long)kl_rows * 2 * zd; i += 256) dqzp[i] = 0.f;
+        }
+    }
     if (threadIdx.x == 0) {
         const float l0 = s0 * scale_mse, l1 = s1 * scale_rec;
         out[0] = l0; out[1] = l1; out[2] = s3; out[3] = s2;
@@ -1999,15 +2029,17 @@ extern "C" int sttode_loss_objective(const float* pred, const float* rec, const 
     STT_REQUIRE(pred && rec && fut && past && qzp && out && dpred && drec && dqzp && scratch, "sttode_loss_objective: null pointer");
     STT_REQUIRE(n > 0 && K1 >= 2 && K1 <= 65 && D > 0 && Dp > 0 && zd > 0, "sttode_loss_objective: bad sizes (2 <= K1 <= 65)");
     STT_REQUIRE(scene_ptr ? (S > 0 && agent_scene) : kl_denom > 0.f, "sttode_loss_objective: scene_ptr needs S > 0 and agent_scene, otherwise kl_denom > 0");
-    const int nb = scene_ptr ? S : 1;
-    STT_REQUIRE(3L * n + nb <= scratch_floats, "sttode_loss_objective: scratch too small (3 n + S floats)");
+    const int nb = scene_ptr ? S : 0;             // KL blocks: one per scene of a batch; the single-value case rides in the agents' blocks
+    const int kl_rows = scene_ptr ? 0 : n;
+    STT_REQUIRE(3L * n + (scene_ptr ? S : n) <= scratch_floats, "sttode_loss_objective: scratch too small (3 n + max(S, n) floats)");
     ObjArgs o;
     o.pred = pred; o.rec = rec; o.fut = fut; o.past = past; o.qzp = qzp; o.scene_ptr = scene_ptr; o.agent_scene = agent_scene;
     o.dpred = dpred; o.drec = drec; o.dqzp = dqzp; o.part = scratch;
-    o.n = n; o.K1 = K1; o.D = D; o.Dp = Dp; o.zd = zd; o.nb = nb;
+    o.n = n; o.K1 = K1; o.D = D; o.Dp = Dp; o.zd = zd; o.nb = nb; o.kl_rows = kl_rows;
     o.scale_mse = scale_mse; o.scale_rec = scale_rec; o.kl_denom = kl_denom; o.min_clip = min_clip;
     hipLaunchKernelGGL(objective_kernel, dim3(n + nb), dim3(256), 0, (hipStream_t)stream, o);
-    hipLaunchKernelGGL(objective_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, nb, scale_mse, scale_rec, out);
+    hipLaunchKernelGGL(objective_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, nb, scale_mse, scale_rec, out, kl_rows, kl_denom,
+                       min_clip, dqzp, zd);
     STT_HIP(hipGetLastError());
     return 0;
 }
