@@ -322,7 +322,7 @@ class Leg:
             out = self._finish(self.pending.pop(0))
         return out
 
-    def timed(self, steps, warmup, dist, time_every, serial=False, d2h=False, gather=False):
+    def timed(self, steps, warmup, dist, time_every, serial=False, d2h=False, gather=False, prewarm=0):
         """W untimed + exactly `steps` timed steps, barrier + synchronize on both sides, MAX over ranks.
         d2h: additionally copy every step's futures to pinned host memory inside the timed region.
         gather: additionally all-gather every step's futures [n_r, K, Tf, 2] over the ranks (parallel.gather_futures: RCCL over xGMI),
@@ -349,8 +349,8 @@ class Leg:
         gc.collect()                                              # before the warm-up: a collector run between warm-up and region would idle the GPU
         gc.disable()                                              # no collector pause inside a timed region of a few milliseconds
         clk = torch.zeros(4, dtype=torch.int64, device=dev)
-        for _ in range(warmup):
-            self.step(serial)
+        for _ in range(prewarm + warmup):                         # (prewarm: extra untimed steps in front of the W warm-up steps -- the shader clock
+            self.step(serial)                                     # needs 25-40 ms of load to climb from ~2.1 to 2.4 GHz after an idle gap; --prewarm)
         self.drain()
         capi.call('sttode_clock_probe', clk, capi.stream_ptr())   # shader clock the region starts with (20 us, ahead of the synchronize)
         torch.cuda.synchronize()
@@ -745,6 +745,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--prewarm', type=int, default=int(os.environ.get('STTODE_BENCH_PREWARM', '0')),
+                    help='extra UNTIMED steps in front of the --warmup steps of the headline region (brings the shader clock up; reported as clock_prewarm_steps)')
     ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU per step of the headline workload')
     ap.add_argument('--cpu-seconds', type=float, default=8.0, help='budget of the headline CPU-baseline sample at 16 threads (half of it again at 1 thread)')
     ap.add_argument('--leg-cpu-seconds', type=float, default=1.5, help='CPU-baseline budget of each secondary leg')
@@ -811,7 +813,7 @@ def main():
             dist.destroy_process_group()
         return 0
     head = Leg('eth_512', rank, dev, size=args.scenes)
-    r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial)
+    r = head.timed(args.steps, args.warmup, dist, args.time_every, serial=args.serial, prewarm=args.prewarm)
     roof, kern = head.roofline(r['stage_ms'], r['value'] / world, args.time_every, calls=None if args.serial else args.steps)
     if roof:
         roof['path_frac_survey_flops_superseded'] = r['value'] / world * F_TRAJ_SURVEY / PEAK_F32_MFMA
@@ -831,7 +833,7 @@ def main():
            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist is not None and dist.get_backend() == 'nccl' else 0,
            'dist_backend': dist.get_backend() if dist is not None else None, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': r['ms_per_step'], 'host_enqueue_ms_per_step': r['host_ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'clock_ghz': r['clock_ghz'],
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'clock_ghz': r['clock_ghz'], 'clock_prewarm_steps': args.prewarm,
            'config': head.config(world), 'roofline': roof, 'kernels': kern,
            'timed_region': 'per step: H2D of the scene batch (pinned host -> HBM), set_scene_batch, z ~ N(0,I) on device, the whole forward, '
                            'device-side best-of-K ADE/FDE; D2H of the futures excluded (value_incl_d2h includes it)',
