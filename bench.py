@@ -595,9 +595,17 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
     model = STTODENet(make_args('eth', TP, TF), dev)
     model.load_state_dict(sd, strict=True)
     model.train()
-    # torch.optim.Adam as in train.py; fused=True is torch's one-kernel-per-step implementation of the same update (the default
-    # 'foreach' form costs ~0.6 ms of host time per step on 88 small parameters); --train-adam foreach restores the default
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, **({'fused': True} if args.train_adam == 'fused' else {}))   # (fused=False would select the single-tensor loop)
+    # Adam as in train.py:122.  'hip' (default): sttode_amd.optim.Adam -- torch.optim.Adam's state and semantics, the step of all 88 parameters as
+    # ONE HIP launch (csrc/train.hip adam_step_kernel); 'fused': torch.optim.Adam(fused=True) (three multi_tensor_apply launches of ~42 us);
+    # 'foreach': torch's default form (what the reference's line constructs: ~0.3 ms of host time per step on 88 small parameters).  The
+    # other two are timed on the same loop right after and reported beside it, never instead of it.
+    from sttode_amd.optim import Adam as HipAdam
+
+    def make_opt(kind):
+        if kind == 'hip':
+            return HipAdam(model.parameters(), lr=1e-4)
+        return torch.optim.Adam(model.parameters(), lr=1e-4, **({'fused': True} if kind == 'fused' else {}))
+    opt = make_opt(args.train_adam)
     nsc = args.train_scenes
     data = [scenes.eth_scene(100000 + rank * nsc + i) for i in range(nsc)]
     data = [(torch.from_numpy(o).to(dev), torch.from_numpy(p).to(dev)) for o, p in data]
@@ -649,12 +657,13 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
            'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
            'data': 'synthetic', 'config': {'workload': f'train.py:72-95 loop over {nsc} synthetic ETH-shaped scenes per GPU (2..32 '
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
-                                                       '(rotation + positional dropout), torch.optim.Adam lr 1e-4 (' + args.train_adam + ')',
+                                                       '(rotation + positional dropout), Adam lr 1e-4 (' + args.train_adam + ')',
                                            'parallelism': f'scenes x{world}' + (' + flat gradient all-reduce' if world > 1 else '')}}
-    if args.train_adam == 'fused':
-        # the same steps with torch's DEFAULT optimizer form (foreach; what the reference's train.py:122 constructs): a second optimizer on
-        # the same parameters, its own warm-up, the same timed loop -- reported beside the fused figure, never instead of it
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    out['optimizer'] = {'hip': 'sttode_amd.optim.Adam (one HIP launch per step)', 'fused': 'torch.optim.Adam(fused=True)',
+                        'foreach': 'torch.optim.Adam() (torch default, the reference\'s line)'}[args.train_adam]
+    for kind in [k for k in ('fused', 'foreach') if k != args.train_adam] if args.train_adam == 'hip' else (['foreach'] if args.train_adam == 'fused' else []):
+        # the same steps with torch's own optimizer forms: another optimizer on the same parameters, its own warm-up, the same timed loop
+        opt = make_opt(kind)
         for i in range(nsc):
             step(i)
         if dist is not None:
@@ -667,8 +676,8 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
             dist.barrier()
         torch.cuda.synchronize()
         dtf = time.perf_counter() - t0
-        out['ms_per_step_foreach_adam'] = 1e3 * dtf / steps
-        out['steps_per_s_foreach_adam'] = world * steps / dtf
+        out[f'ms_per_step_{kind}_adam'] = 1e3 * dtf / steps
+        out[f'steps_per_s_{kind}_adam'] = world * steps / dtf
     if cpu and rank == 0 and world == 1 and not args.no_cpu:
         train_cpu_baseline(args, out)
     return out
@@ -759,7 +768,7 @@ def main():
     ap.add_argument('--train', action='store_true', help='print ONLY the training line (secondary metric: train.py:72-95 loop)')
     ap.add_argument('--no-train', action='store_true', help='skip the "train" object of the default line')
     ap.add_argument('--train-batch', type=int, default=1, help='scenes per optimizer step (1 = the reference loop)')
-    ap.add_argument('--train-adam', choices=('fused', 'foreach'), default='fused')
+    ap.add_argument('--train-adam', choices=('hip', 'fused', 'foreach'), default='hip')
     ap.add_argument('--train-scenes', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=200)
     ap.add_argument('--train-cpu-seconds', type=float, default=4.0)
@@ -934,8 +943,9 @@ def main():
     if train is not None:
         if do_cpu:
             train_cpu_baseline(args, train)
-        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config',
-                                              'cpu_baseline', 'speedup_vs_cpu_baseline') if k in train}
+        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'optimizer', 'ms_per_step_fused_adam', 'steps_per_s_fused_adam',
+                                              'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config', 'cpu_baseline',
+                                              'speedup_vs_cpu_baseline') if k in train}
     if rank == 0 and world == 1 and not args.no_per_scene and not args.only_leg:
         out['per_scene'] = per_scene_leg(dev)
     if rank == 0:

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 MODE=$1; OUT=$PWD/gpurun_out/$2; shift 2
 mkdir -p "$OUT"
 short() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M traj/s', round(d['ms_per_step'],3), 'ms', 'frac', round(d['roofline']['frac'],3) if d.get('roofline') else '')"; }
-trainline() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('one-scene step', round(d['ms_per_step'],4), 'ms fused Adam,', round(d.get('ms_per_step_foreach_adam',0),4), 'ms foreach')"; }
+trainline() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('one-scene step', round(d['ms_per_step'],4), 'ms', d.get('optimizer'), '|', round(d.get('ms_per_step_fused_adam',0),4), 'ms torch fused |', round(d.get('ms_per_step_foreach_adam',0),4), 'ms torch foreach')"; }
 case $MODE in
 tests)
     timeout -k 10 1100 python -m pytest tests -m gpu -q $1 > "$OUT/gputests.log" 2>&1; tail -5 "$OUT/gputests.log" ;;
@@ -31,8 +31,9 @@ bench)
     timeout -k 10 1100 python bench.py $1 > "$OUT/bench.json" 2> "$OUT/bench.err"; short < "$OUT/bench.json" ;;
 prof)
     NAME=$1; shift 2
-    cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_$NAME" -o "$NAME" -- "$@" > "$OUT/prof_$NAME.log" 2>&1
-    cd - > /dev/null
+    R=$PWD; ARGS=(); for a in "$@"; do if [ -e "$R/$a" ]; then ARGS+=("$R/$a"); else ARGS+=("$a"); fi; done; set -- "${ARGS[@]}"   # (rocprofv3 runs from /tmp: repo files by absolute path)
+    cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$NAME" -o "$NAME" -- "$@" > "$OUT/prof_$NAME.log" 2>&1
+    cd "$R"
     f=$(find "$OUT/prof_$NAME" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${NAME}_kernel_stats.csv" && head -12 "$OUT/${NAME}_kernel_stats.csv" | cut -c1-160 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

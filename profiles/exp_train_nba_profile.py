@@ -9,7 +9,8 @@ Tp, Tf = 5, 10
 m = STTODENet(make_args('nba', Tp, Tf), dev); m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=Tp, future_length=Tf))); m.train()
 d = scenes.nba_batch(1, 32)
 data = {k: (torch.from_numpy(v) if hasattr(v, 'shape') else v) for k, v in d.items()}
-opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
+from sttode_amd.optim import Adam
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True) if os.environ.get('STTODE_TORCH_ADAM') else Adam(m.parameters(), lr=1e-4)
 def step():
     m.set_data_nba(data); tot = m.forward()[0]; opt.zero_grad(); tot.backward(); opt.step()
 for _ in range(3): step()

@@ -64,6 +64,7 @@ SIGNATURES = {
     'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P],
     'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _I, _P],
+    'sttode_adam_step': [_P, _I, _L, _P, _F, _F, _F, _F, _F, _L, _P],
     'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
     'sttode_loss_kl': [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     'sttode_loss_diverse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],

@@ -1807,6 +1807,74 @@ extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* d
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Adam (train.py:122 torch.optim.Adam(model.parameters(), lr); its step at train.py:66,87) for ALL parameters of the model in ONE launch:
+//     m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)      (g += wd p first)
+// torch's fused implementation walks the 88 small tensors with multi_tensor_apply: 3 launches of 41-44 us each per step (131 us of a 2.3-ms
+// NBA-size step, 140 us of a 1.05-ms one-scene step: profiles/r05/prof_train_nba_kernel_stats_before_adam.csv); the whole update moves
+// 1.6 M parameters x 4 tensors = 26 MB.  Here a device table lists the tensors (parameter, first / second moment, gradient offset, element
+// count, first chunk); block b finds its tensor by binary search over the chunk prefix and updates one 1024-element chunk in 16-byte pieces.
+// Gradients are addressed as gbase + offset: the training engine hands out every step's gradients as views of ONE flat buffer with a fixed
+// layout, so the table is uploaded once and only gbase changes.
+// ---------------------------------------------------------------------------------------------------
+struct AdamItem { float* p; float* m; float* v; long goff; long numel; long chunk0; };   // goff: floats from gbase; chunk0: first 1024-element chunk
+#define ADAM_CHUNK 1024
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamItem* __restrict__ items, int n, const float* __restrict__ gbase, float lr_over_bc1,
+                                                        float b1, float b2, float eps, float inv_bc2_sqrt, float wd) {
+    const long b = blockIdx.x;
+    int lo = 0, hi = n - 1;                       // largest t with chunk0[t] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].chunk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const AdamItem it = items[lo];
+    const long e0 = (b - it.chunk0) * ADAM_CHUNK + 4 * (long)threadIdx.x;
+    if (e0 >= it.numel) return;
+    const float* g = gbase + it.goff;
+    float pv[4], mv[4], vv[4], gv[4];
+    const bool vec = e0 + 3 < it.numel && ((((size_t)(it.p + e0)) | ((size_t)(it.m + e0)) | ((size_t)(it.v + e0)) | ((size_t)(g + e0))) & 15) == 0;
+    const int cnt = it.numel - e0 < 4 ? (int)(it.numel - e0) : 4;
+    if (vec) {
+        const f32x4 P = ld4(it.p + e0), M = ld4(it.m + e0), V = ld4(it.v + e0), G = ld4(g + e0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = P[r]; mv[r] = M[r]; vv[r] = V[r]; gv[r] = G[r]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < cnt) { pv[r] = it.p[e0 + r]; mv[r] = it.m[e0 + r]; vv[r] = it.v[e0 + r]; gv[r] = g[e0 + r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r >= cnt) break;
+        float gr = gv[r];
+        if (wd != 0.f) gr = fmaf(wd, pv[r], gr);
+        mv[r] = mv[r] + (1.0f - b1) * (gr - mv[r]);                  // exp_avg.lerp_(grad, 1 - beta1)
+        vv[r] = vv[r] * b2 + (1.0f - b2) * gr * gr;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(vv[r]) * inv_bc2_sqrt + eps;
+        pv[r] = pv[r] - lr_over_bc1 * (mv[r] / denom);
+    }
+    if (vec) {
+        st4(it.p + e0, f32x4{pv[0], pv[1], pv[2], pv[3]});
+        st4(it.m + e0, f32x4{mv[0], mv[1], mv[2], mv[3]});
+        st4(it.v + e0, f32x4{vv[0], vv[1], vv[2], vv[3]});
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < cnt) { it.p[e0 + r] = pv[r]; it.m[e0 + r] = mv[r]; it.v[e0 + r] = vv[r]; }
+    }
+}
+// items: DEVICE array of n AdamItem (6 x 8 bytes each: p, m, v pointers, goff, numel, chunk0), chunk0 ascending from 0; chunks = their total
+extern "C" int sttode_adam_step(const void* items, int n, long chunks, const float* gbase, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, long step, void* stream) {
+    STT_REQUIRE(items && n > 0 && chunks > 0 && chunks < (1L << 31) && step >= 1, "sttode_adam_step: bad argument");
+    STT_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "sttode_adam_step: bad hyper-parameter");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const AdamItem*)items, n, gbase,
+                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // losses (model/STTODE.py:372-395) -- values and their gradients; out[] slots written by single-WG reductions
 // ---------------------------------------------------------------------------------------------------
 static __device__ float block_sum(float v, float* red) {

@@ -3364,3 +3364,76 @@ def test_unsupported_arguments_are_refused_in_one_place():
         assert frag in generic.unsupported_reason(a)
         with pytest.raises(NotImplementedError, match=frag):
             STTODENet(a, _gpu())
+
+
+def test_hip_adam_is_torch_adam_in_one_launch():
+    """sttode_amd.optim.Adam: torch.optim.Adam's update (train.py:122,66,87) for all parameters as ONE HIP launch.  Against torch's own
+    single-tensor implementation on tensors of assorted sizes (odd lengths, one element, a 1 M-element matrix), with and without weight
+    decay, a changing learning rate (StepLR) and gradients that arrive as views of one flat buffer: parameters and both moments agree to fp32
+    rounding after 6 steps; the state_dicts are interchangeable with torch's class."""
+    from sttode_amd.optim import Adam
+    dev = _gpu()
+    torch.manual_seed(5)
+    shapes = [(7,), (1,), (33, 5), (1024, 1024), (3, 3, 3), (4096,), (1025,)]
+    for wd in (0.0, 0.01):
+        ps_a = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+        ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+        oa = Adam(ps_a, lr=3e-3, weight_decay=wd)
+        ob = torch.optim.Adam(ps_b, lr=3e-3, weight_decay=wd, foreach=False)
+        sa = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5)
+        sb = torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.5)
+        tot = sum(((p.numel() + 3) // 4) * 4 for p in ps_a)
+        for it in range(6):
+            flat = torch.randn(tot, device=dev)                   # this step's gradients: views of ONE fresh flat buffer (the engine's layout)
+            off = 0
+            for pa, pb in zip(ps_a, ps_b):
+                g = flat[off: off + pa.numel()].view(pa.shape)
+                pa.grad, pb.grad = g, g.clone()
+                off += ((pa.numel() + 3) // 4) * 4
+            oa.step(); ob.step(); sa.step(); sb.step()
+        for pa, pb in zip(ps_a, ps_b):
+            assert_close(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=2e-7, what='parameter')
+            for k in ('exp_avg', 'exp_avg_sq'):
+                assert_close(oa.state[pa][k].cpu().numpy(), ob.state[pb][k].cpu().numpy(), rtol=2e-6, atol=1e-9, what=k)
+            assert float(oa.state[pa]['step']) == float(ob.state[pb]['step']) == 6
+        ob2 = torch.optim.Adam(ps_b, lr=1.0, foreach=False)
+        ob2.load_state_dict(oa.state_dict())                      # torch's class takes our state ...
+        oa2 = Adam(ps_a, lr=1.0)
+        oa2.load_state_dict(ob.state_dict())                      # ... and ours takes torch's
+        assert oa2.param_groups[0]['lr'] == ob.param_groups[0]['lr']
+    # options the kernel does not implement take torch's own step
+    p = torch.nn.Parameter(torch.randn(10, device=dev))
+    o = Adam([p], lr=1e-2, amsgrad=True)
+    p.grad = torch.randn(10, device=dev)
+    o.step()
+    assert 'max_exp_avg_sq' in o.state[p]
+
+
+def test_training_loop_with_hip_adam_equals_torch_fused_adam():
+    """The train.py:72-95 loop (set_data, forward, zero_grad, backward, step) over a few scenes with sttode_amd.optim.Adam against the same
+    loop with torch.optim.Adam(fused=True) from the same weights and noises: the loss trajectories agree to fp32 rounding."""
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.optim import Adam
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    data = [scenes.eth_scene(81000 + i, n_min=5, n_max=12) for i in range(4)]
+    runs = []
+    for kind in ('hip', 'torch'):
+        m = STTODENet(make_args('eth', 8, 12), dev).eval()
+        m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+        opt = Adam(m.parameters(), lr=1e-3) if kind == 'hip' else torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+        g = torch.Generator(device='cpu').manual_seed(3)
+        losses = []
+        for it in range(8):
+            o, p = data[it % 4]
+            n = o.shape[0]
+            m.set_data(None, torch.from_numpy(o), torch.from_numpy(p))
+            eq, ep, e20 = torch.randn(n, 32, generator=g), torch.randn(n, 32, generator=g), torch.randn(n * 20, 32, generator=g)
+            tot = m.forward(eps_q=eq, eps_p=ep, eps20=e20)[0]
+            opt.zero_grad()
+            tot.backward()
+            opt.step()
+            losses.append(float(tot.detach()))
+        runs.append(losses)
+    np.testing.assert_allclose(runs[0], runs[1], rtol=2e-4)
+    assert abs(runs[0][-1] - runs[0][0]) > 1e-3 * abs(runs[0][0])   # (the parameters did move)
