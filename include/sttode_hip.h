@@ -287,8 +287,8 @@ int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L,
  * in floats from gbase, element count, first 1024-element chunk (ascending from 0; `chunks` = their total).  step = t >= 1 (bias
  * corrections 1 - beta^t).  m = beta1 m + (1 - beta1) g; v = beta2 v + (1 - beta2) g^2; p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 -
  * beta2^t) + eps); weight_decay adds weight_decay * p to g first (torch's L2 form).  amsgrad / maximize: not built (the caller falls back). */
-int sttode_adam_step(const void* items, int n, long chunks, const float* gbase, float lr, float beta1, float beta2, float eps, float weight_decay,
-                     long step, void* stream);
+int sttode_adam_step(const void* items, int n, long chunks, const float* gbase, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, long step, void* stream);
 /* out[0] = scale * sum (pred - target)^2 (calculate_loss_pred / _recover, :372-376,384-388); dpred optional. */
 int sttode_loss_sqerr(const float* pred, const float* target, long count, float scale, float* out, float* dpred, void* stream);
 /* KL term (:378-382, utils/dist.py:26-29), params [rows,2*zd].  scene_ptr NULL: out[0] = clamp_min(sum KL / denom, min_clip).

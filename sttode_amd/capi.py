@@ -10,7 +10,7 @@ import os
 _LIB = None
 LIB_PATH = os.environ.get('STTODE_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsttode_hip.so')
 
-_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 ABI_VERSION = 7   # == STTODE_ABI_VERSION of include/sttode_hip.h; lib() refuses a library built from another header
 
 # name -> argtypes (mirrors include/sttode_hip.h; tests/test_capi_symbols.py checks header == table == .so)
@@ -64,7 +64,7 @@ SIGNATURES = {
     'sttode_conv_fwd': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'sttode_conv_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P],
     'sttode_mhgsa_attn_bwd': [_P, _P, _P, _I, _I, _I, _P],
-    'sttode_adam_step': [_P, _I, _L, _P, _F, _F, _F, _F, _F, _L, _P],
+    'sttode_adam_step': [_P, _I, _L, _P, _D, _D, _D, _D, _D, _L, _P],
     'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
     'sttode_loss_kl': [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     'sttode_loss_diverse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],

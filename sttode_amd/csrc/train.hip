@@ -1819,7 +1819,7 @@ extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* d
 struct AdamItem { float* p; float* m; float* v; long goff; long numel; long chunk0; };   // goff: floats from gbase; chunk0: first 1024-element chunk
 #define ADAM_CHUNK 1024
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamItem* __restrict__ items, int n, const float* __restrict__ gbase, float lr_over_bc1,
-                                                        float b1, float b2, float eps, float inv_bc2_sqrt, float wd) {
+                                                        float omb1, float b2, float omb2, float eps, float inv_bc2_sqrt, float wd) {
     const long b = blockIdx.x;
     int lo = 0, hi = n - 1;                       // largest t with chunk0[t] <= b
     while (lo < hi) {
@@ -1847,8 +1847,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamItem* __restri
         if (r >= cnt) break;
         float gr = gv[r];
         if (wd != 0.f) gr = fmaf(wd, pv[r], gr);
-        mv[r] = mv[r] + (1.0f - b1) * (gr - mv[r]);                  // exp_avg.lerp_(grad, 1 - beta1)
-        vv[r] = vv[r] * b2 + (1.0f - b2) * gr * gr;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        mv[r] = mv[r] + omb1 * (gr - mv[r]);                         // exp_avg.lerp_(grad, 1 - beta1): 1 - beta formed in double on the host, as torch does
+        vv[r] = vv[r] * b2 + omb2 * gr * gr;                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
         const float denom = sqrtf(vv[r]) * inv_bc2_sqrt + eps;
         pv[r] = pv[r] - lr_over_bc1 * (mv[r] / denom);
     }
@@ -1863,13 +1863,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamItem* __restri
     }
 }
 // items: DEVICE array of n AdamItem (6 x 8 bytes each: p, m, v pointers, goff, numel, chunk0), chunk0 ascending from 0; chunks = their total
-extern "C" int sttode_adam_step(const void* items, int n, long chunks, const float* gbase, float lr, float beta1, float beta2, float eps,
-                                float weight_decay, long step, void* stream) {
+extern "C" int sttode_adam_step(const void* items, int n, long chunks, const float* gbase, double lr, double beta1, double beta2, double eps,
+                                double weight_decay, long step, void* stream) {
     STT_REQUIRE(items && n > 0 && chunks > 0 && chunks < (1L << 31) && step >= 1, "sttode_adam_step: bad argument");
-    STT_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "sttode_adam_step: bad hyper-parameter");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    STT_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., "sttode_adam_step: bad hyper-parameter");
+    // (hyper-parameters as doubles: torch forms 1 - beta, the bias corrections and the step size in Python floats and rounds once)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const AdamItem*)items, n, gbase,
-                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay);
+                       (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(1.0 / sqrt(bc2)), (float)weight_decay);
     STT_HIP(hipGetLastError());
     return 0;
 }

@@ -44,6 +44,8 @@ def test_ctypes_table_matches_header():
                 assert re.match(r'^int\s+\w+$', decl), (name, decl)
             elif ct is ctypes.c_float:
                 assert decl.startswith('float '), (name, decl)
+            elif ct is ctypes.c_double:
+                assert decl.startswith('double '), (name, decl)
             elif ct is ctypes.c_long:
                 assert decl.startswith('long '), (name, decl)
             elif ct is ctypes.c_ulonglong:
@@ -90,7 +92,7 @@ def test_every_entry_point_rejects_null_arguments():
         for t in argtypes:
             if t in (ctypes.c_int, ctypes.c_long, ctypes.c_ulonglong):
                 args.append(0)
-            elif t is ctypes.c_float:
+            elif t in (ctypes.c_float, ctypes.c_double):
                 args.append(0.0)
             else:
                 args.append(None)
