@@ -79,6 +79,31 @@ int stt_post_attn_stage(const float* const* W, const float* state, const float* 
 
 static std::mutex g_stream_mu;   // guards the creation of the process-wide streams (sA / sB / sB2 / side, per device)
 
+// The models' host-visible time-out words come from ONE process-wide pinned block (allocated with the first model, never freed): a model
+// may be destroyed by a garbage collector at any moment -- also while some stream of the process is being captured into a hipGraph, where
+// hipHostFree (a synchronising call) aborts the process.  Words are handed out from a free list.
+#define STT_TMO_WORDS 4096
+static unsigned* g_tmo_pool = nullptr;
+static std::vector<int> g_tmo_free;
+static unsigned* tmo_word_take() {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    if (!g_tmo_pool) {
+        if (hipHostMalloc((void**)&g_tmo_pool, STT_TMO_WORDS * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { g_tmo_pool = nullptr; return nullptr; }
+        memset(g_tmo_pool, 0, STT_TMO_WORDS * sizeof(unsigned));
+        for (int i = STT_TMO_WORDS - 1; i >= 0; --i) g_tmo_free.push_back(i);
+    }
+    if (g_tmo_free.empty()) return nullptr;
+    const int i = g_tmo_free.back();
+    g_tmo_free.pop_back();
+    g_tmo_pool[i] = 0u;
+    return g_tmo_pool + i;
+}
+static void tmo_word_give(unsigned* w) {
+    if (!w || !g_tmo_pool) return;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_tmo_free.push_back((int)(w - g_tmo_pool));
+}
+
 static inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // 256-byte alignment in floats
 
 extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights, int count, int Tp, int Tf, int K,
@@ -172,13 +197,12 @@ extern "C" int sttode_model_create(SttodeModel** out, const void* const* weights
     ok = ok && hipEventCreateWithFlags(&m->ev_call, hipEventDisableTiming) == hipSuccess;
     // the model's time-out word lives in pinned host memory (device-visible): a group that gives up stores to it with system scope, the
     // host reads it without any synchronisation (sttode_timeout_word)
-    ok = ok && hipHostMalloc((void**)&m->tmo_host, 64, hipHostMallocDefault) == hipSuccess;
-    if (ok) memset(m->tmo_host, 0, 64);
+    if (ok) { m->tmo_host = tmo_word_take(); ok = m->tmo_host != nullptr; }
     for (int p = 0; p < STT_MAX_SLOTS && ok; ++p)
         ok = hipEventCreateWithFlags(&m->evA_done[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evB_done[p], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
-        if (m->tmo_host) (void)hipHostFree(m->tmo_host);
+        tmo_word_give(m->tmo_host);
         delete m;
         stt_set_error("sttode_model_create: could not create streams / events");
         return 2;
@@ -203,7 +227,7 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     // sA / sB / sB2 are process-wide (sttode_model_create)
     (void)hipEventDestroy(m->ev_call);
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
-    if (m->tmo_host) (void)hipHostFree(m->tmo_host);
+    tmo_word_give(m->tmo_host);   // (back to the process-wide block: no hipHostFree here -- a destructor may run during a stream capture)
     delete m;
     return 0;
 }

@@ -33,7 +33,7 @@ def _add_ln(x, r, norm):
     x2, r2 = x.reshape(-1, 64).contiguous(), r.reshape(-1, 64).contiguous()
     rows = x2.shape[0]
     y, xh, rs = torch.empty_like(x2), torch.empty_like(x2), torch.empty(rows, device=x.device)
-    capi.call('sttode_add_ln_fwd', x2, r2, norm.weight, norm.bias, y, xh, rs, rows, capi.stream_ptr())
+    capi.call('sttode_add_ln_fwd', x2, r2, norm.weight, norm.bias, y, xh, rs, rows, x2.shape[-1], capi.stream_ptr())
     return y.view(shape)
 
 
