@@ -799,7 +799,7 @@ class _LossFn(torch.autograd.Function):
             G = views
         else:
             G = ctx.engine.run_backward(gout, ctx.step_id)
-        _hand_over(G, ctx.names, ctx.params)
+        _hand_over(G, ctx.names, ctx.params, rotating=ctx.ready is not None)
         return None, None, None, None, None, None
 
 
@@ -812,16 +812,20 @@ def _consume(state):
     state['consumed'] = True
 
 
-def _hand_over(G, names, params):
+def _hand_over(G, names, params, rotating=False):
     """The gradients of a step become the parameters' ``.grad``: autograd's AccumulateGrad would copy each of the 88 views of the flat
     buffer into a fresh tensor (88 extra kernels per step).  The flat buffer is private to this step, so the views can BE the .grad
-    tensors; an existing .grad (gradient accumulation) is added to in place."""
+    tensors; an existing .grad (gradient accumulation) is added to -- in place when the step's buffer is its own (eager steps), OUT of
+    place when it is one of a replayed step's two rotating buffers (the existing .grad may itself be a view of one of them, which a later
+    replay overwrites)."""
     for nm, p in zip(names, params):
         g = G.get(nm)
         if g is None or not p.requires_grad:
             continue
         if p.grad is None:
             p.grad = g
+        elif rotating:
+            p.grad = p.grad + g
         else:
             p.grad.add_(g)
 
@@ -842,7 +846,7 @@ class _LossTensor(torch.Tensor):
             G = ready[1]                                           # graph replay already produced the gradients
         else:
             G = engine.run_backward(None, step_id)
-        _hand_over(G, names, params)
+        _hand_over(G, names, params, rotating=ready is not None)
 
 
 class _GraphedStep:
@@ -895,13 +899,24 @@ class _GraphedStep:
         for k, v in self.attrs.items():
             setattr(self.net, k, v)
         losses, flat, G = self.out
-        flat = flat.clone()                                        # .grad must not alias the graph's static output
-        views, off = {}, 0
-        for k, v in self.eng.P.items():
-            if k in G:
-                views[k] = flat[off: off + v.numel()].view(v.shape)
-            off += ((v.numel() + 3) // 4) * 4
-        return losses.clone(), (flat, views, {'consumed': False})
+        # .grad must not alias the graph's static output: the step's gradients are copied (ONE D2D copy) into one of TWO persistent flat
+        # buffers used in turn, whose per-parameter views are built once -- a fresh clone per step needed 88 slice + view operations, ~0.15 ms
+        # of host time on the host-bound one-scene step.  A step's gradients therefore stay valid until the step after the next one runs;
+        # gradients that are ACCUMULATED across steps never live in these buffers (_hand_over adds out of place).
+        if getattr(self, 'rot', None) is None:
+            self.rot, self.rot_i = [], 0
+            for _ in range(2):
+                buf = torch.empty_like(flat)
+                views, off = {}, 0
+                for k, v in self.eng.P.items():
+                    if k in G:
+                        views[k] = buf[off: off + v.numel()].view(v.shape)
+                    off += ((v.numel() + 3) // 4) * 4
+                self.rot.append((buf, views))
+        buf, views = self.rot[self.rot_i]
+        self.rot_i ^= 1
+        buf.copy_(flat)
+        return losses.clone(), (buf, views, {'consumed': False, 'rotating': True})
 
 
 def _names_params(eng, net):

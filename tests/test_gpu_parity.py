@@ -3438,3 +3438,45 @@ def test_training_loop_with_hip_adam_equals_torch_fused_adam():
         runs.append(losses)
     np.testing.assert_allclose(runs[0], runs[1], rtol=2e-4)
     assert abs(runs[0][-1] - runs[0][0]) > 1e-3 * abs(runs[0][0])   # (the parameters did move)
+
+
+def test_replayed_steps_gradients_rotate_and_accumulate_correctly(golden):
+    """Graph-replayed training steps hand their gradients over as views of two persistent buffers used in turn (round 5: no 88 view
+    operations per step).  (a) a step's gradients are still intact after the NEXT step ran; (b) gradient accumulation over several replayed
+    steps without zero_grad (p.grad += g) gives exactly k times one step's gradient and is not corrupted by later replays; (c) the values are
+    those of an eager step."""
+    from sttode_amd import STTODENet
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    g = golden('eth_forward_losses')
+    m = STTODENet(make_args('eth', 8, 12), _gpu()).eval()
+    m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+    n = g['obs'].shape[0]
+    eps = [torch.from_numpy(np.random.default_rng(5).standard_normal(s).astype(np.float32)) for s in ((n, 32), (n, 32), (n * 20, 32))]
+
+    def step():
+        m.set_data(None, torch.from_numpy(g['obs']), torch.from_numpy(g['pred']))
+        return m.forward(eps[0], eps[1], eps[2])[0]
+    w = m.decoder.decompose[1].decoder_x.layers[0].weight
+    m.train_graphs = False
+    step().backward()
+    eager = w.grad.clone()
+    m.train_graphs = True
+    for _ in range(3):                            # eager -> capture -> replay
+        m.zero_grad()
+        step().backward()
+    assert torch.allclose(w.grad, eager, rtol=1e-6, atol=1e-7 * float(eager.abs().max()))
+    first = w.grad                                # a view of rotating buffer A
+    keep = first.clone()
+    m.zero_grad()
+    step().backward()                             # buffer B
+    assert torch.equal(first, keep)               # (a) the previous step's gradients are intact
+    # (b) accumulate over 4 replayed steps
+    m.zero_grad()
+    for _ in range(4):
+        step().backward()
+    assert torch.allclose(w.grad, 4 * keep, rtol=1e-6, atol=1e-6 * float(keep.abs().max()))
+    acc = w.grad.clone()
+    for p in m.parameters():
+        p.grad = None if p is not w else p.grad   # keep accumulating on one parameter only
+    step().backward(); step().backward()
+    assert torch.allclose(w.grad, acc + 2 * keep, rtol=1e-6, atol=1e-6 * float(keep.abs().max()))
