@@ -754,7 +754,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--prewarm', type=int, default=int(os.environ.get('STTODE_BENCH_PREWARM', '0')),
+    ap.add_argument('--prewarm', type=int, default=int(os.environ.get('STTODE_BENCH_PREWARM', '40')),
                     help='extra UNTIMED steps in front of the --warmup steps of the headline region (brings the shader clock up; reported as clock_prewarm_steps)')
     ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU per step of the headline workload')
     ap.add_argument('--cpu-seconds', type=float, default=8.0, help='budget of the headline CPU-baseline sample at 16 threads (half of it again at 1 thread)')
