@@ -312,9 +312,12 @@ enum SttodeTrunkPtr {
     STT_TT_ENC_IN /* [n,T,4] */, STT_TT_LAST /* int32 [n] */, STT_TT_PE /* [>=T,64] */, STT_TT_DROP /* [n*T,64] keep mask / keep, or NULL */,
     STT_TT_POSIN /* [n*T,128] */, STT_TT_TP /* [n*T,64] */, STT_TT_H3IN /* [n,68] */, STT_TT_FEAT, STT_TT_XC /* [n,64] */,
     STT_TT_QKV /* [n,192] */, STT_TT_AO, STT_TT_TT, STT_TT_SS, STT_TT_H, STT_TT_XH1 /* [n,64] each */, STT_TT_RS1 /* [n] */,
-    STT_TT_F1 /* [n,1024] */, STT_TT_XH2, STT_TT_RS2, STT_TT_ODE, STT_TT_COUNT
+    STT_TT_F1 /* [n,1024] */, STT_TT_XH2, STT_TT_RS2, STT_TT_ODE,
+    STT_TT_ATTN /* [n,64]: phase 2 only -- the attention output (before out_proj) of sttode_mhgsa_attn over the forward-call batch */, STT_TT_COUNT
 };
-int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, void* stream);
+/* phase 0: the whole trunk (attention length 1).  Attention over the forward-call batch (the NBA branch): phase 1 = up to the in-projection
+ * (writes qkv, xc, feat[:, :64]), then sttode_mhgsa_attn(_groups) as its own launch, then phase 2 = from ptrs[STT_TT_ATTN] on. */
+int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, int phase, void* stream);
 
 /* The four terms of forward()'s objective (:372-395,553-568) and all their gradients for ONE decoder pass over K1 = 1 + K samples per
  * agent (sample 0: decoded from the posterior draw, enters the prediction / recover terms; samples 1..K: the prior draws, best-of-K):

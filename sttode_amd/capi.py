@@ -68,7 +68,7 @@ SIGNATURES = {
     'sttode_loss_sqerr': [_P, _P, _L, _F, _P, _P, _P],
     'sttode_loss_kl': [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     'sttode_loss_diverse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    'sttode_ttrunk_fwd': [_P, _I, _I, _I, _L, _F, _P],
+    'sttode_ttrunk_fwd': [_P, _I, _I, _I, _L, _F, _I, _P],
     'sttode_loss_objective': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _L, _P],
     # manifold op library (csrc/pmath.hip)
     'sttode_pmath_rowop': [_I, _P, _P, _P, _P, _I, _I, _F, _P],
@@ -127,7 +127,7 @@ WEIGHT_ORDER = ([('past', k) for k in ('fc1P', 'fc1b', 'posP', 'peb', 'fc2P', 'f
                 + [('role32', k) for k in ('pool', 'prog_scenes', 'prog_nba', 'consts_scenes', 'consts_nba')])
 TRUNK_PTRS = ('fc1_w', 'fc1_b', 'pos_w', 'pos_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b', 'inproj_w', 'inproj_b', 'out_w', 'out_b', 'info_w', 'info_b',
               'gate_w', 'gate_b', 'ln1_w', 'ln1_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'ln2_w', 'ln2_b', 'enc_in', 'last', 'pe', 'drop', 'posin', 'tp',
-              'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode')   # enum SttodeTrunkPtr
+              'h3in', 'feat', 'xc', 'qkv', 'ao', 'tt', 'ss', 'h', 'xh1', 'rs1', 'f1', 'xh2', 'rs2', 'ode', 'attn')   # enum SttodeTrunkPtr
 BUFFERS = ('scene_orig', 'agent_scene', 'xpad', 'enc_in', 'cur', 'orig', 'last', 'g', 'qkv', 'attn', 'pf', 'state0', 'A0x', 'A0y',
            'A1y', 'dbuf', 'ybuf', 'state1', 'queue', 'flags', 'ode')
 STAGES = ('frontend', 'embed_qkv', 'mhgsa_attn', 'post_attn', 'gru_cols[block0,agents]', 'agent_preact', 'mlp_block0',

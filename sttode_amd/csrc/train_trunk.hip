@@ -18,6 +18,9 @@ struct TrunkArgs {
     int n, T;
     long ld_feat;
     float ode_time;
+    int phase;   // 0: the whole trunk (attention length 1: the attention output is v); attention over the forward-call batch (the NBA branch,
+                 // round 5): 1 = up to the in-projection (writes qkv), the attention kernel runs between, 2 = from the attention output
+                 // p[STT_TT_ATTN] [n,64] on -- two launches per trunk instead of twelve layer launches
 };
 
 // A fragment (row tile it, k tile T) of a row-major weight W [I, ld]: lane (i, q) holds W[16 it + i][16 T + 4 q + 0..3]
@@ -39,6 +42,8 @@ static __device__ __forceinline__ void ttrunk_fwd_body(const TrunkArgs& a, int t
     const int col = tile * 16 + c;
     const int colc = col < n ? col : n - 1;
     const bool live = col < n;
+    f32x4 x[4], wof[4], wif[4], wgf[4];
+    if (a.phase != 2) {   // (uniform) ---------------------------------------------------------------- up to the in-projection
     // ---- frames: input_fc (K = 4: one MFMA per row tile) -> cat(., pe[t]) -> pos fc -> dropout
     f32x4 b1[4];
     float f1w[4];
@@ -90,7 +95,7 @@ static __device__ __forceinline__ void ttrunk_fwd_body(const TrunkArgs& a, int t
         sPt[(t * 4 + w) * 64 + lane] = acc;
     }
     // fragments of the small layers behind the barriers travel now (a load cannot be hoisted across a workgroup barrier by the compiler)
-    f32x4 w3f[4], win[3][4], wof[4], wif[4], wgf[4];
+    f32x4 w3f[4], win[3][4];
 #pragma unroll
     for (int Tk = 0; Tk < 4; ++Tk) {
         w3f[Tk] = wfrag<false>(P[STT_TT_FC3_W], 67, w, Tk, lane);
@@ -133,7 +138,6 @@ static __device__ __forceinline__ void ttrunk_fwd_body(const TrunkArgs& a, int t
     sX[(0 * 4 + w) * 64 + lane] = f;
     __syncthreads();
     // ---- input_fc3 (67 inputs: 64 features + category), row tile w  ->  x = ftraj_input
-    f32x4 x[4];
     {
         f32x4 acc = ld4(P[STT_TT_FC3_B] + 16 * w + 4 * q);
 #pragma unroll
@@ -163,6 +167,17 @@ static __device__ __forceinline__ void ttrunk_fwd_body(const TrunkArgs& a, int t
             if (live) st4(qkv + (long)col * 192 + 16 * it + 4 * q, acc);
             if (i == 2) sX[(2 * 4 + w) * 64 + lane] = acc;
         }
+    }
+    if (a.phase == 1) return;   // (uniform) the attention over the forward-call batch runs as its own launch; phase 2 continues behind it
+    } else {              // (uniform) ---------------------------------------------------------------- phase 2: from the attention output on
+#pragma unroll
+        for (int Tk = 0; Tk < 4; ++Tk) {
+            wof[Tk] = wfrag<true>(P[STT_TT_OUT_W], 64, w, Tk, lane);
+            wif[Tk] = wfrag<true>(P[STT_TT_INFO_W], 64, w, Tk, lane);
+            wgf[Tk] = wfrag<true>(P[STT_TT_GATE_W], 64, w, Tk, lane);
+            x[Tk] = ld4(P[STT_TT_XC] + (long)colc * 64 + 16 * Tk + 4 * q);
+        }
+        sX[(2 * 4 + w) * 64 + lane] = ld4(P[STT_TT_ATTN] + (long)colc * 64 + 16 * w + 4 * q);   // slot 2: the attention output (before out_proj)
     }
     __syncthreads();
     // ---- out_proj(v), row tile w
@@ -312,17 +327,17 @@ int stt_trunk_group(int on) {
     return 0;
 }
 
-extern "C" int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, void* stream) {
+extern "C" int sttode_ttrunk_fwd(const void* const* ptrs, int count, int n, int T, long ld_feat, float ode_time, int phase, void* stream) {
     STT_REQUIRE(ptrs && count == STT_TT_COUNT, "sttode_ttrunk_fwd: pointer table must have STT_TT_COUNT entries");
-    STT_REQUIRE(n > 0 && T >= 1 && ld_feat >= 128 && (ld_feat % 4) == 0, "sttode_ttrunk_fwd: bad n / T / ld_feat");
+    STT_REQUIRE(n > 0 && T >= 1 && ld_feat >= 128 && (ld_feat % 4) == 0 && phase >= 0 && phase <= 2, "sttode_ttrunk_fwd: bad n / T / ld_feat / phase");
     const size_t lds = ((size_t)T * 256 + 1024) * 16;
     STT_REQUIRE(lds <= 64 * 1024, "sttode_ttrunk_fwd: T too large for the fused form (T <= 12): use the layer-by-layer path");
     TrunkArgs a;
     for (int i = 0; i < STT_TT_COUNT; ++i) {
         a.p[i] = (const float*)ptrs[i];
-        STT_REQUIRE(a.p[i] || i == STT_TT_DROP || i == STT_TT_LAST, "sttode_ttrunk_fwd: null pointer in the table");
+        STT_REQUIRE(a.p[i] || i == STT_TT_DROP || i == STT_TT_LAST || (i == STT_TT_ATTN && phase != 2), "sttode_ttrunk_fwd: null pointer in the table");
     }
-    a.n = n; a.T = T; a.ld_feat = ld_feat; a.ode_time = ode_time;
+    a.n = n; a.T = T; a.ld_feat = ld_feat; a.ode_time = ode_time; a.phase = phase;
     std::lock_guard<std::mutex> lk(g_tq_mu);
     if (g_tq.on && g_tq.have && g_tq.stream == stream) {   // the group's second trunk: both in one launch
         g_tq.have = false;

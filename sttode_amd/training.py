@@ -206,10 +206,26 @@ class Engine:
             n, T = enc_in.shape[0], enc_in.shape[1]
             S.append(dict(t={'n': n, 'T': T, 'pre': pre, 'feat': feat}, pre=pre, a=pre + _ATT, n=n, T=T, X0=enc_in.reshape(n * T, 4), last=last, feat=feat,
                           drop=drop_mask))
-        if net._mode != 'nba' and all(s['T'] <= 12 for s in S) and self.fused_trunk and D == 64:
-            with (self.group() if len(S) > 1 else contextlib.nullcontext()):
-                return [self._trunk_fwd_fused(s['t'], s['X0'], s['last'], s['feat'], s['drop']) for s in S]
         L, Nb = (net.batch_size, net._N) if net._mode == 'nba' else (1, None)
+        if all(s['T'] <= 12 for s in S) and self.fused_trunk and D == 64:
+            if L == 1:
+                with (self.group() if len(S) > 1 else contextlib.nullcontext()):
+                    return [self._trunk_fwd_fused(s['t'], s['X0'], s['last'], s['feat'], s['drop']) for s in S]
+            # attention over the forward-call batch (the NBA branch): each trunk as TWO launches -- up to the in-projection, then (the attention
+            # kernel between) from the attention output on -- instead of twelve layer launches; both trunks of a phase in one launch
+            with (self.group() if len(S) > 1 else contextlib.nullcontext()):
+                tabs = [self._trunk_fwd_fused(s['t'], s['X0'], s['last'], s['feat'], s['drop'], phase=1) for s in S]
+            G = getattr(net, '_G', 1)
+            for s, (t, src) in zip(S, tabs):
+                qkv, e = src['qkv'], 4
+                capi.call('sttode_mhgsa_attn_groups', qkv.data_ptr() + 64 * e, qkv.data_ptr(), qkv.data_ptr() + 128 * e, src['attn'], G, L * Nb * 192,
+                          L * Nb * 192, L * Nb * 192, L * Nb * 64, L, L, Nb, Nb * 192, 192, Nb * 192, 192, Nb * 192, 192, Nb * 64, 64, 1.0, 8.0 ** -0.5, 8, self.st)
+            with (self.group() if len(S) > 1 else contextlib.nullcontext()):
+                for s, (t, src) in zip(S, tabs):
+                    self._trunk_launch(src, s['n'], s['T'], s['feat'], 2)
+            for t, src in tabs:
+                t.update(L=L, Nb=Nb, attn=src['attn'])
+            return [t for t, _ in tabs]
         with self.group():
             for s in S:
                 s['posin'] = self.new(s['n'] * s['T'], 2 * D)
@@ -291,9 +307,15 @@ class Engine:
             out.append(t)
         return out
 
-    def _trunk_fwd_fused(self, t, X0, last, feat, drop_mask):
+    def _trunk_launch(self, src, n, T, feat, phase):
+        import ctypes
+        tbl = (ctypes.c_void_p * len(capi.TRUNK_PTRS))(*[(src[k].data_ptr() if src.get(k) is not None else None) for k in capi.TRUNK_PTRS])
+        capi.call('sttode_ttrunk_fwd', tbl, len(capi.TRUNK_PTRS), n, T, feat.stride(0), float(self.net.ODE_TIME), phase, self.st)
+
+    def _trunk_fwd_fused(self, t, X0, last, feat, drop_mask, phase=0):
         """The same forward and the same tape in ONE launch (csrc/train_trunk.hip, attention length 1): the step is bound by the number of
-        launches, and a trunk is 21 of them layer by layer."""
+        launches, and a trunk is 21 of them layer by layer.  ``phase=1``: only up to the in-projection (attention over the forward-call batch:
+        the caller runs the attention and then phase 2 through _trunk_launch); returns (tape, pointer sources) then."""
         import ctypes
         P, net = self.P, self.net
         pre, n, T = t['pre'], t['n'], t['T']
@@ -313,10 +335,11 @@ class Engine:
                    enc_in=X0, last=last, pe=getattr(net, pre[:-1]).pos_encoder.pe, drop=drop_mask, feat=feat, **out)
         for k, v in src.items():
             assert v is None or v.is_contiguous() or k == 'feat', k
-        tbl = (ctypes.c_void_p * len(capi.TRUNK_PTRS))(*[(src[k].data_ptr() if src[k] is not None else None) for k in capi.TRUNK_PTRS])
-        capi.call('sttode_ttrunk_fwd', tbl, len(capi.TRUNK_PTRS), n, T, feat.stride(0), float(net.ODE_TIME), self.st)
+        if phase == 1:
+            src['attn'] = self.new(n, 64)
+        self._trunk_launch(src, n, T, feat, phase)
         t.update(X0=X0, drop=drop_mask, attn=out['qkv'][:, 128:], L=1, Nb=n, **out)
-        return t
+        return (t, src) if phase == 1 else t
 
     @contextlib.contextmanager
     def group(self):
