@@ -328,6 +328,13 @@ int sttode_loss_objective(const float* pred, const float* rec, const float* fut,
                           const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd, float scale_mse,
                           float scale_rec, float kl_denom, float min_clip, float* out, float* dpred, float* drec, float* dqzp,
                           float* scratch, long scratch_floats, void* stream);
+/* forward() returns its four loss terms as Python floats (model/STTODE.py:568: four `.item()`, each a synchronisation with the END of the
+ * queue).  Inside a replayed step the values exist after the forward half: sttode_publish_values (one launch, capturable) copies
+ * vals [n <= 64] (DEVICE) into host_vals [n] (pinned HOST memory, device-accessible), increments *dev_seq (DEVICE, zero before the first
+ * launch) and stores the new count into *host_seq (pinned HOST); sttode_wait_value spins on the host until *host_seq == (unsigned)want (0) or
+ * timeout_s seconds have passed (non-zero) -- no stream, no event: whatever is queued behind the publishing launch keeps running. */
+int sttode_publish_values(const float* vals, int n, float* host_vals, unsigned* dev_seq, unsigned* host_seq, void* stream);
+int sttode_wait_value(const unsigned* host_seq, long want, double timeout_s);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone manifold op library (not on the model's data flow; op-level parity).
@@ -437,6 +444,11 @@ int sttode_debug_drop_role_flag(SttodeModel* m, int tile);
  * fut [N][2][Tf] (HOST pointers, the loader's layout; fut may be NULL with Tf = 0) are transposed into a pinned ring slot and copied to
  * dev [N*Tp*2 + N*Tf*2] (DEVICE: past [N][Tp][2] followed by future [N][Tf][2]) with one asynchronous copy on `stream`. */
 int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream);
+/* The same ring for a batch whose host layout IS the device layout (set_data_nba, model/STTODE.py:463-486: past_traj [B,N,Tp,2],
+ * future_traj [B,N,Tf,2]): a [na] and b [nb] floats (HOST, pageable; b may be NULL with nb = 0) -> dev [na4 + nb] (DEVICE; a at 0, b at
+ * na4 = na rounded up to a multiple of 4, so both start on 16-byte boundaries) with one
+ * asynchronous copy on `stream` (a pageable `.to(device)` waits for everything queued on the stream: in train.py:61-67 the previous step). */
+int sttode_stage_rows(const float* a, long na, const float* b, long nb, float* dev, void* stream);
 /* The pipeline stream the next sttode_inference_*_async call of n agents will run on (*stream; NULL when the call will not take the
  * one-stream fused form).  Inputs prepared on that stream, and the call issued from it, need no cross-stream event. */
 int sttode_async_next_stream(SttodeModel* m, int n, void** stream);

@@ -93,6 +93,9 @@ SIGNATURES = {
     'sttode_debug_drop_role_flag': [_P, _I],
     'sttode_set_scene_launch': [_P, _I],
     'sttode_stage_scene': [_P, _P, _I, _I, _I, _P, _P],
+    'sttode_stage_rows': [_P, _L, _P, _L, _P, _P],
+    'sttode_publish_values': [_P, _I, _P, _P, _P, _P],
+    'sttode_wait_value': [_P, _L, _D],
     'sttode_async_next_stream': [_P, _I, _P],
     'sttode_async_best_of_k': [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P],
     'sttode_fused_block_of': [_L, _L, _L, _L, _L],

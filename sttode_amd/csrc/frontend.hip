@@ -301,29 +301,26 @@ extern "C" int sttode_copy_to_host(void* dst, const void* src, long bytes, int w
 // in ONE asynchronous copy on the caller's stream.  A ring of four slots per device, each guarded by an event: the slot is reused only
 // once the copy that last read it has completed (normally long ago).  Replaces a dozen torch calls (~35 us of host time per scene).
 // ---------------------------------------------------------------------------------------------------
+#include <cstring>
 #include <mutex>
 struct StageSlot { float* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
 static StageSlot g_stage[STT_ATTR_DEVICES][4];
 static int g_stage_k[STT_ATTR_DEVICES];
 static std::mutex g_stage_mu[STT_ATTR_DEVICES];   // one per device: staging threads of different devices do not serialise on each other
 
-extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream) {
-    STT_REQUIRE(pre && dev, "sttode_stage_scene: null pointer");
-    STT_REQUIRE(N > 0 && Tp > 0 && Tf >= 0 && (fut || Tf == 0), "sttode_stage_scene: bad N/Tp/Tf");
-    // the ring of the device that OWNS `dev` (a model on a non-current device must not be staged on the current device's ring and stream)
+// the next slot of device d's ring with room for `need` floats, its last copy complete (d: the device that owns the destination; must be current)
+static int stage_slot_take(const void* dev, size_t need, StageSlot** out, const char* who) {
     int d = 0;
     hipPointerAttribute_t pa;
     if (hipPointerGetAttributes(&pa, dev) == hipSuccess) d = pa.device;
     else { (void)hipGetLastError(); STT_HIP(hipGetDevice(&d)); }
-    STT_REQUIRE(d >= 0 && d < STT_ATTR_DEVICES, "sttode_stage_scene: device index beyond the staging table");
+    STT_REQUIRE(d >= 0 && d < STT_ATTR_DEVICES, "host staging: device index beyond the staging table");
     // the ring's event and pinned buffer belong to device d and the event is recorded on the caller's stream: all three must be device d's
     // (round-4 advice: created on the current device they mixed devices for a model on another one)
     int cur_dev = 0;
     STT_HIP(hipGetDevice(&cur_dev));
-    STT_REQUIRE(cur_dev == d, "sttode_stage_scene: the current device must be the one that owns `dev` (hipSetDevice / torch.cuda.device first)");
-    std::lock_guard<std::mutex> lock(g_stage_mu[d]);
+    if (cur_dev != d) { stt_set_error(who); return 1; }
     StageSlot& s = g_stage[d][g_stage_k[d] = (g_stage_k[d] + 1) & 3];
-    const size_t need = (size_t)N * (Tp + Tf) * 2;
     if (s.ev) STT_HIP(hipEventSynchronize(s.ev));   // the copy that last read this slot is done
     else STT_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.cap < need) {
@@ -334,6 +331,25 @@ extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int
         STT_HIP(hipHostMalloc((void**)&s.host, want * sizeof(float), hipHostMallocDefault));
         s.cap = want;
     }
+    *out = &s;
+    return 0;
+}
+static inline int stage_device_of(const void* dev) {
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, dev) == hipSuccess && pa.device >= 0 && pa.device < STT_ATTR_DEVICES) return pa.device;
+    (void)hipGetLastError();
+    return 0;
+}
+
+extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int Tp, int Tf, float* dev, void* stream) {
+    STT_REQUIRE(pre && dev, "sttode_stage_scene: null pointer");
+    STT_REQUIRE(N > 0 && Tp > 0 && Tf >= 0 && (fut || Tf == 0), "sttode_stage_scene: bad N/Tp/Tf");
+    // the ring of the device that OWNS `dev` (a model on a non-current device must not be staged on the current device's ring and stream)
+    std::lock_guard<std::mutex> lock(g_stage_mu[stage_device_of(dev)]);
+    const size_t need = (size_t)N * (Tp + Tf) * 2;
+    StageSlot* sp = nullptr;
+    if (int rc = stage_slot_take(dev, need, &sp, "sttode_stage_scene: the current device must be the one that owns `dev` (hipSetDevice / torch.cuda.device first)")) return rc;
+    StageSlot& s = *sp;
     float* h = s.host;
     for (int a = 0; a < N; ++a)
         for (int t = 0; t < Tp; ++t) {
@@ -348,5 +364,23 @@ extern "C" int sttode_stage_scene(const float* pre, const float* fut, int N, int
         }
     STT_HIP(hipMemcpyAsync(dev, h, need * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
     STT_HIP(hipEventRecord(s.ev, (hipStream_t)stream));
+    return 0;
+}
+// ... and of a batch whose host layout is already the device layout (set_data_nba, model/STTODE.py:463-486: past_traj [B,N,Tp,2],
+// future_traj [B,N,Tf,2]): a [na] and b [nb] (HOST, pageable; b may be NULL with nb = 0) go through one ring slot into dev [na4 + nb]
+// (na4 = na rounded up to a multiple of 4: a at 0, b at na4) with
+// ONE asynchronous copy -- `.to(device)` of a pageable tensor waits for everything queued on the stream first, which in a training loop
+// is the previous step's whole backward pass.
+extern "C" int sttode_stage_rows(const float* a, long na, const float* b, long nb, float* dev, void* stream) {
+    STT_REQUIRE(a && dev && na > 0 && nb >= 0 && (b || nb == 0), "sttode_stage_rows: null pointer or bad counts");
+    std::lock_guard<std::mutex> lock(g_stage_mu[stage_device_of(dev)]);
+    StageSlot* sp = nullptr;
+    const long nap = (na + 3) / 4 * 4;               // b starts on a 16-byte boundary of dev
+    if (int rc = stage_slot_take(dev, (size_t)(nap + nb), &sp, "sttode_stage_rows: the current device must be the one that owns `dev` (hipSetDevice / torch.cuda.device first)")) return rc;
+    memcpy(sp->host, a, (size_t)na * sizeof(float));
+    for (long i = na; i < nap; ++i) sp->host[i] = 0.f;
+    if (nb) memcpy(sp->host + nap, b, (size_t)nb * sizeof(float));
+    STT_HIP(hipMemcpyAsync(dev, sp->host, (size_t)(nap + nb) * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    STT_HIP(hipEventRecord(sp->ev, (hipStream_t)stream));
     return 0;
 }

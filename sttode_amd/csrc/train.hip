@@ -9,6 +9,7 @@
 // plus the element-wise forward/backward pieces (GRU cell, conv1d k=3, LayerNorm, gate, Euler+relu,
 // geodesic attention backward, reparameterisation + KL, squared-error / best-of-K losses).
 #include "api_util.hpp"
+#include <chrono>
 #include <mutex>
 #include "chain.hpp"
 
@@ -2136,4 +2137,39 @@ extern "C" int sttode_loss_diverse(const float* pred, const float* target, const
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, out);
     STT_HIP(hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Values a replayed step hands to the HOST in the middle of its graph (STTODENet.forward() returns four Python floats,
+// model/STTODE.py:568 -- `.item()` there is a device synchronisation at the END of whatever is queued; the loss values exist after the
+// forward half of the step).  publish: one lane copies n values into pinned host memory with system-scope stores, then bumps a DEVICE
+// counter (a replayed graph cannot carry a per-replay argument) and stores the new count into the host's sequence word (release).
+// wait: the host spins on that word -- no stream or event is involved, so the rest of the graph (the backward pass) keeps running
+// while the caller goes on to zero_grad / backward / optimizer.step and queues them behind it.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void publish_kernel(const float* __restrict__ vals, int n, float* host_vals, unsigned* dev_seq, unsigned* host_seq) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) __hip_atomic_store(host_vals + i, vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned s = *dev_seq + 1u;
+    *dev_seq = s;
+    __hip_atomic_store(host_seq, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int sttode_publish_values(const float* vals, int n, float* host_vals, unsigned* dev_seq, unsigned* host_seq, void* stream) {
+    STT_REQUIRE(vals && host_vals && dev_seq && host_seq && n > 0 && n <= 64, "sttode_publish_values: null pointer or n outside 1..64");
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, n, host_vals, dev_seq, host_seq);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_wait_value(const unsigned* host_seq, long want, double timeout_s) {
+    STT_REQUIRE(host_seq && timeout_s > 0, "sttode_wait_value: null pointer or no time-out");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(host_seq, __ATOMIC_ACQUIRE) == (unsigned)want) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            stt_set_error("sttode_wait_value: the sequence word did not reach the expected count in time");
+            return 1;
+        }
+    }
 }

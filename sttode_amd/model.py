@@ -448,7 +448,20 @@ class STTODENet(nn.Module):
         batch of B scenes (what G reference calls compute, test.py:520-524), everything else over all G B N agents (include/sttode_hip.h
         sttode_inference_nba_groups); ``batch_size`` / ``agent_num`` stay B / N, results come back for G B N agents in (g, b, n) order."""
         a, dev = self.args, self.device
-        pt = _f32(data['past_traj'], dev)
+        pt, ft = data['past_traj'], (data.get('future_traj') if hasattr(data, 'get') else None)
+        if (dev.type == 'cuda' and type(pt) is torch.Tensor and pt.dtype is torch.float32 and not pt.is_cuda and pt.is_contiguous() and pt.numel() > 0
+                and (ft is None or (type(ft) is torch.Tensor and ft.dtype is torch.float32 and not ft.is_cuda and ft.is_contiguous()))
+                and dev.index in (None, torch.cuda.current_device())):
+            # the loader's pageable host tensors (train.py:61): both through a pinned ring slot and ONE asynchronous copy (csrc/frontend.hip
+            # sttode_stage_rows) -- `.to(device)` of a pageable tensor first waits for everything queued on the stream, i.e. for the previous
+            # training step's whole backward pass and optimizer step
+            na, nb = pt.numel(), (ft.numel() if ft is not None else 0)
+            na4 = (na + 3) // 4 * 4
+            buf = torch.empty(na4 + nb, dtype=torch.float32, device=dev)
+            capi.call('sttode_stage_rows', pt, na, ft, nb, buf, capi.stream_ptr())
+            pt, ft = buf[:na].view(pt.shape), (buf[na4:].view(ft.shape) if ft is not None else None)
+        else:
+            pt = _f32(pt, dev)
         self.data = data
         self._G = 1
         if pt.dim() == 5:
@@ -456,7 +469,6 @@ class STTODENet(nn.Module):
             pt = pt.reshape(-1, *pt.shape[2:])
         self.batch_size, self.agent_num = pt.shape[0] // self._G, pt.shape[1]
         self._past = pt.reshape(pt.shape[0] * self.agent_num, a.past_length, 2).contiguous()
-        ft = data.get('future_traj') if hasattr(data, 'get') else None
         self._future = _f32(ft, dev).reshape(-1, a.future_length, 2).contiguous() if ft is not None else None
         self._mode = 'nba'
         self._N = self.agent_num

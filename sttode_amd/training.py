@@ -717,6 +717,8 @@ class Engine:
             sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
             capi.call('sttode_loss_objective', d['pred'], d['rec'], fut, past, qzp, sp, ags, S, n, K1, 2 * Tf, 2 * Tp, zd, 1.0 / (B * Tf),
                       1.0 / (B * Tp), float(B * N), float(a.min_clip), losses, dpred, drec, dqzp, self.scratch, self.scratch.numel(), self.st)
+            if getattr(self, 'publish', None) is not None:         # a step being captured: the values reach the host from HERE (see _GraphedStep)
+                capi.call('sttode_publish_values', losses, 5, *self.publish, self.st)
             self.step_id = getattr(self, 'step_id', 0) + 1
             self.tape = dict(step_id=self.step_id, tp=V['tp'], tf=V['tf'], hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d=d, dpred=dpred,
                              drec=drec, dqzp=dqzp, n=n, zd=zd, K1=K1)
@@ -896,14 +898,26 @@ class _GraphedStep:
         eng, st = self.eng, self.static
         segs = eng.forward_segments(st['eps_q'], st['eps20'], st['drop_past'], st['drop_future'], streams=False)
         torch.cuda.synchronize()
+        # The loss values leave for the host in the MIDDLE of the graph (after the forward half): forward() returns them as Python floats
+        # (model/STTODE.py:568), and reading them off the end of the queue (`.tolist()`) left the GPU idle for the whole host side of
+        # train.py:61-67 -- zero_grad, backward's hand-over, optimizer.step, the next set_data and draws: 0.21 ms of a 0.81 ms one-scene step
+        # (profiles/r05/train_host_window.txt).  One launch publishes them to pinned memory with a sequence count; run() spins on that word.
+        self.host_vals = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.host_seq = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.dev_seq = torch.zeros(2, dtype=torch.int32, device=eng.dev)
+        self.host_np, self.replays = self.host_vals.numpy(), 0
         self.graph_obj = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_obj):
-            eng.run_segments(segs)
-            try:
-                eng.run_segments(eng.backward_segments())
-            except BaseException:
-                capi.call('sttode_twgrad_defer', -1, None, 0)
-                raise
+        eng.publish = (self.host_vals, self.dev_seq, self.host_seq)
+        try:
+            with torch.cuda.graph(self.graph_obj):
+                eng.run_segments(segs)
+                try:
+                    eng.run_segments(eng.backward_segments())
+                except BaseException:
+                    capi.call('sttode_twgrad_defer', -1, None, 0)
+                    raise
+        finally:
+            eng.publish = None
         self.keep = (eng._hold, eng.V, eng.G, eng.main_scratch, eng.red_scratch)        # static buffers of the graph
         eng._hold = []
         self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
@@ -939,7 +953,12 @@ class _GraphedStep:
         buf, views = self.rot[self.rot_i]
         self.rot_i ^= 1
         buf.copy_(flat)
-        return losses.clone(), (buf, views, {'consumed': False, 'rotating': True})
+        total = losses[4].clone()
+        self.replays = (self.replays + 1) & 0xFFFFFFFF
+        if capi.lib().sttode_wait_value(self.host_seq.data_ptr(), self.replays, 60.0):
+            torch.cuda.synchronize()
+            raise capi.SttodeError('the replayed step did not publish its loss values: ' + capi.lib().sttode_last_error().decode())
+        return (total, self.host_np[:4].tolist()), (buf, views, {'consumed': False, 'rotating': True})
 
 
 def _names_params(eng, net):
@@ -1020,9 +1039,13 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
             net._graph_seen.add(key)                                # first time: eager (also warms one-time kernel attributes)
     if ready is None:
         losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)
+        tot_dev, lv = losses[4], None
+    else:
+        tot_dev, lv = losses                                        # a replayed step: the four values are on the host already
     if getattr(eng, 'anchor', None) is None:
         eng.anchor = torch.zeros((), device=dev, requires_grad=True)
-    total = _LossFn.apply(losses[4], eng, names, ready, params, eng.anchor).as_subclass(_LossTensor)
+    total = _LossFn.apply(tot_dev, eng, names, ready, params, eng.anchor).as_subclass(_LossTensor)
     total._sttode_step = (eng, names, ready, params, eng.tape['step_id'] if (ready is None and eng.tape is not None) else None)
-    lv = losses.tolist()
+    if lv is None:
+        lv = losses.tolist()
     return total, lv[0], lv[1], lv[2], lv[3]

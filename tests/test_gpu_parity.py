@@ -3480,3 +3480,106 @@ def test_replayed_steps_gradients_rotate_and_accumulate_correctly(golden):
         p.grad = None if p is not w else p.grad   # keep accumulating on one parameter only
     step().backward(); step().backward()
     assert torch.allclose(w.grad, acc + 2 * keep, rtol=1e-6, atol=1e-6 * float(keep.abs().max()))
+
+
+@pytest.mark.gpu
+def test_published_values_reach_the_host_while_the_stream_is_still_busy():
+    """sttode_publish_values / sttode_wait_value (round 5): values written by one launch are read by the host WITHOUT any stream or event
+    synchronisation -- with a long queue behind the publishing launch, the wait returns while that queue is still running; a count that never
+    comes times out with an error instead of hanging."""
+    from sttode_amd import capi
+    dev = _gpu()
+    L = capi.lib()
+    vals = torch.arange(5, dtype=torch.float32, device=dev) * 1.5 + 0.25
+    host_vals, host_seq = torch.zeros(8).pin_memory(), torch.zeros(2, dtype=torch.int32).pin_memory()
+    dev_seq = torch.zeros(2, dtype=torch.int32, device=dev)
+    a = torch.randn(4096, 4096, device=dev)
+    torch.cuda.synchronize()
+    for k in (1, 2, 3):
+        vals.add_(1.0)
+        capi.call('sttode_publish_values', vals, 5, host_vals, dev_seq, host_seq, capi.stream_ptr())
+        for _ in range(40):                           # ~40 x 0.9 ms of matrix products queued BEHIND the publishing launch
+            a = (a @ a).clamp_(-1, 1)
+        assert L.sttode_wait_value(host_seq.data_ptr(), k, 20.0) == 0
+        busy = not torch.cuda.current_stream().query()
+        assert host_vals[:5].tolist() == [0.25 + 1.5 * i + k for i in range(5)]
+        assert busy, 'the wait outlasted the queue behind the publishing launch: it did not return early'
+        torch.cuda.synchronize()
+    assert int(dev_seq[0]) == 3
+    assert L.sttode_wait_value(host_seq.data_ptr(), 9, 0.05) != 0 and b'did not reach' in L.sttode_last_error()
+    with pytest.raises(capi.SttodeError, match='null pointer'):
+        capi.call('sttode_publish_values', None, 5, host_vals, dev_seq, host_seq, capi.stream_ptr())
+
+
+@pytest.mark.gpu
+def test_nba_batches_are_staged_without_waiting_for_the_stream():
+    """set_data_nba with the loader's pageable host tensors (train.py:61): one asynchronous copy through the pinned ring
+    (sttode_stage_rows) -- the bytes of `.to(device)`, for sizes whose first array ends off a 16-byte boundary too, over more calls than the
+    ring has slots, and issued while the stream is busy."""
+    from sttode_amd import STTODENet, scenes
+    dev = _gpu()
+    m = STTODENet(make_args('nba', 5, 10), dev).eval()
+    a = torch.randn(2048, 2048, device=dev)
+    for i, (B, N) in enumerate([(1, 11), (3, 11), (32, 11), (7, 3), (2, 1), (128, 11), (5, 11)]):
+        d = scenes.nba_batch(300 + i, B, N=N)
+        data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+        for _ in range(10):
+            a = (a @ a).clamp_(-1, 1)
+        m.set_data_nba(data)
+        assert torch.equal(m._past.cpu().view(B, N, 5, 2), data['past_traj']) and torch.equal(m._future.cpu().view(B, N, 10, 2), data['future_traj'])
+        assert m._past.data_ptr() % 16 == 0 and m._future.data_ptr() % 16 == 0
+        m.set_data_nba({'past_traj': data['past_traj']})                      # no future: inference-only callers
+        assert m._future is None and torch.equal(m._past.cpu().view(B, N, 5, 2), data['past_traj'])
+    z = torch.randn(5 * 11 * 20, 32, device=dev)
+    m.load_state_dict(__import__('sttode_amd.weights', fromlist=['x']).to_torch_state_dict(__import__('sttode_amd.weights', fromlist=['x']).make_weights(1234, past_length=5, future_length=10)))
+    m.set_data_nba(data)
+    out = m.inference(data, z=z)
+    m.set_data_nba({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items()})   # device-resident inputs: the old route
+    assert torch.equal(out, m.inference(data, z=z))
+
+
+@pytest.mark.gpu
+def test_replayed_step_returns_its_losses_before_the_backward_half_has_run(golden):
+    """A replayed training step publishes its four loss values from the middle of its graph (round 5): forward() returns the same floats
+    as the eager step's `.tolist()`, the train.py:61-67 loop run back to back WITHOUT any synchronisation in between moves the parameters
+    exactly like the same loop with a device synchronisation after every call, and total.item() still is the step's total."""
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.optim import Adam
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    d = scenes.nba_batch(11, 16)
+    data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+    n = 16 * 11
+    gen = torch.Generator().manual_seed(9)
+    eps = [(torch.randn(n, 32, generator=gen), torch.randn(n, 32, generator=gen), torch.randn(n * 20, 32, generator=gen)) for _ in range(6)]
+    runs = []
+    for sync in (True, False):
+        m = STTODENet(make_args('nba', 5, 10), dev).eval()
+        m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=5, future_length=10)), strict=True)
+        opt = Adam(m.parameters(), lr=1e-3)
+        vals = []
+        for it in range(6):
+            m.set_data_nba(data)
+            out = m.forward(*eps[it])
+            if sync:
+                torch.cuda.synchronize()
+            opt.zero_grad(); out[0].backward(); opt.step()
+            if sync:
+                torch.cuda.synchronize()
+            vals.append((out[0], out[1:]))
+        torch.cuda.synchronize()
+        for tot, four in vals:
+            assert all(isinstance(v, float) for v in four)
+            assert abs(float(tot) - sum(four)) <= 1e-5 * abs(float(tot))
+        runs.append(([four for _, four in vals], [float(t) for t, _ in vals], [p.detach().clone() for p in m.parameters()]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]                  # replayed steps are deterministic: the same floats
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    # ... and a replayed step's values are the eager step's (same weights: no optimizer in between)
+    m = STTODENet(make_args('nba', 5, 10), dev).eval()
+    m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=5, future_length=10)), strict=True)
+    got = []
+    for _ in range(3):                                                            # eager -> capture + replay -> replay
+        m.set_data_nba(data)
+        got.append(m.forward(*eps[0])[1:])
+    assert got[1] == got[2]
+    np.testing.assert_allclose(got[2], got[0], rtol=1e-5)
