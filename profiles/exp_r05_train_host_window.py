@@ -1,6 +1,7 @@
 """Where a replayed training step's wall time goes on the HOST (train.py:59-95 loop: set_data -> forward() [returns four Python floats: a
 sync] -> zero_grad -> backward -> optimizer.step): per-phase perf_counter means over 200 steps, with the graph's own GPU time from events
-around the replay.  The GPU idles in every phase but the wait inside forward()."""
+around the replay (second loop).  Round 5, first half: forward() waited for the END of the queue and the GPU idled through every other
+phase (train_host_window_before.txt); now the loss values leave the graph after its forward half and the host phases overlap the backward half."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(sys.path[0], 'tests'))
 from helpers import make_args
@@ -14,10 +15,9 @@ def run(tag, m, set_data):
     opt = Adam(m.parameters(), lr=1e-4)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     orig = training._GraphedStep.run
-    gpu = []
 
     def timed_run(self, inputs):
-        ev[0].record(); r = orig(self, inputs); ev[1].record(); gpu.append(None)
+        ev[0].record(); r = orig(self, inputs); ev[1].record()
         return r
     def step(acc=None):
         t0 = time.perf_counter(); set_data(); t1 = time.perf_counter(); tot = m.forward()[0]; t2 = time.perf_counter()
@@ -26,15 +26,18 @@ def run(tag, m, set_data):
             for i, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 acc[i] += d
     for _ in range(5): step()
-    training._GraphedStep.run = timed_run
-    acc, N, g = [0.0] * 5, 200, 0.0
+    acc, N = [0.0] * 5, 200
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(N):
-        step(acc); g += ev[0].elapsed_time(ev[1])       # (forward() synchronised after the replay: the events are complete)
+        step(acc)                                       # free-running: nothing in the loop waits for the end of the queue
     torch.cuda.synchronize(); wall = (time.perf_counter() - t) / N
+    training._GraphedStep.run = timed_run               # the replay's own GPU time: a second loop that synchronises after every step
+    g = 0.0
+    for _ in range(50):
+        step(); torch.cuda.synchronize(); g += ev[0].elapsed_time(ev[1])
     training._GraphedStep.run = orig
-    names = ('set_data', 'forward (draws + replay + wait for the four loss values)', 'zero_grad', 'backward (hand-over)', 'optimizer.step')
-    print(f'{tag}: {wall * 1e3:.3f} ms/step; replay + gradient copy on the GPU {g / N:.3f} ms')
+    names = ('set_data', 'forward (draws, replay, wait for the four loss values)', 'zero_grad', 'backward (hand-over)', 'optimizer.step')
+    print(f'{tag}: {wall * 1e3:.3f} ms/step; replay + gradient copy on the GPU {g / 50:.3f} ms; host time per step {sum(acc) / N * 1e3:.3f} ms, of which')
     for nme, v in zip(names, acc):
         print(f'    {nme:58s} {v / N * 1e6:7.1f} us')
 

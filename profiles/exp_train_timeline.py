@@ -12,7 +12,8 @@ if os.environ.get('NO_GRAPHS'): m.train_graphs = False
 ob, pr = scenes.eth_scene(1, n_min=32, n_max=32)
 ob, pr = torch.from_numpy(ob), torch.from_numpy(pr)
 mk = (torch.ones(32, Tp), torch.ones(32, Tf))
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+from sttode_amd.optim import Adam
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True) if os.environ.get('STTODE_TORCH_ADAM') else Adam(m.parameters(), lr=1e-4)
 T = [0.0] * 5
 def step(rec):
     t0 = time.perf_counter()
