@@ -879,9 +879,16 @@ class _GraphedStep:
     (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
     the loss values and the flat gradient buffer are static outputs."""
 
-    def __init__(self, eng, net, inputs):
+    def __init__(self, eng, net, inputs, drawn=None):
         self.eng, self.net = eng, net
         self.static = {k: (v.clone() if v is not None else None) for k, v in inputs.items()}
+        # drawn: name -> (rows, cols, kind) of the random inputs the GRAPH draws itself (torch's generator is graph-safe: a captured
+        # normal_() / bernoulli_() reads seed and offset at replay, and replay() advances the offset by the graph's total) -- in the order
+        # and with the calls of the eager step, so a seeded run draws the same numbers either way
+        self.drawn = drawn or {}
+        for k, (rows, cols, kind) in self.drawn.items():
+            if kind != 'unused':
+                self.static[k] = torch.empty(rows, cols, device=eng.dev)
         self.graph = None
 
     def _bind(self):
@@ -910,6 +917,13 @@ class _GraphedStep:
         eng.publish = (self.host_vals, self.dev_seq, self.host_seq)
         try:
             with torch.cuda.graph(self.graph_obj):
+                for k, (rows, cols, kind) in self.drawn.items():
+                    if kind == 'unused':
+                        torch.randn(rows, cols, device=eng.dev)     # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
+                    elif kind == 'bern':
+                        st[k].bernoulli_(_DROP_KEEP).div_(_DROP_KEEP)
+                    else:
+                        st[k].normal_()
                 eng.run_segments(segs)
                 try:
                     eng.run_segments(eng.backward_segments())
@@ -924,7 +938,7 @@ class _GraphedStep:
 
     def run(self, inputs):
         for k, v in inputs.items():
-            if v is not None and v is not self.static[k]:           # (the step's random draws are made into the static buffers directly)
+            if v is not None and v is not self.static[k]:           # (random inputs nobody passed in are drawn by the graph itself)
                 self.static[k].copy_(v)
         self._bind()
         if self.graph is None:
@@ -988,6 +1002,7 @@ def _names_params(eng, net):
 
 
 _GRAPH_MAX_AGENTS = int(os.environ.get('STTODE_TRAIN_GRAPH_MAX', '512'))
+_DROP_KEEP = 0.9
 
 
 def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
@@ -1001,41 +1016,46 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
         net._graphs, net._graph_seen = {}, set()
     names, params, ptr_token = _names_params(eng, net)
     ready = None
-    keep = 0.9                                                      # nn.Dropout(0.1) after the positional fc, both encoders (train mode)
+    keep = _DROP_KEEP                                               # nn.Dropout(0.1) after the positional fc, both encoders (train mode)
+    # random inputs the caller did not pass in, in the order the eager step draws them: (name, rows, cols, kind)
+    want = [('eps_q', n, a.zdim, 'normal' if eps_q is None else None), ('eps_p', n, a.zdim, 'unused' if eps_p is None else None),
+            ('eps20', n * 20, a.zdim, 'normal' if eps20 is None else None),
+            ('drop_past', n * a.past_length, a.hidden_dim, 'bern' if (drop_past is None and net.training) else None),
+            ('drop_future', n * a.future_length, a.hidden_dim, 'bern' if (drop_future is None and net.training) else None)]
+    drawn = {nm: (r, c, kind) for nm, r, c, kind in want if kind is not None}
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None or net.training,
-           drop_future is not None or net.training,
+           drop_future is not None or net.training, tuple(drawn),
            ptr_token, params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
            float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
     # a step is ~170 launches of 5-30 us each and the host needs ~15 us to enqueue one: replay wins as long as the launches are short
     # (one scene: launch-bound; an NBA batch of 32 x 11 agents: 3.5 ms eager for 2.5 ms of kernels)
     graphs = getattr(net, 'train_graphs', os.environ.get('STTODE_TRAIN_GRAPHS', '1') != '0') and net._future is not None and n <= _GRAPH_MAX_AGENTS
-    gs = net._graphs.get(key) if graphs else None
-    st = gs.static if gs is not None and gs.graph is not None else None   # a captured step: the draws land in its static inputs (no copies)
+    replay = graphs and (key in net._graphs or key in net._graph_seen)
 
-    def draw(given, name, rows, cols, bern=False):
-        if given is not None:
-            return given.to(dev, torch.float32).contiguous()
-        out = st[name] if st is not None and st.get(name) is not None and st[name].shape == (rows, cols) else torch.empty(rows, cols, device=dev)
-        return out.bernoulli_(keep).div_(keep) if bern else out.normal_()
-    eps_q = draw(eps_q, 'eps_q', n, a.zdim)
-    if eps_p is None:
-        torch.randn(n, a.zdim, device=dev)                          # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
-    eps20 = draw(eps20, 'eps20', n * 20, a.zdim)
-    if net.training:
-        if drop_past is None:
-            drop_past = draw(None, 'drop_past', n * a.past_length, a.hidden_dim, bern=True)
-        if drop_future is None:
-            drop_future = draw(None, 'drop_future', n * a.future_length, a.hidden_dim, bern=True)
-    if graphs:
-        if key in net._graphs or key in net._graph_seen:
-            inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,
-                          eps_q=eps_q, eps20=eps20, drop_past=drop_past, drop_future=drop_future)
-            if key not in net._graphs:
-                if len(net._graphs) >= 48:
-                    net._graphs.clear()
-                net._graphs[key] = _GraphedStep(eng, net, inputs)
-            losses, ready = net._graphs[key].run(inputs)
-        else:
+    def given(t):
+        return None if t is None else t.to(dev, torch.float32).contiguous()
+    if replay:                                                      # the graph draws what is missing (see _GraphedStep)
+        eps_q, eps20, drop_past, drop_future = given(eps_q), given(eps20), given(drop_past), given(drop_future)
+        inputs = dict(past=net._past, future=net._future, scene_ptr=net._scene_ptr if net._mode == 'scenes' else None,
+                      eps_q=eps_q, eps20=eps20, drop_past=drop_past, drop_future=drop_future)
+        if key not in net._graphs:
+            if len(net._graphs) >= 48:
+                net._graphs.clear()
+            net._graphs[key] = _GraphedStep(eng, net, inputs, drawn)
+        losses, ready = net._graphs[key].run(inputs)
+    else:
+        def draw(t, name):
+            if t is not None or name not in drawn:
+                return given(t)
+            rows, cols, kind = drawn[name]
+            out = torch.empty(rows, cols, device=dev)
+            return out.bernoulli_(keep).div_(keep) if kind == 'bern' else out.normal_()
+        eps_q = draw(eps_q, 'eps_q')
+        if 'eps_p' in drawn:
+            torch.randn(n, a.zdim, device=dev)                      # pz_distribution.rsample(): drawn, never used (model/STTODE.py:525)
+        eps20 = draw(eps20, 'eps20')
+        drop_past, drop_future = draw(drop_past, 'drop_past'), draw(drop_future, 'drop_future')
+        if graphs:
             net._graph_seen.add(key)                                # first time: eager (also warms one-time kernel attributes)
     if ready is None:
         losses = eng.run_forward(eps_q, eps20, drop_past, drop_future)

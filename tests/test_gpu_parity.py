@@ -3583,3 +3583,31 @@ def test_replayed_step_returns_its_losses_before_the_backward_half_has_run(golde
         got.append(m.forward(*eps[0])[1:])
     assert got[1] == got[2]
     np.testing.assert_allclose(got[2], got[0], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_replayed_step_draws_its_own_noise_like_the_eager_step(mode):
+    """The random inputs nobody passes in (posterior / prior noise, the two dropout masks in train mode) are drawn INSIDE the replayed graph
+    (round 5; torch's generator is graph-safe) by the calls of the eager step in the same order: under one torch.manual_seed a run of
+    replayed steps sees the numbers the eager run sees -- same loss values step by step -- and two replays never see the same noise."""
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    o, p = scenes.eth_scene(4242, n_min=9, n_max=9)
+    o, p = torch.from_numpy(o), torch.from_numpy(p)
+    runs = []
+    for graphs in (False, True):
+        m = STTODENet(make_args('eth', 8, 12), dev)
+        m.load_state_dict(to_torch_state_dict(make_weights(1234)), strict=True)
+        m.train() if mode == 'train' else m.eval()
+        m.train_graphs = graphs
+        torch.manual_seed(77); np.random.seed(77)
+        vals = []
+        for it in range(5):
+            m.set_data(None, o, p, theta=0.3 * it)
+            vals.append(m.forward()[1:])
+        runs.append(vals)
+    for a, b in zip(*runs):
+        np.testing.assert_allclose(b, a, rtol=2e-5)
+    assert len({v[0] for v in runs[1]}) == 5                        # every replay drew fresh noise
