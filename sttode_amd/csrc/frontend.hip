@@ -381,6 +381,8 @@ extern "C" int sttode_stage_rows(const float* a, long na, const float* b, long n
     for (long i = na; i < nap; ++i) sp->host[i] = 0.f;
     if (nb) memcpy(sp->host + nap, b, (size_t)nb * sizeof(float));
     STT_HIP(hipMemcpyAsync(dev, sp->host, (size_t)(nap + nb) * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    // (measured and not adopted: a small kernel reading the pinned slot instead of the DMA copy, to keep the copy in the compute queue of a
+    // busy stream -- 0.788 against 0.787 ms per free-running one-scene step, profiles/r05/train_stress.txt)
     STT_HIP(hipEventRecord(sp->ev, (hipStream_t)stream));
     return 0;
 }
