@@ -328,6 +328,20 @@ int sttode_loss_objective(const float* pred, const float* rec, const float* fut,
                           const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd, float scale_mse,
                           float scale_rec, float kl_denom, float min_clip, float* out, float* dpred, float* drec, float* dqzp,
                           float* scratch, long scratch_floats, void* stream);
+/* The same objective, gradients for the LIVE decoder columns only.  Of an agent's K1 trajectory columns only sample 0 (posterior draw: the
+ * mse and recover terms, model/STTODE.py:553-560) and the best of samples 1..K (loss_diverse takes the min over K, :390-395: torch's min
+ * passes its gradient to the selected sample alone) receive a gradient; the decoder treats columns independently, so the backward pass of
+ * every other column is exactly zero.  -> dpred2 [n,2,D], drec2 [n,2,Dp] (row 1 zero), best [n] (1..K: which sample row 1 is), out / dqzp
+ * as above.  The reference's autograd multiplies through the zero rows; a backward pass over 2 n instead of K1 n columns is the same
+ * gradient (tests/test_gpu_parity.py::test_training_step_vs_reference_*). */
+int sttode_loss_objective_live(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                               const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd, float scale_mse,
+                               float scale_rec, float kl_denom, float min_clip, float* out, float* dpred2, float* drec2, float* dqzp,
+                               int* best, float* scratch, long scratch_floats, void* stream);
+/* ... and the rows of the forward pass's tape for those columns: items = HOST array of `count` <= 32 records {const float* src; float* dst;
+ * long src_plane; long dst_plane; int row; int outer;} (40 bytes): src is `outer` planes (src_plane floats apart) of [n K1] rows of `row`
+ * floats, dst `outer` planes (dst_plane apart) of [2 n] rows; dst row 2 a + j = src row a K1 + (j ? best[a] : 0).  One launch. */
+int sttode_live_rows_gather(const void* items, int count, const int* best, int n, int K1, void* stream);
 /* forward() returns its four loss terms as Python floats (model/STTODE.py:568: four `.item()`, each a synchronisation with the END of the
  * queue).  Inside a replayed step the values exist after the forward half: sttode_publish_values (one launch, capturable) copies
  * vals [n <= 64] (DEVICE) into host_vals [n] (pinned HOST memory, device-accessible), increments *dev_seq (DEVICE, zero before the first

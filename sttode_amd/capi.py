@@ -94,6 +94,8 @@ SIGNATURES = {
     'sttode_set_scene_launch': [_P, _I],
     'sttode_stage_scene': [_P, _P, _I, _I, _I, _P, _P],
     'sttode_stage_rows': [_P, _L, _P, _L, _P, _P],
+    'sttode_loss_objective_live': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P],
+    'sttode_live_rows_gather': [_P, _I, _P, _I, _I, _P],
     'sttode_publish_values': [_P, _I, _P, _P, _P, _P],
     'sttode_wait_value': [_P, _L, _D],
     'sttode_async_next_stream': [_P, _I, _P],

@@ -1987,6 +1987,11 @@ struct ObjArgs {
                    // the row's UNCLAMPED gradient; objective_sum adds them up, applies the clamp and -- where it is active -- zeroes dqzp.  (Round 4:
                    // one block walked all n zd terms twice, 43 us of a 2.3-ms NBA-size step.)
     float scale_mse, scale_rec, kl_denom, min_clip;
+    // live form (best != nullptr; sttode_loss_objective_live): of an agent's K1 decoder columns only sample 0 (posterior: mse + recover terms)
+    // and the best of the prior samples (the min over K of loss_diverse, model/STTODE.py:390-395) receive a gradient -- every other
+    // column's is exactly zero.  The gradients are written for those two columns only, dpred2 [n][2][D] / drec2 [n][2][Dp] (row 1 of
+    // drec2 = 0), and best [n] names the second one (1..K); dpred / drec are not written.
+    int* best; float* dpred2; float* drec2;
 };
 __global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
     __shared__ float red[256];
@@ -2023,9 +2028,12 @@ __global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
     const float* ra = o.rec + (long)a * K1 * Dp;
     // sample 0: squared errors + gradients
     float e0 = 0.f, e1 = 0.f;
-    for (int d = t; d < D; d += 256) { const float df = pa[d] - o.fut[(long)a * D + d]; e0 += df * df; o.dpred[(long)a * K1 * D + d] = 2.0f * o.scale_mse * df; }
-    for (int d = t; d < Dp; d += 256) { const float df = ra[d] - o.past[(long)a * Dp + d]; e1 += df * df; o.drec[(long)a * K1 * Dp + d] = 2.0f * o.scale_rec * df; }
-    for (int i = Dp + t; i < K1 * Dp; i += 256) o.drec[(long)a * K1 * Dp + i] = 0.f;
+    const bool live = o.best != nullptr;
+    float* dp0 = live ? o.dpred2 + (long)a * 2 * D : o.dpred + (long)a * K1 * D;
+    float* dr0 = live ? o.drec2 + (long)a * 2 * Dp : o.drec + (long)a * K1 * Dp;
+    for (int d = t; d < D; d += 256) { const float df = pa[d] - o.fut[(long)a * D + d]; e0 += df * df; dp0[d] = 2.0f * o.scale_mse * df; }
+    for (int d = t; d < Dp; d += 256) { const float df = ra[d] - o.past[(long)a * Dp + d]; e1 += df * df; dr0[d] = 2.0f * o.scale_rec * df; }
+    for (int i = Dp + t; i < (live ? 2 : K1) * Dp; i += 256) dr0[i] = 0.f;
     const float s0 = block_sum(e0, red), s1 = block_sum(e1, red);
     // samples 1..K: first minimum of the summed squared error (torch.min), weight 1 / (agents of the scene)
     float wgt = 1.0f / (float)o.n;
@@ -2050,9 +2058,14 @@ __global__ __launch_bounds__(256) void objective_kernel(ObjArgs o) {
     }
     __syncthreads();
     const int bk = sk + 1;
-    for (int i = D + t; i < K1 * D; i += 256) {
-        const int k = i / D, d = i % D;
-        o.dpred[(long)a * K1 * D + i] = k == bk ? 2.0f * (pa[i] - o.fut[(long)a * D + d]) * wgt : 0.f;
+    if (live) {
+        for (int d = t; d < D; d += 256) dp0[D + d] = 2.0f * (pa[(long)bk * D + d] - o.fut[(long)a * D + d]) * wgt;
+        if (t == 0) o.best[a] = bk;
+    } else {
+        for (int i = D + t; i < K1 * D; i += 256) {
+            const int k = i / D, d = i % D;
+            o.dpred[(long)a * K1 * D + i] = k == bk ? 2.0f * (pa[i] - o.fut[(long)a * D + d]) * wgt : 0.f;
+        }
     }
     if (t == 0) { o.part[a] = s0; o.part[o.n + a] = s1; o.part[2 * (long)o.n + a] = sv[0] * wgt; }
     if (o.kl_rows) {                  // this agent's row of the KL term (arithmetic of kl_kernel), gradient as if the clamp were inactive
@@ -2092,10 +2105,10 @@ __global__ __launch_bounds__(256) void objective_sum_kernel(const float* part, i
         out[4] = ((l0 + l1) + s3) + s2;   // total_loss (model/STTODE.py:568)
     }
 }
-extern "C" int sttode_loss_objective(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
-                                     const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd,
-                                     float scale_mse, float scale_rec, float kl_denom, float min_clip, float* out, float* dpred,
-                                     float* drec, float* dqzp, float* scratch, long scratch_floats, void* stream) {
+static int loss_objective_impl(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                               const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd,
+                               float scale_mse, float scale_rec, float kl_denom, float min_clip, float* out, float* dpred,
+                               float* drec, float* dqzp, int* best, float* scratch, long scratch_floats, void* stream) {
     STT_REQUIRE(pred && rec && fut && past && qzp && out && dpred && drec && dqzp && scratch, "sttode_loss_objective: null pointer");
     STT_REQUIRE(n > 0 && K1 >= 2 && K1 <= 65 && D > 0 && Dp > 0 && zd > 0, "sttode_loss_objective: bad sizes (2 <= K1 <= 65)");
     STT_REQUIRE(scene_ptr ? (S > 0 && agent_scene) : kl_denom > 0.f, "sttode_loss_objective: scene_ptr needs S > 0 and agent_scene, otherwise kl_denom > 0");
@@ -2104,12 +2117,70 @@ extern "C" int sttode_loss_objective(const float* pred, const float* rec, const 
     STT_REQUIRE(3L * n + (scene_ptr ? S : n) <= scratch_floats, "sttode_loss_objective: scratch too small (3 n + max(S, n) floats)");
     ObjArgs o;
     o.pred = pred; o.rec = rec; o.fut = fut; o.past = past; o.qzp = qzp; o.scene_ptr = scene_ptr; o.agent_scene = agent_scene;
-    o.dpred = dpred; o.drec = drec; o.dqzp = dqzp; o.part = scratch;
+    o.dpred = best ? nullptr : dpred; o.drec = best ? nullptr : drec; o.dqzp = dqzp; o.part = scratch;
+    o.best = best; o.dpred2 = best ? dpred : nullptr; o.drec2 = best ? drec : nullptr;
     o.n = n; o.K1 = K1; o.D = D; o.Dp = Dp; o.zd = zd; o.nb = nb; o.kl_rows = kl_rows;
     o.scale_mse = scale_mse; o.scale_rec = scale_rec; o.kl_denom = kl_denom; o.min_clip = min_clip;
     hipLaunchKernelGGL(objective_kernel, dim3(n + nb), dim3(256), 0, (hipStream_t)stream, o);
     hipLaunchKernelGGL(objective_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n, nb, scale_mse, scale_rec, out, kl_rows, kl_denom,
                        min_clip, dqzp, zd);
+    STT_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int sttode_loss_objective(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                                     const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd,
+                                     float scale_mse, float scale_rec, float kl_denom, float min_clip, float* out, float* dpred,
+                                     float* drec, float* dqzp, float* scratch, long scratch_floats, void* stream) {
+    return loss_objective_impl(pred, rec, fut, past, qzp, scene_ptr, agent_scene, S, n, K1, D, Dp, zd, scale_mse, scale_rec, kl_denom, min_clip, out,
+                               dpred, drec, dqzp, nullptr, scratch, scratch_floats, stream);
+}
+extern "C" int sttode_loss_objective_live(const float* pred, const float* rec, const float* fut, const float* past, const float* qzp,
+                                          const int* scene_ptr, const int* agent_scene, int S, int n, int K1, int D, int Dp, int zd,
+                                          float scale_mse, float scale_rec, float kl_denom, float min_clip, float* out, float* dpred2,
+                                          float* drec2, float* dqzp, int* best, float* scratch, long scratch_floats, void* stream) {
+    STT_REQUIRE(best, "sttode_loss_objective_live: null pointer");
+    return loss_objective_impl(pred, rec, fut, past, qzp, scene_ptr, agent_scene, S, n, K1, D, Dp, zd, scale_mse, scale_rec, kl_denom, min_clip, out,
+                               dpred2, drec2, dqzp, best, scratch, scratch_floats, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The rows of the decoder's tape that carry a gradient (sttode_loss_objective_live): per agent, of its K1 trajectory columns, sample 0 and
+// sample best[a] -> rows 2 a and 2 a + 1 of a compact copy.  Every tensor of the tape is rows of `row` floats, `outer` planes of them
+// (the GRU's per-step planes [T][columns][..]); up to STT_GATHER_MAX tensors per launch, one workgroup per (tensor, plane, output row).
+// ---------------------------------------------------------------------------------------------------
+#define STT_GATHER_MAX 32
+struct GatherItem { const float* src; float* dst; long src_plane; long dst_plane; int row; int outer; };   // planes in floats
+struct GatherArgs { GatherItem it[STT_GATHER_MAX]; int blk0[STT_GATHER_MAX + 1]; int count; const int* best; int n, K1; };
+__global__ __launch_bounds__(128) void live_rows_gather_kernel(GatherArgs g) {
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const GatherItem& it = g.it[p];
+    const int local = (int)blockIdx.x - g.blk0[p], rows = 2 * g.n;
+    const int o = local / rows, r = local % rows, a = r >> 1;
+    const int sidx = (r & 1) ? g.best[a] : 0;
+    const float* src = it.src + (long)o * it.src_plane + ((long)a * g.K1 + sidx) * it.row;
+    float* dst = it.dst + (long)o * it.dst_plane + (long)r * it.row;
+    if ((it.row & 3) == 0 && ((((size_t)src) | ((size_t)dst)) & 15) == 0) {
+        for (int i = threadIdx.x; i < it.row / 4; i += 128) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < it.row; i += 128) dst[i] = src[i];
+    }
+}
+extern "C" int sttode_live_rows_gather(const void* items_, int count, const int* best, int n, int K1, void* stream) {
+    const GatherItem* items = (const GatherItem*)items_;
+    STT_REQUIRE(items && best && count > 0 && count <= STT_GATHER_MAX && n > 0 && K1 >= 2, "sttode_live_rows_gather: null pointer or bad counts (at most 32 tensors)");
+    GatherArgs g;
+    g.count = count; g.best = best; g.n = n; g.K1 = K1;
+    long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        STT_REQUIRE(items[i].src && items[i].dst && items[i].row > 0 && items[i].outer > 0, "sttode_live_rows_gather: bad item");
+        g.it[i] = items[i];
+        g.blk0[i] = (int)blocks;
+        blocks += (long)items[i].outer * 2 * n;
+    }
+    STT_REQUIRE(blocks < (1L << 31), "sttode_live_rows_gather: too many rows");
+    g.blk0[count] = (int)blocks;
+    hipLaunchKernelGGL(live_rows_gather_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, g);
     STT_HIP(hipGetLastError());
     return 0;
 }

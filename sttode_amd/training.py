@@ -10,12 +10,23 @@ one ``autograd.Function``, hands the finished gradients to ``.grad`` so that ``o
 There is no eager / CPU fallback.
 """
 import contextlib
+import ctypes
 import os
 
 import torch
 
 from . import capi
 from .capi import SttodeError
+
+# backward over the decoder columns that carry a gradient (Engine.decoder_live); STTODE_TRAIN_LIVE=0: over all 21 per agent, as rounds 1-4
+_LIVE_COLUMNS = os.environ.get('STTODE_TRAIN_LIVE', '1') != '0'
+_GATHER_MAX = 32
+
+
+class _GatherItem(ctypes.Structure):                 # csrc/train.hip GatherItem (include/sttode_hip.h sttode_live_rows_gather)
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('src_plane', ctypes.c_long),
+                ('dst_plane', ctypes.c_long), ('row', ctypes.c_int), ('outer', ctypes.c_int)]
+
 
 EW_MUL, EW_AXPY, EW_GATE_BWD, EW_EULER_FWD, EW_EULER_BWD, EW_RSAMPLE, EW_RELU_BWD, EW_FILL, EW_RSAMPLE_BWD, EW_CUR_ADD = range(10)
 EW_TANH_BWD, EW_LATENT_BWD, EW_SUM_CUR, EW_EULER_BWD_CAT, EW_SCALE_ADD, EW_AXPY_ROWS = 10, 11, 12, 13, 14, 15
@@ -620,6 +631,40 @@ class Engine:
                 self.ew(EW_SUM_CUR, rec, xsum, blocks[-1]['xh'] if nb > 1 else self.zeros(m, 2 * Tp), None, i0=2 * Tp, f0=K)
         return dict(blocks=blocks, b0=blocks[0], b1=blocks[-1], n=n, K=K, m=m, pred=pred, rec=rec, split=self.split)
 
+    def decoder_live(self, d, best):
+        """The decoder's tape reduced to the columns that carry a gradient.  forward() decodes 1 + 20 samples per agent, but the objective
+        (model/STTODE.py:553-568) touches sample 0 (mse + recover terms) and, through the min over K of loss_diverse (:390-395), ONE of
+        the prior samples per agent; the decoder treats trajectory columns independently (conv, GRU and MLPs per column,
+        model/STTODE.py:50-77), so the backward pass of the other 19 columns is exactly zero in every layer and contributes nothing to
+        any parameter gradient.  The reference's autograd multiplies through those zeros; here the tape rows of the two live columns per
+        agent are gathered (ONE launch, csrc/train.hip live_rows_gather_kernel) and the backward pass runs over 2 n columns instead of
+        21 n -- the same gradient (the reference's own backward() digests: tests/test_gpu_parity.py::test_training_step_vs_reference_*)."""
+        n, K1, m2 = d['n'], d['K'], 2 * d['n']
+        items, blocks = [], []
+
+        def take(src, row, outer=1):
+            m = n * K1
+            dst = self.new(outer * m2 * row)
+            assert src.is_contiguous() and src.numel() == outer * m * row
+            items.append(_GatherItem(src.data_ptr(), dst.data_ptr(), m * row, m2 * row, row, outer))
+            return dst
+        for b in d['blocks']:
+            Tp = b['Tp']
+            nb = dict(pre=b['pre'], m=m2, Tp=Tp, K=2, pf=b['pf'])
+            nb['x'] = take(b['x'], 2 * Tp).view(m2, Tp, 2)
+            nb['e'] = take(b['e'], Tp * 32).view(m2 * Tp, 32)
+            nb['H'] = take(b['H'], 96, Tp + 1).view(Tp + 1, m2, 96)
+            nb['tapes'] = take(b['tapes'], 384, Tp).view(Tp, m2, 384)
+            nb['inp'] = take(b['inp'], self.IN).view(m2, self.IN)
+            for key in ('sy', 'sx'):
+                nb[key] = tuple(take(t, t.shape[1]).view(m2, t.shape[1]) for t in b[key]) if b[key] is not None else None
+            blocks.append(nb)
+        for i in range(0, len(items), _GATHER_MAX):
+            chunk = items[i:i + _GATHER_MAX]
+            table = (_GatherItem * len(chunk))(*chunk)              # (a named object: it must outlive the call that reads it)
+            capi.call('sttode_live_rows_gather', table, len(chunk), best, n, K1, self.st)
+        return dict(blocks=blocks, b0=blocks[0], b1=blocks[-1], n=n, K=2, m=m2, split=d.get('split', False))
+
     def decoder_bwd(self, d, dpred, drec, dpf, dz, dpf_accumulate=True):
         """Accumulates dpf [n, 2 D] (+=; ``dpf_accumulate=False``: writes it); writes dz [m, zd] if not None.  Returns the gradient of the
         blocks' summed layer-1 input [m, IN] = cat(d pf_rep | d z | d state) (its columns 2 D .. 2 D + zd - 1 are dz)."""
@@ -710,18 +755,25 @@ class Engine:
             assert zd % 4 == 0 and eps20.is_contiguous() and qz.is_contiguous()
             d = self.decoder_fwd(hcat[:, :PFW], None, K1, past, ws['cur'], True, qz_eps=(qz, eps20))
             losses = self.new(5)                                    # the four terms and their sum
-            dpred, drec, dqzp = self.new(n * K1, 2 * Tf), self.new(n * K1, 2 * Tp), self.new(n, 2 * zd)
+            live = _LIVE_COLUMNS
+            KG = 2 if live else K1                                  # columns per agent that carry a gradient (see decoder_live)
+            dpred, drec, dqzp = self.new(n * KG, 2 * Tf), self.new(n * KG, 2 * Tp), self.new(n, 2 * zd)
+            best = self.hold(torch.empty(n, dtype=torch.int32, device=self.dev)) if live else None
             # several independent scenes in one step (set_scene_batch): the objective is the SUM of the per-scene objectives, i.e. the
             # gradient equals what S reference steps would accumulate (per-scene KL clamp and per-scene mean of the best-of-20 term)
             seg = net._mode == 'scenes' and net._S > 1
             sp, ags, S = (net._scene_ptr, ws['agent_scene'], net._S) if seg else (None, None, 0)
-            capi.call('sttode_loss_objective', d['pred'], d['rec'], fut, past, qzp, sp, ags, S, n, K1, 2 * Tf, 2 * Tp, zd, 1.0 / (B * Tf),
-                      1.0 / (B * Tp), float(B * N), float(a.min_clip), losses, dpred, drec, dqzp, self.scratch, self.scratch.numel(), self.st)
+            if live:
+                capi.call('sttode_loss_objective_live', d['pred'], d['rec'], fut, past, qzp, sp, ags, S, n, K1, 2 * Tf, 2 * Tp, zd, 1.0 / (B * Tf),
+                          1.0 / (B * Tp), float(B * N), float(a.min_clip), losses, dpred, drec, dqzp, best, self.scratch, self.scratch.numel(), self.st)
+            else:
+                capi.call('sttode_loss_objective', d['pred'], d['rec'], fut, past, qzp, sp, ags, S, n, K1, 2 * Tf, 2 * Tp, zd, 1.0 / (B * Tf),
+                          1.0 / (B * Tp), float(B * N), float(a.min_clip), losses, dpred, drec, dqzp, self.scratch, self.scratch.numel(), self.st)
             if getattr(self, 'publish', None) is not None:         # a step being captured: the values reach the host from HERE (see _GraphedStep)
                 capi.call('sttode_publish_values', losses, 5, *self.publish, self.st)
             self.step_id = getattr(self, 'step_id', 0) + 1
             self.tape = dict(step_id=self.step_id, tp=V['tp'], tf=V['tf'], hcat=hcat, hq=hq, qzp=qzp, eps_q=eps_q, d=d, dpred=dpred,
-                             drec=drec, dqzp=dqzp, n=n, zd=zd, K1=K1)
+                             drec=drec, dqzp=dqzp, n=n, zd=zd, K1=K1, best=best)
             V['losses'] = losses
             # attributes the reference sets (read by callers)
             pr = d['pred'].view(n, K1, Tf, 2)
@@ -757,12 +809,15 @@ class Engine:
             if self.red_scratch is not None:                            # batch sizes: the split weight gradients' reductions as one launch per 16
                 capi.call('sttode_twgrad_defer', 1, self.red_scratch, self.red_scratch.numel())
             W['dpf'] = dpf = self.new(n, self.PFW)
-            din = self.decoder_bwd(T['d'], T['dpred'], T['drec'], dpf, None, dpf_accumulate=False)
-            dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent: dz of row a K1
-            if T['d'].get('split'):
-                capi.call('sttode_rows_copy', dqz, zd, din, K1 * self.ZS, n, zd, 1, n, self.st)
+            d, KG = T['d'], K1
+            if T.get('best') is not None:                               # backward over the two columns per agent that carry a gradient
+                d, KG = self.decoder_live(T['d'], T['best']), 2
+            din = self.decoder_bwd(d, T['dpred'], T['drec'], dpf, None, dpf_accumulate=False)
+            dqz = self.new(n, zd)                                       # gradient of the posterior draw = sample 0 of every agent: dz of row a KG
+            if d.get('split'):
+                capi.call('sttode_rows_copy', dqz, zd, din, KG * self.ZS, n, zd, 1, n, self.st)
             else:
-                capi.call('sttode_rows_copy', dqz, zd, din[:, self.PFW:], K1 * self.IN, n, zd, 1, n, self.st)
+                capi.call('sttode_rows_copy', dqz, zd, din[:, self.PFW:], KG * self.IN, n, zd, 1, n, self.st)
             dqzp = T['dqzp']                                            # starts as the KL gradient
             self.ew(EW_RSAMPLE_BWD, dqz, T['qzp'], T['eps_q'], dqzp, i0=zd)
             dhq = self.lin_bwd(dqzp, P['future_encoder.qz_layer.weight'], T['hq'], g('future_encoder.qz_layer.weight'),
@@ -1003,7 +1058,6 @@ def _names_params(eng, net):
 
 _GRAPH_MAX_AGENTS = int(os.environ.get('STTODE_TRAIN_GRAPH_MAX', '512'))
 _DROP_KEEP = 0.9
-
 
 def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, drop_future=None):
     """STTODENet.forward() with autograd support (see module docstring).  Returns the reference's 5-tuple.
