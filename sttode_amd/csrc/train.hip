@@ -1791,6 +1791,93 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* qkv, const f
         }
     }
 }
+// The same backward with the L x L pair work spread over the whole workgroup (round 5): the kernel above gives every key row / query
+// column ONE thread that walks all L partners three times (exp, acos, sqrt per pair) -- at the NBA training batch (L = 32: 32 active
+// lanes per workgroup) 36 us per trunk, 5 % of the step.  Here a thread owns pairs (phases A, C) or one (row, d) output element (phase D);
+// the per-pair terms are computed once and kept in LDS.  Every sum over partners runs in the order of the kernel above and every term
+// is the same expression; only the HD-term tangent projection is a lane butterfly instead of a loop (differences at fp32 rounding).
+// LDS: 3 L^2 + L (4 HD + 4) floats (L <= ~100).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_pairs_kernel(const float* qkv, const float* dO, float* dqkv, int L, int Nb) {
+    constexpr int DM = 8 * HD;
+    extern __shared__ float sm[];
+    float* kh = sm;
+    float* qh = kh + L * HD;
+    float* vv = qh + L * HD;
+    float* dd = vv + L * HD;
+    float* rinv = dd + L * HD;
+    float* rdot = rinv + L;
+    float* kn = rdot + L;
+    float* qn = kn + L;
+    float* E = qn + L;            // [L][L] exp(-acos(.)), then P
+    float* DP = E + L * L;        // [L][L] dO_i . v_j, then g
+    float* G0 = DP + L * L;       // [L][L] sqrt(1 - x^2) inside the clamp, else 0
+    const int slot = blockIdx.x / 8, h = blockIdx.x % 8, t = threadIdx.x;
+    for (int l = t; l < L; l += 256) {
+        const float* row = qkv + ((long)l * Nb + slot) * (3 * DM) + h * HD;
+        float q[HD], k[HD], sq = 0.f, sk = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { q[d] = row[d]; k[d] = row[DM + d]; sq += q[d] * q[d]; sk += k[d] * k[d]; }
+        const float iq = 1.0f / sqrtf(sq), ik = 1.0f / sqrtf(sk);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            qh[l * HD + d] = q[d] * iq;
+            kh[l * HD + d] = k[d] * ik;
+            vv[l * HD + d] = row[2 * DM + d];
+            dd[l * HD + d] = dO[((long)l * Nb + slot) * DM + h * HD + d];
+        }
+        qn[l] = iq;
+        kn[l] = ik;
+    }
+    __syncthreads();
+    const float lo = -1.0f + 1e-4f, hi = 1.0f - 1e-4f;
+    for (int p = t; p < L * L; p += 256) {                     // A: per pair (i = key row, j = query column)
+        const int i = p / L, j = p % L;
+        float dot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dot += kh[i * HD + d] * qh[j * HD + d]; dp += dd[i * HD + d] * vv[j * HD + d]; }
+        const bool inside = dot > lo && dot < hi;
+        const float cl = fminf(fmaxf(dot, lo), hi);
+        E[p] = expf(-acosf(cl));
+        DP[p] = dp;
+        G0[p] = inside ? sqrtf(1.0f - cl * cl) : 0.f;            // (>= 0.014 inside the clamp: 0 marks 'outside')
+    }
+    __syncthreads();
+    for (int i = t; i < L; i += 256) {                         // B: row sums, partners in order
+        float se = 0.f, sp = 0.f;
+        for (int j = 0; j < L; ++j) { const float ex = E[i * L + j]; se += ex; sp += ex * DP[i * L + j]; }
+        rinv[i] = 1.0f / se;
+        rdot[i] = sp / se;
+    }
+    __syncthreads();
+    for (int p = t; p < L * L; p += 256) {                     // C: P and g per pair
+        const int i = p / L;
+        const float P = E[p] * rinv[i];
+        const float dS = P * (DP[p] - rdot[i]);
+        const float g0 = G0[p];
+        E[p] = P;
+        DP[p] = g0 != 0.f ? dS / g0 : 0.f;                     // d(-acos x)/dx = 1/sqrt(1-x^2)
+    }
+    __syncthreads();
+    // D: one output element per thread: (row, d); the tangent projection needs the row's HD elements: they sit in HD consecutive lanes
+    for (int e0 = 0; e0 < L * HD; e0 += 256) {
+        const int e = e0 + t;
+        const bool on = e < L * HD;
+        const int r = on ? e / HD : 0, d = e % HD;
+        float dk = 0.f, dq = 0.f, dv = 0.f;
+        for (int j = 0; j < L; ++j) dk += DP[r * L + j] * qh[j * HD + d];
+        for (int i = 0; i < L; ++i) { dq += DP[i * L + r] * kh[i * HD + d]; dv += E[i * L + r] * dd[i * HD + d]; }
+        float pk = dk * kh[r * HD + d], pq = dq * qh[r * HD + d];
+#pragma unroll
+        for (int sh = 1; sh < HD; sh <<= 1) { pk += __shfl_xor(pk, sh, 64); pq += __shfl_xor(pq, sh, 64); }
+        if (on) {
+            float* o = dqkv + ((long)r * Nb + slot) * (3 * DM) + h * HD + d;
+            o[0] = (dq - qh[r * HD + d] * pq) * qn[r];
+            o[DM] = (dk - kh[r * HD + d] * pk) * kn[r];
+            o[2 * DM] = dv;
+        }
+    }
+}
 extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* dqkv, int L, int Nb, int head_dim, void* stream) {
     STT_REQUIRE(qkv && dO && dqkv && L > 0 && Nb > 0, "sttode_mhgsa_attn_bwd: bad argument");
     STT_REQUIRE(head_dim == 4 || head_dim == 8 || head_dim == 16, "sttode_mhgsa_attn_bwd: head_dim must be 4, 8 or 16 (hidden_dim 32 / 64 / 128)");
@@ -1801,7 +1888,19 @@ extern "C" int sttode_mhgsa_attn_bwd(const float* qkv, const float* dO, float* d
         STT_SET_LDS_ONCE(attn_bwd_kernel<HD>, 160 * 1024);                                                                            \
         hipLaunchKernelGGL(attn_bwd_kernel<HD>, dim3(Nb * 8), dim3(L < 256 ? ((L + 63) / 64) * 64 : 256), shm, (hipStream_t)stream, qkv, dO, dqkv, L, Nb); \
     } while (0)
-    if (head_dim == 8) ATTB_GO(8); else if (head_dim == 4) ATTB_GO(4); else ATTB_GO(16);
+    const size_t shm2 = shm + (size_t)3 * L * L * sizeof(float);
+#define ATTB_PAIRS(HD)                                                                                                                \
+    do {                                                                                                                              \
+        STT_SET_LDS_ONCE(attn_bwd_pairs_kernel<HD>, 160 * 1024);                                                                      \
+        hipLaunchKernelGGL(attn_bwd_pairs_kernel<HD>, dim3(Nb * 8), dim3(256), shm2, (hipStream_t)stream, qkv, dO, dqkv, L, Nb);        \
+    } while (0)
+    static const bool pairs = !(getenv("STTODE_ATTN_BWD_PAIRS") && atoi(getenv("STTODE_ATTN_BWD_PAIRS")) == 0);
+    if (pairs && L >= 4 && shm2 <= 150 * 1024) {
+        if (head_dim == 8) ATTB_PAIRS(8); else if (head_dim == 4) ATTB_PAIRS(4); else ATTB_PAIRS(16);
+    } else {
+        if (head_dim == 8) ATTB_GO(8); else if (head_dim == 4) ATTB_GO(4); else ATTB_GO(16);
+    }
+#undef ATTB_PAIRS
 #undef ATTB_GO
     STT_HIP(hipGetLastError());
     return 0;

@@ -423,12 +423,19 @@ class Engine:
                 s['dattn'] = self.lin_bwd(s['dao'], P[op + 'out_proj.weight'], t['attn'], g(op + 'out_proj.weight'), g(op + 'out_proj.bias'))
         for s in S:
             t = s['t']
-            s['dqkv'] = self.new(s['n'], 3 * D)
-            capi.call('sttode_mhgsa_attn_bwd', t['qkv'], s['dattn'], s['dqkv'], t['L'], t['Nb'], HD, self.st)
+            if t['L'] > 1:
+                s['dqkv'] = self.new(s['n'], 3 * D)
+                capi.call('sttode_mhgsa_attn_bwd', t['qkv'], s['dattn'], s['dqkv'], t['L'], t['Nb'], HD, self.st)
         with self.group():
             for s in S:
                 t, op = s['t'], s['op']
-                self.lin_bwd(s['dqkv'], P[op + 'in_proj_weight'], t['xc'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias'), out=s['dx'], accumulate=True)
+                W, gW, gb = P[op + 'in_proj_weight'], g(op + 'in_proj_weight'), g(op + 'in_proj_bias')
+                if t['L'] > 1:
+                    self.lin_bwd(s['dqkv'], W, t['xc'], gW, gb, out=s['dx'], accumulate=True)
+                else:
+                    # attention length 1 (scene batches): the softmax over one key is 1, the output is v -- dv = dattn, and the gradients of
+                    # q and k are exactly zero (their rows of the in-projection's gradient stay the zeros of the flat buffer)
+                    self.lin_bwd(s['dattn'], W[2 * D:], t['xc'], gW[2 * D:], gb[2 * D:], out=s['dx'], accumulate=True)
         # dx is now the gradient wrt ftraj_input
         with self.group():
             for s in S:

@@ -3611,3 +3611,29 @@ def test_replayed_step_draws_its_own_noise_like_the_eager_step(mode):
     for a, b in zip(*runs):
         np.testing.assert_allclose(b, a, rtol=2e-5)
     assert len({v[0] for v in runs[1]}) == 5                        # every replay drew fresh noise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L,Nb,hd', [(3, 4, 8), (5, 11, 8), (16, 11, 8), (32, 11, 8), (32, 3, 4), (24, 5, 16), (64, 2, 8), (128, 1, 8)])
+def test_attention_backward_kernels_vs_autograd(L, Nb, hd):
+    """sttode_mhgsa_attn_bwd against torch autograd (float64) of the same op -- out_i = sum_j softmax_j(-acos(clamp(k^_i . q^_j))) v_j per
+    (slot, head), scores untransposed (hyptransformerlib.py:261-265) -- for both of its forms: one thread per row (L < 4 or the L x L
+    terms beyond the LDS) and the pair-parallel form of round 5 (4 <= L <= ~100)."""
+    from sttode_amd import capi
+    dev = _gpu()
+    DM = 8 * hd
+    g = torch.Generator().manual_seed(100 * L + hd)
+    qkv = torch.randn(L * Nb, 3 * DM, generator=g)
+    dO = torch.randn(L * Nb, DM, generator=g)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, i * DM:(i + 1) * DM].view(L, Nb, 8, hd) for i in range(3))
+    qn, kn = q / q.norm(dim=-1, keepdim=True), k / k.norm(dim=-1, keepdim=True)
+    dots = torch.einsum('inhd,jnhd->nhij', kn, qn).clamp(-1 + 1e-4, 1 - 1e-4)          # [slot, head, key row i, query column j]
+    P = torch.softmax(-torch.acos(dots), dim=-1)
+    out = torch.einsum('nhij,jnhd->inhd', P, v).reshape(L * Nb, DM)
+    out.backward(dO.double())
+    got = torch.empty(L * Nb, 3 * DM, device=dev)
+    capi.call('sttode_mhgsa_attn_bwd', qkv.to(dev), dO.to(dev), got, L, Nb, hd, capi.stream_ptr())
+    ref = x.grad
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * (1 + ref.abs().max().item()), (err, ref.abs().max().item())
