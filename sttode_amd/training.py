@@ -34,6 +34,7 @@ ACT = {None: 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 _ATT = 'ODE_Encoder.odeblock.odefunc.layers.0.'
 
 
+_AGENT_GRU = os.environ.get('STTODE_TRAIN_AGENT_GRU', '1') != '0'   # the first block's conv + GRU once per agent (0: per trajectory column, A/B)
 _PAIRED = os.environ.get('STTODE_TRAIN_PAIRED', '1') != '0'   # decoder_x / decoder_y of a block layer by layer, grouped launches (0: A/B)
 # Layer 1 of the decoder MLPs split like the inference chain's (round 5): W1 cat(pf_rep, z, state) = (W1[:, pf] pf + b1) per AGENT -- a table of
 # n rows shared by the agent's K samples -- + W1[:, z | state] [z | state] per trajectory: half the layer's products forward and in both
@@ -541,17 +542,28 @@ class Engine:
         pre = f'decoder.decompose.{i}.'
         n, Tp = past.shape[0], past.shape[1]
         m = n * K
-        x, e = self.new(m, Tp, 2), self.new(m * Tp, 32)
-        capi.call('sttode_conv_fwd', past, K, xhat_prev, P[pre + 'conv_past.weight'], P[pre + 'conv_past.bias'], x, e, m, Tp, self.st)
-        gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [m*Tp, 288], row c*Tp + t
-        H = self.new(Tp + 1, m, 96)                                                                      # H[0] = 0 (written by the launch), H[t+1] = h_t
-        tapes = self.new(Tp, m, 384)
+        # The first block reads x_true - 0: its conv + GRU see the same track for every sample of an agent (model/STTODE.py:329-335, x_hat = 0).
+        # Run them ONCE per agent and hand the state to the agent's K columns (the inference path has done so since round 1) -- K = 21 in
+        # forward(): a 21 x smaller input projection and GRU sequence; the backward sums the K columns' state gradients first (block_bwd).
+        agent = xhat_prev is None and K > 1 and _AGENT_GRU
+        mg, Kg = (n, 1) if agent else (m, K)
+        x, e = self.new(mg, Tp, 2), self.new(mg * Tp, 32)
+        capi.call('sttode_conv_fwd', past, Kg, xhat_prev, P[pre + 'conv_past.weight'], P[pre + 'conv_past.bias'], x, e, mg, Tp, self.st)
+        gi = self.lin(e, P[pre + 'encoder_past.weight_ih_l0'], P[pre + 'encoder_past.bias_ih_l0'])       # [mg*Tp, 288], row c*Tp + t
+        H = self.new(Tp + 1, mg, 96)                                                                     # H[0] = 0 (written by the launch), H[t+1] = h_t
+        tapes = self.new(Tp, mg, 384)
         prefix = inp is None                                                                             # cat(pf_rep, z, state): the prefix may come filled (decoder_fwd)
         IN, ST, PFW, ZD = self.IN, self.ST, self.PFW, self.ZD
         if prefix:
             inp = self.new(m, IN)
-        capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
-                  inp[:, ST:], IN, m, Tp, self.st)                                                       # all Tp steps, one launch
+        if agent:
+            state = self.new(n, 96)
+            capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
+                      state, 96, n, Tp, self.st)
+            capi.call('sttode_rows_copy', inp[:, ST:], IN, state, 96, m, 96, K, n, self.st)              # row c of inp <- state of agent c / K
+        else:
+            capi.call('sttode_gru_seq_fwd', gi, P[pre + 'encoder_past.weight_hh_l0'], P[pre + 'encoder_past.bias_hh_l0'], H, tapes,
+                      inp[:, ST:], IN, m, Tp, self.st)                                                   # all Tp steps, one launch
         if prefix:
             if not self.split:                                                                           # (layer-1 split: the pf columns of inp are never read)
                 capi.call('sttode_rows_copy', inp, IN, pf, _ld(pf), m, PFW, K, n, self.st)
@@ -564,7 +576,7 @@ class Engine:
         else:
             yh, sy = self.mlp_fwd(pre + 'decoder_y.', inp, tabs[0], K)
             xh, sx = self.mlp_fwd(pre + 'decoder_x.', inp, tabs[1], K) if want_x else (None, None)
-        return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx, pf=pf if self.split else None)
+        return dict(pre=pre, m=m, Tp=Tp, K=K, x=x, e=e, H=H, tapes=tapes, inp=inp, yh=yh, sy=sy, xh=xh, sx=sx, pf=pf if self.split else None, agent=agent)
 
     def block_bwd(self, b, dyh, dxh, need_dx, dpf=None):
         """Returns (din [m, IN] -- layer-1 split: [m, ZS], the trajectory's own columns [z | state]; the pf part went into dpf -- , dx [m,Tp,2] | None)."""
@@ -580,15 +592,21 @@ class Engine:
             self.mlp_bwd(pre + 'decoder_y.', b['inp'], b['sy'], dyh, din, False, pf, dpf, K)
             if dxh is not None:
                 self.mlp_bwd(pre + 'decoder_x.', b['inp'], b['sx'], dxh, din, True, pf, dpf, K)
-        dgi = self.new(m * Tp, 288)
-        dgh = self.new(Tp, m, 288)
-        capi.call('sttode_gru_seq_bwd', din[:, SO:], LD, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, m, Tp, self.st)
-        self.wgrad(dgh.view(Tp * m, 288), b['H'][:Tp].view(Tp * m, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
+        dstate, lds, mg = din[:, SO:], LD, m
+        if b.get('agent'):                                          # conv + GRU ran once per agent: its state gradient is the sum over the agent's columns
+            assert not need_dx
+            mg = m // K
+            dstate, lds = self.new(mg, 96), 96
+            capi.call('sttode_rows_reduce', dstate, 96, din[:, SO:], LD, mg, 96, K, 0, self.st)
+        dgi = self.new(mg * Tp, 288)
+        dgh = self.new(Tp, mg, 288)
+        capi.call('sttode_gru_seq_bwd', dstate, lds, b['tapes'], b['H'], P[pre + 'encoder_past.weight_hh_l0'], dgi, dgh, mg, Tp, self.st)
+        self.wgrad(dgh.view(Tp * mg, 288), b['H'][:Tp].view(Tp * mg, 96), g(pre + 'encoder_past.weight_hh_l0'), g(pre + 'encoder_past.bias_hh_l0'))
         de = self.lin_bwd(dgi, P[pre + 'encoder_past.weight_ih_l0'], b['e'], g(pre + 'encoder_past.weight_ih_l0'),
                           g(pre + 'encoder_past.bias_ih_l0'), mask=b['e'])
-        dx = self.new(m, Tp, 2) if need_dx else None
+        dx = self.new(mg, Tp, 2) if need_dx else None
         capi.call('sttode_conv_bwd', de, b['x'], P[pre + 'conv_past.weight'], dx, g(pre + 'conv_past.weight'), g(pre + 'conv_past.bias'),
-                  m, Tp, self.scratch, self.scratch.numel(), self.st)
+                  mg, Tp, self.scratch, self.scratch.numel(), self.st)
         return din, dx
 
     def decoder_fwd(self, pf, z, K, past, cur, want_recover, qz_eps=None):
@@ -657,11 +675,14 @@ class Engine:
             return dst
         for b in d['blocks']:
             Tp = b['Tp']
-            nb = dict(pre=b['pre'], m=m2, Tp=Tp, K=2, pf=b['pf'])
-            nb['x'] = take(b['x'], 2 * Tp).view(m2, Tp, 2)
-            nb['e'] = take(b['e'], Tp * 32).view(m2 * Tp, 32)
-            nb['H'] = take(b['H'], 96, Tp + 1).view(Tp + 1, m2, 96)
-            nb['tapes'] = take(b['tapes'], 384, Tp).view(Tp, m2, 384)
+            nb = dict(pre=b['pre'], m=m2, Tp=Tp, K=2, pf=b['pf'], agent=b.get('agent', False))
+            if nb['agent']:                                          # conv + GRU ran per agent: their tape has no column dimension
+                nb.update(x=b['x'], e=b['e'], H=b['H'], tapes=b['tapes'])
+            else:
+                nb['x'] = take(b['x'], 2 * Tp).view(m2, Tp, 2)
+                nb['e'] = take(b['e'], Tp * 32).view(m2 * Tp, 32)
+                nb['H'] = take(b['H'], 96, Tp + 1).view(Tp + 1, m2, 96)
+                nb['tapes'] = take(b['tapes'], 384, Tp).view(Tp, m2, 384)
             nb['inp'] = take(b['inp'], self.IN).view(m2, self.IN)
             for key in ('sy', 'sx'):
                 nb[key] = tuple(take(t, t.shape[1]).view(m2, t.shape[1]) for t in b[key]) if b[key] is not None else None
