@@ -3637,3 +3637,51 @@ def test_attention_backward_kernels_vs_autograd(L, Nb, hd):
     ref = x.grad
     err = (got.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5 * (1 + ref.abs().max().item()), (err, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ds', ['eth', 'nba'])
+def test_live_column_backward_equals_the_dense_backward(ds):
+    """Round 5: the decoder's backward pass runs over the two trajectory columns per agent that carry a gradient (sample 0 and the sample the
+    min over K of loss_diverse selects, model/STTODE.py:390-395), and the first block's conv + GRU once per agent (x_hat = 0 there).  Both are
+    the DENSE backward over all 21 columns per agent with the exact zeros left out: same loss values, every parameter gradient equal to
+    summation-order rounding -- on the same step, same noise, with the two switches off and on."""
+    from sttode_amd import STTODENet, scenes, training
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    dev = _gpu()
+    if ds == 'eth':
+        a, n = make_args('eth', 8, 12), 9
+        o, p = scenes.eth_scene(977, n_min=n, n_max=n)
+        w = make_weights(1234)
+    else:
+        a, n = make_args('nba', 5, 10), 8 * 11
+        d = scenes.nba_batch(41, 8)
+        data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+        w = make_weights(1234, past_length=5, future_length=10)
+    gen = torch.Generator().manual_seed(5)
+    eps = (torch.randn(n, 32, generator=gen), torch.randn(n, 32, generator=gen), torch.randn(n * 20, 32, generator=gen))
+    res = {}
+    saved = training._LIVE_COLUMNS, training._AGENT_GRU
+    try:
+        for live, agent in ((False, False), (True, False), (True, True)):
+            training._LIVE_COLUMNS, training._AGENT_GRU = live, agent
+            m = STTODENet(a, dev).eval()
+            m.load_state_dict(to_torch_state_dict(w), strict=True)
+            m.train_graphs = False
+            if ds == 'eth':
+                m.set_data(None, torch.from_numpy(o), torch.from_numpy(p))
+            else:
+                m.set_data_nba(data)
+            out = m.forward(*eps)
+            out[0].backward()
+            res[(live, agent)] = (out[1:], {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None})
+    finally:
+        training._LIVE_COLUMNS, training._AGENT_GRU = saved
+    dense = res[(False, False)]
+    for key in ((True, False), (True, True)):
+        vals, grads = res[key]
+        np.testing.assert_allclose(vals, dense[0], rtol=1e-6)
+        assert set(grads) == set(dense[1]) and len(grads) > 80
+        for k, g in grads.items():
+            ref = dense[1][k]
+            assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, (key, k, float((g - ref).abs().max()), float(ref.abs().max()))
