@@ -639,14 +639,25 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
         step(i)
     if dist is not None:
         dist.barrier()
+    # A full pass of Python's cyclic collector over everything the earlier legs of this process left on the heap takes ~0.1 s; its
+    # allocation counters used to trip inside this loop (one 100-130 ms pause in 200 steps of 0.6 ms: `ms_per_step_quarters` 0.60 / 3.18 /
+    # 0.60 / 0.59, against 0.60 x 4 for `--train` alone, profiles/r05/train_leg_gc_pause.txt).  Collect now, outside the region, and move the
+    # survivors out of the collector's sight: the loop then pays only for its own garbage, as it does in a process of its own.
+    import gc
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for i in range(steps):
         step(i)
+        if (i + 1) % max(1, steps // 4) == 0:
+            marks.append(time.perf_counter())                       # (host-side marks, no synchronisation: where in the loop the time went)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    quarters = [1e3 * (b - a) / max(1, steps // 4) for a, b in zip([t0] + marks[:-1], marks)]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         allreduce(dist, tmax, op=dist.ReduceOp.MAX)
@@ -659,6 +670,7 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
                                                        f'pedestrians, mean {agents:.1f}), obs={TP} pred={TF}, train() mode '
                                                        '(rotation + positional dropout), Adam lr 1e-4 (' + args.train_adam + ')',
                                            'parallelism': f'scenes x{world}' + (' + flat gradient all-reduce' if world > 1 else '')}}
+    out['ms_per_step_quarters'] = [round(q, 4) for q in quarters]
     out['optimizer'] = {'hip': 'sttode_amd.optim.Adam (one HIP launch per step)', 'fused': 'torch.optim.Adam(fused=True)',
                         'foreach': 'torch.optim.Adam() (torch default, the reference\'s line)'}[args.train_adam]
     for kind in [k for k in ('fused', 'foreach') if k != args.train_adam] if args.train_adam == 'hip' else (['foreach'] if args.train_adam == 'fused' else []):
@@ -943,7 +955,7 @@ def main():
     if train is not None:
         if do_cpu:
             train_cpu_baseline(args, train)
-        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'optimizer', 'ms_per_step_fused_adam', 'steps_per_s_fused_adam',
+        out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'ms_per_step_quarters', 'optimizer', 'ms_per_step_fused_adam', 'steps_per_s_fused_adam',
                                               'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config', 'cpu_baseline',
                                               'speedup_vs_cpu_baseline') if k in train}
     if rank == 0 and world == 1 and not args.no_per_scene and not args.only_leg:
