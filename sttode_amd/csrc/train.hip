@@ -2256,7 +2256,8 @@ __global__ __launch_bounds__(128) void live_rows_gather_kernel(GatherArgs g) {
     const GatherItem& it = g.it[p];
     const int local = (int)blockIdx.x - g.blk0[p], rows = 2 * g.n;
     const int o = local / rows, r = local % rows, a = r >> 1;
-    const int sidx = (r & 1) ? g.best[a] : 0;
+    int sidx = (r & 1) ? g.best[a] : 0;
+    sidx = sidx < 0 ? 0 : (sidx >= g.K1 ? g.K1 - 1 : sidx);     // (a `best` nobody wrote must not turn into an out-of-bounds read)
     const float* src = it.src + (long)o * it.src_plane + ((long)a * g.K1 + sidx) * it.row;
     float* dst = it.dst + (long)o * it.dst_plane + (long)r * it.row;
     if ((it.row & 3) == 0 && ((((size_t)src) | ((size_t)dst)) & 15) == 0) {
@@ -2335,7 +2336,9 @@ extern "C" int sttode_wait_value(const unsigned* host_seq, long want, double tim
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         if (__atomic_load_n(host_seq, __ATOMIC_ACQUIRE) == (unsigned)want) return 0;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((spins & 1023u) == 1023u &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
             stt_set_error("sttode_wait_value: the sequence word did not reach the expected count in time");

@@ -1053,8 +1053,10 @@ class _GraphedStep:
         total = losses[4].clone()
         self.replays = (self.replays + 1) & 0xFFFFFFFF
         if capi.lib().sttode_wait_value(self.host_seq.data_ptr(), self.replays, 60.0):
+            msg = capi.lib().sttode_last_error().decode()
             torch.cuda.synchronize()
-            raise capi.SttodeError('the replayed step did not publish its loss values: ' + capi.lib().sttode_last_error().decode())
+            self.replays = int(self.dev_seq[0].item()) & 0xFFFFFFFF     # whatever did run: the next replay is counted from the device's own count
+            raise capi.SttodeError('the replayed step did not publish its loss values: ' + msg)
         return (total, self.host_np[:4].tolist()), (buf, views, {'consumed': False, 'rotating': True})
 
 
@@ -1106,7 +1108,7 @@ def training_forward(net, eps_q=None, eps_p=None, eps20=None, drop_past=None, dr
             ('drop_future', n * a.future_length, a.hidden_dim, 'bern' if (drop_future is None and net.training) else None)]
     drawn = {nm: (r, c, kind) for nm, r, c, kind in want if kind is not None}
     key = (net._mode, n, net._S if net._mode == 'scenes' else net.batch_size, drop_past is not None or net.training,
-           drop_future is not None or net.training, tuple(drawn),
+           drop_future is not None or net.training, tuple(drawn), _LIVE_COLUMNS, _AGENT_GRU,
            ptr_token, params[0].data_ptr(), params[-1].data_ptr(),     # graphs hold raw parameter pointers ...
            float(a.min_clip), float(net.ODE_TIME))            # ... and bake scalar kernel arguments in
     # a step is ~170 launches of 5-30 us each and the host needs ~15 us to enqueue one: replay wins as long as the launches are short
