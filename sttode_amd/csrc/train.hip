@@ -1562,12 +1562,143 @@ __global__ __launch_bounds__(384) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same two launches for FEW columns (round 5; m <= gseq_small_max(), default 1024: one scene per step, the live columns of a backward
+// pass, the per-agent first block).  The kernels above put 16 columns on a 16-wide MFMA tile and all of a tile's W_hh products on ONE CU:
+// 885 kFLOP per step = 1.4-1.9 us of that CU's matrix pipe per step of the recurrence, whatever m is -- with m = 32 columns two CUs work
+// and 254 idle, 28-33 us per launch, four launches per training step (20 % of a one-scene step).  Here a workgroup owns FOUR columns and
+// the products run on the vector ALUs with the weight row (forward: W_hh[row][0..95]; backward: 72 of W_hh[..][f]'s 288) in registers and
+// h / the gate gradients broadcast from LDS: 4x more workgroups, ~0.5 us per step.  Same tape layout, same arithmetic per element; the
+// 96- / 288-term sums run as four interleaved partial sums instead of the MFMA's blocked order (differences at fp32 rounding).
+// ---------------------------------------------------------------------------------------------------
+#define GSEQ_SC 4
+__global__ __launch_bounds__(384) void gru_seq_fwd_small_kernel(const float* __restrict__ gi, const float* __restrict__ Whh,
+                                                                const float* __restrict__ bhh, float* __restrict__ H,
+                                                                float* __restrict__ tapes, float* __restrict__ hfinal, long ldhf, int m,
+                                                                int Tp) {
+    __shared__ __attribute__((aligned(16))) float sH[GSEQ_SC][96];
+    __shared__ float sA[GSEQ_SC][288];
+    const int tid = threadIdx.x;
+    const bool mv = tid < 288;                       // matvec thread: one row of W_hh
+    float w[96];
+    float bias = 0.f;
+    if (mv) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const f32x4 v = ld4(Whh + (long)tid * 96 + 4 * k);
+            w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
+        }
+        bias = bhh[tid];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 96; ++k) w[k] = 0.f;
+    }
+    const int c = tid / 96, f = tid % 96;            // gate thread: (column, feature)
+    const int col = blockIdx.x * GSEQ_SC + c;
+    const bool ok = col < m;
+    sH[c][f] = 0.f;
+    if (ok) H[(long)col * 96 + f] = 0.f;             // H[0] = h_{-1} = 0: the backward pass reads it
+    __syncthreads();
+    const float* gic = gi + (long)(ok ? col : 0) * Tp * 288;
+    for (int t = 0; t < Tp; ++t) {
+        const float gr = gic[(long)t * 288 + f], gz = gic[(long)t * 288 + 96 + f], gn = gic[(long)t * 288 + 192 + f];   // (in flight under the products)
+        if (mv) {
+            f32x4 acc[GSEQ_SC];                       // four partial sums per column (k mod 4): short dependency chains, blocked like the MFMA's sums
+#pragma unroll
+            for (int cc = 0; cc < GSEQ_SC; ++cc) acc[cc] = splat4(0.f);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+#pragma unroll
+                for (int cc = 0; cc < GSEQ_SC; ++cc) {
+                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sH[cc][4 * k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(w[4 * k + e], h4[e], acc[cc][e]);
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < GSEQ_SC; ++cc) sA[cc][tid] = bias + ((acc[cc][0] + acc[cc][1]) + (acc[cc][2] + acc[cc][3]));
+        }
+        __syncthreads();
+        const float a2 = sA[c][192 + f], hp = sH[c][f];
+        const float r = sigmoidf_(gr + sA[c][f]);
+        const float z = sigmoidf_(gz + sA[c][96 + f]);
+        const float n = tanhf_(gn + r * a2);
+        const float hn = (1.0f - z) * n + z * hp;
+        if (ok) {
+            float* tp = tapes + ((long)t * m + col) * 384;
+            tp[f] = r; tp[96 + f] = z; tp[192 + f] = n; tp[288 + f] = a2;
+            H[((long)(t + 1) * m + col) * 96 + f] = hn;
+            if (hfinal && t == Tp - 1) hfinal[(long)col * ldhf + f] = hn;
+        }
+        sH[c][f] = ok ? hn : 0.f;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(384) void gru_seq_bwd_small_kernel(const float* __restrict__ dh_last, long lddh, const float* __restrict__ tapes,
+                                                                const float* __restrict__ H, const float* __restrict__ Whh,
+                                                                float* __restrict__ dgi, float* __restrict__ dgh, int m, int Tp) {
+    __shared__ __attribute__((aligned(16))) float sG[GSEQ_SC][288];   // (dr | dz | dhn) of the step
+    __shared__ float sP[4][GSEQ_SC][96];                              // partial products of the four k ranges
+    const int tid = threadIdx.x;
+    const int c = tid / 96, f = tid % 96;            // element thread (column, feature); product thread (k range c, feature f)
+    const int col = blockIdx.x * GSEQ_SC + c;
+    const bool ok = col < m;
+    float w[72];                                      // W_hh[72 c + k][f]: this thread's quarter of the 288-term sum for feature f
+#pragma unroll
+    for (int k = 0; k < 72; ++k) w[k] = Whh[(long)(72 * c + k) * 96 + f];
+    float dh = ok ? dh_last[(long)col * lddh + f] : 0.f;
+    for (int t = Tp - 1; t >= 0; --t) {
+        float dr = 0.f, dz = 0.f, dn = 0.f, dhn = 0.f, dhz = 0.f;
+        if (ok) {
+            const float* tp = tapes + ((long)t * m + col) * 384;
+            const float r = tp[f], z = tp[96 + f], n = tp[192 + f], hn = tp[288 + f];
+            const float hp = H[((long)t * m + col) * 96 + f];
+            const float dnp = dh * (1.0f - z) * (1.0f - n * n);
+            dn = dnp;
+            dr = dnp * hn * r * (1.0f - r);
+            dz = dh * (hp - n) * z * (1.0f - z);
+            dhn = dnp * r;
+            dhz = dh * z;
+            float* gi = dgi + ((long)col * Tp + t) * 288;
+            gi[f] = dr; gi[96 + f] = dz; gi[192 + f] = dn;
+            float* gh = dgh + ((long)t * m + col) * 288;
+            gh[f] = dr; gh[96 + f] = dz; gh[192 + f] = dhn;
+        }
+        sG[c][f] = dr; sG[c][96 + f] = dz; sG[c][192 + f] = dhn;
+        __syncthreads();
+        f32x4 acc[GSEQ_SC];
+#pragma unroll
+        for (int cc = 0; cc < GSEQ_SC; ++cc) acc[cc] = splat4(0.f);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+#pragma unroll
+            for (int cc = 0; cc < GSEQ_SC; ++cc) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sG[cc][72 * c + 4 * k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(g4[e], w[4 * k + e], acc[cc][e]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < GSEQ_SC; ++cc) sP[c][cc][f] = (acc[cc][0] + acc[cc][1]) + (acc[cc][2] + acc[cc][3]);
+        __syncthreads();
+        dh = dhz + (((sP[0][c][f] + sP[1][c][f]) + sP[2][c][f]) + sP[3][c][f]);
+        // (sG and sP are rewritten only after the next step's first barrier / this step's readers are past the second one)
+    }
+}
+static inline int gseq_small_max() {
+    static const int v = getenv("STTODE_GRU_SMALL_MAX") ? atoi(getenv("STTODE_GRU_SMALL_MAX")) : 1024;
+    return v;
+}
+
 extern "C" int sttode_gru_seq_fwd(const float* gi, const float* Whh, const float* bhh, float* H, float* tapes, float* hfinal,
                                   long ldhf, int m, int Tp, void* stream) {
     STT_REQUIRE(gi && Whh && bhh && H && tapes && m > 0 && Tp > 0, "sttode_gru_seq_fwd: bad argument");
     STT_REQUIRE(((size_t)Whh) % 16 == 0 && ((size_t)gi) % 16 == 0, "sttode_gru_seq_fwd: pointers must be 16-byte aligned");
     STT_REQUIRE(!hfinal || (((size_t)hfinal) % 16 == 0 && ldhf % 4 == 0 && ldhf >= 96), "sttode_gru_seq_fwd: hfinal must be 16-byte aligned rows of >= 96 floats");
-    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, hfinal, ldhf, m, Tp);
+    if (m <= gseq_small_max())
+        hipLaunchKernelGGL(gru_seq_fwd_small_kernel, dim3((m + GSEQ_SC - 1) / GSEQ_SC), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, hfinal, ldhf, m, Tp);
+    else
+        hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, gi, Whh, bhh, H, tapes, hfinal, ldhf, m, Tp);
     STT_HIP(hipGetLastError());
     return 0;
 }
@@ -1575,7 +1706,10 @@ extern "C" int sttode_gru_seq_bwd(const float* dh_last, long lddh, const float* 
                                   float* dgh, int m, int Tp, void* stream) {
     STT_REQUIRE(dh_last && tapes && H && Whh && dgi && dgh && m > 0 && Tp > 0, "sttode_gru_seq_bwd: bad argument");
     STT_REQUIRE(((size_t)dh_last) % 16 == 0 && lddh % 4 == 0 && lddh >= 96, "sttode_gru_seq_bwd: dh_last must be 16-byte aligned rows of >= 96 floats");
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, dh_last, lddh, tapes, H, Whh, dgi, dgh, m, Tp);
+    if (m <= gseq_small_max())
+        hipLaunchKernelGGL(gru_seq_bwd_small_kernel, dim3((m + GSEQ_SC - 1) / GSEQ_SC), dim3(384), 0, (hipStream_t)stream, dh_last, lddh, tapes, H, Whh, dgi, dgh, m, Tp);
+    else
+        hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((m + 15) / 16), dim3(384), 0, (hipStream_t)stream, dh_last, lddh, tapes, H, Whh, dgi, dgh, m, Tp);
     STT_HIP(hipGetLastError());
     return 0;
 }

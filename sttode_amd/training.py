@@ -998,6 +998,13 @@ class _GraphedStep:
         self.host_np, self.replays = self.host_vals.numpy(), 0
         self.graph_obj = torch.cuda.CUDAGraph()
         eng.publish = (self.host_vals, self.dev_seq, self.host_seq)
+        # No cyclic-collector run inside the capture: the body allocates thousands of Python objects, and a collection it trips may destroy
+        # whatever garbage the process holds -- other models' native handles (streams, events), pinned buffers, older graphs -- whose
+        # destructors make HIP calls that are not permitted while a stream captures (the runtime aborts the process: seen once a
+        # collection happened to fall into _grad_views under capture).  torch.cuda.graph collects on entry; from there to the end: off.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(self.graph_obj):
                 for k, (rows, cols, kind) in self.drawn.items():
@@ -1015,6 +1022,8 @@ class _GraphedStep:
                     raise
         finally:
             eng.publish = None
+            if gc_was_on:
+                gc.enable()
         self.keep = (eng._hold, eng.V, eng.G, eng.main_scratch, eng.red_scratch)        # static buffers of the graph
         eng._hold = []
         self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
