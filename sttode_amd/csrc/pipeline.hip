@@ -220,6 +220,12 @@ extern "C" int sttode_model_set_weight(SttodeModel* m, int index, const void* pt
 
 extern "C" int sttode_model_destroy(SttodeModel* m) {
     if (!m) return 0;
+    // A destructor runs whenever the host language's collector decides -- possibly while some stream of the process is being captured
+    // (global capture mode: stream / event destruction from any thread is then refused, and the capture invalidated).  Relaxed mode for
+    // the duration of the clean-up: these objects belong to no capture.
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    if (!exchanged) (void)hipGetLastError();
     for (auto& r : m->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : m->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); (void)hipEventDestroy(m->ev_agents);
@@ -229,6 +235,7 @@ extern "C" int sttode_model_destroy(SttodeModel* m) {
     for (int p = 0; p < STT_MAX_SLOTS; ++p) { (void)hipEventDestroy(m->evA_done[p]); (void)hipEventDestroy(m->evB_done[p]); }
     tmo_word_give(m->tmo_host);   // (back to the process-wide block: no hipHostFree here -- a destructor may run during a stream capture)
     delete m;
+    if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);   // back to the caller's mode
     return 0;
 }
 
