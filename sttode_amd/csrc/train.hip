@@ -1755,7 +1755,8 @@ __global__ void conv_bwd_x_kernel(const float* de, const float* w, float* dx, in
 // (row lane 0..7, oc 0..31) reads de[row][oc] (one 128-byte line per row across the 32 oc threads) and the row's 3 x 2 inputs,
 // keeps its 6 weight partials + 1 bias partial in registers, the 8 row lanes are combined through LDS and every WG writes one
 // partial vector [224]; a second single-WG pass adds the partials in order (deterministic).
-__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const float* x, float* part, int m, int T, int rows_per_wg) {
+__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const float* x, float* part, int m, int T, int rows_per_wg, float* dw,
+                                                         float* db) {   // dw != nullptr: ONE workgroup, its sums go straight into dw / db (no reduction launch)
     __shared__ float red[8][224];
     const int oc = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const long rows = (long)m * T;
@@ -1782,7 +1783,12 @@ __global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float* de, const 
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += red[i][threadIdx.x];
-        part[(long)blockIdx.x * 224 + threadIdx.x] = s;
+        if (dw) {
+            if (threadIdx.x < 192) dw[threadIdx.x] += s;
+            else db[threadIdx.x - 192] += s;
+        } else {
+            part[(long)blockIdx.x * 224 + threadIdx.x] = s;
+        }
     }
 }
 // one wave per output j: lane l adds the partials g = l, l + 64, ... in order, then a fixed xor-shuffle tree (deterministic); a single
@@ -1817,8 +1823,13 @@ extern "C" int sttode_conv_bwd(const float* de, const float* x, const float* w, 
     int G = (int)((rows + 63) / 64);     // 8 rows per thread at scene sizes (512 per workgroup made an 11-workgroup launch of 43 us)
     if (G > 256) G = 256;
     STT_REQUIRE(scratch_floats >= (long)G * 224, "sttode_conv_bwd: scratch too small");
+    if (rows <= 128) {                   // very few rows (16 trips of the row loop): one workgroup adds into dw / db itself -- one launch, not two
+        hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, de, x, scratch, m, T, (int)rows, dw, db);
+        STT_HIP(hipGetLastError());
+        return 0;
+    }
     const int rpw = (int)((rows + G - 1) / G);
-    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, de, x, scratch, m, T, rpw);
+    hipLaunchKernelGGL(conv_bwd_w_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, de, x, scratch, m, T, rpw, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(conv_bwd_w_reduce_kernel, dim3(224), dim3(64), 0, (hipStream_t)stream, scratch, G, dw, db);
     STT_HIP(hipGetLastError());
     return 0;

@@ -1029,7 +1029,10 @@ class _GraphedStep:
         self.out = (eng.V['losses'], eng.Gflat, {k: eng.G[k] for k in eng.touched})
 
     def run(self, inputs):
+        one_scene = self.graph is not None and self.net._mode == 'scenes' and self.net._S == 1
         for k, v in inputs.items():
+            if k == 'scene_ptr' and one_scene:                      # [0, n] for ONE scene of n agents (n is part of the graph's key): copied when captured
+                continue
             if v is not None and v is not self.static[k]:           # (random inputs nobody passed in are drawn by the graph itself)
                 self.static[k].copy_(v)
         self._bind()
