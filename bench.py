@@ -690,9 +690,48 @@ def train_bench(args, rank, world, dev, dist, cpu=True):
         dtf = time.perf_counter() - t0
         out[f'ms_per_step_{kind}_adam'] = 1e3 * dtf / steps
         out[f'steps_per_s_{kind}_adam'] = world * steps / dtf
+    if TB == 1 and world == 1:
+        out['nba_size_step'] = train_nba_step(dev, HipAdam)
     if cpu and rank == 0 and world == 1 and not args.no_cpu:
         train_cpu_baseline(args, out)
     return out
+
+
+def train_nba_step(dev, Adam, steps=100):
+    """The NBA branch of the same loop (train.py:59-71: set_data_nba, forward, zero_grad, backward, Adam) at the reference's batch: 32 scenes x 11
+    agents per step, obs 5 / pred 10 (7 392 trajectory columns in forward()'s decoder pass)."""
+    import gc
+    import torch
+    from helpers import make_args
+    from sttode_amd import STTODENet, scenes
+    from sttode_amd.weights import make_weights, to_torch_state_dict
+    m = STTODENet(make_args('nba', 5, 10), dev)
+    m.load_state_dict(to_torch_state_dict(make_weights(1234, past_length=5, future_length=10)), strict=True)
+    m.train()
+    opt = Adam(m.parameters(), lr=1e-4)
+    data = []
+    for i in range(4):
+        d = scenes.nba_batch(900 + i, 32)
+        data.append({k: (torch.from_numpy(v) if hasattr(v, 'shape') else v) for k, v in d.items()})   # the loader's host tensors
+
+    def step(i):
+        m.set_data_nba(data[i % 4])
+        tot = m.forward()[0]
+        opt.zero_grad()
+        tot.backward()
+        opt.step()
+    for i in range(8):
+        step(i)
+    gc.collect()
+    gc.freeze()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'optimizer': 'sttode_amd.optim.Adam',
+            'workload': 'train.py:59-71 loop, 32 scenes x 11 agents per step, obs=5 pred=10, train() mode, host batches staged by set_data_nba'}
 
 
 def train_cpu_baseline(args, out):
@@ -956,7 +995,7 @@ def main():
         if do_cpu:
             train_cpu_baseline(args, train)
         out['train'] = {k: train[k] for k in ('metric', 'steps_per_s', 'ms_per_step', 'ms_per_step_quarters', 'optimizer', 'ms_per_step_fused_adam', 'steps_per_s_fused_adam',
-                                              'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config', 'cpu_baseline',
+                                              'ms_per_step_foreach_adam', 'steps_per_s_foreach_adam', 'steps', 'config', 'nba_size_step', 'cpu_baseline',
                                               'speedup_vs_cpu_baseline') if k in train}
     if rank == 0 and world == 1 and not args.no_per_scene and not args.only_leg:
         out['per_scene'] = per_scene_leg(dev)
