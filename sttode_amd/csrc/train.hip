@@ -574,8 +574,17 @@ __global__ __launch_bounds__(256) void tgemm_reduce_kernel(TGRed r) {
 
 // columns above which the LDS-tiled kernel takes over from the generic ones (STTODE_TGEMM_MIN_COLS: experiments; measured at 1024: the
 // one-scene step the same 1.04-1.08 ms, and the NBA 16 x 11 gradient yardstick fails -- profiles/r04/tgemm_min_cols_ab.txt)
+// Round 5: the BACKWARD products (input gradient, weight gradient) switch at 600 columns (STTODE_TGEMM_MIN_COLS_BWD).  With the decoder's
+// backward over the live columns only, an NBA-size step's backward products have 2 n = 704 columns -- below 2048, on the generic kernels:
+// 1.155 -> 1.086 ms per step with the LDS-tiled kernel (profiles/r05/train_tgemm_min_cols_ab.txt, measured with both thresholds at 600;
+// the forward products keep 2048: at 600 the forward of a 32-agent scene (672 columns) changes its summation order and three gradient
+// yardsticks on the known ill-conditioned rows move from 0.8 to 1.05-1.8 of their bounds, for no gain at one scene per step).
 static inline int tg_min_cols() {
     static const int v = getenv("STTODE_TGEMM_MIN_COLS") ? atoi(getenv("STTODE_TGEMM_MIN_COLS")) : 2048;
+    return v;
+}
+static inline int tg_min_cols_bwd() {
+    static const int v = getenv("STTODE_TGEMM_MIN_COLS_BWD") ? atoi(getenv("STTODE_TGEMM_MIN_COLS_BWD")) : 600;
     return v;
 }
 static inline int aligned16(const void* p, long ld) { return (((size_t)p) % 16 == 0) && (ld % 4 == 0); }
@@ -769,7 +778,7 @@ static int tlinear_impl(const float* X, long ldx, int xdiv, const float* W, long
     a.xvec = aligned16(X, ldx); a.wvec = aligned16(W, ldw); a.yvec = aligned16(Y, ldy);
     a.evec = I % 4 == 0 && a.yvec && (!bias || aligned16(bias, 4)) && (!mask || aligned16(mask, ldm)) && (!accumulate || aligned16(asrc, ldas));
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);   // STTODE_TGEMM=0: the generic kernels (A/B)
-    if (tg_on && cols > tg_min_cols()) {   // batch sizes: the LDS-tiled kernel (64-column tiles: below ~2 k columns its grid leaves most of the chip empty)
+    if (tg_on && cols > (trans ? tg_min_cols_bwd() : tg_min_cols())) {   // batch sizes: the LDS-tiled kernel (trans: an input gradient)
         TG g;
         g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
         g.M = cols; g.N = I; g.Kt = J; g.adiv = xdiv; g.bkdiv = 1; g.ones_row = -1;
@@ -938,7 +947,7 @@ extern "C" int sttode_twgrad(const float* dY, long ldy, const float* X, long ldx
     const int chunks = (cols + 15) / 16;
     const long per = (long)N * (K + 1);
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
-    if (tg_on && cols > tg_min_cols()) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
+    if (tg_on && cols > tg_min_cols_bwd()) {   // batch sizes: the LDS-tiled kernel, reduction over the columns split so that the chip is full
         std::lock_guard<std::mutex> lk(g_red_mu);
         TG g;
         if (tg_wgrad_fill(g, dY, ldy, X, ldx, xdiv, dW, ldw, db, cols, N, K, scratch, scratch_floats, 480, stream)) {
@@ -975,7 +984,7 @@ extern "C" int sttode_tlinear_bwd(const float* dY, long ldy, const float* W, lon
     STT_REQUIRE(cols > 0 && N > 0 && K > 0 && Kdx > 0 && Kdx <= K && xdiv > 0, "sttode_tlinear_bwd: bad sizes");
     static const bool tg_on = !(getenv("STTODE_TGEMM") && atoi(getenv("STTODE_TGEMM")) == 0);
     static const bool fuse_on = !(getenv("STTODE_TGEMM_BWD") && atoi(getenv("STTODE_TGEMM_BWD")) == 0);   // =0: the two products as two launches (A/B)
-    if (tg_on && fuse_on && cols > tg_min_cols() && xdiv == 1) {   // batch sizes: both products of the layer's backward in ONE launch
+    if (tg_on && fuse_on && cols > tg_min_cols_bwd() && xdiv == 1) {   // batch sizes: both products of the layer's backward in ONE launch
         STT_REQUIRE(ldy >= N && ldx >= K && ldgw >= K && ldw >= K && lddx >= Kdx, "sttode_tlinear_bwd: leading dimension smaller than the row length");
         std::lock_guard<std::mutex> lk(g_red_mu);
         TG gx;

@@ -741,7 +741,7 @@ class Engine:
         n, Tp, Tf, zd = net._past.shape[0], a.past_length, a.future_length, a.zdim
         mode = 0 if net._mode == 'scenes' else 1
         K1 = 21
-        if n * K1 * Tp > int(os.environ.get('STTODE_TGEMM_MIN_COLS', '2048')) and self.red_scratch is None:         # batch sizes: room for a backward pass's deferred split sums
+        if n * K1 * Tp > int(os.environ.get('STTODE_TGEMM_MIN_COLS_BWD', '600')) and self.red_scratch is None:         # batch sizes: room for a backward pass's deferred split sums
             self.red_scratch = torch.empty(_SCRATCH_BATCH, dtype=torch.float32, device=self.dev)
         V = self.V = {}
 

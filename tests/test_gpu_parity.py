@@ -2580,10 +2580,11 @@ def test_training_step_edge_scene_sizes_vs_oracle(N):
     _compare_grads(grads2, {k: v for k, v in grads.items()}, rtol=1e-6)
 
 
-@pytest.mark.parametrize('B,N,Tp,Tf', [(16, 11, 5, 10), (3, 10, 10, 40)])
+@pytest.mark.parametrize('B,N,Tp,Tf', [(16, 11, 5, 10), (3, 10, 10, 40), (32, 11, 5, 10)])
 def test_training_step_nba_shapes_vs_oracle(B, N, Tp, Tf):
     """NBA training step at a longer attention group (L = 16: geodesic-attention backward over 16 x 16 score blocks) and at the
-    BASELINE config-5 horizon (obs 10 / pred 40, N = 10): losses and all gradients vs float64 oracle autograd."""
+    BASELINE config-5 horizon (obs 10 / pred 40, N = 10); round 5: at the reference's batch (32 x 11: the live backward's 704 columns run on the
+    LDS-tiled GEMMs): losses and all gradients vs float64 oracle autograd."""
     from sttode_amd import scenes
     _gpu()
     d = scenes.nba_batch(50 + B, B, N=N, obs_len=Tp, pred_len=Tf)
@@ -3642,7 +3643,7 @@ def test_attention_backward_kernels_vs_autograd(L, Nb, hd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('ds', ['eth', 'nba'])
+@pytest.mark.parametrize('ds', ['eth', 'nba', 'nba32'])
 def test_live_column_backward_equals_the_dense_backward(ds):
     """Round 5: the decoder's backward pass runs over the two trajectory columns per agent that carry a gradient (sample 0 and the sample the
     min over K of loss_diverse selects, model/STTODE.py:390-395), and the first block's conv + GRU once per agent (x_hat = 0 there).  Both are
@@ -3656,8 +3657,9 @@ def test_live_column_backward_equals_the_dense_backward(ds):
         o, p = scenes.eth_scene(977, n_min=n, n_max=n)
         w = make_weights(1234)
     else:
-        a, n = make_args('nba', 5, 10), 8 * 11
-        d = scenes.nba_batch(41, 8)
+        B = 32 if ds == 'nba32' else 8                            # 32 x 11: the dense backward's 7 392 and the live one's 704 columns both on the LDS-tiled GEMMs
+        a, n = make_args('nba', 5, 10), B * 11
+        d = scenes.nba_batch(41, B)
         data = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
         w = make_weights(1234, past_length=5, future_length=10)
     gen = torch.Generator().manual_seed(5)
