@@ -957,6 +957,9 @@ class _LossTensor(torch.Tensor):
         _hand_over(G, names, params, rotating=ready is not None)
 
 
+_PARKED_GRAPHS = []
+
+
 class _GraphedStep:
     """One hipGraph per step shape: the ~165 launches of forward-with-tape + backward replayed as a single graph launch
     (the training step is launch-latency-bound at the reference's scene sizes).  Inputs are copied into static buffers,
@@ -973,6 +976,19 @@ class _GraphedStep:
             if kind != 'unused':
                 self.static[k] = torch.empty(rows, cols, device=eng.dev)
         self.graph = None
+
+    def __del__(self):
+        # torch's CUDAGraph destructor synchronises the device on ROCm; while a stream of the process is being captured that call is refused
+        # and the failed check inside a destructor aborts the process (profiles/exp_r05_capture_gc_stress.py: a model collected inside a
+        # user's own torch.cuda.graph block).  A graph that dies during a capture is parked instead and released by the next replay.
+        g = getattr(self, 'graph_obj', None)
+        if g is not None:
+            try:
+                capturing = torch.cuda.is_current_stream_capturing()
+            except Exception:
+                capturing = False
+            if capturing:
+                _PARKED_GRAPHS.append(g)
 
     def _bind(self):
         net, st = self.net, self.static
@@ -1036,6 +1052,8 @@ class _GraphedStep:
             if v is not None and v is not self.static[k]:           # (random inputs nobody passed in are drawn by the graph itself)
                 self.static[k].copy_(v)
         self._bind()
+        if _PARKED_GRAPHS:                                          # graphs that died during somebody's capture (see __del__): nothing captures now
+            _PARKED_GRAPHS.clear()
         if self.graph is None:
             self._capture()
             self.graph = True
