@@ -981,14 +981,12 @@ class _GraphedStep:
         # torch's CUDAGraph destructor synchronises the device on ROCm; while a stream of the process is being captured that call is refused
         # and the failed check inside a destructor aborts the process (profiles/exp_r05_capture_gc_stress.py: a model collected inside a
         # user's own torch.cuda.graph block).  A graph that dies during a capture is parked instead and released by the next replay.
-        g = getattr(self, 'graph_obj', None)
-        if g is not None:
-            try:
-                capturing = torch.cuda.is_current_stream_capturing()
-            except Exception:
-                capturing = False
-            if capturing:
+        try:
+            g = getattr(self, 'graph_obj', None)
+            if g is not None and torch.cuda.is_current_stream_capturing():
                 _PARKED_GRAPHS.append(g)
+        except Exception:                                           # (interpreter shutdown: the module's globals may be gone)
+            pass
 
     def _bind(self):
         net, st = self.net, self.static
