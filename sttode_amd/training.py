@@ -745,7 +745,7 @@ class Engine:
             self.red_scratch = torch.empty(_SCRATCH_BATCH, dtype=torch.float32, device=self.dev)
         V = self.V = {}
 
-        D, PFW = self.D, self.PFW
+        PFW = self.PFW
 
         def f_front():
             V['ws'] = ws = net._frontend(vel_from_norm=0)
